@@ -1,0 +1,179 @@
+"""
+oracle/torch_ref.py -- fp32 CPU ORACLE of the floating-point half of the hot path
+(test infrastructure, NOT product; only tests/, smoke() and bench.py's cpu_baseline import it).
+
+A functional, plain-torch restatement (weights are passed in as a dict with the reference's
+state_dict key names) of:
+  mean_aggregator        nn_modules.py:196-204
+  pool_aggregator        nn_modules.py:223-232 (+ :235-256 for the max / mean pool_fn)
+  attention_aggregator   nn_modules.py:305-321
+  prep_*                 nn_modules.py:112-166
+  forward                models.py:71-91      (frontier, gather, layer stacking, normalize, fc)
+  loss_*                 problem.py:26-38
+  clip / adam            models.py:97-104 -> torch.nn.utils.clip_grad_norm(5) + optim.Adam
+Parity status: PINNED against tests/golden/{agg,prep,model}_kat.npz (tests/test_oracle_float.py),
+tolerance 1e-5 relative (fp32, different summation order only).
+
+The sampler step inside `forward` uses oracle/cpu.py (C) with an explicit `sel`, so the whole
+forward is a deterministic function of (weights, ids, sels).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import cpu as ocpu
+
+
+def _act(name):
+    return {"relu": torch.relu, "identity": (lambda t: t)}[name]
+
+
+def _segments(x, neibs):
+    return neibs.reshape(x.shape[0], -1, neibs.shape[1])
+
+
+def _combine(x, agg, w, act):
+    out = torch.cat([x @ w["fc_x.weight"].t(), agg @ w["fc_neib.weight"].t()], dim=1)
+    return _act(act)(out)
+
+
+def mean_aggregator(x, neibs, w, act):
+    return _combine(x, _segments(x, neibs).mean(dim=1), w, act)
+
+
+def pool_aggregator(x, neibs, w, act, pool):
+    h = torch.relu(neibs @ w["mlp.0.weight"].t() + w["mlp.0.bias"])
+    seg = _segments(x, h)
+    agg = seg.max(dim=1)[0] if pool == "max" else seg.mean(dim=1)
+    return _combine(x, agg, w, act)
+
+
+def attention_aggregator(x, neibs, w, act):
+    def att(t):
+        return torch.tanh(t @ w["att.0.weight"].t()) @ w["att.2.weight"].t()
+    na = _segments(x, att(neibs))                       # [M, n, 32]
+    xa = att(x).unsqueeze(2)                            # [M, 32, 1]
+    scores = torch.bmm(na, xa).squeeze(2)               # [M, n]  (n>1, M>1: same as .squeeze())
+    ws = torch.softmax(scores, dim=1)
+    agg = (_segments(x, neibs) * ws.unsqueeze(-1)).sum(dim=1)
+    return _combine(x, agg, w, act)
+
+
+def aggregator(name, x, neibs, w, act):
+    if name == "mean":
+        return mean_aggregator(x, neibs, w, act)
+    if name == "max_pool":
+        return pool_aggregator(x, neibs, w, act, "max")
+    if name == "mean_pool":
+        return pool_aggregator(x, neibs, w, act, "mean")
+    if name == "attention":
+        return attention_aggregator(x, neibs, w, act)
+    raise KeyError(name)
+
+
+def prep(name, ids, feats, w, n_nodes, layer_idx):
+    if name == "identity":
+        return feats
+    if name == "linear":
+        return feats @ w["fc.weight"].t()
+    if name == "node_embedding":
+        # seeds (layer_idx 0) all read the extra row `n_nodes`, never their own (nn_modules.py:145-149)
+        rows = ids if layer_idx > 0 else torch.full_like(ids, n_nodes)
+        e = w["embedding.weight"][rows] @ w["fc.weight"].t() + w["fc.bias"]
+        return e if feats is None else torch.cat([feats, e], dim=1)
+    raise KeyError(name)
+
+
+def split_weights(w):
+    """state_dict of GSSupervised -> (prep dict, [layer dicts], fc dict)."""
+    prep_w = {k[len("prep."):]: v for k, v in w.items() if k.startswith("prep.")}
+    layers = []
+    li = 0
+    while any(k.startswith("agg_layers.%d." % li) for k in w):
+        pre = "agg_layers.%d." % li
+        layers.append({k[len(pre):]: v for k, v in w.items() if k.startswith(pre)})
+        li += 1
+    fc = {"weight": w["fc.weight"], "bias": w["fc.bias"]}
+    return prep_w, layers, fc
+
+
+def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes,
+            acts=("relu", "identity")):
+    """models.py:71-91 with the sampler's `sel` supplied per hop."""
+    prep_w, layers, fc = split_weights(w)
+    ids = torch.as_tensor(ids, dtype=torch.long)
+    take = (lambda i: feats[i]) if feats is not None else (lambda i: None)
+    hs = [prep(prep_name, ids, take(ids), prep_w, n_nodes, 0)]
+    cur = ids
+    for hop, n in enumerate(fanouts):
+        nxt = ocpu.sample_csr_sel(indptr, data, cur.numpy(), int(n), sels[hop])
+        cur = torch.from_numpy(nxt)
+        hs.append(prep(prep_name, cur, take(cur), prep_w, n_nodes, hop + 1))
+    for li, lw in enumerate(layers):
+        hs = [aggregator(agg_name, hs[k], hs[k + 1], lw, acts[li]) for k in range(len(hs) - 1)]
+    assert len(hs) == 1
+    out = F.normalize(hs[0], p=2, dim=1, eps=1e-12)
+    return out @ fc["weight"].t() + fc["bias"]
+
+
+def loss(task, preds, targets):
+    t = targets.squeeze()
+    if task == "classification":
+        return F.cross_entropy(preds, t)
+    if task == "multilabel_classification":
+        return F.multilabel_soft_margin_loss(preds, t)
+    if task == "regression_mae":
+        return F.l1_loss(preds, t)
+    raise KeyError(task)
+
+
+def clip_(grads, max_norm=5.0):
+    """torch.nn.utils.clip_grad_norm (models.py:101): global L2 norm, coef = max/(norm+1e-6),
+    applied only when < 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = max_norm / (float(total) + 1e-6)
+    if coef < 1.0:
+        for g in grads.values():
+            g.mul_(coef)
+    return float(total)
+
+
+class Adam(object):
+    """torch.optim.Adam(betas=(0.9,0.999), eps=1e-8, L2 weight_decay) as used at models.py:69."""
+
+    def __init__(self, weight_decay=0.0):
+        self.t = 0
+        self.m = {}
+        self.v = {}
+        self.wd = weight_decay
+
+    def step(self, w, grads, lr):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for k, g in grads.items():
+            p = w[k]
+            if self.wd:
+                g = g + self.wd * p
+            m = self.m.setdefault(k, torch.zeros_like(p))
+            v = self.v.setdefault(k, torch.zeros_like(p))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = v.sqrt() / np.sqrt(1 - b2 ** self.t) + eps
+            p.addcdiv_(m, denom, value=-lr / (1 - b1 ** self.t))
+
+
+def train_step(w, opt, lr, task, ids, feats, targets, indptr, data, fanouts, sels, agg_name,
+               prep_name, n_nodes):
+    """models.py:97-104.  `w` is updated in place.  Returns dict(preds, loss, gradnorm, grads,
+    clipped)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
+    preds = forward(params, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes)
+    l = loss(task, preds, targets)
+    l.backward()
+    grads = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}
+    raw = {k: g.clone() for k, g in grads.items()}
+    gn = clip_(grads)
+    with torch.no_grad():
+        opt.step(w, grads, lr)
+    return {"preds": preds.detach(), "loss": float(l.detach()), "gradnorm": gn, "grads": raw,
+            "clipped": grads}
