@@ -1,0 +1,176 @@
+/*
+ * gsage.h -- C ABI of libgsage_hip.so, the MI355X (gfx950) GraphSAGE hot path.
+ *
+ * This is the drop-in boundary.  The reference (bkj/pytorch-graphsage) is pure Python with no
+ * FFI of its own; its plugin surface is three string->class tables
+ * (nn_modules.py:104-107, :169-173, :324-330) plus GSSupervised (models.py:21-104).  The
+ * entry points below are what a ctypes binding inside those classes would call -- one per
+ * tensor-level operation of the hot path -- and INTEGRATION.md shows that binding.  Each
+ * declaration cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Unless marked [host], every pointer is a DEVICE pointer (HBM) owned by the caller;
+ *     nothing is allocated or freed behind the caller's back, outputs are caller-allocated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only
+ *     enqueues work on that stream and returns; no call synchronises.  All kernels are
+ *     hipGraph-capturable (no allocation, no sync, no host-side state besides launch counters).
+ *   - Return value: 0 on success, a negative GSAGE_E* code otherwise; gsage_last_error()
+ *     returns a thread-local message.  Asynchronous data errors (an id outside the graph) are
+ *     reported through the caller-supplied `err_flag` device word (0 = ok).
+ *   - dtype codes: GSAGE_F32 / GSAGE_BF16 (bf16 = upper 16 bits of an IEEE fp32, RNE).
+ *   - Graph layout ("device CSR", built once from the reference's scipy csr_matrix in the
+ *     (v,r,c) convention of problem.py:70-72 / utils/convert.py:100-126):
+ *         rowptr int64 [n_rows+1]   rowptr[i+1]-rowptr[i] = degree of node i
+ *         col    int32 [nnz]        neighbour ids (1-based; 0 is the dummy node), stored in
+ *                                   column order 0..deg-1 of the reference matrix
+ *   - Feature-table layout: row-major [n_rows, ld] with ld >= D; vectorised paths need
+ *     ld % 8 == 0 (bf16) / ld % 4 == 0 (fp32) and columns [D, ld) equal to zero.
+ */
+#ifndef GSAGE_H
+#define GSAGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSAGE_ABI_VERSION 1
+
+enum { GSAGE_F32 = 0, GSAGE_BF16 = 1 };
+enum {
+    GSAGE_OK = 0,
+    GSAGE_EINVAL = -1,   /* bad argument (null pointer, bad size / alignment / dtype) */
+    GSAGE_ELAUNCH = -2,  /* hipLaunchKernel / runtime error (message in gsage_last_error) */
+    GSAGE_ENODEV = -3    /* no gfx950 device visible */
+};
+enum { GSAGE_POOL_MAX = 0, GSAGE_POOL_MEAN = 1 };
+enum { GSAGE_ACT_NONE = 0, GSAGE_ACT_RELU = 1, GSAGE_ACT_TANH = 2 };
+
+int gsage_abi_version(void);
+const char *gsage_last_error(void);
+/* Number of kernels this library has launched since load (tests use it to prove the HIP path
+ * ran instead of some fallback). */
+uint64_t gsage_launch_count(void);
+/* [host] device name / CU count of the current device; returns GSAGE_ENODEV without a GPU. */
+int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  neighbour sampler     replaces SparseUniformNeighborSampler.__call__, nn_modules.py:80-101
+ *     (and __init__, :72-78: degrees are rowptr differences, nothing is precomputed)
+ *
+ *     out[i*n+j] = col[rowptr[ids[i]] + sel[i*n+j] % deg_i]   (deg_i > 0)      nn_modules.py:89-93
+ *                = 0 (the dummy node)                          (deg_i == 0)
+ * ---------------------------------------------------------------------------------------- */
+
+/* `sel` supplied by the caller (int32 [M*n], each in [0, max_deg)): parity level 1, and the
+ * device half of compat mode where sel comes from the legacy MT19937 stream (gsage_mt_*). */
+int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
+                         const int64_t *ids, int64_t M, int32_t n, const int32_t *sel,
+                         int64_t *out, int32_t *err_flag, void *stream);
+
+/* Counter mode (throughput): sel is generated in-kernel by Philox4x32-10,
+ *     g    = g0 + i*n + j                      global sample index of the whole job
+ *     call = call_base + (call_ctr ? *call_ctr : 0)        (call_ctr: device word, may be NULL;
+ *            lets a captured hipGraph advance the stream between replays)
+ *     word = philox4x32_10({lo(g>>2), hi(g>>2), lo(call), hi(call)}, {lo(seed), hi(seed)})[g&3]
+ *     sel  = (word * max_deg) >> 32
+ * `sel_out` (int32 [M*n], may be NULL) receives sel for verification. */
+int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
+                            const int64_t *ids, int64_t M, int32_t n, uint32_t max_deg,
+                            uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
+                            uint64_t g0, int64_t *out, int32_t *sel_out, int32_t *err_flag,
+                            void *stream);
+
+/* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
+int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
+
+/* [host] the numpy legacy MT19937 stream the reference draws from (helpers.py:15,
+ * nn_modules.py:88, problem.py:146), for compat mode.  All pointers here are HOST pointers. */
+void *gsage_mt_create(uint32_t seed);
+void gsage_mt_destroy(void *mt);
+void gsage_mt_seed(void *mt, uint32_t seed);
+/* np.random.choice(high, count) -> int32 out[count]; returns 32-bit words consumed. */
+int64_t gsage_mt_choice_i32(void *mt, int64_t high, int64_t count, int32_t *out);
+/* np.random.permutation(n) -> int64 out[n]. */
+void gsage_mt_permutation(void *mt, int64_t n, int64_t *out);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  gather + mean         replaces feats[ids] (models.py:76,80) followed by
+ *                           neibs.view(M,-1,D).mean(dim=1) (nn_modules.py:197-198)
+ *
+ *     out[i, c] = (1/n) * sum_j table[rows(i,j), c],   rows(i,j) = ids ? ids[i*n+j] : i*n+j
+ *     n == 1 is the plain row gather feats[ids].  fp32 accumulation; `out` has `out_dtype`.
+ *     Columns [D, round_up(D, vec)) of out are written as zero.
+ * ---------------------------------------------------------------------------------------- */
+int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
+                      int32_t n, int64_t D, void *out, int out_dtype, int64_t out_ld,
+                      void *stream);
+
+/* Backward of the segment mean w.r.t. contiguous neighbour rows (autograd of nn_modules.py:198):
+ *     dneibs[i*n+j, c] = dagg[i, c] / n          (fp32 in, fp32 out) */
+int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, int64_t D,
+                           float *dneibs, int64_t out_ld, void *stream);
+
+/* K6  table_grad[ids[i], c] += scale * rows[i / n, c]   for i in [0, M*n)  (atomic fp32).
+ *     Backward of gather_mean w.r.t. a trainable table (the dense nn.Embedding gradient of
+ *     NodeEmbeddingPrep, nn_modules.py:134,146-149); n = 1, scale = 1 for a plain gather. */
+int gsage_scatter_add_rows(const float *rows, int64_t ld, const int64_t *ids, int64_t M,
+                           int32_t n, int64_t D, float scale, float *table_grad,
+                           int64_t table_ld, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  projection GEMM (MFMA) replaces fc_x(x), fc_neib(agg), cat, activation
+ *                           (nn_modules.py:200-202) and every other nn.Linear on the path
+ *
+ *     act in GSAGE_ACT_{NONE,RELU,TANH}.
+ *     for g in [0, groups):   C[m, g*c_gstride + j] = act( sum_k A_g[m,k] * W_g[j,k] + bias_g[j] )
+ *         A_g row m  = (a_rows ? A + a_rows[m]*lda : A + m*lda) + g*a_gstride      [M, K]
+ *         W_g        = W + g*w_gstride                                             [N, K] row-major
+ *         bias_g     = bias ? bias + g*N : none                                    fp32
+ *     groups = 2 writes both halves of the concat in one launch (x | agg against Wx | Wn).
+ *     `a_rows` (int64 [M], may be NULL, group 0 only when `a_rows_group0_only`) fuses the row
+ *     gather feats[ids] into the A-operand load.
+ *     dtype = type of A and W (bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32),
+ *     fp32 accumulation, C stored as c_dtype.  Needs lda, ldw % (16/sizeof) == 0 and zero
+ *     padding of A and W in columns [K, round_up(K, 16/sizeof)).
+ * ---------------------------------------------------------------------------------------- */
+int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
+                    int a_rows_group0_only, const void *W, int64_t ldw, const float *bias,
+                    void *C, int c_dtype, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                    int groups, int64_t a_gstride, int64_t w_gstride, int64_t c_gstride,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  pooling MLP           replaces mlp(neibs) -> view(M,-1,H) -> max/mean over the fanout
+ *                           (nn_modules.py:224-226 with pool_fn of :240 / :252)
+ *
+ *     pooled[i, j] = pool_{r in [0,n)} relu( sum_k A[i*n+r, k] * W[j,k] + bias[j] )
+ *     A rows are gathered through a_rows when given (A row = A + a_rows[i*n+r]*lda).
+ *     argmax (int32 [M, H], may be NULL; max pool only) receives the winning r for backward.
+ *     The [M*n, H] hidden activations are never written to HBM.
+ * ---------------------------------------------------------------------------------------- */
+int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
+                   int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
+                   int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  attention aggregation  replaces AttentionAggregator.forward's weighting,
+ *                            nn_modules.py:307-315 (scores, softmax over the fanout, weighted
+ *                            sum of the RAW neighbour rows)
+ *
+ *     na[i,r,:] given (att(neibs), [M*n, Ha] fp32), xa[i,:] given (att(x), [M, Ha] fp32)
+ *     s[i,r] = <na[i,r,:], xa[i,:]>;  w = softmax_r(s);  agg[i,:] = sum_r w[i,r] * neibs[i*n+r,:]
+ *     neibs rows are gathered from `table` through ids when ids != NULL.
+ *     ws (fp32 [M, n]) is written for backward.
+ * ---------------------------------------------------------------------------------------- */
+int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld,
+                         const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
+                         int32_t n, int64_t Ha, int64_t D, float *agg, int64_t agg_ld, float *ws,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSAGE_H */

@@ -1,0 +1,113 @@
+"""
+_native.py -- ctypes binding of libgsage_hip.so (C ABI declared in include/gsage.h).
+
+The library is the product; there is no Python or CPU substitute for it.  `lib()` raises
+`NativeLibraryError` when the shared object is missing or does not export the full ABI, and
+every GPU op in ops.py goes through `lib()`, so a GPU run can never silently use something else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
+
+F32, BF16 = 0, 1
+POOL_MAX, POOL_MEAN = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes): must list every symbol include/gsage.h declares
+SIGNATURES = {
+    "gsage_abi_version": (_int, []),
+    "gsage_last_error": (ctypes.c_char_p, []),
+    "gsage_launch_count": (_u64, []),
+    "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
+                                       _vp, _vp, _vp, _vp]),
+    "gsage_counter_add": (_int, [_vp, _u64, _vp]),
+    "gsage_mt_create": (_vp, [_u32]),
+    "gsage_mt_destroy": (None, [_vp]),
+    "gsage_mt_seed": (None, [_vp, _u32]),
+    "gsage_mt_choice_i32": (_i64, [_vp, _i64, _i64, _vp]),
+    "gsage_mt_permutation": (None, [_vp, _i64, _vp]),
+    "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
+    "gsage_segment_mean_bwd": (_int, [_vp, _i64, _i64, _i32, _i64, _vp, _i64, _vp]),
+    "gsage_scatter_add_rows": (_int, [_vp, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _i64, _vp]),
+    "gsage_linear_nt": (_int, [_vp, _int, _i64, _vp, _int, _vp, _i64, _vp, _vp, _int, _i64, _i64,
+                               _i64, _i64, _int, _int, _i64, _i64, _i64, _vp]),
+    "gsage_pool_mlp": (_int, [_vp, _int, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _int,
+                              _vp, _i64, _vp, _vp]),
+    "gsage_attn_aggregate": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
+                                    _i64, _vp, _i64, _vp, _vp]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    """Load libgsage_hip.so once; raise loudly if it is absent or incomplete."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "libgsage_hip.so is missing (%s). Build it with `make hip` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`; there is no fallback path."
+            % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise NativeLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if L.gsage_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("ABI version mismatch: library %d, binding %d"
+                                 % (L.gsage_abi_version(), ABI_VERSION))
+    _LIB = L
+    return _LIB
+
+
+def available():
+    try:
+        lib()
+        return True
+    except NativeLibraryError:
+        return False
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().gsage_last_error()
+        raise RuntimeError("gsage %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def launch_count():
+    return int(lib().gsage_launch_count())
+
+
+def device_info():
+    arch = ctypes.create_string_buffer(64)
+    cu, ws = _int(0), _int(0)
+    rc = lib().gsage_device_info(arch, 64, ctypes.byref(cu), ctypes.byref(ws))
+    if rc != 0:
+        return None
+    return {"arch": arch.value.decode(), "cu_count": cu.value, "wave_size": ws.value}

@@ -1,0 +1,82 @@
+// gsage_common.h -- shared device/host helpers for the gfx950 GraphSAGE kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <atomic>
+
+#include "../../include/gsage.h"
+
+namespace gsage {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+extern std::atomic<uint64_t> g_launches;
+
+#define GSAGE_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::gsage::set_error(__VA_ARGS__);     \
+            return GSAGE_EINVAL;                 \
+        }                                        \
+    } while (0)
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    return GSAGE_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> fp32 (bf16 = upper half of an IEEE fp32, round-to-nearest-even) ------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// 16-byte vector of raw bits; the unit every memory-bound kernel moves per lane.
+struct __attribute__((aligned(16))) vec16 { uint32_t w[4]; };
+struct __attribute__((aligned(8))) vec8 { uint32_t w[2]; };
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) -----------------------------------------------------
+struct philox4 { uint32_t v[4]; };
+
+__host__ __device__ __forceinline__ philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                          uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+}  // namespace gsage

@@ -1,0 +1,255 @@
+// gsage_gather.hip -- K2 gather+mean, its backward, and K6 scatter-add (gfx950).
+//
+// Replaces feats[ids] (reference models.py:76,80: an index_select that MATERIALISES the
+// [B*f1*f2, D] frontier, 308 MB fp32 per 512-seed batch at Reddit shapes) followed by
+// neibs.view(M,-1,D).mean(1) (nn_modules.py:197-198) that re-reads it.  Here each sampled
+// row is read from the HBM-resident table exactly once and only the [M, D] means are written.
+//
+// HBM-bandwidth bound.  Work item = one 16-byte column chunk of one OUTPUT row: lanes of a wave
+// cover consecutive chunks of the same row (coalesced 1 KiB per wave-instruction for D >= 512),
+// each lane streams the n neighbour rows of its output row with the loop unrolled so that
+// >= 4 independent 16-B loads are in flight per lane, accumulates in fp32 registers and writes
+// one 16-B chunk.  No LDS: there is no reuse inside a workgroup to stage (every neighbour row is
+// needed by exactly one output row); L2 / Infinity Cache absorb the duplicates that sampling
+// with replacement produces.
+#include "gsage_common.h"
+
+namespace gsage {
+
+template <typename T, int VEC>
+struct chunk_io;
+
+// bf16 storage: VEC bf16 per chunk
+template <int VEC>
+struct chunk_io<uint16_t, VEC> {
+    static constexpr int kWords = (VEC * 2 + 3) / 4;
+    struct __attribute__((aligned(VEC * 2))) raw { uint16_t h[VEC]; };
+    __device__ static __forceinline__ void accumulate(const raw &r, float (&acc)[VEC])
+    {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += bf16_to_f32(r.h[e]);
+    }
+    __device__ static __forceinline__ raw pack(const float (&v)[VEC])
+    {
+        raw r;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.h[e] = f32_to_bf16(v[e]);
+        return r;
+    }
+};
+
+template <int VEC>
+struct chunk_io<float, VEC> {
+    struct __attribute__((aligned(VEC * 4))) raw { float h[VEC]; };
+    __device__ static __forceinline__ void accumulate(const raw &r, float (&acc)[VEC])
+    {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += r.h[e];
+    }
+    __device__ static __forceinline__ raw pack(const float (&v)[VEC])
+    {
+        raw r;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.h[e] = v[e];
+        return r;
+    }
+};
+
+// TI = table element type, TO = output element type, VEC elements per chunk (both sides).
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather_mean(const TI *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M,
+              int32_t n, int32_t D, int32_t chunks, TO *__restrict__ out, int64_t out_ld)
+{
+    using in_io = chunk_io<TI, VEC>;
+    using out_io = chunk_io<TO, VEC>;
+    using in_raw = typename in_io::raw;
+    using out_raw = typename out_io::raw;
+
+    const int64_t total = M * (int64_t)chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float fn = (float)n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t row = (total <= 0xffffffffLL) ? (int64_t)((uint32_t)t / (uint32_t)chunks)
+                                                    : t / chunks;
+        const int32_t c0 = (int32_t)(t - row * chunks) * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+
+        const int64_t base = row * (int64_t)n;
+        int32_t j = 0;
+        // 4 independent loads in flight per lane
+        for (; j + 4 <= n; j += 4) {
+            int64_t r0, r1, r2, r3;
+            if (ids) {
+                r0 = ids[base + j]; r1 = ids[base + j + 1]; r2 = ids[base + j + 2]; r3 = ids[base + j + 3];
+            } else {
+                r0 = base + j; r1 = r0 + 1; r2 = r0 + 2; r3 = r0 + 3;
+            }
+            const in_raw a = *reinterpret_cast<const in_raw *>(table + r0 * ld + c0);
+            const in_raw b = *reinterpret_cast<const in_raw *>(table + r1 * ld + c0);
+            const in_raw c = *reinterpret_cast<const in_raw *>(table + r2 * ld + c0);
+            const in_raw d = *reinterpret_cast<const in_raw *>(table + r3 * ld + c0);
+            in_io::accumulate(a, acc);
+            in_io::accumulate(b, acc);
+            in_io::accumulate(c, acc);
+            in_io::accumulate(d, acc);
+        }
+        for (; j < n; ++j) {
+            const int64_t r = ids ? ids[base + j] : base + j;
+            const in_raw a = *reinterpret_cast<const in_raw *>(table + r * ld + c0);
+            in_io::accumulate(a, acc);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = (c0 + e < D) ? acc[e] / fn : 0.f;   // n == 1: exact
+        *reinterpret_cast<out_raw *>(out + row * out_ld + c0) = out_io::pack(acc);
+    }
+}
+
+// dneibs[i*n+j, :] = dagg[i, :] / n     (fp32, 16-byte chunks when aligned)
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_segment_mean_bwd(const float *__restrict__ dagg, int64_t ld, int64_t M, int32_t n, int32_t D,
+                   int32_t chunks, float *__restrict__ dneibs, int64_t out_ld)
+{
+    using io = chunk_io<float, VEC>;
+    using raw = typename io::raw;
+    const int64_t total = M * (int64_t)n * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float fn = (float)n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t orow = t / chunks;
+        const int32_t c0 = (int32_t)(t - orow * chunks) * VEC;
+        const int64_t i = orow / n;
+        float v[VEC];
+        if (VEC > 1) {
+            const raw r = *reinterpret_cast<const raw *>(dagg + i * ld + c0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = r.h[e] / fn;
+            *reinterpret_cast<raw *>(dneibs + orow * out_ld + c0) = io::pack(v);
+        } else {
+            if (c0 < D) dneibs[orow * out_ld + c0] = dagg[i * ld + c0] / fn;
+        }
+    }
+}
+
+// table_grad[ids[r], c] += scale * rows[r / n, c]
+__global__ void __launch_bounds__(256)
+k_scatter_add_rows(const float *__restrict__ rows, int64_t ld, const int64_t *__restrict__ ids,
+                   int64_t total_rows, int32_t n, int32_t D, float scale,
+                   float *__restrict__ table_grad, int64_t table_ld)
+{
+    const int64_t total = total_rows * (int64_t)D;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t r = t / D;
+        const int32_t c = (int32_t)(t - r * D);
+        const float v = rows[(r / n) * ld + c] * scale;
+        atomicAdd(table_grad + ids[r] * table_ld + c, v);      // device-scope fp32 add
+    }
+}
+
+static inline int grid_for(int64_t work_items)
+{
+    int64_t blocks = ceil_div(work_items, 256);
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static inline bool aligned_to(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+template <typename TI, typename TO, int VEC>
+static int launch_gather_mean(const void *table, int64_t ld, const int64_t *ids, int64_t M,
+                              int32_t n, int64_t D, void *out, int64_t out_ld, hipStream_t s)
+{
+    const int32_t chunks = (int32_t)ceil_div(D, VEC);
+    hipLaunchKernelGGL((k_gather_mean<TI, TO, VEC>), dim3(grid_for(M * chunks)), dim3(256), 0, s,
+                       (const TI *)table, ld, ids, M, n, (int32_t)D, chunks, (TO *)out, out_ld);
+    return check_launch("gather_mean");
+}
+
+template <typename TI, typename TO>
+static int dispatch_vec(const void *table, int64_t ld, const int64_t *ids, int64_t M, int32_t n,
+                        int64_t D, void *out, int64_t out_ld, hipStream_t s)
+{
+    // widest chunk both sides can take: VEC elements must be a 16/8/4/2-byte aligned unit in
+    // both the table and the output, and round_up(D, VEC) must fit in both leading dimensions.
+    constexpr int kMax = (sizeof(TI) == 2 && sizeof(TO) == 2) ? 8 : 4;
+    auto ok = [&](int vec) {
+        return ld % vec == 0 && out_ld % vec == 0 && aligned_to(table, vec * sizeof(TI)) &&
+               aligned_to(out, vec * sizeof(TO)) && ceil_div(D, vec) * vec <= ld &&
+               ceil_div(D, vec) * vec <= out_ld;
+    };
+    if (kMax == 8 && ok(8)) return launch_gather_mean<TI, TO, (kMax == 8 ? 8 : 4)>(table, ld, ids, M, n, D, out, out_ld, s);
+    if (ok(4)) return launch_gather_mean<TI, TO, 4>(table, ld, ids, M, n, D, out, out_ld, s);
+    if (ok(2)) return launch_gather_mean<TI, TO, 2>(table, ld, ids, M, n, D, out, out_ld, s);
+    return launch_gather_mean<TI, TO, 1>(table, ld, ids, M, n, D, out, out_ld, s);
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
+                      int32_t n, int64_t D, void *out, int out_dtype, int64_t out_ld, void *stream)
+{
+    GSAGE_REQUIRE(n > 0 && M >= 0 && D > 0, "gather_mean: bad sizes M=%lld n=%d D=%lld",
+                  (long long)M, n, (long long)D);
+    GSAGE_REQUIRE(ld >= D && out_ld >= D, "gather_mean: leading dimension smaller than D");
+    GSAGE_REQUIRE(D <= 0x7fffffff, "gather_mean: D too large");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(table && out, "gather_mean: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GSAGE_BF16 && out_dtype == GSAGE_BF16)
+        return dispatch_vec<uint16_t, uint16_t>(table, ld, ids, M, n, D, out, out_ld, s);
+    if (dtype == GSAGE_BF16 && out_dtype == GSAGE_F32)
+        return dispatch_vec<uint16_t, float>(table, ld, ids, M, n, D, out, out_ld, s);
+    if (dtype == GSAGE_F32 && out_dtype == GSAGE_F32)
+        return dispatch_vec<float, float>(table, ld, ids, M, n, D, out, out_ld, s);
+    if (dtype == GSAGE_F32 && out_dtype == GSAGE_BF16)
+        return dispatch_vec<float, uint16_t>(table, ld, ids, M, n, D, out, out_ld, s);
+    set_error("gather_mean: unsupported dtype pair %d -> %d", dtype, out_dtype);
+    return GSAGE_EINVAL;
+}
+
+int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, int64_t D,
+                           float *dneibs, int64_t out_ld, void *stream)
+{
+    GSAGE_REQUIRE(n > 0 && M >= 0 && D > 0, "segment_mean_bwd: bad sizes");
+    GSAGE_REQUIRE(ld >= D && out_ld >= D, "segment_mean_bwd: leading dimension smaller than D");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(dagg && dneibs, "segment_mean_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = D % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0 && aligned_to(dagg, 16) &&
+                    aligned_to(dneibs, 16);
+    if (v4) {
+        const int32_t chunks = (int32_t)(D / 4);
+        hipLaunchKernelGGL((k_segment_mean_bwd<4>), dim3(grid_for(M * n * chunks)), dim3(256), 0, s,
+                           dagg, ld, M, n, (int32_t)D, chunks, dneibs, out_ld);
+    } else {
+        hipLaunchKernelGGL((k_segment_mean_bwd<1>), dim3(grid_for(M * n * D)), dim3(256), 0, s,
+                           dagg, ld, M, n, (int32_t)D, (int32_t)D, dneibs, out_ld);
+    }
+    return check_launch("segment_mean_bwd");
+}
+
+int gsage_scatter_add_rows(const float *rows, int64_t ld, const int64_t *ids, int64_t M, int32_t n,
+                           int64_t D, float scale, float *table_grad, int64_t table_ld,
+                           void *stream)
+{
+    GSAGE_REQUIRE(n > 0 && M >= 0 && D > 0, "scatter_add_rows: bad sizes");
+    GSAGE_REQUIRE(ld >= D && table_ld >= D, "scatter_add_rows: leading dimension smaller than D");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(rows && ids && table_grad, "scatter_add_rows: null pointer");
+    const int64_t total_rows = M * (int64_t)n;
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(total_rows * D)), dim3(256), 0,
+                       (hipStream_t)stream, rows, ld, ids, total_rows, n, (int32_t)D, scale,
+                       table_grad, table_ld);
+    return check_launch("scatter_add_rows");
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// gsage_sample.hip -- K1: CSR uniform neighbour sampler (gfx950) + the host-side legacy stream.
+//
+// Replaces SparseUniformNeighborSampler (reference nn_modules.py:52-101): the reference pulls
+// ids to the host, slices a scipy CSR (copying every full adjacency row), draws `sel` from
+// numpy's global MT19937 and copies the result back (2 D2H + 2 H2D syncs per step).  Here the
+// graph is resident in HBM as (rowptr int64, col int32) and one launch per hop does
+//     out[i*n+j] = col[rowptr[id_i] + sel[i,j] % deg_i]      (0 when deg_i == 0)
+// HBM-latency bound integer work: one lane per sample (sel mode) or per Philox block of four
+// samples (counter mode); rowptr[id], rowptr[id+1] are adjacent 8-byte words, the n lanes of a
+// parent hit the same two words (TA broadcast), the only scattered traffic is one 4-byte `col`
+// read and one 8-byte write per sample.
+#include "gsage_common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+namespace gsage {
+
+// ---- library-wide state -------------------------------------------------------------------------
+static thread_local char t_err[512] = "";
+std::atomic<uint64_t> g_launches{0};
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- device code ----------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t pick_neighbor(const int64_t *__restrict__ rowptr,
+                                                 const int32_t *__restrict__ col, int64_t n_rows,
+                                                 int64_t id, uint32_t s, int32_t *err_flag)
+{
+    if ((uint64_t)id >= (uint64_t)n_rows) {          // the reference raises IndexError here
+        if (err_flag) *err_flag = 1;
+        return 0;
+    }
+    const int64_t beg = rowptr[id];
+    const int64_t deg = rowptr[id + 1] - beg;
+    if (deg <= 0) return 0;                          // numpy: x % 0 == 0 -> column 0 of an empty row
+    const uint64_t off = (deg <= 0xffffffffLL) ? (uint64_t)(s % (uint32_t)deg) : (uint64_t)s;
+    return (int64_t)col[beg + (int64_t)off];
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_sel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t n_rows,
+             const int64_t *__restrict__ ids, int64_t total, uint32_t n,
+             const int32_t *__restrict__ sel, int64_t *__restrict__ out, int32_t *err_flag)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        const int64_t i = (total <= 0xffffffffLL) ? (int64_t)((uint32_t)g / n) : g / (int64_t)n;
+        out[g] = pick_neighbor(rowptr, col, n_rows, ids[i], (uint32_t)sel[g], err_flag);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_philox(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                int64_t n_rows, const int64_t *__restrict__ ids, int64_t total, uint32_t n,
+                uint32_t max_deg, uint32_t seed_lo, uint32_t seed_hi,
+                const uint64_t *__restrict__ call_ctr, uint64_t call_base, uint64_t g0,
+                int64_t *__restrict__ out, int32_t *__restrict__ sel_out, int32_t *err_flag)
+{
+    const uint64_t call = call_base + (call_ctr ? *call_ctr : 0ull);
+    const uint64_t blk0 = g0 >> 2;
+    const uint64_t nblk = ((g0 + (uint64_t)total - 1) >> 2) - blk0 + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += stride) {
+        const uint64_t blk = blk0 + b;
+        const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
+                                        (uint32_t)(call >> 32), seed_lo, seed_hi);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t g = (blk << 2) + (uint64_t)k;
+            if (g < g0 || g >= g0 + (uint64_t)total) continue;
+            const int64_t t = (int64_t)(g - g0);
+            const uint32_t s = (uint32_t)(((uint64_t)r.v[k] * (uint64_t)max_deg) >> 32);
+            const int64_t i = (total <= 0xffffffffLL) ? (int64_t)((uint32_t)t / n) : t / (int64_t)n;
+            if (sel_out) sel_out[t] = (int32_t)s;
+            out[t] = pick_neighbor(rowptr, col, n_rows, ids[i], s, err_flag);
+        }
+    }
+}
+
+__global__ void k_counter_add(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
+
+static inline int grid_for(int64_t work_items)
+{
+    int64_t blocks = ceil_div(work_items, 256);
+    if (blocks > 8192) blocks = 8192;          // grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---- host-side legacy MT19937 (numpy global stream) -------------------------------------------
+// Compat mode only: reproduces what the reference consumes through np.random.seed /
+// np.random.choice / np.random.permutation (helpers.py:15, nn_modules.py:88, problem.py:146).
+class LegacyStream {
+public:
+    explicit LegacyStream(uint32_t seed) { reseed(seed); }
+
+    void reseed(uint32_t seed)
+    {
+        s_[0] = seed;
+        for (uint32_t i = 1; i < kN; ++i) s_[i] = 1812433253u * (s_[i - 1] ^ (s_[i - 1] >> 30)) + i;
+        idx_ = kN;
+    }
+
+    uint32_t next()
+    {
+        if (idx_ >= kN) refill();
+        uint32_t y = s_[idx_++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+
+    // uniform on [0, top] by masked rejection of 32-bit words (top < 2^32)
+    uint32_t bounded(uint32_t top, uint32_t mask, int64_t *words)
+    {
+        uint32_t v;
+        do {
+            v = next() & mask;
+            ++*words;
+        } while (v > top);
+        return v;
+    }
+
+    static uint32_t mask_for(uint32_t top)
+    {
+        uint32_t m = top;
+        m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+        return m;
+    }
+
+private:
+    static constexpr uint32_t kN = 624, kM = 397;
+    uint32_t s_[kN];
+    uint32_t idx_;
+
+    static uint32_t mix(uint32_t hi, uint32_t lo)
+    {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+
+    void refill()
+    {
+        for (uint32_t k = 0; k < kN; ++k)
+            s_[k] = s_[(k + kM) % kN] ^ mix(s_[k], s_[(k + 1) % kN]);
+        idx_ = 0;
+    }
+};
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int gsage_abi_version(void) { return GSAGE_ABI_VERSION; }
+const char *gsage_last_error(void) { return t_err; }
+uint64_t gsage_launch_count(void) { return g_launches.load(); }
+
+int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size)
+{
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible");
+        return GSAGE_ENODEV;
+    }
+    if (arch && arch_len > 0) {
+        strncpy(arch, p.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    return GSAGE_OK;
+}
+
+int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
+                         const int64_t *ids, int64_t M, int32_t n, const int32_t *sel,
+                         int64_t *out, int32_t *err_flag, void *stream)
+{
+    GSAGE_REQUIRE(n > 0, "sample_csr_sel: n_samples must be > 0");      // nn_modules.py:81
+    GSAGE_REQUIRE(M >= 0 && n_rows >= 0, "sample_csr_sel: negative size");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(rowptr && col && ids && sel && out, "sample_csr_sel: null pointer");
+    const int64_t total = M * (int64_t)n;
+    hipLaunchKernelGGL(k_sample_sel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, col, n_rows, ids, total, (uint32_t)n, sel, out, err_flag);
+    return check_launch("sample_csr_sel");
+}
+
+int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
+                            const int64_t *ids, int64_t M, int32_t n, uint32_t max_deg,
+                            uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
+                            uint64_t g0, int64_t *out, int32_t *sel_out, int32_t *err_flag,
+                            void *stream)
+{
+    GSAGE_REQUIRE(n > 0, "sample_csr_philox: n_samples must be > 0");
+    GSAGE_REQUIRE(M >= 0 && n_rows >= 0, "sample_csr_philox: negative size");
+    GSAGE_REQUIRE(max_deg > 0, "sample_csr_philox: max_deg must be > 0");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(rowptr && col && ids && out, "sample_csr_philox: null pointer");
+    const int64_t total = M * (int64_t)n;
+    hipLaunchKernelGGL(k_sample_philox, dim3(grid_for(total / 4 + 2)), dim3(256), 0,
+                       (hipStream_t)stream, rowptr, col, n_rows, ids, total, (uint32_t)n, max_deg,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), call_ctr, call_base, g0, out,
+                       sel_out, err_flag);
+    return check_launch("sample_csr_philox");
+}
+
+int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream)
+{
+    GSAGE_REQUIRE(ctr, "counter_add: null pointer");
+    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    return check_launch("counter_add");
+}
+
+void *gsage_mt_create(uint32_t seed) { return new LegacyStream(seed); }
+void gsage_mt_destroy(void *mt) { delete static_cast<LegacyStream *>(mt); }
+void gsage_mt_seed(void *mt, uint32_t seed) { static_cast<LegacyStream *>(mt)->reseed(seed); }
+
+int64_t gsage_mt_choice_i32(void *mt, int64_t high, int64_t count, int32_t *out)
+{
+    LegacyStream *st = static_cast<LegacyStream *>(mt);
+    int64_t words = 0;
+    if (high <= 1) {                               // range of one value: numpy draws nothing
+        for (int64_t i = 0; i < count; ++i) out[i] = 0;
+        return 0;
+    }
+    const uint32_t top = (uint32_t)(high - 1);
+    const uint32_t mask = LegacyStream::mask_for(top);
+    for (int64_t i = 0; i < count; ++i) out[i] = (int32_t)st->bounded(top, mask, &words);
+    return words;
+}
+
+void gsage_mt_permutation(void *mt, int64_t n, int64_t *out)
+{
+    LegacyStream *st = static_cast<LegacyStream *>(mt);
+    int64_t words = 0;
+    for (int64_t i = 0; i < n; ++i) out[i] = i;
+    for (int64_t i = n - 1; i >= 1; --i) {
+        const uint32_t j = st->bounded((uint32_t)i, LegacyStream::mask_for((uint32_t)i), &words);
+        const int64_t t = out[i];
+        out[i] = out[j];
+        out[j] = t;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""
+models.py -- GSSupervised, the layer-stacking loop and train_step (reference models.py:21-104),
+kept drop-in: same constructor keywords (as passed at train.py:94-123), same methods
+(`forward(ids, feats, train)`, `set_progress`, `train_step`), same parameter names.
+
+What changes underneath: the frontier is built on the device by K1, the
+per-hop `feats[ids]` gathers are row *references* consumed inside the aggregator kernels
+(K2-K5) instead of materialised [B*f1*f2, D] tensors, and `train_step` has a gradient-sync
+hook between backward and clip for data-parallel runs (one flat RCCL all-reduce, dist.py).
+"""
+from functools import partial
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .lr import LRSchedule
+from .store import FeatureStore
+
+
+class GSSupervised(nn.Module):
+    def __init__(self, input_dim, n_nodes, n_classes, layer_specs, aggregator_class, prep_class,
+                 sampler_class, adj, train_adj, lr_init=0.01, weight_decay=0.0,
+                 lr_schedule='constant', epochs=10):
+        super(GSSupervised, self).__init__()
+
+        # samplers: training walks train_adj, evaluation the full graph (models.py:41-44)
+        self.train_sampler = sampler_class(adj=train_adj)
+        self.val_sampler = sampler_class(adj=adj)
+        self.train_sample_fns = [partial(self.train_sampler, n_samples=spec['n_train_samples'])
+                                 for spec in layer_specs]
+        self.val_sample_fns = [partial(self.val_sampler, n_samples=spec['n_val_samples'])
+                               for spec in layer_specs]
+
+        self.prep = prep_class(input_dim=input_dim, n_nodes=n_nodes)
+        width = self.prep.output_dim
+
+        stack = []
+        for spec in layer_specs:
+            layer = aggregator_class(input_dim=width, output_dim=spec['output_dim'],
+                                     activation=spec['activation'])
+            stack.append(layer)
+            width = layer.output_dim          # 2 * output_dim for the concat (models.py:59)
+        self.agg_layers = nn.Sequential(*stack)
+        self.fc = nn.Linear(width, n_classes, bias=True)
+
+        # schedule is a function of progress only: `epochs` is not forwarded (models.py:67)
+        self.lr_scheduler = partial(getattr(LRSchedule, lr_schedule), lr_init=lr_init)
+        self.lr = self.lr_scheduler(0.0)
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=weight_decay)
+
+        self.grad_sync = None                 # set by dist.attach(): called after backward
+        self._wrapped = {}
+
+    # ------------------------------------------------------------------------------------
+    def _rows_of(self, feats):
+        """What `feats[ids]` should index: FeatureStore as is; a CUDA tensor is wrapped zero-copy
+        so its gathers are fused too; CPU tensors keep stock indexing (host mode)."""
+        if feats is None or isinstance(feats, FeatureStore) or not feats.is_cuda:
+            return feats
+        key = (feats.data_ptr(), tuple(feats.shape), feats.dtype)
+        if key not in self._wrapped:
+            self._wrapped = {key: FeatureStore.wrap(feats)}
+        return self._wrapped[key]
+
+    def forward(self, ids, feats, train=True):
+        sample_fns = self.train_sample_fns if train else self.val_sample_fns
+        table = self._rows_of(feats)
+        rows = (lambda i: table[i]) if table is not None else (lambda i: None)
+
+        # frontier: [B], [B*f1], [B*f1*f2], ...  (models.py:75-81)
+        hops = [self.prep(ids, rows(ids), layer_idx=0)]
+        for hop, sample in enumerate(sample_fns):
+            ids = sample(ids=ids).contiguous().view(-1)
+            hops.append(self.prep(ids, rows(ids), layer_idx=hop + 1))
+
+        # layer l maps every adjacent pair of hop representations; shared weights (models.py:85-86)
+        for layer in self.agg_layers.children():
+            hops = [layer(hops[k], hops[k + 1]) for k in range(len(hops) - 1)]
+        assert len(hops) == 1, "len(all_feats) != 1"
+
+        out = F.normalize(hops[0].float(), dim=1)
+        return self.fc(out)
+
+    def set_progress(self, progress):
+        self.lr = self.lr_scheduler(progress)
+        LRSchedule.set_lr(self.optimizer, self.lr)
+
+    def train_step(self, ids, feats, targets, loss_fn):
+        self.optimizer.zero_grad()
+        preds = self(ids, feats, train=True)
+        loss = loss_fn(preds, targets.squeeze())
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self)
+        torch.nn.utils.clip_grad_norm_(self.parameters(), 5)
+        self.optimizer.step()
+        return preds

@@ -1,0 +1,555 @@
+"""
+ops.py -- tensor-level operators of the hot path, bound to libgsage_hip.so through ctypes.
+
+PyTorch is plumbing here: it owns device memory, streams and autograd bookkeeping; the work is
+done by the HIP kernels behind include/gsage.h.  Dispatch rule (no silent fallback):
+  * CUDA tensors  -> the native library, always; a missing / stale library raises
+                     NativeLibraryError (see _native.py).
+  * CPU tensors   -> "host mode": the same operator written with stock torch ops, used only for
+                     the reference's CPU configuration (`train.py --no-cuda`, BASELINE config 1)
+                     and for the multi-process gloo tests.  Never reached from a CUDA tensor.
+
+Reference call sites each operator replaces are cited per function.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native as nat
+from .store import FeatureStore, RowRef, _round_up
+
+_vp = ctypes.c_void_p
+
+
+class _Config(object):
+    compute_dtype = "bf16"      # "bf16": MFMA bf16 in / fp32 accumulate;  "fp32": exact-fp32 MFMA
+    mm_out_f32 = None           # does torch.mm(bf16, bf16, out_dtype=fp32) work on this build?
+
+
+config = _Config()
+
+
+def set_compute_dtype(name):
+    assert name in ("bf16", "fp32")
+    config.compute_dtype = name
+
+
+def torch_dtype(name=None):
+    return {"bf16": torch.bfloat16, "fp32": torch.float32}[name or config.compute_dtype]
+
+
+def _code(dtype):
+    if dtype == torch.float32:
+        return nat.F32
+    if dtype == torch.bfloat16:
+        return nat.BF16
+    raise TypeError("gsage: unsupported dtype %s" % dtype)
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def warmup(device):
+    """Probe optional torch features once, outside any graph capture."""
+    if config.mm_out_f32 is None:
+        try:
+            a = torch.zeros(8, 8, dtype=torch.bfloat16, device=device)
+            r = torch.mm(a, a, out_dtype=torch.float32)
+            config.mm_out_f32 = (r.dtype == torch.float32)
+        except Exception:
+            config.mm_out_f32 = False
+    nat.lib()
+
+
+def _mm_f32(a, b):
+    """a @ b with an fp32 result (plain library GEMM used for the backward contractions)."""
+    if a.dtype == torch.float32:
+        return torch.mm(a, b)
+    if config.mm_out_f32:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a.float(), b.float())
+
+
+def _pad_cast(t, dtype, mult):
+    """[M, D] -> contiguous [M, round_up(D, mult)] of `dtype`, zero padded (no copy if already so)."""
+    M, D = t.shape
+    ld = _round_up(D, mult)
+    if t.dtype == dtype and ld == D and t.is_contiguous():
+        return t
+    out = torch.zeros(M, ld, dtype=dtype, device=t.device) if ld != D else \
+        torch.empty(M, ld, dtype=dtype, device=t.device)
+    out[:, :D] = t
+    return out
+
+
+# =============================================================================================
+# K1  sampler
+# =============================================================================================
+def _philox_host(seed, call, g0, count, max_deg):
+    """numpy Philox4x32-10 for host mode; same definition as the kernel (include/gsage.h)."""
+    g = np.arange(g0, g0 + count, dtype=np.uint64)
+    blk = g >> np.uint64(2)
+    c = [(blk & np.uint64(0xFFFFFFFF)), (blk >> np.uint64(32)),
+         np.full(count, call & 0xFFFFFFFF, dtype=np.uint64),
+         np.full(count, (call >> 32) & 0xFFFFFFFF, dtype=np.uint64)]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0)) & mask, p1 & mask,
+             ((p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1)) & mask, p0 & mask]
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    words = np.stack(c, axis=1)[np.arange(count), (g & np.uint64(3)).astype(np.int64)]
+    return ((words * np.uint64(max_deg)) >> np.uint64(32)).astype(np.int64)
+
+
+def sample_csr(csr, ids, n, sel=None, philox=None):
+    """SparseUniformNeighborSampler.__call__ (nn_modules.py:80-101).
+
+    ids: LongTensor [M] on csr.device.  Exactly one of
+      sel    : IntTensor [M*n] in [0, max_deg)   (parity level 1 / compat mode)
+      philox : dict(seed, call_base, g0, call_ctr=None|cuda uint64-as-int64 tensor[1])
+    Returns LongTensor [M*n] on the same device."""
+    assert n > 0, "SparseUniformNeighborSampler: n_samples must be set explicitly"
+    ids = ids.contiguous().view(-1)
+    M = int(ids.shape[0])
+    if ids.is_cuda:
+        L = nat.lib()
+        out = torch.empty(M * n, dtype=torch.int64, device=ids.device)
+        if sel is not None:
+            sel = sel.contiguous().view(-1)
+            assert sel.dtype == torch.int32 and sel.shape[0] == M * n and sel.is_cuda
+            nat.check(L.gsage_sample_csr_sel(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, _ptr(ids),
+                                             M, n, _ptr(sel), _ptr(out), _ptr(csr.err_flag),
+                                             _stream()), "sample_csr_sel")
+        else:
+            ctr = philox.get("call_ctr")
+            sel_out = philox.get("sel_out")
+            nat.check(L.gsage_sample_csr_philox(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows,
+                                                _ptr(ids), M, n, csr.max_deg, int(philox["seed"]),
+                                                _ptr(ctr), int(philox.get("call_base", 0)),
+                                                int(philox.get("g0", 0)), _ptr(out), _ptr(sel_out),
+                                                _ptr(csr.err_flag), _stream()), "sample_csr_philox")
+        return out
+    # ---- host mode
+    idn = ids.numpy()
+    if idn.size and (idn.min() < 0 or idn.max() >= csr.n_rows):
+        raise IndexError("sampler: node id out of range of the adjacency")
+    if sel is None:
+        ctr = philox.get("call_ctr")
+        call = int(philox.get("call_base", 0)) + (int(ctr.item()) if ctr is not None else 0)
+        seln = _philox_host(int(philox["seed"]), call, int(philox.get("g0", 0)), M * n, csr.max_deg)
+    else:
+        seln = sel.numpy().reshape(-1).astype(np.int64)
+    rp = csr.rowptr.numpy()
+    beg = np.repeat(rp[idn], n)
+    deg = np.repeat(rp[idn + 1] - rp[idn], n)
+    off = np.where(deg > 0, seln % np.maximum(deg, 1), 0)
+    col = csr.col.numpy()
+    vals = col[np.minimum(beg + off, max(col.shape[0] - 1, 0))] if col.shape[0] else np.zeros_like(off)
+    return torch.from_numpy(np.where(deg > 0, vals, 0).astype(np.int64))
+
+
+# =============================================================================================
+# K2 / K6  gather + mean, segment mean, scatter-add
+# =============================================================================================
+def _gather_mean_raw(table, D, ids, M, n, out_dtype, out_ld=None):
+    """out[i] = mean_j table[ids[i*n+j]] (ids None: rows i*n+j).  table: [R, ld] tensor."""
+    if out_ld is None:
+        out_ld = D
+    if table.is_cuda:
+        out = (torch.zeros if out_ld != D else torch.empty)(M, out_ld, dtype=out_dtype,
+                                                            device=table.device)
+        nat.check(nat.lib().gsage_gather_mean(_ptr(table), _code(table.dtype), table.stride(0),
+                                              _ptr(ids), M, n, D, _ptr(out), _code(out_dtype),
+                                              out_ld, _stream()), "gather_mean")
+        return out
+    rows = table[ids.view(-1), :D] if ids is not None else table[:M * n, :D]
+    res = rows.float().view(M, n, D).mean(dim=1) if n > 1 else rows.float().view(M, D)
+    out = torch.zeros(M, out_ld, dtype=out_dtype)
+    out[:, :D] = res.to(out_dtype)
+    return out
+
+
+class _GatherTrainable(torch.autograd.Function):
+    """Row gather from a TRAINABLE fp32 table with the reference's dense gradient
+    (nn.Embedding, nn_modules.py:134,146-149): backward = K6 scatter-add into a zeroed table."""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        ctx.save_for_backward(ids)
+        ctx.tshape = table.shape
+        return _gather_mean_raw(table.detach(), table.shape[1], ids, int(ids.shape[0]), 1,
+                                torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        grad = torch.zeros(ctx.tshape, dtype=torch.float32, device=g.device)
+        if g.is_cuda:
+            nat.check(nat.lib().gsage_scatter_add_rows(_ptr(g), g.stride(0), _ptr(ids),
+                                                       int(ids.shape[0]), 1, g.shape[1], 1.0,
+                                                       _ptr(grad), grad.stride(0), _stream()),
+                      "scatter_add_rows")
+        else:
+            grad.index_add_(0, ids, g)
+        return grad, None
+
+
+def embedding_rows(table, ids):
+    """table[ids] for a trainable parameter (dense-grad semantics of the reference)."""
+    return _GatherTrainable.apply(table, ids.contiguous().view(-1))
+
+
+def gather_rows(store, ids, out_dtype=torch.float32):
+    """feats[ids] (models.py:76,80) materialised: [M, D] tensor of `out_dtype`."""
+    ids = ids.contiguous().view(-1)
+    return _gather_mean_raw(store.data, store.dim, ids, int(ids.shape[0]), 1, out_dtype)
+
+
+def gather_mean(store, ids, M, n, out_dtype=torch.float32, out_ld=None):
+    """feats[ids].view(M, n, D).mean(1) without materialising feats[ids]
+    (models.py:80 + nn_modules.py:197-198)."""
+    ids = ids.contiguous().view(-1)
+    assert ids.shape[0] == M * n
+    if out_ld is not None and out_ld == store.ld:
+        # the table's pad columns are zero, so averaging them writes the output's pad columns
+        return _gather_mean_raw(store.data, store.ld, ids, M, n, out_dtype, out_ld)
+    return _gather_mean_raw(store.data, store.dim, ids, M, n, out_dtype, out_ld)
+
+
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, neibs, M, out_dtype):
+        n = neibs.shape[0] // M
+        ctx.dims = (M, n, neibs.shape[1], neibs.dtype)
+        src = neibs.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        return _gather_mean_raw(src, src.shape[1], None, M, n, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        M, n, D, dt = ctx.dims
+        g = g.contiguous().float()
+        if g.is_cuda:
+            out = torch.empty(M * n, D, dtype=torch.float32, device=g.device)
+            nat.check(nat.lib().gsage_segment_mean_bwd(_ptr(g), g.stride(0), M, n, D, _ptr(out), D,
+                                                       _stream()), "segment_mean_bwd")
+        else:
+            out = (g / n).repeat_interleave(n, dim=0)
+        return out.to(dt), None, None
+
+
+def segment_mean(neibs, M, out_dtype=torch.float32):
+    """neibs.view(M, -1, D).mean(dim=1) (nn_modules.py:197-198) for an in-order tensor."""
+    assert neibs.shape[0] % M == 0
+    return _SegmentMean.apply(neibs, M, out_dtype)
+
+
+# =============================================================================================
+# K5  projection GEMM
+# =============================================================================================
+def _linear_launch(A, lda, a_rows, a_rows_g0, W, ldw, bias, C, ldc, M, N, K, act, groups,
+                   a_gs, w_gs, c_gs, dtype_code, c_code):
+    nat.check(nat.lib().gsage_linear_nt(A, dtype_code, lda, a_rows, a_rows_g0, W, ldw, bias, C,
+                                        c_code, ldc, M, N, K, act, groups, a_gs, w_gs, c_gs,
+                                        _stream()), "linear_nt")
+
+
+def _prep_weight(W, cdt, epc):
+    """[N, K] fp32 parameter -> [N, round_up(K, epc)] compute dtype, zero padded."""
+    return _pad_cast(W.detach(), cdt, epc)
+
+
+class _Linear(torch.autograd.Function):
+    """act(x @ W^T + b) on the matrix cores; backward contractions are plain library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, cdt_name, out_dtype):
+        cdt = torch_dtype(cdt_name)
+        epc = 8 if cdt == torch.bfloat16 else 4
+        M, K = x.shape
+        N = W.shape[0]
+        xa = _pad_cast(x.detach(), cdt, epc)
+        wa = _prep_weight(W, cdt, epc)
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+        bf = b.detach().float().contiguous() if b is not None else None
+        _linear_launch(_ptr(xa), xa.stride(0), None, 0, _ptr(wa), wa.stride(0), _ptr(bf),
+                       _ptr(out), N, M, N, K, act, 1, 0, 0, 0, _code(cdt), _code(out_dtype))
+        ctx.save_for_backward(xa, wa, out if act != nat.ACT_NONE else None)
+        ctx.meta = (act, K, x.dtype, b is not None, W.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, wa, out = ctx.saved_tensors
+        act, K, xdt, has_b, wdt = ctx.meta
+        g = g.float()
+        if act == nat.ACT_RELU:
+            g = g * (out > 0)
+        elif act == nat.ACT_TANH:
+            o = out.float()
+            g = g * (1 - o * o)
+        gc = g.to(xa.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _mm_f32(gc, wa)[:, :K].to(xdt)
+        if ctx.needs_input_grad[1]:
+            dw = _mm_f32(gc.t(), xa)[:, :K].to(wdt)
+        if has_b and ctx.needs_input_grad[2]:
+            db = g.sum(dim=0)
+        return dx, dw, db, None, None, None
+
+
+def linear(x, W, b=None, act=nat.ACT_NONE, compute_dtype=None, out_dtype=torch.float32):
+    """nn.Linear (+ fused activation) on CUDA through K5; host mode uses F.linear."""
+    if not x.is_cuda:
+        y = F.linear(x.float(), W, b)
+        if act == nat.ACT_RELU:
+            y = torch.relu(y)
+        elif act == nat.ACT_TANH:
+            y = torch.tanh(y)
+        return y
+    return _Linear.apply(x, W, b, act, compute_dtype or config.compute_dtype, out_dtype)
+
+
+class _SageProject(torch.autograd.Function):
+    """act(cat[x @ Wx^T, agg @ Wn^T], dim=1) (nn_modules.py:200-202 and its twins at :228-230,
+    :317-319) as ONE grouped MFMA launch writing both halves of the concat.  x may be a row
+    reference (table, ids): then the A tile of group 0 is gathered inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, agg, Wx, Wn, x_table, x_ids, x_dim, act, cdt_name, out_dtype):
+        cdt = torch_dtype(cdt_name)
+        epc = 8 if cdt == torch.bfloat16 else 4
+        h = Wx.shape[0]
+        M = agg.shape[0]
+        Dn = Wn.shape[1]
+        an = _pad_cast(agg.detach(), cdt, epc)
+        if x_ids is not None:
+            Dx = x_dim
+            if x_table.dtype != cdt or x_table.stride(0) % epc != 0:
+                xa = _gather_mean_raw(x_table, Dx, x_ids, M, 1, cdt, _round_up(Dx, epc))
+                a_rows = None
+            else:
+                xa, a_rows = x_table, x_ids
+        else:
+            Dx = x.shape[1]
+            xa, a_rows = _pad_cast(x.detach(), cdt, epc), None
+        out = torch.empty(M, 2 * h, dtype=out_dtype, device=agg.device)
+        esz = xa.element_size()
+        delta = an.data_ptr() - xa.data_ptr()
+        # one grouped launch when both halves share K and a leading dimension: group 1's A
+        # operand is addressed as A + a_gstride, i.e. the agg buffer relative to the x operand
+        grouped = (Dx == Dn and delta % esz == 0 and xa.stride(0) == an.stride(0))
+        if grouped:
+            ldw = _round_up(Dx, epc)
+            w2 = torch.zeros(2, h, ldw, dtype=cdt, device=agg.device)
+            w2[0, :, :Dx] = Wx.detach()
+            w2[1, :, :Dn] = Wn.detach()
+        if grouped:
+            _linear_launch(_ptr(xa), xa.stride(0), _ptr(a_rows), 1, _ptr(w2), ldw, None, _ptr(out),
+                           2 * h, M, h, Dx, act, 2, delta // esz, h * ldw, h, _code(cdt),
+                           _code(out_dtype))
+            wxa, wna = w2[0], w2[1]
+        else:
+            wxa = _prep_weight(Wx, cdt, epc)
+            wna = _prep_weight(Wn, cdt, epc)
+            _linear_launch(_ptr(xa), xa.stride(0), _ptr(a_rows), 1, _ptr(wxa), wxa.stride(0), None,
+                           _ptr(out), 2 * h, M, h, Dx, act, 1, 0, 0, 0, _code(cdt), _code(out_dtype))
+            _linear_launch(_ptr(an), an.stride(0), None, 0, _ptr(wna), wna.stride(0), None,
+                           _vp(out.data_ptr() + h * out.element_size()), 2 * h, M, h, Dn, act, 1,
+                           0, 0, 0, _code(cdt), _code(out_dtype))
+        ctx.save_for_backward(xa, a_rows, an, wxa, wna, out if act == nat.ACT_RELU else None)
+        ctx.meta = (act, h, Dx, Dn, x.dtype if x is not None else None, agg.dtype, Wx.dtype, cdt, epc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, a_rows, an, wxa, wna, out = ctx.saved_tensors
+        act, h, Dx, Dn, xdt, adt, wdt, cdt, epc = ctx.meta
+        g = g.float()
+        if act == nat.ACT_RELU:
+            g = g * (out > 0)
+        gc = g.to(cdt)
+        gx, gn = gc[:, :h], gc[:, h:]
+        dx = dagg = dwx = dwn = None
+        if ctx.needs_input_grad[2]:
+            if a_rows is not None:
+                M = an.shape[0]
+                xm = _gather_mean_raw(xa, Dx, a_rows, M, 1, cdt, _round_up(Dx, epc))
+            else:
+                xm = xa
+            dwx = _mm_f32(gx.t(), xm)[:, :Dx].to(wdt)
+        if ctx.needs_input_grad[3]:
+            dwn = _mm_f32(gn.t(), an)[:, :Dn].to(wdt)
+        if ctx.needs_input_grad[0]:
+            dx = _mm_f32(gx, wxa)[:, :Dx].to(xdt)
+        if ctx.needs_input_grad[1]:
+            dagg = _mm_f32(gn, wna)[:, :Dn].to(adt)
+        return dx, dagg, dwx, dwn, None, None, None, None, None, None
+
+
+def sage_project(x, agg, Wx, Wn, act=nat.ACT_NONE, compute_dtype=None, out_dtype=torch.float32):
+    """x: Tensor [M, Dx] or RowRef; agg: Tensor [M, Dn].  Returns [M, 2h]."""
+    if not agg.is_cuda:
+        xt = x.materialize() if isinstance(x, RowRef) else x
+        y = torch.cat([F.linear(xt.float(), Wx), F.linear(agg.float(), Wn)], dim=1)
+        return torch.relu(y) if act == nat.ACT_RELU else y
+    cd = compute_dtype or config.compute_dtype
+    if isinstance(x, RowRef):
+        return _SageProject.apply(None, agg, Wx, Wn, x.store.data, x.ids, x.store.dim, act, cd,
+                                  out_dtype)
+    return _SageProject.apply(x, agg, Wx, Wn, None, None, 0, act, cd, out_dtype)
+
+
+# =============================================================================================
+# K3  pooling MLP
+# =============================================================================================
+class _PoolMLP(torch.autograd.Function):
+    """pool_r relu(neibs @ Wm^T + bm) over each group of n rows (nn_modules.py:224-226,:240,:252);
+    the [M*n, H] hidden activations stay on chip.  Backward recomputes nothing it can route
+    through argmax: d hidden is non-zero only at the winning row of each (segment, channel)."""
+
+    @staticmethod
+    def forward(ctx, neibs, Wm, bm, table, ids, dim, M, n, mode, cdt_name):
+        cdt = torch_dtype(cdt_name)
+        epc = 8 if cdt == torch.bfloat16 else 4
+        H = Wm.shape[0]
+        if ids is not None:
+            K = dim
+            if table.dtype != cdt or table.stride(0) % epc != 0:
+                A = _gather_mean_raw(table, K, ids, M * n, 1, cdt, _round_up(K, epc))
+                a_rows = None
+            else:
+                A, a_rows = table, ids
+        else:
+            K = neibs.shape[1]
+            A, a_rows = _pad_cast(neibs.detach(), cdt, epc), None
+        wa = _prep_weight(Wm, cdt, epc)
+        bf = bm.detach().float().contiguous()
+        pooled = torch.empty(M, H, dtype=torch.float32, device=A.device)
+        argmax = torch.empty(M, H, dtype=torch.int32, device=A.device) if mode == nat.POOL_MAX else None
+        nat.check(nat.lib().gsage_pool_mlp(_ptr(A), _code(cdt), A.stride(0), _ptr(a_rows), _ptr(wa),
+                                           wa.stride(0), _ptr(bf), M, n, H, K, mode, _ptr(pooled),
+                                           H, _ptr(argmax), _stream()), "pool_mlp")
+        ctx.save_for_backward(A, a_rows, wa, bf, pooled, argmax)
+        ctx.meta = (M, n, H, K, mode, cdt, neibs.dtype if neibs is not None else None, Wm.dtype, epc)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        A, a_rows, wa, bf, pooled, argmax = ctx.saved_tensors
+        M, n, H, K, mode, cdt, ndt, wdt, epc = ctx.meta
+        g = g.float()
+        rows = A if a_rows is None else _gather_mean_raw(A, K, a_rows, M * n, 1, cdt,
+                                                         _round_up(K, epc))
+        if mode == nat.POOL_MAX:
+            gh = torch.zeros(M, n, H, dtype=torch.float32, device=g.device)
+            gh.scatter_(1, argmax.long().unsqueeze(1), (g * (pooled > 0)).unsqueeze(1))
+            gh = gh.view(M * n, H)
+        else:
+            hid = torch.relu(_mm_f32(rows, wa.t()) + bf)             # recompute (mean pool only)
+            gh = (g / n).repeat_interleave(n, dim=0) * (hid > 0)
+        ghc = gh.to(cdt)
+        dn = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dn = _mm_f32(ghc, wa)[:, :K].to(ndt)
+        if ctx.needs_input_grad[1]:
+            dw = _mm_f32(ghc.t(), rows)[:, :K].to(wdt)
+        if ctx.needs_input_grad[2]:
+            db = gh.sum(dim=0)
+        return dn, dw, db, None, None, None, None, None, None, None
+
+
+def pool_mlp(neibs, Wm, bm, M, mode, compute_dtype=None):
+    """neibs: Tensor [M*n, D] or RowRef.  Returns pooled [M, H] fp32."""
+    total = neibs.shape[0]
+    assert total % M == 0
+    n = total // M
+    if not neibs.is_cuda:
+        nb = neibs.materialize() if isinstance(neibs, RowRef) else neibs
+        hid = torch.relu(F.linear(nb.float(), Wm, bm)).view(M, n, -1)
+        return hid.max(dim=1)[0] if mode == nat.POOL_MAX else hid.mean(dim=1)
+    cd = compute_dtype or config.compute_dtype
+    if n > 64:      # tile holds whole segments only up to 64 rows: unfused route, still K5
+        nb = neibs.materialize() if isinstance(neibs, RowRef) else neibs
+        hid = linear(nb, Wm, bm, nat.ACT_RELU, cd).view(M, n, -1)
+        return hid.max(dim=1)[0] if mode == nat.POOL_MAX else hid.mean(dim=1)
+    if isinstance(neibs, RowRef):
+        return _PoolMLP.apply(None, Wm, bm, neibs.store.data, neibs.ids, neibs.store.dim, M, n,
+                              mode, cd)
+    return _PoolMLP.apply(neibs, Wm, bm, None, None, 0, M, n, mode, cd)
+
+
+# =============================================================================================
+# K4  attention weighting
+# =============================================================================================
+class _AttnAggregate(torch.autograd.Function):
+    """softmax_r(<na[i,r], xa[i]>) weighted sum of the raw neighbour rows (nn_modules.py:309-315)."""
+
+    @staticmethod
+    def forward(ctx, na, xa, neibs, table, ids, dim, M, n):
+        na = na.contiguous().float()
+        xa = xa.contiguous().float()
+        if ids is not None:
+            T, D, rows_ids = table, dim, ids
+        else:
+            T = neibs.detach()
+            T = T if T.is_contiguous() else T.contiguous()
+            D, rows_ids = T.shape[1], None
+        agg = torch.empty(M, D, dtype=torch.float32, device=na.device)
+        ws = torch.empty(M, n, dtype=torch.float32, device=na.device)
+        nat.check(nat.lib().gsage_attn_aggregate(_ptr(na), na.stride(0), _ptr(xa), xa.stride(0),
+                                                 _ptr(T), _code(T.dtype), T.stride(0),
+                                                 _ptr(rows_ids), M, n, na.shape[1], D, _ptr(agg), D,
+                                                 _ptr(ws), _stream()), "attn_aggregate")
+        ctx.save_for_backward(na, xa, T, rows_ids, ws)
+        ctx.meta = (M, n, D, neibs.dtype if neibs is not None else None)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        na, xa, T, rows_ids, ws = ctx.saved_tensors
+        M, n, D, ndt = ctx.meta
+        g = g.float()
+        rows = T if rows_ids is None else _gather_mean_raw(T, D, rows_ids, M * n, 1, torch.float32)
+        rows = rows[:, :D].float().view(M, n, D)
+        dws = torch.bmm(rows, g.unsqueeze(2)).squeeze(2)                    # [M, n]
+        ds = ws * (dws - (dws * ws).sum(dim=1, keepdim=True))               # softmax backward
+        nav = na.view(M, n, -1)
+        dna = (ds.unsqueeze(2) * xa.unsqueeze(1)).reshape(M * n, -1)
+        dxa = torch.bmm(ds.unsqueeze(1), nav).squeeze(1)
+        dneibs = None
+        if ctx.needs_input_grad[2]:
+            dneibs = (ws.unsqueeze(2) * g.unsqueeze(1)).reshape(M * n, D).to(ndt)
+        return dna, dxa, dneibs, None, None, None, None, None
+
+
+def attn_aggregate(na, xa, neibs, M):
+    """na: att(neibs) [M*n, Ha]; xa: att(x) [M, Ha]; neibs: Tensor [M*n, D] or RowRef."""
+    n = na.shape[0] // M
+    if not na.is_cuda:
+        nb = neibs.materialize() if isinstance(neibs, RowRef) else neibs
+        s = torch.bmm(na.view(M, n, -1), xa.view(M, -1, 1)).squeeze(2)
+        w = torch.softmax(s, dim=1)
+        return (nb.float().view(M, n, -1) * w.unsqueeze(-1)).sum(dim=1)
+    if n > 64:
+        nb = neibs.materialize() if isinstance(neibs, RowRef) else neibs
+        s = torch.bmm(na.view(M, n, -1), xa.view(M, -1, 1)).squeeze(2)
+        w = torch.softmax(s, dim=1)
+        return (nb.float().view(M, n, -1) * w.unsqueeze(-1)).sum(dim=1)
+    if isinstance(neibs, RowRef):
+        return _AttnAggregate.apply(na, xa, None, neibs.store.data, neibs.ids, neibs.store.dim, M, n)
+    return _AttnAggregate.apply(na, xa, neibs, None, None, 0, M, n)

@@ -1,0 +1,168 @@
+"""
+problem.py -- NodeProblem: the data container the train loop iterates (reference
+problem.py:74-153) plus the loss / metric tables (problem.py:26-64).
+
+Same attributes (`adj, train_adj, feats, feats_dim, n_nodes, n_classes, loss_fn, metric_fn,
+nodes, task`) and the same `iterate(mode, batch_size, shuffle)` generator, including its
+chunking rule (n_chunks = len // batch_size + 1, np.array_split) and its draw from numpy's
+global stream for the shuffle.  Differences:
+  * the file may be the reference's HDF5 (needs h5py) or an .npz twin with the same keys
+    (h5py is absent from the build image);
+  * with cuda=True the feature matrix becomes a store.FeatureStore resident in HBM
+    (bf16 rows padded to 128 B; fp32 when ops.config.compute_dtype == "fp32") instead of a
+    FloatTensor, so per-batch gathers are fused into the aggregator kernels.
+"""
+from __future__ import division, print_function
+
+import numpy as np
+import torch
+from scipy import sparse
+from scipy.sparse import csr_matrix
+from torch.nn import functional as F
+
+from . import ops
+from .store import FeatureStore
+
+
+class ProblemLosses:
+    """problem.py:26-38."""
+
+    @staticmethod
+    def multilabel_classification(preds, targets):
+        return F.multilabel_soft_margin_loss(preds, targets)
+
+    @staticmethod
+    def classification(preds, targets):
+        return F.cross_entropy(preds, targets)
+
+    @staticmethod
+    def regression_mae(preds, targets):
+        # NB: called with targets.squeeze() (models.py:100): [B,1] vs [B] broadcasts to [B,B] in
+        # the reference; kept as is (it is what the recorded Pokec result was trained with).
+        return F.l1_loss(preds, targets)
+
+
+class ProblemMetrics:
+    """problem.py:44-64 (host-side sklearn, like the reference)."""
+
+    @staticmethod
+    def _f1(y_true, y_pred):
+        from sklearn import metrics
+        return {
+            "micro": float(metrics.f1_score(y_true, y_pred, average="micro")),
+            "macro": float(metrics.f1_score(y_true, y_pred, average="macro")),
+        }
+
+    @staticmethod
+    def multilabel_classification(y_true, y_pred):
+        return ProblemMetrics._f1(y_true, (y_pred > 0).astype(int))
+
+    @staticmethod
+    def classification(y_true, y_pred):
+        return ProblemMetrics._f1(y_true, np.argmax(y_pred, axis=1))
+
+    @staticmethod
+    def regression_mae(y_true, y_pred):
+        return float(np.abs(y_true - y_pred).mean())
+
+
+def parse_csr_matrix(x):
+    """(v, r, c) triple -> csr_matrix with inferred shape (problem.py:70-72)."""
+    v, r, c = x
+    return csr_matrix((v, (r, c)))
+
+
+def _scalar(v):
+    v = np.asarray(v)
+    v = v.item() if v.shape == () else v
+    return v.decode() if isinstance(v, bytes) else v
+
+
+def _read_problem(path):
+    """Returns a dict with the keys of utils/convert.py:192-202."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as f:
+            return {k: f[k] for k in f.files}
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("reading %s needs h5py; convert it to the .npz twin "
+                          "(same keys) with utils/h5_to_npz.py on a machine that has it" % path)
+    with h5py.File(path, "r") as f:
+        return {k: f[k][()] for k in f.keys()}
+
+
+def save_problem_npz(path, problem):
+    """Writes the .npz twin of the reference's problem.h5 (same keys; sparse adjacencies as the
+    [3, nnz] (v, r, c) array of utils/convert.py:128-131)."""
+    out = {}
+    for k, v in problem.items():
+        if v is None:
+            continue
+        if sparse.issparse(v):
+            coo = v.tocoo()
+            v = np.vstack([coo.data, coo.row, coo.col])
+        out[k] = np.asarray(v)
+    np.savez(path, **out)
+
+
+class NodeProblem(object):
+    def __init__(self, problem_path, cuda=True):
+        print('NodeProblem: loading started')
+        f = _read_problem(problem_path)
+        self.task = str(_scalar(f['task']))
+        self.n_classes = int(_scalar(f['n_classes'])) if 'n_classes' in f else 1
+        self.feats = f['feats'] if 'feats' in f else None
+        self.folds = np.array([s.decode() if isinstance(s, bytes) else str(s) for s in f['folds']])
+        self.targets = f['targets']
+        if 'sparse' in f and bool(_scalar(f['sparse'])):
+            self.adj = parse_csr_matrix(f['adj'])
+            self.train_adj = parse_csr_matrix(f['train_adj'])
+        else:
+            self.adj = f['adj']
+            self.train_adj = f['train_adj']
+
+        self.feats_dim = self.feats.shape[1] if self.feats is not None else None
+        self.n_nodes = self.adj.shape[0]
+        self.cuda = cuda
+        self._to_device()
+
+        self.nodes = {mode: np.where(self.folds == mode)[0] for mode in ("train", "val", "test")}
+        self.loss_fn = getattr(ProblemLosses, self.task)
+        self.metric_fn = getattr(ProblemMetrics, self.task)
+        print('NodeProblem: loading finished')
+
+    def _to_device(self):
+        if not sparse.issparse(self.adj):
+            self.adj = torch.LongTensor(np.asarray(self.adj))
+            self.train_adj = torch.LongTensor(np.asarray(self.train_adj))
+            if self.cuda:
+                self.adj, self.train_adj = self.adj.cuda(), self.train_adj.cuda()
+        if self.feats is not None:
+            if self.cuda:
+                self.feats = FeatureStore.from_array(self.feats, torch.device("cuda"),
+                                                     dtype=ops.config.compute_dtype)
+            else:
+                self.feats = torch.FloatTensor(np.asarray(self.feats, dtype=np.float32))
+
+    def _batch(self, mids, targets):
+        mids = torch.LongTensor(mids)
+        if self.task == 'classification':
+            targets = torch.LongTensor(targets)
+        elif self.task == 'multilabel_classification' or 'regression' in self.task:
+            targets = torch.FloatTensor(np.asarray(targets, dtype=np.float32))
+        else:
+            raise Exception('NodeDataLoader: unknown task: %s' % self.task)
+        if self.cuda:
+            mids, targets = mids.cuda(), targets.cuda()
+        return mids, targets
+
+    def iterate(self, mode, batch_size=512, shuffle=False):
+        nodes = self.nodes[mode]
+        order = np.arange(nodes.shape[0])
+        if shuffle:
+            order = np.random.permutation(order)          # global legacy stream (problem.py:146)
+        n_chunks = order.shape[0] // batch_size + 1       # never exactly batch_size (quirk 6)
+        for chunk_id, chunk in enumerate(np.array_split(order, n_chunks)):
+            mids = nodes[chunk]
+            yield self._batch(mids, self.targets[mids]) + (chunk_id / n_chunks,)

@@ -1,0 +1,153 @@
+"""
+store.py -- HBM-resident data layouts of the hot path.
+
+  DeviceCSR     the adjacency the sampler walks: (rowptr int64 [n_rows+1], col int32 [nnz]) built
+                once from the reference's scipy csr_matrix (problem.py:70-72: csr_matrix((v,(r,c)))
+                in the convention of utils/convert.py:100-126 -- ids 1-based, row 0 the dummy,
+                row i's neighbours in columns 0..deg_i-1).
+  FeatureStore  the node-feature table feats[N+1, D] (problem.py:118-121) kept in HBM as a
+                row-major [n_rows, ld] matrix, bf16 (default on GPU) or fp32, rows padded with zeros
+                to a multiple of 128 bytes so every row is a whole number of cache lines and
+                16-byte lane loads are aligned.
+  RowRef        what `feats[ids]` (models.py:76,80) returns for a FeatureStore: a *reference* to
+                rows, consumed by the fused gather kernels; the [B*f1*f2, D] frontier the reference
+                materialises per batch never exists unless someone asks for `.materialize()`.
+"""
+import numpy as np
+import torch
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class DeviceCSR(object):
+    def __init__(self, rowptr, col, n_rows, max_deg):
+        self.rowptr = rowptr          # int64 [n_rows + 1]
+        self.col = col                # int32 [nnz]
+        self.n_rows = int(n_rows)     # adj.shape[0]  (counts the dummy row)
+        self.max_deg = int(max_deg)   # adj.shape[1]: the population `sel` is drawn from
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=rowptr.device)
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    @property
+    def nnz(self):
+        return int(self.col.shape[0])
+
+    @staticmethod
+    def from_scipy(adj, device):
+        """adj: scipy.sparse matrix in the reference convention.  Checks the convention instead
+        of silently re-interpreting it: the reference indexes a row by COLUMN (nn_modules.py:90-93),
+        which equals the position inside the row only when columns are 0..deg-1."""
+        from scipy import sparse
+        assert sparse.issparse(adj), "SparseUniformNeighborSampler: not sparse.issparse(adj)"
+        adj = adj.tocsr()
+        if not adj.has_sorted_indices:
+            adj = adj.sorted_indices()
+        indptr = np.asarray(adj.indptr, dtype=np.int64)
+        deg = np.diff(indptr)
+        expect = np.arange(indptr[-1], dtype=np.int64) - np.repeat(indptr[:-1], deg)
+        if not np.array_equal(np.asarray(adj.indices, dtype=np.int64), expect):
+            raise ValueError("adjacency is not in the reference's sparse convention "
+                             "(row i must hold its neighbours in columns 0..deg_i-1)")
+        data = np.asarray(adj.data)
+        if data.size and (data.min() <= 0 or data.max() >= 2 ** 31):
+            raise ValueError("neighbour ids must be 1-based positive int32 values")
+        rowptr = torch.from_numpy(indptr).to(device)
+        col = torch.from_numpy(data.astype(np.int32)).to(device)
+        return DeviceCSR(rowptr, col, adj.shape[0], adj.shape[1])
+
+    def check(self):
+        """Raise IndexError if a kernel saw an id outside the graph (synchronises)."""
+        if int(self.err_flag.item()) != 0:
+            self.err_flag.zero_()
+            raise IndexError("sampler: node id out of range of the adjacency")
+
+
+class FeatureStore(object):
+    """Device-resident node-feature table.  Quacks enough like the reference's `problem.feats`
+    tensor for models.py / train.py: `.shape`, `.size()`, `feats[ids]`, `.is_cuda`."""
+
+    def __init__(self, data, dim):
+        assert data.dim() == 2 and data.is_contiguous()
+        self.data = data               # [n_rows, ld]
+        self.dim = int(dim)            # logical D (columns [D, ld) are zero)
+
+    @staticmethod
+    def from_array(feats, device, dtype="bf16"):
+        feats = torch.as_tensor(np.asarray(feats) if not torch.is_tensor(feats) else feats)
+        n_rows, dim = feats.shape
+        tdt = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
+        ld = _round_up(dim, 128 // (2 if dtype == "bf16" else 4))
+        data = torch.zeros(n_rows, ld, dtype=tdt, device=device)
+        data[:, :dim] = feats.to(device=device, dtype=torch.float32).to(tdt)
+        return FeatureStore(data, dim)
+
+    @staticmethod
+    def wrap(t):
+        """Zero-copy view of an existing [n_rows, D] fp32 / bf16 tensor (ld == D)."""
+        return FeatureStore(t.detach().contiguous(), t.shape[1])
+
+    @property
+    def shape(self):
+        return (self.data.shape[0], self.dim)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    @property
+    def ld(self):
+        return int(self.data.shape[1])
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    def cuda(self):
+        return FeatureStore(self.data.cuda(), self.dim)
+
+    def __getitem__(self, ids):
+        return RowRef(self, ids)
+
+    def dense(self):
+        """fp32 [n_rows, D] copy (tests / CPU mode)."""
+        return self.data[:, :self.dim].float()
+
+
+class RowRef(object):
+    """`store[ids]`: rows of a FeatureStore selected by a LongTensor, not yet gathered."""
+
+    def __init__(self, store, ids):
+        self.store = store
+        self.ids = ids.contiguous().view(-1)
+
+    @property
+    def shape(self):
+        return (int(self.ids.shape[0]), self.store.dim)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    @property
+    def is_cuda(self):
+        return self.store.is_cuda
+
+    @property
+    def device(self):
+        return self.store.device
+
+    def materialize(self, dtype=torch.float32):
+        """The reference's `feats[ids]` as a real [M, D] tensor (one gather kernel)."""
+        from . import ops
+        return ops.gather_rows(self.store, self.ids, out_dtype=dtype)

@@ -1,0 +1,70 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/gsage.h
+declares, and its host-side legacy stream equals numpy's (the stream the reference consumes)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gsage.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsage_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    gs = pkg()
+    names = _declared()
+    assert len(names) >= 15
+    lib = ctypes.CDLL(gs._native.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libgsage_hip.so does not export %s" % n
+        assert n in gs._native.SIGNATURES, "ctypes binding lacks %s" % n
+    assert set(gs._native.SIGNATURES) == set(names)
+    assert gs._native.lib().gsage_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    gs = pkg()
+    monkeypatch.setattr(gs._native, "_LIB", None)
+    monkeypatch.setattr(gs._native, "LIB_PATH", "/nonexistent/libgsage_hip.so")
+    with pytest.raises(gs._native.NativeLibraryError):
+        gs._native.lib()
+    assert not gs._native.available()
+
+
+def test_bad_arguments_return_einval_without_gpu():
+    L = pkg()._native.lib()
+    rc = L.gsage_sample_csr_sel(None, None, 10, None, 4, 0, None, None, None, None)
+    assert rc == -1 and b"n_samples" in L.gsage_last_error()
+    rc = L.gsage_gather_mean(None, 7, 8, None, 4, 1, 8, None, 0, 8, None)
+    assert rc == -1
+    rc = L.gsage_linear_nt(ctypes.c_void_p(16), 1, 7, None, 0, ctypes.c_void_p(16), 8, None,
+                           ctypes.c_void_p(16), 0, 8, 4, 4, 4, 0, 1, 0, 0, 0, None)
+    assert rc == -1 and b"lda" in L.gsage_last_error()
+
+
+@pytest.mark.parametrize("seed", [0, 123, 15129])
+def test_host_legacy_stream_equals_numpy(seed):
+    L = pkg()._native.lib()
+    mt = L.gsage_mt_create(seed)
+    try:
+        np.random.seed(seed)
+        for high, count in ((21657, 1000), (8, 64), (1, 5), (2 ** 31 - 1, 10)):
+            out = np.empty(count, dtype=np.int32)
+            L.gsage_mt_choice_i32(mt, high, count, out.ctypes.data_as(ctypes.c_void_p))
+            assert np.array_equal(out.astype(np.int64), np.random.choice(high, count))
+        perm = np.empty(1030, dtype=np.int64)
+        L.gsage_mt_permutation(mt, 1030, perm.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(perm, np.random.permutation(np.arange(1030)))
+        L.gsage_mt_seed(mt, seed + 1)
+        np.random.seed(seed + 1)
+        out = np.empty(7, dtype=np.int32)
+        L.gsage_mt_choice_i32(mt, 100, 7, out.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(out, np.random.choice(100, 7))
+    finally:
+        L.gsage_mt_destroy(mt)

@@ -1,0 +1,226 @@
+"""Host logic of the drop-in boundary (no GPU): the product's plugin classes, GSSupervised,
+NodeProblem.iterate, LRSchedule and train.py plumbing on CPU tensors, checked against the golden
+vectors generated from the reference.  CPU tensors take ops.py's explicit host mode (the
+reference's `--no-cuda` configuration); the HIP path is covered by the -m gpu tests."""
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+from util import ACTS, SelReplay, build_model, close, csr_of, weights
+
+gs = pkg()
+
+
+def test_lookup_tables_match_reference_surface():
+    assert set(gs.sampler_lookup) == {"uniform_neighbor_sampler", "sparse_uniform_neighbor_sampler"}
+    assert set(gs.prep_lookup) == {"identity", "node_embedding", "linear"}
+    assert set(gs.aggregator_lookup) == {"mean", "max_pool", "mean_pool", "lstm", "attention"}
+
+
+def test_sparse_sampler_compat_stream_bit_exact():
+    g = load_golden("sampler_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=csr_of(g, "g%d_" % int(g[p + "graph"])))
+        np.random.seed(int(g[p + "seed"]))
+        out = s(torch.LongTensor(g[p + "ids"]), n_samples=int(g[p + "n"]))
+        assert out.dtype == torch.int64 and out.dim() == 1
+        assert np.array_equal(out.numpy(), g[p + "out"]), c
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g[p + "tail"])
+    assert np.array_equal(s.degrees, g["g2_degrees"])
+
+
+def test_sparse_sampler_errors():
+    g = load_golden("sampler_kat.npz")
+    s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=csr_of(g, "g0_"))
+    with pytest.raises(AssertionError):
+        s(torch.LongTensor([1, 2]), n_samples=0)
+    with pytest.raises(IndexError):
+        s(torch.LongTensor([1, 10 ** 6]), n_samples=2)
+    with pytest.raises(AssertionError):
+        gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=np.zeros((3, 3)))
+    assert s(torch.LongTensor([]), n_samples=3).numel() == 0           # empty batch
+
+
+def test_philox_host_equals_oracle_and_is_shard_invariant():
+    from oracle import cpu as ocpu
+    g = load_golden("sampler_kat.npz")
+    adj = csr_of(g, "g2_")
+    ids = torch.LongTensor(np.random.RandomState(0).randint(0, adj.shape[0], size=64))
+    s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="philox", seed=99)
+    out = s(ids, n_samples=10)
+    sel = ocpu.philox_sel(99, 0, 0, 640, adj.shape[1])
+    assert np.array_equal(out.numpy(), ocpu.sample_csr_sel(adj.indptr, adj.data, ids.numpy(), 10, sel))
+    halves = []
+    for rank in (0, 1):
+        t = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="philox", seed=99)
+        t.shard = (rank, 2)
+        halves.append(t(ids[rank * 32:(rank + 1) * 32], n_samples=10).numpy())
+    assert np.array_equal(np.concatenate(halves), out.numpy())
+
+
+def test_dense_sampler_matches_reference():
+    g = load_golden("dense_sampler_kat.npz")
+    s = gs.sampler_lookup["uniform_neighbor_sampler"](adj=torch.LongTensor(g["adj"]))
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        gs.set_seeds(int(g[p + "seed"]))
+        out = s(torch.LongTensor(g[p + "ids"]), n_samples=int(g[p + "n"]))
+        assert np.array_equal(out.numpy(), g[p + "out"])
+
+
+def test_aggregators_host_mode_forward_backward():
+    g = load_golden("agg_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        name, act = str(g[p + "name"]), str(g[p + "act"])
+        M, n, D, h = [int(v) for v in g[p + "dims"]]
+        agg = gs.aggregator_lookup[name](input_dim=D, output_dim=h, activation=ACTS[act])
+        agg.load_state_dict(weights(g, p + "w_"))
+        assert agg.output_dim == int(g[p + "output_dim"])
+        x = torch.from_numpy(g[p + "x"].copy()).requires_grad_(True)
+        nb = torch.from_numpy(g[p + "neibs"].copy()).requires_grad_(True)
+        out = agg(x, nb)
+        close(out.detach().numpy(), g[p + "out"], (c, name))
+        (out * torch.from_numpy(g[p + "G"])).sum().backward()
+        close(x.grad.numpy(), g[p + "dx"], (c, name, "dx"))
+        close(nb.grad.numpy(), g[p + "dneibs"], (c, name, "dneibs"))
+        for k, v in agg.named_parameters():
+            close(v.grad.numpy(), g[p + "g_" + k], (c, name, k))
+
+
+def test_attention_refuses_squeeze_quirk_shapes():
+    agg = gs.aggregator_lookup["attention"](input_dim=4, output_dim=3, activation=None)
+    with pytest.raises(AssertionError):
+        agg(torch.zeros(3, 4), torch.zeros(3, 4))          # fanout 1
+
+
+def test_preps_host_mode():
+    g = load_golden("prep_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        name = str(g[p + "name"])
+        idim = int(g[p + "input_dim"]) or None
+        prep = gs.prep_lookup[name](input_dim=idim, n_nodes=int(g[p + "n_nodes"]))
+        prep.load_state_dict(weights(g, p + "w_"))
+        assert prep.output_dim == int(g[p + "output_dim"])
+        feats = torch.from_numpy(g[p + "feats"]) if (p + "feats") in g.files else None
+        out = prep(torch.from_numpy(g[p + "ids"]), feats, layer_idx=int(g[p + "layer_idx"]))
+        close(out.detach().numpy(), g[p + "out"], (c, name))
+        if (p + "G") in g.files:
+            (out * torch.from_numpy(g[p + "G"])).sum().backward()
+            for k, v in prep.named_parameters():
+                ref = g[p + "g_" + k]
+                close(v.grad.numpy() if v.grad is not None else np.zeros_like(ref), ref, (c, name, k))
+
+
+def test_full_model_host_mode_train_steps():
+    g = load_golden("model_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        model, feats, task = build_model(gs, g, p)
+        loss_fn = getattr(gs.ProblemLosses, task)
+        ids = torch.from_numpy(g[p + "ids"])
+        tg = torch.from_numpy(g[p + "targets"])
+        with SelReplay([g[p + "eval_sel0"], g[p + "eval_sel1"]]):
+            ev = model(ids, feats, train=False)
+        close(ev.detach().numpy(), g[p + "eval_preds"], (c, "eval"))
+        for step in range(2):
+            model.set_progress(0.25 * step)
+            assert abs(model.lr - float(g[p + "lr%d" % step])) < 1e-12
+            with SelReplay([g[p + "s%d_sel0" % step], g[p + "s%d_sel1" % step]]):
+                preds = model.train_step(ids=ids, feats=feats, targets=tg, loss_fn=loss_fn)
+            close(preds.detach().numpy(), g[p + "s%d_preds" % step], (c, step, "preds"), 1e-4, 1e-5)
+            for k, v in model.named_parameters():
+                close(v.grad.numpy(), g[p + "s%d_cg_%s" % (step, k)], (c, step, "cg", k), 1e-4, 1e-5)
+            for k, v in model.state_dict().items():
+                close(v.numpy(), g[p + "w%d_%s" % (step + 1, k)], (c, step, "w", k), 1e-4, 1e-5)
+
+
+def _tiny_problem(tmp_path, sparse_adj=True, task="classification"):
+    rng = np.random.RandomState(0)
+    n = 150
+    from scipy import sparse
+    degs = rng.randint(1, 9, size=n + 1)
+    degs[0] = 0
+    rows = np.repeat(np.arange(n + 1), degs)
+    cols = np.concatenate([np.arange(d) for d in degs])
+    vals = rng.randint(1, n + 1, size=rows.shape[0])
+    adj = sparse.csr_matrix((vals, (rows, cols)))
+    folds = np.array(["train"] * 100 + ["val"] * 30 + ["test"] * 21)
+    folds[0] = "dummy"
+    prob = {"task": task, "n_classes": 4, "feats": rng.normal(size=(n + 1, 9)).astype(np.float32),
+            "folds": folds, "targets": rng.randint(0, 4, size=(n + 1, 1)), "sparse": True,
+            "adj": adj, "train_adj": adj}
+    if not sparse_adj:
+        dense = rng.randint(0, n, size=(n + 1, 8))
+        prob.update({"sparse": False, "adj": dense, "train_adj": dense})
+    path = os.path.join(str(tmp_path), "problem.npz")
+    gs.problem.save_problem_npz(path, prob)
+    return path
+
+
+def test_node_problem_iterate_matches_reference_chunking(tmp_path):
+    g = load_golden("iterate_kat.npz")
+    prob = gs.NodeProblem(_tiny_problem(tmp_path), cuda=False)
+    assert prob.n_nodes == 151 and prob.feats_dim == 9 and prob.n_classes == 4
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        prob.nodes["train"] = g[p + "nodes"]
+        prob.targets = g[p + "targets_all"]
+        gs.set_seeds(int(g[p + "seed"]))
+        ids, tgs, progs = [], [], []
+        for i, t, pr in prob.iterate("train", batch_size=int(g[p + "bs"]), shuffle=bool(int(g[p + "shuffle"]))):
+            assert i.dtype == torch.int64 and t.dtype == torch.int64
+            ids.append(i.numpy()); tgs.append(t.numpy().reshape(-1)); progs.append(pr)
+        assert [len(i) for i in ids] == list(g[p + "sizes"])
+        assert np.array_equal(np.concatenate(ids), g[p + "ids"])
+        assert np.array_equal(np.concatenate(tgs), g[p + "targets"])
+        assert np.allclose(progs, g[p + "progress"])
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g[p + "tail"])
+
+
+def test_lr_schedule_and_metrics_match_reference():
+    g = load_golden("misc_kat.npz")
+    for name in ("constant", "linear", "cyclical"):
+        fn = getattr(gs.LRSchedule, name)
+        assert np.allclose([fn(float(x), lr_init=0.01) for x in g["lr_x"]], g["lr_" + name])
+        assert np.allclose([fn(float(x), lr_init=0.05, epochs=4) for x in g["lr_x"]], g["lr_%s_e4" % name])
+    with pytest.raises(TypeError):       # `step` cannot be selected
+        gs.GSSupervised(input_dim=4, n_nodes=5, n_classes=2, layer_specs=[], aggregator_class=None,
+                        prep_class=gs.prep_lookup["identity"],
+                        sampler_class=gs.sampler_lookup["uniform_neighbor_sampler"],
+                        adj=torch.zeros(2, 2).long(), train_adj=torch.zeros(2, 2).long(),
+                        lr_schedule="step")
+    m = gs.ProblemMetrics.classification(g["cls_y"], g["cls_logits"])
+    assert abs(m["micro"] - float(g["cls_micro"])) < 1e-12 and abs(m["macro"] - float(g["cls_macro"])) < 1e-12
+    m = gs.ProblemMetrics.multilabel_classification(g["ml_y"], g["ml_logits"])
+    assert abs(m["micro"] - float(g["ml_micro"])) < 1e-12 and abs(m["macro"] - float(g["ml_macro"])) < 1e-12
+    assert abs(gs.ProblemMetrics.regression_mae(g["mae_y"], g["mae_pred"]) - float(g["mae"])) < 1e-6
+    for key, fn, y in (("cls", gs.ProblemLosses.classification, torch.LongTensor(g["cls_y"]).squeeze()),
+                       ("ml", gs.ProblemLosses.multilabel_classification, torch.FloatTensor(g["ml_y"].astype(np.float32)))):
+        assert abs(float(fn(torch.FloatTensor(g[key + "_logits"]), y)) - float(g[key + "_loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("sampler,sparse_adj", [("sparse_uniform_neighbor_sampler", True),
+                                                ("uniform_neighbor_sampler", False)])
+def test_train_py_cli_runs_on_cpu(tmp_path, capsys, sampler, sparse_adj):
+    """BASELINE config 1 plumbing: the reference's flags, JSON log schema, no GPU."""
+    path = _tiny_problem(tmp_path, sparse_adj=sparse_adj)
+    gs.train = __import__("importlib").import_module("pytorch-graphsage_amd.train")
+    gs.train.main(["--problem-path", path, "--no-cuda", "--epochs", "2", "--batch-size", "32",
+                   "--sampler-class", sampler, "--n-train-samples", "5,5", "--n-val-samples", "5,5",
+                   "--output-dims", "16,16", "--show-test"])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    per_batch = [l for l in lines if "epoch_progress" in l]
+    assert len(per_batch) == 2 * (100 // 32 + 1)
+    assert set(per_batch[0]) == {"epoch", "epoch_progress", "train_metric", "val_metric", "time"}
+    assert per_batch[0]["val_metric"] is None and per_batch[-1]["val_metric"] is not None
+    assert set(lines[-2]) == {"epoch", "train_metric", "val_metric", "time"}
+    assert set(lines[-1]) == {"test_f1"} and set(lines[-1]["test_f1"]) == {"micro", "macro"}

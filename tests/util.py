@@ -1,0 +1,79 @@
+"""Shared helpers for the product tests."""
+import numpy as np
+import torch
+from scipy import sparse
+from torch.nn import functional as F
+
+
+def csr_of(g, pre):
+    return sparse.csr_matrix((g[pre + "data"], g[pre + "indices"], g[pre + "indptr"]),
+                             shape=tuple(int(v) for v in g[pre + "shape"]))
+
+
+def weights(g, prefix, device="cpu"):
+    return {k[len(prefix):]: torch.from_numpy(g[k].copy()).to(device) for k in g.files
+            if k.startswith(prefix)}
+
+
+def close(a, b, what, rtol=1e-5, atol=2e-6):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= (atol + rtol) * scale, (what, "max abs err %g at scale %g" % (err, scale))
+
+
+class SelReplay(object):
+    """Feeds recorded `sel` matrices to a compat-mode sampler (monkeypatches np.random.choice
+    exactly where the reference, and the product in compat mode, draw them)."""
+
+    def __init__(self, sels):
+        self.sels = [np.asarray(s) for s in sels]
+        self.orig = np.random.choice
+
+    def __enter__(self):
+        def fake(a, size=None, *args, **kw):
+            s = self.sels.pop(0)
+            assert tuple(s.shape) == tuple(size), (s.shape, size)
+            return s.copy()
+        np.random.choice = fake
+        return self
+
+    def __exit__(self, *exc):
+        np.random.choice = self.orig
+
+
+ACTS = {"relu": F.relu, "identity": (lambda x: x)}
+
+
+def build_model(gs, g, p, device="cpu", feats_dtype=None):
+    """GSSupervised for golden model case `p` with the recorded initial weights."""
+    aggn, prepn, task, sched = [str(s) for s in g[p + "cfg"]]
+    has_feats = bool(int(g[p + "has_feats"]))
+    fan = [int(v) for v in g[p + "fanouts"]]
+    odims = [int(v) for v in g[p + "out_dims"]]
+    adj, tadj = csr_of(g, p + "adj_"), csr_of(g, p + "tadj_")
+    feats = None
+    if has_feats:
+        if device == "cpu":
+            feats = torch.from_numpy(g[p + "feats"].copy())
+        else:
+            feats = gs.FeatureStore.from_array(g[p + "feats"], torch.device(device),
+                                               dtype=feats_dtype or gs.ops.config.compute_dtype)
+    model = gs.GSSupervised(
+        sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=tadj,
+        prep_class=gs.prep_lookup[prepn], aggregator_class=gs.aggregator_lookup[aggn],
+        input_dim=g[p + "feats"].shape[1] if has_feats else None, n_nodes=adj.shape[0],
+        n_classes=int(g[p + "n_classes"]),
+        layer_specs=[{"n_train_samples": fan[0], "n_val_samples": fan[0], "output_dim": odims[0],
+                      "activation": F.relu},
+                     {"n_train_samples": fan[1], "n_val_samples": fan[1], "output_dim": odims[1],
+                      "activation": lambda x: x}],
+        lr_init=0.01, lr_schedule=sched, weight_decay=float(g[p + "weight_decay"]))
+    model.load_state_dict(weights(g, p + "w0_"))
+    model = model.to(device)
+    # Adam state must live where the parameters are
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=model.lr,
+                                       weight_decay=float(g[p + "weight_decay"]))
+    return model, feats, task
