@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""
+bench.py -- seed-nodes/sec of the GraphSAGE training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1: plain python
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one `train_step` (reference models.py:97-104) over one batch of 512 seed nodes per
+GPU: K1 sample (fanout 25, 10) -> K2 gather+mean -> K5 project (2 layers, hidden 128) -> loss ->
+backward -> [RCCL grad all-reduce] -> clip -> Adam.  Workload = BASELINE config 2 ("Reddit mean
+2-layer 25/10 h=128 bf16"), synthetic at Reddit's shape: N=232 965 nodes,
+lognormal degrees clipped to [1, 21 657], D=602 bf16 features, 41 classes; graph + features are
+resident in HBM before the timed region.  Timing: W untimed steps, then exactly K steps between
+barrier + torch.cuda.synchronize() on both sides, max over ranks; rank 0 prints ONE JSON line.
+
+Extra objects on the line (tier contract, section 4 of the task):
+  roofline     the dominant kernel = the hop-2 k_gather_mean launch (250 of the 276 rows/seed):
+               algorithmic bytes = B*f1*f2*D*2 per launch / its mean duration, HIP events on the
+               launch stream, fresh frontier per launch; peak = 8 TB/s HBM3E.
+  cpu_baseline the oracle (oracle/torch_ref.py + oracle/gsage_oracle.c: a port of the reference's
+               CPU op sequence) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_NODES, MAX_DEG, FEAT_DIM, N_CLASSES = 232965, 21657, 602, 41
+FANOUT, HIDDEN, BATCH = (25, 10), (128, 128), 512
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+
+
+def synthetic_reddit(n_nodes=N_NODES, seed=0, feat_dim=FEAT_DIM, max_deg=MAX_DEG):
+    """Reddit-shaped problem in the reference's sparse convention (ids 1-based, row 0 dummy).
+    Returns dict(adj=scipy csr, feats=callable(device, dtype)->FeatureStore, feats_np=callable,
+    train_ids, targets)."""
+    from scipy import sparse
+    gs = importlib.import_module("pytorch-graphsage_amd")
+    rng = np.random.default_rng(seed)               # PCG64: ~10x faster than the legacy stream
+    deg = np.clip(np.exp(rng.normal(5.2, 1.3, size=n_nodes + 1)).astype(np.int64), 1, max_deg)
+    deg[0] = 0
+    deg[1] = max_deg                                  # pins adj.shape[1] (the sel population)
+    indptr = np.zeros(n_nodes + 2, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    nnz = int(indptr[-1])
+    data = rng.integers(1, n_nodes + 1, size=nnz, dtype=np.int32)
+    indices = gs.store.row_positions(indptr)
+    adj = sparse.csr_matrix((data, indices, indptr), shape=(n_nodes + 1, max_deg))
+    adj.has_sorted_indices = True
+    n_train = int(0.6586 * n_nodes)                   # 153 431 / 232 965
+    train_ids = rng.permutation(np.arange(1, n_nodes + 1))[:n_train]
+    targets = rng.integers(0, N_CLASSES, size=(n_nodes + 1, 1))
+
+    def feats_np():
+        frng = np.random.default_rng(seed + 1)
+        f = frng.standard_normal(size=(n_nodes + 1, feat_dim), dtype=np.float32)
+        f[0] = 0
+        return f
+
+    def feats(device, dtype="bf16"):
+        return gs.FeatureStore.from_array(feats_np(), torch.device(device), dtype=dtype)
+
+    return {"adj": adj, "feats": feats, "feats_np": feats_np, "train_ids": train_ids,
+            "targets": targets, "nnz": nnz}
+
+
+def build_model(gs, adj, aggregator="mean", rng="philox", seed=123):
+    from torch.nn import functional as F
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = rng
+    model = gs.GSSupervised(
+        sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+        prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup[aggregator],
+        input_dim=FEAT_DIM, n_nodes=adj.shape[0], n_classes=N_CLASSES,
+        layer_specs=[{"n_train_samples": FANOUT[0], "n_val_samples": FANOUT[0],
+                      "output_dim": HIDDEN[0], "activation": F.relu},
+                     {"n_train_samples": FANOUT[1], "n_val_samples": FANOUT[1],
+                      "output_dim": HIDDEN[1], "activation": lambda x: x}],
+        lr_init=0.01, lr_schedule="constant", weight_decay=0.0)
+    model.train_sampler.seed = seed
+    model.val_sampler.seed = seed
+    return model
+
+
+def cpu_baseline(data, budget_s=15.0, batch=BATCH):
+    """Oracle train_step (port of the reference CPU path) on the host cores, bounded sample."""
+    from oracle import cpu as ocpu
+    from oracle import torch_ref as tref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    adj = data["adj"]
+    indptr, dat = adj.indptr.astype(np.int64), adj.data.astype(np.int64)
+    feats = torch.from_numpy(data["feats_np"]())
+    gen = torch.Generator().manual_seed(0)
+    D, h = FEAT_DIM, HIDDEN[0]
+    w = {"agg_layers.0.fc_x.weight": torch.randn(h, D, generator=gen) / 25,
+         "agg_layers.0.fc_neib.weight": torch.randn(h, D, generator=gen) / 25,
+         "agg_layers.1.fc_x.weight": torch.randn(h, 2 * h, generator=gen) / 16,
+         "agg_layers.1.fc_neib.weight": torch.randn(h, 2 * h, generator=gen) / 16,
+         "fc.weight": torch.randn(N_CLASSES, 2 * h, generator=gen) / 16,
+         "fc.bias": torch.zeros(N_CLASSES)}
+    opt = tref.Adam()
+    rng = np.random.RandomState(0)
+    stream = ocpu.LegacyMT19937(123 ** 2)
+    done, t0 = -2, time.time()                     # two untimed warm-up steps (page faults, threads)
+    while True:
+        if done == 0:
+            t0 = time.time()
+        ids = data["train_ids"][rng.randint(0, len(data["train_ids"]), size=batch)]
+        tg = torch.from_numpy(data["targets"][ids])
+        sels = [stream.choice(adj.shape[1], (batch, FANOUT[0])),
+                stream.choice(adj.shape[1], (batch * FANOUT[0], FANOUT[1]))]
+        tref.train_step(w, opt, 0.01, "classification", ids, feats, tg, indptr, dat, FANOUT, sels,
+                        "mean", "identity", adj.shape[0])
+        done += 1
+        if done >= 3 and time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": done * batch / dt, "unit": "seed-nodes/sec", "cores": cores, "kind": "port",
+            "sample": "%d train_steps of %d seeds (oracle/torch_ref.py fp32 + C sampler, "
+                      "torch %d threads, %.1f s)" % (done, batch, cores, dt)}
+
+
+def dominant_kernel_roofline(gs, model, store, data, dev, reps=40, n_frontiers=8):
+    """Mean duration of the hop-2 k_gather_mean launch on fresh frontiers, HIP events on the launch
+    stream (torch's current stream is the stream ops.py launches on)."""
+    ops = gs.ops
+    rng = np.random.RandomState(7)
+    fronts = []
+    for _ in range(n_frontiers):
+        ids0 = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=BATCH)]).to(dev)
+        ids1 = model.train_sampler(ids0, n_samples=FANOUT[0])
+        fronts.append(model.train_sampler(ids1, n_samples=FANOUT[1]))
+    M = BATCH * FANOUT[0]
+    cdt = ops.torch_dtype()
+    for f in fronts:                                   # warm
+        ops.gather_mean(store, f, M, FANOUT[1], out_dtype=cdt, out_ld=store.ld)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for r in range(reps):
+        ops.gather_mean(store, fronts[r % n_frontiers], M, FANOUT[1], out_dtype=cdt, out_ld=store.ld)
+    stop.record()
+    torch.cuda.synchronize()
+    dur_s = start.elapsed_time(stop) / 1e3 / reps
+    elem = store.data.element_size()
+    alg_bytes = BATCH * FANOUT[0] * FANOUT[1] * FEAT_DIM * elem
+    achieved = alg_bytes / dur_s / 1e9
+    return {"bound": "hbm", "kernel": "k_gather_mean (hop 2: 250 of 276 rows/seed)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "alg_bytes_per_launch": alg_bytes, "avg_launch_us": dur_s * 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-size", type=int, default=BATCH, help="seed nodes per GPU per step")
+    ap.add_argument("--aggregator", type=str, default="mean")
+    ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import __graft_entry__
+    __graft_entry__.ensure_built()
+    gs = importlib.import_module("pytorch-graphsage_amd")
+    ops = gs.ops
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    ddp = gs.dist.init_from_env(cuda=True)
+    rank = ddp.rank if ddp is not None else 0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.set_compute_dtype(args.precision)
+    ops.warmup(dev)
+
+    data = synthetic_reddit(seed=0)
+    store = data["feats"](dev, args.precision)
+    model = build_model(gs, data["adj"], aggregator=args.aggregator, rng="philox").to(dev)
+    if ddp is not None:
+        gs.dist.attach(model, ddp, seed=123)
+    model.train_sampler.csr(dev)                       # upload the CSR before timing
+    loss_fn = gs.ProblemLosses.classification
+    B = args.batch_size
+
+    # seed batches resident in HBM before the timed region; rank r owns rows [r*B, (r+1)*B)
+    total = args.steps + args.warmup
+    rng = np.random.RandomState(1234)
+    pick = rng.randint(0, len(data["train_ids"]), size=(total, world * B))
+    ids_all = torch.from_numpy(data["train_ids"][pick][:, rank * B:(rank + 1) * B]).to(dev)
+    tg_all = torch.from_numpy(data["targets"][data["train_ids"][pick]][:, rank * B:(rank + 1) * B]).to(dev)
+
+    use_graph = not args.no_graph
+    step_fn = None
+    if use_graph:
+        try:
+            step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
+        except Exception as e:                          # report, then measure eager launches
+            if rank == 0:
+                print("graph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
+            use_graph = False
+    if step_fn is None:
+        def step_fn(ids, tg):
+            return model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+
+    def sync():
+        if ddp is not None:
+            ddp.barrier()
+        torch.cuda.synchronize()
+
+    launches0 = gs._native.launch_count()
+    for k in range(args.warmup):
+        step_fn(ids_all[k], tg_all[k])
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, total):
+        step_fn(ids_all[k], tg_all[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if ddp is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    model.train_sampler.csr(dev).check()
+
+    if rank == 0:
+        value = args.steps * B * world / elapsed
+        roof = dominant_kernel_roofline(gs, model, store, data, dev)
+        line = {
+            "metric": "seed-nodes/sec", "value": value, "unit": "seed-nodes/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "Reddit-shaped %s-aggregator 2-layer fanout 25/10 hidden 128 "
+                                   "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
+                       "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
+                       "hip_graph": use_graph, "parallelism": "dp%d" % world,
+                       "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
+                       if not use_graph else None},
+            "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if ddp is not None:
+        ddp.barrier()
+        ddp.close()
+
+
+if __name__ == "__main__":
+    main()

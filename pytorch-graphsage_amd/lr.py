@@ -13,7 +13,10 @@ class LRSchedule(object):
     @staticmethod
     def set_lr(optimizer, lr):
         for group in optimizer.param_groups:
-            group['lr'] = lr
+            if hasattr(group['lr'], 'fill_'):      # tensor lr of a graph-captured optimizer
+                group['lr'].fill_(float(lr))
+            else:
+                group['lr'] = lr
 
     @staticmethod
     def constant(x, lr_init=0.1, epochs=1):

@@ -21,6 +21,21 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def row_positions(indptr):
+    """[0..deg_0-1, 0..deg_1-1, ...] for a CSR row pointer, via one cumsum (np.repeat on 1e8
+    entries is ~10x slower)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    nnz = int(indptr[-1])
+    if nnz == 0:
+        return np.zeros(0, dtype=np.int32)
+    deg = np.diff(indptr)
+    rows = np.flatnonzero(deg > 0)
+    step = np.ones(nnz, dtype=np.int32)
+    step[0] = 0
+    step[indptr[rows[1:]]] -= deg[rows[:-1]].astype(np.int32)
+    return np.cumsum(step, dtype=np.int32)
+
+
 class DeviceCSR(object):
     def __init__(self, rowptr, col, n_rows, max_deg):
         self.rowptr = rowptr          # int64 [n_rows + 1]
@@ -48,9 +63,7 @@ class DeviceCSR(object):
         if not adj.has_sorted_indices:
             adj = adj.sorted_indices()
         indptr = np.asarray(adj.indptr, dtype=np.int64)
-        deg = np.diff(indptr)
-        expect = np.arange(indptr[-1], dtype=np.int64) - np.repeat(indptr[:-1], deg)
-        if not np.array_equal(np.asarray(adj.indices, dtype=np.int64), expect):
+        if not np.array_equal(np.asarray(adj.indices), row_positions(indptr)):
             raise ValueError("adjacency is not in the reference's sparse convention "
                              "(row i must hold its neighbours in columns 0..deg_i-1)")
         data = np.asarray(adj.data)

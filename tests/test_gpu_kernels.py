@@ -1,0 +1,277 @@
+"""-m gpu: every entry point of the C ABI (include/gsage.h) against the CPU oracle on the same
+seeded inputs.  Integer results bit-exact; fp32 paths 1e-5 relative; bf16-storage paths are
+compared against the oracle evaluated on the bf16-rounded inputs (so only accumulation order and
+the final rounding differ): 1e-5 relative for fp32 outputs, 2^-8 for bf16 outputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+from util import close, csr_of
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+nat = gs._native
+DEV = "cuda"
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+def dcsr(adj):
+    return gs.DeviceCSR.from_scipy(adj, torch.device(DEV))
+
+
+def test_device_and_library():
+    info = nat.device_info()
+    assert info is not None and info["arch"].startswith("gfx950"), info
+    assert info["wave_size"] == 64
+    assert nat.lib().gsage_abi_version() == 1
+
+
+def test_sampler_sel_bit_exact_all_golden_cases():
+    from oracle import cpu as ocpu
+    g = load_golden("sampler_kat.npz")
+    csrs = [dcsr(csr_of(g, "g%d_" % i)) for i in range(3)]
+    before = nat.launch_count()
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        csr = csrs[int(g[p + "graph"])]
+        ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+        sel = torch.from_numpy(g[p + "sel"].astype(np.int32)).to(DEV)
+        out = ops.sample_csr(csr, ids, int(g[p + "n"]), sel=sel)
+        assert out.dtype == torch.int64 and out.is_cuda
+        assert np.array_equal(out.cpu().numpy(), g[p + "out"]), c
+        csr.check()
+    assert nat.launch_count() - before == int(g["n_cases"])       # the HIP path really ran
+
+
+def test_sampler_philox_equals_oracle_and_counter():
+    from oracle import cpu as ocpu
+    g = load_golden("sampler_kat.npz")
+    adj = csr_of(g, "g2_")
+    csr = dcsr(adj)
+    rng = np.random.RandomState(1)
+    for (M, n, g0, call) in [(1, 1, 0, 0), (5, 3, 0, 7), (129, 25, 3, 1), (1000, 10, 123457, 2 ** 33 + 5)]:
+        ids = rng.randint(0, adj.shape[0], size=M)
+        sel_out = torch.empty(M * n, dtype=torch.int32, device=DEV)
+        out = ops.sample_csr(csr, torch.from_numpy(ids).to(DEV), n,
+                             philox={"seed": 2 ** 40 + 17, "call_base": call, "g0": g0, "sel_out": sel_out})
+        sel = ocpu.philox_sel(2 ** 40 + 17, call, g0, M * n, adj.shape[1])
+        assert np.array_equal(sel_out.cpu().numpy().astype(np.int64), sel)
+        assert np.array_equal(out.cpu().numpy(), ocpu.sample_csr_sel(adj.indptr, adj.data, ids, n, sel))
+    # device-side call counter (what a captured graph advances between replays)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ids = torch.from_numpy(rng.randint(0, adj.shape[0], size=40)).to(DEV)
+    a = ops.sample_csr(csr, ids, 5, philox={"seed": 3, "call_ctr": ctr, "call_base": 1})
+    nat.check(nat.lib().gsage_counter_add(ctr.data_ptr(), 2, None))
+    torch.cuda.synchronize()
+    assert int(ctr.item()) == 2
+    b = ops.sample_csr(csr, ids, 5, philox={"seed": 3, "call_ctr": ctr, "call_base": 1})
+    ref_a = ocpu.sample_csr_sel(adj.indptr, adj.data, ids.cpu().numpy(), 5, ocpu.philox_sel(3, 1, 0, 200, adj.shape[1]))
+    ref_b = ocpu.sample_csr_sel(adj.indptr, adj.data, ids.cpu().numpy(), 5, ocpu.philox_sel(3, 3, 0, 200, adj.shape[1]))
+    assert np.array_equal(a.cpu().numpy(), ref_a) and np.array_equal(b.cpu().numpy(), ref_b)
+
+
+def test_sampler_edge_cases():
+    g = load_golden("sampler_kat.npz")
+    csr = dcsr(csr_of(g, "g0_"))
+    assert ops.sample_csr(csr, torch.empty(0, dtype=torch.int64, device=DEV), 3,
+                          sel=torch.empty(0, dtype=torch.int32, device=DEV)).numel() == 0
+    with pytest.raises(AssertionError):
+        ops.sample_csr(csr, torch.zeros(2, dtype=torch.int64, device=DEV), 0,
+                       sel=torch.empty(0, dtype=torch.int32, device=DEV))
+    out = ops.sample_csr(csr, torch.tensor([1, 10 ** 6, 0, 3], device=DEV), 2,
+                         sel=torch.zeros(8, dtype=torch.int32, device=DEV))
+    assert out[2:4].tolist() == [0, 0] and out[4:].tolist() == [0, 0, 0, 0]    # bad id / dummy / deg 0
+    with pytest.raises(IndexError):
+        csr.check()
+    csr.check()                                                             # flag was cleared
+
+
+@pytest.mark.parametrize("D,ld", [(602, 640), (602, 602), (64, 64), (7, 7), (130, 136), (1433, 1472)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gather_mean_vs_oracle(D, ld, dtype):
+    from oracle import cpu as ocpu
+    rng = np.random.RandomState(D + ld)
+    R = 500
+    tdt = ops.torch_dtype(dtype)
+    host = rng.normal(size=(R, D)).astype(np.float32)
+    host[0] = 0
+    table = torch.zeros(R, ld, dtype=tdt, device=DEV)
+    table[:, :D] = torch.from_numpy(host).to(DEV).to(tdt)
+    ref_table = table[:, :D].float().cpu().numpy()
+    store = gs.FeatureStore(table, D)
+    for (M, n) in [(1, 1), (33, 10), (16, 25), (257, 3), (40, 1)]:
+        ids = torch.from_numpy(rng.randint(0, R, size=M * n)).to(DEV)
+        ref = ocpu.gather_mean_f32(ref_table, ids.cpu().numpy(), M, n)
+        out = ops.gather_mean(store, ids, M, n, out_dtype=torch.float32)
+        close(out.cpu().numpy(), ref, (D, ld, dtype, M, n), 1e-5, 1e-6)
+        if n == 1:
+            assert np.array_equal(out.cpu().numpy(), ref)            # a plain gather is exact
+        outb = ops.gather_mean(store, ids, M, n, out_dtype=tdt, out_ld=ld if ld % 8 == 0 else None)
+        assert outb.shape[1] == (ld if ld % 8 == 0 else D)
+        close(outb[:, :D].float().cpu().numpy(), ref, ("lowp", D, ld, dtype, M, n), 2 ** -8, 2 ** -8)
+        assert float(outb[:, D:].float().abs().sum()) == 0.0        # padding stays zero
+    # in-order rows (ids == NULL): segment mean of a tensor
+    M, n = 20, 5
+    ref = ocpu.gather_mean_f32(ref_table[:M * n], None, M, n)
+    out = ops._gather_mean_raw(table, D, None, M, n, torch.float32)
+    close(out.cpu().numpy(), ref, "inorder", 1e-5, 1e-6)
+
+
+def test_segment_mean_autograd_and_scatter_add():
+    rng = np.random.RandomState(5)
+    M, n, D = 37, 10, 50
+    nb = torch.from_numpy(rng.normal(size=(M * n, D)).astype(np.float32)).to(DEV).requires_grad_(True)
+    out = ops.segment_mean(nb, M)
+    close(out.detach().cpu().numpy(), nb.detach().cpu().numpy().reshape(M, n, D).mean(1), "fwd", 1e-5, 1e-6)
+    G = torch.from_numpy(rng.normal(size=(M, D)).astype(np.float32)).to(DEV)
+    (out * G).sum().backward()
+    close(nb.grad.cpu().numpy(), np.repeat(G.cpu().numpy() / n, n, axis=0), "bwd", 1e-6, 1e-7)
+    # K6: dense embedding gradient
+    table = torch.nn.Parameter(torch.from_numpy(rng.normal(size=(30, 16)).astype(np.float32)).to(DEV))
+    ids = torch.from_numpy(rng.randint(0, 30, size=200)).to(DEV)
+    rows = ops.embedding_rows(table, ids)
+    assert np.array_equal(rows.detach().cpu().numpy(), table.detach().cpu().numpy()[ids.cpu().numpy()])
+    G = torch.from_numpy(rng.normal(size=(200, 16)).astype(np.float32)).to(DEV)
+    (rows * G).sum().backward()
+    ref = np.zeros((30, 16), dtype=np.float64)
+    np.add.at(ref, ids.cpu().numpy(), G.cpu().numpy().astype(np.float64))
+    close(table.grad.cpu().numpy(), ref, "scatter", 1e-5, 1e-5)
+
+
+def _lin_ref(A, W, b, act):
+    y = A.astype(np.float64) @ W.astype(np.float64).T
+    if b is not None:
+        y = y + b.astype(np.float64)
+    if act == 1:
+        y = np.maximum(y, 0)
+    elif act == 2:
+        y = np.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (64, 128, 64), (65, 129, 70), (513, 41, 256), (200, 512, 602), (31, 32, 1433)])
+def test_linear_nt_mfma_layouts(dtype, M, N, K):
+    """Asymmetric random operands: catches any row/column/k-slot mix-up of the MFMA fragments."""
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    W = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    if dtype == "bf16":
+        A, W = bf16_round(A), bf16_round(W)
+    At, Wt, bt = [torch.from_numpy(v).to(DEV) for v in (A, W, b)]
+    for act in (0, 1, 2):
+        for bias in (None, bt):
+            out = ops.linear(At, Wt, bias, act, compute_dtype=dtype)
+            ref = _lin_ref(A, W, b if bias is not None else None, act)
+            close(out.cpu().numpy(), ref, (dtype, M, N, K, act, bias is not None), 2e-5, 2e-6)
+    if dtype == "bf16":
+        outb = ops.linear(At, Wt, bt, 1, compute_dtype=dtype, out_dtype=torch.bfloat16)
+        close(outb.float().cpu().numpy(), _lin_ref(A, W, b, 1), "bf16 out", 2 ** -8, 2 ** -8)
+
+
+def test_linear_identity_times_asymmetric():
+    """A = I: output must be exactly W^T laid out [m, j] (guide: transpose-detecting check)."""
+    K = 64
+    W = torch.arange(96 * K, dtype=torch.float32, device=DEV).view(96, K) / 64.0
+    for dtype in ("fp32", "bf16"):
+        out = ops.linear(torch.eye(K, device=DEV), W, None, 0, compute_dtype=dtype)
+        ref = W.t() if dtype == "fp32" else W.bfloat16().float().t()
+        assert torch.equal(out, ref.contiguous())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sage_project_grouped_gathered_and_backward(dtype):
+    rng = np.random.RandomState(3)
+    R, D, h, M, n = 400, 602, 128, 70, 10
+    store = gs.FeatureStore.from_array(rng.normal(size=(R, D)).astype(np.float32), torch.device(DEV), dtype=dtype)
+    tab = store.dense().cpu().numpy()
+    ids_x = torch.from_numpy(rng.randint(0, R, size=M)).to(DEV)
+    ids_n = torch.from_numpy(rng.randint(0, R, size=M * n)).to(DEV)
+    Wx = torch.nn.Parameter(torch.from_numpy((rng.normal(size=(h, D)) / 25).astype(np.float32)).to(DEV))
+    Wn = torch.nn.Parameter(torch.from_numpy((rng.normal(size=(h, D)) / 25).astype(np.float32)).to(DEV))
+    ops.set_compute_dtype(dtype)
+    try:
+        before = nat.launch_count()
+        agg = ops.gather_mean(store, ids_n, M, n, out_dtype=ops.torch_dtype(dtype), out_ld=store.ld)
+        out = ops.sage_project(store[ids_x], agg, Wx, Wn, nat.ACT_RELU, dtype, torch.float32)
+        assert nat.launch_count() - before == 2          # one gather+mean, ONE grouped GEMM
+        wx = Wx.detach().cpu().numpy(); wn = Wn.detach().cpu().numpy()
+        if dtype == "bf16":
+            wx, wn = bf16_round(wx), bf16_round(wn)
+        aggr = agg[:, :D].float().cpu().numpy()
+        ref = np.maximum(np.concatenate([tab[ids_x.cpu().numpy()].astype(np.float64) @ wx.T.astype(np.float64),
+                                         aggr.astype(np.float64) @ wn.T.astype(np.float64)], axis=1), 0)
+        close(out.detach().cpu().numpy(), ref, ("fwd", dtype), 2e-5, 2e-6)
+        G = torch.from_numpy(rng.normal(size=(M, 2 * h)).astype(np.float32)).to(DEV)
+        (out * G).sum().backward()
+        g = G.cpu().numpy() * (ref > 0)
+        tol = (1e-4, 1e-5) if dtype == "fp32" else (2e-2, 2e-2)      # bf16: dOut is rounded to bf16
+        close(Wx.grad.cpu().numpy(), g[:, :h].T @ tab[ids_x.cpu().numpy()], ("dWx", dtype), *tol)
+        close(Wn.grad.cpu().numpy(), g[:, h:].T @ aggr, ("dWn", dtype), *tol)
+    finally:
+        ops.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["max", "mean"])
+@pytest.mark.parametrize("M,n,D,H", [(5, 10, 70, 512), (33, 25, 602, 512), (7, 1, 16, 130), (64, 3, 256, 64), (3, 64, 40, 128)])
+def test_pool_mlp_vs_reference_math(dtype, mode, M, n, D, H):
+    rng = np.random.RandomState(M + n + D)
+    nb = rng.normal(size=(M * n, D)).astype(np.float32)
+    W = (rng.normal(size=(H, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.normal(size=(H,)).astype(np.float32)
+    if dtype == "bf16":
+        nb, W = bf16_round(nb), bf16_round(W)
+    hid = np.maximum(nb.astype(np.float64) @ W.T.astype(np.float64) + b, 0).reshape(M, n, H)
+    ref = hid.max(1) if mode == "max" else hid.mean(1)
+    code = nat.POOL_MAX if mode == "max" else nat.POOL_MEAN
+    nbt = torch.from_numpy(nb).to(DEV).requires_grad_(True)
+    Wt = torch.nn.Parameter(torch.from_numpy(W).to(DEV))
+    bt = torch.nn.Parameter(torch.from_numpy(b).to(DEV))
+    out = ops.pool_mlp(nbt, Wt, bt, M, code, compute_dtype=dtype)
+    close(out.detach().cpu().numpy(), ref, (dtype, mode, M, n, D, H), 2e-5, 2e-6)
+    G = rng.normal(size=(M, H)).astype(np.float32)
+    (out * torch.from_numpy(G).to(DEV)).sum().backward()
+    if mode == "max":
+        gh = np.zeros_like(hid)
+        am = hid.argmax(1)
+        np.put_along_axis(gh, am[:, None, :], (G * (ref > 0))[:, None, :], axis=1)
+    else:
+        gh = np.repeat((G / n)[:, None, :], n, axis=1) * (hid > 0)
+    gh = gh.reshape(M * n, H)
+    tol = (1e-4, 1e-5) if dtype == "fp32" else (2e-2, 2e-2)
+    close(Wt.grad.cpu().numpy(), gh.T @ nb, ("dW", dtype, mode), *tol)
+    close(bt.grad.cpu().numpy(), gh.sum(0), ("db", dtype, mode), *tol)
+    close(nbt.grad.cpu().numpy(), gh @ W, ("dneibs", dtype, mode), *tol)
+    # gathered variant: rows come from a table through ids
+    store = gs.FeatureStore.from_array(nb, torch.device(DEV), dtype=dtype)
+    perm = torch.from_numpy(rng.permutation(M * n)).to(DEV)
+    inv = torch.argsort(perm)
+    shuffled = gs.FeatureStore(store.data[perm].contiguous(), D)
+    out2 = ops.pool_mlp(shuffled[inv], Wt, bt, M, code, compute_dtype=dtype)
+    close(out2.detach().cpu().numpy(), ref, ("gathered", dtype, mode), 2e-5, 2e-6)
+
+
+def test_attn_aggregate_forward_backward():
+    rng = np.random.RandomState(9)
+    for (M, n, Ha, D) in [(6, 5, 32, 20), (33, 20, 32, 64), (9, 15, 32, 602), (2, 64, 8, 9)]:
+        na = torch.from_numpy(rng.normal(size=(M * n, Ha)).astype(np.float32)).to(DEV).requires_grad_(True)
+        xa = torch.from_numpy(rng.normal(size=(M, Ha)).astype(np.float32)).to(DEV).requires_grad_(True)
+        nb = torch.from_numpy(rng.normal(size=(M * n, D)).astype(np.float32)).to(DEV).requires_grad_(True)
+        out = ops.attn_aggregate(na, xa, nb, M)
+        na_c, xa_c, nb_c = [t.detach().cpu().double().requires_grad_(True) for t in (na, xa, nb)]
+        s = torch.bmm(na_c.view(M, n, Ha), xa_c.view(M, Ha, 1)).squeeze(2)
+        ref = (nb_c.view(M, n, D) * torch.softmax(s, dim=1).unsqueeze(-1)).sum(1)
+        close(out.detach().cpu().numpy(), ref.detach().numpy(), ("attn fwd", M, n), 1e-5, 1e-6)
+        G = torch.from_numpy(rng.normal(size=(M, D)).astype(np.float32))
+        (out * G.to(DEV)).sum().backward()
+        (ref * G.double()).sum().backward()
+        close(na.grad.cpu().numpy(), na_c.grad.numpy(), "dna", 1e-4, 1e-5)
+        close(xa.grad.cpu().numpy(), xa_c.grad.numpy(), "dxa", 1e-4, 1e-5)
+        close(nb.grad.cpu().numpy(), nb_c.grad.numpy(), "dnb", 1e-4, 1e-5)

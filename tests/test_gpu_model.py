@@ -1,0 +1,157 @@
+"""-m gpu: the drop-in boundary end to end on the MI355X -- aggregator / prep / full-model golden
+vectors through the HIP path (fp32 mode: tight; bf16 mode: loose), plus size-independent
+properties at BASELINE.json's full Reddit shapes where the oracle is too slow to run."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+from util import ACTS, SelReplay, build_model, close, csr_of, weights
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+nat = gs._native
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _warm():
+    ops.warmup(torch.device(DEV))
+    yield
+    ops.set_compute_dtype("bf16")
+
+
+TOL = {"fp32": (1e-4, 1e-5), "bf16": (4e-2, 4e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_aggregator_golden_vectors_on_gpu(dtype):
+    ops.set_compute_dtype(dtype)
+    g = load_golden("agg_kat.npz")
+    before = nat.launch_count()
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        name, act = str(g[p + "name"]), str(g[p + "act"])
+        M, n, D, h = [int(v) for v in g[p + "dims"]]
+        agg = gs.aggregator_lookup[name](input_dim=D, output_dim=h, activation=ACTS[act])
+        agg.load_state_dict(weights(g, p + "w_"))
+        agg = agg.to(DEV)
+        x = torch.from_numpy(g[p + "x"].copy()).to(DEV).requires_grad_(True)
+        nb = torch.from_numpy(g[p + "neibs"].copy()).to(DEV).requires_grad_(True)
+        out = agg(x, nb)
+        assert out.shape == g[p + "out"].shape
+        close(out.detach().float().cpu().numpy(), g[p + "out"], (c, name, "out"), *TOL[dtype])
+        (out.float() * torch.from_numpy(g[p + "G"]).to(DEV)).sum().backward()
+        close(x.grad.cpu().numpy(), g[p + "dx"], (c, name, "dx"), *TOL[dtype])
+        close(nb.grad.cpu().numpy(), g[p + "dneibs"], (c, name, "dneibs"), *TOL[dtype])
+        for k, v in agg.named_parameters():
+            close(v.grad.cpu().numpy(), g[p + "g_" + k], (c, name, k), *TOL[dtype])
+    assert nat.launch_count() - before >= 2 * int(g["n_cases"])
+
+
+def test_aggregator_rowref_equals_tensor_path():
+    """feats[ids] as a lazy RowRef (fused gather) must equal the materialised-tensor route."""
+    ops.set_compute_dtype("fp32")
+    rng = np.random.RandomState(0)
+    R, D, h, M, n = 300, 50, 16, 40, 7
+    feats = torch.from_numpy(rng.normal(size=(R, D)).astype(np.float32)).to(DEV)
+    store = gs.FeatureStore.from_array(feats.cpu().numpy(), torch.device(DEV), dtype="fp32")
+    idx = torch.from_numpy(rng.randint(0, R, size=M)).to(DEV)
+    idn = torch.from_numpy(rng.randint(0, R, size=M * n)).to(DEV)
+    for name in ("mean", "max_pool", "mean_pool", "attention"):
+        torch.manual_seed(1)
+        agg = gs.aggregator_lookup[name](input_dim=D, output_dim=h, activation=torch.relu).to(DEV)
+        a = agg(store[idx], store[idn])
+        b = agg(feats[idx], feats[idn])
+        close(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), name, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_model_golden_train_steps_on_gpu(dtype):
+    ops.set_compute_dtype(dtype)
+    g = load_golden("model_kat.npz")
+    rtol, atol = TOL[dtype]
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        model, feats, task = build_model(gs, g, p, device=DEV)
+        loss_fn = getattr(gs.ProblemLosses, task)
+        ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+        tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+        with SelReplay([g[p + "eval_sel0"], g[p + "eval_sel1"]]):
+            ev = model(ids, feats, train=False)
+        close(ev.detach().cpu().numpy(), g[p + "eval_preds"], (c, "eval"), rtol, atol)
+        for step in range(2):
+            model.set_progress(0.25 * step)
+            with SelReplay([g[p + "s%d_sel0" % step], g[p + "s%d_sel1" % step]]):
+                preds = model.train_step(ids=ids, feats=feats, targets=tg, loss_fn=loss_fn)
+            close(preds.detach().cpu().numpy(), g[p + "s%d_preds" % step], (c, step, "preds"), rtol, atol)
+            if dtype == "fp32":
+                for k, v in model.named_parameters():
+                    close(v.grad.cpu().numpy(), g[p + "s%d_cg_%s" % (step, k)], (c, step, "cg", k), 2e-4, 2e-5)
+                for k, v in model.state_dict().items():
+                    close(v.cpu().numpy(), g[p + "w%d_%s" % (step + 1, k)], (c, step, "w", k), 2e-4, 2e-5)
+        model.train_sampler.csr(DEV).check()
+
+
+def test_stream_kat_on_gpu_compat_mode_is_bit_identical():
+    """Same seed -> same epoch shuffle AND same sampled frontier as the reference (level 2)."""
+    g = load_golden("stream_kat.npz")
+    adj = csr_of(g, "g_")
+    s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="compat")
+    nodes = g["nodes"]
+    gs.set_seeds(int(g["seed"]) ** 2)
+    order = np.random.permutation(np.arange(nodes.shape[0]))
+    for b, chunk in enumerate(np.array_split(order, nodes.shape[0] // 64 + 1)):
+        ids = torch.from_numpy(nodes[chunk]).to(DEV)
+        assert np.array_equal(ids.cpu().numpy(), g["b%d_ids" % b])
+        h1 = s(ids, n_samples=5)
+        h2 = s(h1, n_samples=3)
+        assert np.array_equal(h1.cpu().numpy(), g["b%d_h1" % b])
+        assert np.array_equal(h2.cpu().numpy(), g["b%d_h2" % b])
+    assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g["tail"])
+
+
+# ------------------------------------------------------------------------ full-size properties
+def _reddit_like(n_nodes=232965, seed=0):
+    import bench
+    return bench.synthetic_reddit(n_nodes=n_nodes, seed=seed)
+
+
+def test_full_size_reddit_properties():
+    """BASELINE config 2 shapes (N=232 965, D=602, B=512, fanout 25/10): sampled ids are real
+    neighbours; gather+mean is linear in the table; means of a constant table are that constant."""
+    import bench
+    ops.set_compute_dtype("bf16")
+    data = bench.synthetic_reddit(seed=0)
+    adj = data["adj"]
+    s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="philox", seed=1)
+    ids0 = torch.from_numpy(np.random.RandomState(0).randint(1, adj.shape[0], size=512)).to(DEV)
+    ids1 = s(ids0, n_samples=25)
+    ids2 = s(ids1, n_samples=10)
+    assert ids1.numel() == 12800 and ids2.numel() == 128000
+    s.csr(DEV).check()
+    # membership: every sample of parent p is one of p's neighbours (or 0 for an isolated parent)
+    ip, dat = adj.indptr, adj.data
+    par = ids1.cpu().numpy().repeat(10)
+    ch = ids2.cpu().numpy()
+    for k in np.random.RandomState(1).randint(0, ch.shape[0], size=2000):
+        row = dat[ip[par[k]]:ip[par[k] + 1]]
+        assert (ch[k] == 0 and row.size == 0) or ch[k] in row
+    # determinism + counter sensitivity
+    s2 = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="philox", seed=1)
+    assert torch.equal(s2(ids0, n_samples=25), ids1)
+    assert not torch.equal(s2(ids0, n_samples=25), ids1)            # next call index
+    store = data["feats"](DEV, "bf16")
+    a = ops.gather_mean(store, ids2, 12800, 10, out_dtype=torch.float32)
+    ones = gs.FeatureStore(torch.ones_like(store.data), store.dim)
+    assert torch.equal(ops.gather_mean(ones, ids2, 12800, 10, out_dtype=torch.float32),
+                       torch.ones(12800, store.dim, device=DEV))
+    dbl = gs.FeatureStore(store.data * 2, store.dim)
+    assert torch.equal(ops.gather_mean(dbl, ids2, 12800, 10, out_dtype=torch.float32), a * 2)
+    # spot-check 64 rows against the oracle
+    from oracle import cpu as ocpu
+    sub = ids2[:640].cpu().numpy()
+    uniq, inv = np.unique(sub, return_inverse=True)
+    small = store.data[torch.from_numpy(uniq).to(DEV), :store.dim].float().cpu().numpy()
+    close(a[:64].cpu().numpy(), ocpu.gather_mean_f32(small, inv, 64, 10), "oracle spot", 1e-5, 1e-6)
