@@ -59,15 +59,18 @@ k_attn_aggregate(const float *__restrict__ na, int64_t na_ld, const float *__res
     const float w = e / denom;
     if (lane < n) ws[i * n + lane] = w;
 
-    // weighted sum of the raw rows; lanes stride over columns
-    for (int c = lane; c < D; c += 64) {
+    // weighted sum of the raw rows; lanes stride over columns.  The trip count is wave-uniform
+    // (c0, not c, bounds the loop) so every lane takes part in the weight broadcast.
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        const int c = c0 + lane;
+        const bool live = c < D;
         float acc = 0.f;
         for (int r = 0; r < n; ++r) {
             const float wr = __shfl(w, r, 64);
             const int64_t row = ids ? ids[i * n + r] : i * n + r;
-            acc += wr * load_elem<T>(table + row * ld + c);
+            if (live) acc += wr * load_elem<T>(table + row * ld + c);
         }
-        agg[i * agg_ld + c] = acc;
+        if (live) agg[i * agg_ld + c] = acc;
     }
 }
 

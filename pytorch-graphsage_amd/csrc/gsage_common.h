@@ -51,9 +51,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
-// 16-byte vector of raw bits; the unit every memory-bound kernel moves per lane.
-struct __attribute__((aligned(16))) vec16 { uint32_t w[4]; };
-struct __attribute__((aligned(8))) vec8 { uint32_t w[2]; };
+// 16-byte vector of raw bits; the unit every kernel moves per lane.  A first-class vector type
+// (not a struct with an array member): hipcc keeps these in VGPRs, whereas the struct form was
+// observed to live in scratch memory when selected/zeroed conditionally.
+typedef uint32_t vec16 __attribute__((ext_vector_type(4)));
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) -----------------------------------------------------
 struct philox4 { uint32_t v[4]; };

@@ -83,19 +83,24 @@ struct mma_chunk<float> {
     {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w[e]),
-                                                       __uint_as_float(b.w[e]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]),
+                                                       acc, 0, 0, 0);
     }
 };
 
 __device__ __forceinline__ float apply_act(float v, int act)
 {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_TANH) {
+        // tanh(v) = sign(v) * (1 - 2 / (exp(2|v|) + 1)): full-precision expf, |err| ~ 1e-7
+        const float e = expf(2.f * fabsf(v));
+        const float t = 1.f - 2.f / (e + 1.f);
+        return v < 0.f ? -t : t;
+    }
     return v;
 }
 
-template <typename T, bool POOL>
+template <typename T, bool POOL, int ACT>
 __global__ void __launch_bounds__(256)
 k_linear_nt(const LinearParams p)
 {
@@ -118,69 +123,90 @@ k_linear_nt(const LinearParams p)
     const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
 
     // ---- staging assignment: 8 consecutive lanes fetch one full 128-byte line ----------------
+    // Out-of-range rows / K-chunks read a valid (clamped) address and are zeroed afterwards, so
+    // every load is unconditional and the staging registers stay in VGPRs (no scratch).
     const int srow = tid >> 3;           // 0..31
     const int sch = tid & 7;             // chunk inside the tile row
-    const T *a_ptr[2];
-    const T *w_ptr[4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int row = srow + 32 * s;
-        const int64_t m = m0 + row;
-        a_ptr[s] = nullptr;
-        if (row < rows_per_wg && m < p.M) {
-            const int64_t r = a_rows ? a_rows[m] : m;
-            a_ptr[s] = A + r * p.lda + sch * EPC;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int64_t j = n0 + srow + 32 * s;
-        w_ptr[s] = (j < p.N) ? W + j * p.ldw + sch * EPC : nullptr;
-    }
     const int kchunks = (int)((p.K + EPC - 1) / EPC);
     const int nk = (kchunks + CH - 1) / CH;
 
-    vec16 ra[2], rw[4];
-    const vec16 zero = {{0u, 0u, 0u, 0u}};
-    auto load_tile = [&](int kt) {
-        const bool kin = (kt * CH + sch) < kchunks;
-        const int64_t koff = (int64_t)kt * CH * EPC;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            ra[s] = (a_ptr[s] && kin) ? *reinterpret_cast<const vec16 *>(a_ptr[s] + koff) : zero;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            rw[s] = (w_ptr[s] && kin) ? *reinterpret_cast<const vec16 *>(w_ptr[s] + koff) : zero;
-    };
+    const T *a_ptr0, *a_ptr1, *w_ptr0, *w_ptr1, *w_ptr2, *w_ptr3;
+    bool a_ok0, a_ok1, w_ok0, w_ok1, w_ok2, w_ok3;
+    {
+        auto a_row = [&](int row, bool &ok) -> const T * {
+            const int64_t m = m0 + row;
+            ok = row < rows_per_wg && m < p.M;
+            const int64_t mm = ok ? m : 0;
+            const int64_t r = a_rows ? a_rows[mm] : mm;
+            return A + r * p.lda;
+        };
+        auto w_row = [&](int row, bool &ok) -> const T * {
+            const int64_t j = n0 + row;
+            ok = j < p.N;
+            return W + (ok ? j : 0) * p.ldw;
+        };
+        a_ptr0 = a_row(srow, a_ok0);
+        a_ptr1 = a_row(srow + 32, a_ok1);
+        w_ptr0 = w_row(srow, w_ok0);
+        w_ptr1 = w_row(srow + 32, w_ok1);
+        w_ptr2 = w_row(srow + 64, w_ok2);
+        w_ptr3 = w_row(srow + 96, w_ok3);
+    }
+    const vec16 zero = {0u, 0u, 0u, 0u};
+    vec16 ra0, ra1, rw0, rw1, rw2, rw3;
+    bool kin_held = false;               // does the tile held in registers lie inside K?
+
+#define GSAGE_LOAD_TILE(kt)                                                                   \
+    do {                                                                                      \
+        const int kc_ = (kt) * CH + sch;                                                      \
+        const bool kin_ = kc_ < kchunks;                                                      \
+        const int64_t ko_ = (int64_t)(kin_ ? kc_ : 0) * EPC;                                  \
+        ra0 = *reinterpret_cast<const vec16 *>(a_ptr0 + ko_);                                 \
+        ra1 = *reinterpret_cast<const vec16 *>(a_ptr1 + ko_);                                 \
+        rw0 = *reinterpret_cast<const vec16 *>(w_ptr0 + ko_);                                 \
+        rw1 = *reinterpret_cast<const vec16 *>(w_ptr1 + ko_);                                 \
+        rw2 = *reinterpret_cast<const vec16 *>(w_ptr2 + ko_);                                 \
+        rw3 = *reinterpret_cast<const vec16 *>(w_ptr3 + ko_);                                 \
+        kin_held = kin_;                                                                      \
+    } while (0)
 
     const int wm = wave & 1;
     const int wn = wave >> 1;
-    f32x16_t acc[2];
+    f32x16_t acc0, acc1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    load_tile(0);
+    // LDS slots this thread writes (staging) and reads (fragments) are loop invariant
+    const int wsa0 = lds_slot(srow, sch), wsa1 = lds_slot(srow + 32, sch);
+    const int wsw0 = lds_slot(srow, sch), wsw1 = lds_slot(srow + 32, sch);
+    const int wsw2 = lds_slot(srow + 64, sch), wsw3 = lds_slot(srow + 96, sch);
+    const int arow = wm * 32 + (lane & 31);
+    const int wrow0 = wn * 64 + (lane & 31), wrow1 = wrow0 + 32;
+
+    GSAGE_LOAD_TILE(0);
     for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) sA[lds_slot(srow + 32 * s, sch)] = ra[s];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sW[lds_slot(srow + 32 * s, sch)] = rw[s];
+        // masking happens here, at the consumer, so the loads above stay in flight during the
+        // previous tile's MFMAs instead of being waited for right after issue
+        sA[wsa0] = (kin_held && a_ok0) ? ra0 : zero;
+        sA[wsa1] = (kin_held && a_ok1) ? ra1 : zero;
+        sW[wsw0] = (kin_held && w_ok0) ? rw0 : zero;
+        sW[wsw1] = (kin_held && w_ok1) ? rw1 : zero;
+        sW[wsw2] = (kin_held && w_ok2) ? rw2 : zero;
+        sW[wsw3] = (kin_held && w_ok3) ? rw3 : zero;
         __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) GSAGE_LOAD_TILE(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ch = kk * 2 + (lane >> 5);
-            const vec16 a = sA[lds_slot(wm * 32 + (lane & 31), ch)];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const vec16 b = sW[lds_slot(wn * 64 + t * 32 + (lane & 31), ch)];
-                mma_chunk<T>::run(a, b, acc[t]);
-            }
+            const vec16 a = sA[lds_slot(arow, ch)];
+            const vec16 b0 = sW[lds_slot(wrow0, ch)];
+            const vec16 b1 = sW[lds_slot(wrow1, ch)];
+            mma_chunk<T>::run(a, b0, acc0);
+            mma_chunk<T>::run(a, b1, acc1);
         }
         __syncthreads();
     }
+#undef GSAGE_LOAD_TILE
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // C/D layout of the 32x32 MFMA: lane l, register r -> column (l & 31),
@@ -189,6 +215,7 @@ k_linear_nt(const LinearParams p)
         const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            const f32x16_t &acc = t ? acc1 : acc0;
             const int64_t j = n0 + wn * 64 + t * 32 + (lane & 31);
             const float bj = (bias && j < p.N) ? bias[j] : 0.f;
 #pragma unroll
@@ -196,7 +223,7 @@ k_linear_nt(const LinearParams p)
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t m = m0 + wm * 32 + i;
                 if (m < p.M && j < p.N) {
-                    const float v = apply_act(acc[t][r] + bj, p.act);
+                    const float v = apply_act(acc[r] + bj, ACT);
                     const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
                     if (p.c_dtype == GSAGE_BF16)
                         ((uint16_t *)p.C)[off] = f32_to_bf16(v);
@@ -210,13 +237,14 @@ k_linear_nt(const LinearParams p)
         float *tile = reinterpret_cast<float *>(smem);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            const f32x16_t &acc = t ? acc1 : acc0;
             const int jl = wn * 64 + t * 32 + (lane & 31);
             const int64_t j = n0 + jl;
             const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = acc[t][r] + bj;
+                const float v = acc[r] + bj;
                 tile[i * BN + jl] = v > 0.f ? v : 0.f;
             }
         }
@@ -287,10 +315,21 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     p.pool_n = 0; p.pool_groups = 0; p.pool_mode = 0; p.pooled = nullptr; p.pooled_ld = 0;
     p.argmax = nullptr;
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
+    hipStream_t s = (hipStream_t)stream;
+#define GSAGE_LAUNCH_LINEAR(T)                                                                    \
+    do {                                                                                          \
+        if (act == ACT_RELU)                                                                      \
+            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_RELU>), grid, dim3(256), 0, s, p);      \
+        else if (act == ACT_TANH)                                                                 \
+            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_TANH>), grid, dim3(256), 0, s, p);      \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_NONE>), grid, dim3(256), 0, s, p);      \
+    } while (0)
     if (dtype == GSAGE_BF16)
-        hipLaunchKernelGGL((k_linear_nt<uint16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        GSAGE_LAUNCH_LINEAR(uint16_t);
     else
-        hipLaunchKernelGGL((k_linear_nt<float, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        GSAGE_LAUNCH_LINEAR(float);
+#undef GSAGE_LAUNCH_LINEAR
     return check_launch("linear_nt");
 }
 
@@ -313,9 +352,9 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     p.pooled_ld = pooled_ld; p.argmax = argmax;
     dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, BN), 1);
     if (dtype == GSAGE_BF16)
-        hipLaunchKernelGGL((k_linear_nt<uint16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_linear_nt<uint16_t, true, ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((k_linear_nt<float, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_linear_nt<float, true, ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("pool_mlp");
 }
 

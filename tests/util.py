@@ -24,6 +24,17 @@ def close(a, b, what, rtol=1e-5, atol=2e-6):
     assert err <= (atol + rtol) * scale, (what, "max abs err %g at scale %g" % (err, scale))
 
 
+def close_fro(a, b, what, tol):
+    """Norm-wise check for low-precision gradients: a bf16 forward can flip the ReLU mask of a
+    pre-activation that is ~0, which moves single gradient entries by O(1) -- bounded in
+    Frobenius norm, not element-wise."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float(np.linalg.norm(a - b)) / max(float(np.linalg.norm(b)), 1e-12)
+    assert err <= tol, (what, "relative Frobenius error %g" % err)
+
+
 class SelReplay(object):
     """Feeds recorded `sel` matrices to a compat-mode sampler (monkeypatches np.random.choice
     exactly where the reference, and the product in compat mode, draw them)."""
