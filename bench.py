@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--aggregator", type=str, default="mean")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"],
+                    help="fused: engine.FusedMeanTrainStep (no autograd below the head); "
+                         "autograd: GSSupervised.train_step (captured unless --no-graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -220,7 +223,13 @@ def main():
 
     use_graph = not args.no_graph
     step_fn = None
-    if use_graph:
+    engine = args.engine
+    if engine == "fused" and not gs.engine.FusedMeanTrainStep.supports(model, store):
+        engine = "autograd"
+    if engine == "fused":
+        step_fn = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
+                                               capture=use_graph)
+    elif use_graph:
         try:
             step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
         except Exception as e:                          # report, then measure eager launches
@@ -262,7 +271,7 @@ def main():
             "config": {"workload": "Reddit-shaped %s-aggregator 2-layer fanout 25/10 hidden 128 "
                                    "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
-                       "hip_graph": use_graph, "parallelism": "dp%d" % world,
+                       "engine": engine, "hip_graph": use_graph, "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
                        if not use_graph else None},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),

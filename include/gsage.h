@@ -142,6 +142,23 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
                     int groups, int64_t a_gstride, int64_t w_gstride, int64_t c_gstride,
                     void *stream);
 
+/* K5b weight gradient (MFMA, bf16 in / fp32 out): the backward of the projection above w.r.t. its
+ *     weights (autograd of nn_modules.py:189-190,200 under loss.backward(), models.py:100)
+ *
+ *     out[g*out_gstride + n*K + k] = sum_m dC[m, g*n_per_group + n] * A_g[m, k]
+ *         A_g row m = (a_rows ? A + a_rows[m]*lda : A + m*lda) + g*a_gstride   (a_rows: group 0
+ *         only when a_rows_group0_only)            dC, A: bf16;  out: fp32 [groups, n_per_group, K]
+ *     The reduction over M is split into ceil(M / rows_per_split) slices whose partial tiles are
+ *     written to `slabs` (fp32 [slices, Ntot, ldk], caller-allocated) and summed deterministically.
+ *     Needs ldc, lda, ldk % 4 == 0, Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0,
+ *     n_per_group % 128 == 0 unless there is a single group. */
+int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, const int64_t *a_rows,
+                int a_rows_group0_only, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
+                int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
+                int64_t out_gstride, void *stream);
+/* [host] number of slabs gsage_wgrad writes for (M, rows_per_split). */
+int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split);
+
 /* ------------------------------------------------------------------------------------------
  * K3  pooling MLP           replaces mlp(neibs) -> view(M,-1,H) -> max/mean over the fanout
  *                           (nn_modules.py:224-226 with pool_fn of :240 / :252)
@@ -169,6 +186,45 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
                          const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
                          int32_t n, int64_t Ha, int64_t D, float *agg, int64_t agg_ld, float *ws,
                          void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86
+ * under autograd), used by the hipGraph engine.
+ * ---------------------------------------------------------------------------------------- */
+
+/* clip_grad_norm(params, max_norm) + Adam(betas, eps, L2 weight_decay) over FLAT fp32 buckets of n
+ * elements: p (parameters), g (gradients; overwritten with the clipped gradient), m, v (Adam
+ * moments).  lr and step are DEVICE scalars (float / int64) so a captured graph follows the LR
+ * schedule and counts steps; step is incremented by one.  partial: fp32 scratch of
+ * gsage_adam_partials(n) elements.  norm_out (may be NULL) receives the pre-clip gradient norm. */
+int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
+                         const float *lr, int64_t *step, float beta1, float beta2, float eps,
+                         float weight_decay, float max_norm, float *norm_out, void *stream);
+int gsage_adam_partials(int64_t n);
+
+/* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
+ * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy
+ * dst_t[c, r] (leading dimension dst_t_ld).  `descs` is a DEVICE array of n_desc descriptors;
+ * padding columns of dst / dst_t are not written (allocate them zeroed).
+ * max_elems = max rows*cols over the descriptors. */
+typedef struct {
+    const float *src;
+    uint16_t *dst;
+    uint16_t *dst_t;
+    int32_t rows, cols, dst_ld, dst_t_ld;
+} gsage_prep_desc;
+int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, void *stream);
+
+/* Gradient of a level's ReLU output H (bf16 [R, ldh], rows = hops concatenated, hop k starting at
+ * row off[k] with fan-out fan[k] relative to hop k-1):
+ *     dH[m] = (H[m] > 0) * ( (m < r_x ? DG[m, 0:D] : 0)
+ *                          + (hop(m) >= 1 ? DG[parent(m), dagg_off : dagg_off + D] / fan[hop(m)] : 0) )
+ *     parent(m) = off[k-1] + (m - off[k]) / fan[k]
+ * DG: fp32 [r_x, ldg] = the level above's (dX | dAgg); dH: bf16 [R, ldo].  off / fan: HOST arrays
+ * of n_hops (<= 6) entries. */
+int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
+                    void *dH, int64_t ldo, int64_t R, int64_t r_x, int32_t D, int32_t n_hops,
+                    const int64_t *off, const int32_t *fan, void *stream);
 
 #ifdef __cplusplus
 }

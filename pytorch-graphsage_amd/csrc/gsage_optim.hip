@@ -1,0 +1,223 @@
+// gsage_optim.hip -- the elementwise tail of train_step fused into three launches (gfx950):
+//   k_grad_sqnorm   sum of squares of the flat gradient bucket (per-block partials, deterministic)
+//   k_adam_clip     clip_grad_norm(5) + Adam update over the flat parameter bucket
+//   k_prep_weights  fp32 parameters -> bf16 operand copies ([N, ld] padded, and transposed) for K5
+//   k_bwd_merge     ReLU mask + routing of a layer's input gradient back to the hop rows
+//
+// Replaces, for the fused engine, what the reference does with ~60 tiny framework kernels per
+// step: torch.nn.utils.clip_grad_norm(params, 5) and optimizer.step() (reference models.py:101-102;
+// Adam betas (0.9, 0.999), eps 1e-8, L2 weight decay as at models.py:69) and autograd's
+// relu / mean / index backward between layers (models.py:85-86).  All HBM-bound, 16-byte lanes.
+#include "gsage_common.h"
+
+namespace gsage {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[b] = sum over this block's grid-stride slice of g[i]^2
+__global__ void __launch_bounds__(256)
+k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partial)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = g[i];
+        s += v * v;
+    }
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+struct AdamParams {
+    float *p, *g, *m, *v;
+    const float *partial;       // per-block squared-norm partials of g
+    const float *lr;            // device scalar (a captured graph sees schedule changes)
+    int64_t *step;              // device step counter; this launch uses *step + 1
+    float *norm_out;            // optional: total gradient norm before clipping
+    int64_t n;
+    int32_t n_partial;
+    float beta1, beta2, eps, weight_decay, max_norm;
+};
+
+__global__ void __launch_bounds__(256)
+k_adam_clip(const AdamParams a)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
+    const float sq = block_sum_256(s, red);
+    const float total = sqrtf(sq);
+    float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+    coef = coef < 1.f ? coef : 1.f;
+    const float t = (float)(*a.step + 1);
+    const float bc1 = 1.f - powf(a.beta1, t);
+    const float bc2 = 1.f - powf(a.beta2, t);
+    const float step_size = *a.lr / bc1;
+    const float rsqrt_bc2 = 1.f / sqrtf(bc2);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = total;
+
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        float g = a.g[i] * coef;
+        a.g[i] = g;                                     // clipped gradient stays visible (p.grad)
+        float p = a.p[i];
+        if (a.weight_decay != 0.f) g += a.weight_decay * p;
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+    }
+}
+
+__global__ void k_step_inc(int64_t *step) { *step += 1; }
+
+// ---- weight operand copies ------------------------------------------------------------------------
+struct PrepDesc {
+    const float *src;      // [rows, cols] fp32, contiguous
+    uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
+    uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
+    int32_t rows, cols, dst_ld, dst_t_ld;
+};
+
+__global__ void __launch_bounds__(256)
+k_prep_weights(const PrepDesc *__restrict__ descs)
+{
+    const PrepDesc d = descs[blockIdx.y];
+    const int64_t total = (int64_t)d.rows * d.cols;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int r = (int)(t / d.cols), c = (int)(t - (int64_t)r * d.cols);
+        const uint16_t b = f32_to_bf16(d.src[t]);
+        if (d.dst) d.dst[(int64_t)r * d.dst_ld + c] = b;
+        if (d.dst_t) d.dst_t[(int64_t)c * d.dst_t_ld + r] = b;
+    }
+}
+
+// ---- inter-layer backward routing ---------------------------------------------------------------
+// Rows of a level's output are the hops concatenated: [hop 0 | hop 1 | ... | hop nh-1].  Row m of
+// hop k received the level above's x-gradient dX[m] if m < r_x, and -- when k >= 1 -- 1/fan[k] of
+// its parent's aggregate gradient dAgg[off[k-1] + (m - off[k]) / fan[k]].  dH = (H > 0) * that.
+struct MergeParams {
+    const uint16_t *H;       // [R, ldh] bf16 post-ReLU output of the level (for the mask)
+    const float *DG;         // [r_x, ldg] fp32: cols [0, D) = dX, cols [dagg_off, dagg_off + D) = dAgg
+    uint16_t *dH;            // [R, ldo] bf16
+    int64_t ldh, ldg, ldo, dagg_off;
+    int64_t R, r_x;
+    int32_t D, n_hops;
+    int64_t off[6];
+    int32_t fan[6];
+};
+
+__global__ void __launch_bounds__(256)
+k_bwd_merge(const MergeParams q)
+{
+    const int chunks = q.D / 4;
+    const int64_t total = q.R * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t m = t / chunks;
+        const int c = (int)(t - m * chunks) * 4;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (m < q.r_x) g = *reinterpret_cast<const f32x4 *>(q.DG + m * q.ldg + c);
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 6; ++j)
+            if (j < q.n_hops && m >= q.off[j]) k = j;
+        if (k >= 1) {
+            const int64_t parent = q.off[k - 1] + (m - q.off[k]) / q.fan[k];
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(q.DG + parent * q.ldg + q.dagg_off + c);
+            const float inv = 1.f / (float)q.fan[k];
+            g += a * inv;
+        }
+        const uint2 h = *reinterpret_cast<const uint2 *>(q.H + m * q.ldh + c);
+        const float h0 = bf16_to_f32((uint16_t)(h.x & 0xffff)), h1 = bf16_to_f32((uint16_t)(h.x >> 16));
+        const float h2 = bf16_to_f32((uint16_t)(h.y & 0xffff)), h3 = bf16_to_f32((uint16_t)(h.y >> 16));
+        uint2 o;
+        o.x = pack_bf16x2(h0 > 0.f ? g[0] : 0.f, h1 > 0.f ? g[1] : 0.f);
+        o.y = pack_bf16x2(h2 > 0.f ? g[2] : 0.f, h3 > 0.f ? g[3] : 0.f);
+        *reinterpret_cast<uint2 *>(q.dH + m * q.ldo + c) = o;
+    }
+}
+
+static inline int grid_for(int64_t items, int cap)
+{
+    int64_t b = ceil_div(items, 256);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int gsage_adam_partials(int64_t n)
+{
+    return grid_for(n, 1024);
+}
+
+int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
+                         const float *lr, int64_t *step, float beta1, float beta2, float eps,
+                         float weight_decay, float max_norm, float *norm_out, void *stream)
+{
+    GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
+    GSAGE_REQUIRE(n > 0, "clip_adam_step: empty bucket");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for(n, 1024);
+    hipLaunchKernelGGL(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
+    int rc = check_launch("grad_sqnorm");
+    if (rc != GSAGE_OK) return rc;
+    AdamParams a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
+    a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.weight_decay = weight_decay; a.max_norm = max_norm;
+    hipLaunchKernelGGL(k_adam_clip, dim3(grid_for(n, 2048)), dim3(256), 0, s, a);
+    rc = check_launch("adam_clip");
+    if (rc != GSAGE_OK) return rc;
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, step);
+    return check_launch("step_inc");
+}
+
+int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, void *stream)
+{
+    GSAGE_REQUIRE(descs && n_desc > 0 && max_elems > 0, "prep_weights: bad arguments");
+    hipLaunchKernelGGL(k_prep_weights, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
+                       (hipStream_t)stream, (const PrepDesc *)descs);
+    return check_launch("prep_weights");
+}
+
+int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
+                    void *dH, int64_t ldo, int64_t R, int64_t r_x, int32_t D, int32_t n_hops,
+                    const int64_t *off, const int32_t *fan, void *stream)
+{
+    GSAGE_REQUIRE(H && DG && dH && off && fan, "bwd_merge: null pointer");
+    GSAGE_REQUIRE(n_hops >= 1 && n_hops <= 6, "bwd_merge: 1..6 hops");
+    GSAGE_REQUIRE(D > 0 && D % 4 == 0 && ldh % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && dagg_off % 4 == 0,
+                  "bwd_merge: D and leading dimensions must be multiples of 4");
+    if (R == 0) return GSAGE_OK;
+    MergeParams q;
+    q.H = (const uint16_t *)H; q.DG = DG; q.dH = (uint16_t *)dH; q.ldh = ldh; q.ldg = ldg; q.ldo = ldo;
+    q.dagg_off = dagg_off; q.R = R; q.r_x = r_x; q.D = D; q.n_hops = n_hops;
+    for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }
+    hipLaunchKernelGGL(k_bwd_merge, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, q);
+    return check_launch("bwd_merge");
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// gsage_wgrad.hip -- weight-gradient contraction on the gfx950 matrix cores.
+//
+// Replaces what autograd runs for the backward of nn.Linear's weight on the hot path
+// (reference: loss.backward() at models.py:100, through fc_x / fc_neib of nn_modules.py:189-190):
+//
+//     dW_g[n, k] = sum_m dC[m, g*n_per_group + n] * A_g[m, k]          fp32 result
+//
+// Both operands are "M-major" (the reduction index m is the SLOW dimension of both matrices),
+// the opposite of what v_mfma_f32_32x32x16_bf16 wants (8 consecutive reduction elements per
+// lane).  Instead of transposing through LDS, each lane loads, for 8 consecutive rows m, the 8
+// bytes holding 4 adjacent columns, and re-packs them in registers with v_perm_b32 into four
+// operands -- one per column residue e -- so MFMA #e owns output rows n = 4*i + e (a fixed
+// interleave of the output, undone for free in the epilogue's addressing).  Same trick on the A
+// side.  Every global load is a full, coalesced row segment (32 lanes x 8 B = 256 B).
+//
+// Decomposition: wave tile = 128 (n) x 128 (k) = 16 accumulators (256 AGPRs, one wave per SIMD);
+// a workgroup = 4 waves on 4 adjacent k-tiles sharing the dC rows through L1; the reduction over
+// M is split across grid.x into `rows_per_split` slices whose partial tiles go to fp32 slabs
+// (deterministic; summed by k_reduce_slabs -- no atomics).  MFMA-bound per wave, L2-bound overall.
+// A rows may be gathered through a_rows (feats[ids] is never materialised for the backward).
+#include "gsage_common.h"
+
+namespace gsage {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const uint16_t *dC;
+    const uint16_t *A;
+    const int64_t *a_rows;
+    float *slabs;
+    int64_t ldc, lda, a_gstride;
+    int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
+    int32_t a_rows_group0_only;
+};
+
+// operand for column residue E out of eight 8-byte row segments
+template <int E>
+__device__ __forceinline__ u32x4 pack_column(const u32x2 (&v)[8])
+{
+    constexpr uint32_t sel = (E & 1) ? 0x07060302u : 0x05040100u;     // hi|hi : lo|lo halves
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        o[q] = __builtin_amdgcn_perm(v[2 * q + 1][E >> 1], v[2 * q][E >> 1], sel);
+    return o;
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_wgrad_bf16(const WgradParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ii = lane & 31;
+    const int half = lane >> 5;
+    const int64_t n_base = (int64_t)blockIdx.y * 128;
+    const int64_t k_base = ((int64_t)blockIdx.z * 4 + wave) * 128;
+    if (k_base >= p.ldk) return;                                   // wave-uniform; no barriers below
+    const int g = (int)(n_base / p.n_per_group);
+    const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
+    const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
+
+    const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_split;
+    const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
+
+    // column validity is loop invariant; invalid columns read column 0 and are zeroed
+    const bool n_ok = n_base + 4 * ii + 3 < p.ldc && n_base + 4 * ii < p.Ntot;
+    const bool k_ok = k_base + 4 * ii + 3 < p.lda;
+    const int64_t n_off = n_ok ? n_base + 4 * ii : 0;
+    const int64_t k_off = k_ok ? k_base + 4 * ii : 0;
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+    u32x2 c_nxt[8], a_nxt[8];
+    auto load_step = [&](int64_t m0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t m = m0 + 8 * half + r;
+            const bool ok = m < m_end;
+            const int64_t mm = ok ? m : m_begin;
+            const int64_t ar = a_rows ? a_rows[mm] : mm;
+            u32x2 c = *reinterpret_cast<const u32x2 *>(p.dC + mm * p.ldc + n_off);
+            u32x2 a = *reinterpret_cast<const u32x2 *>(A + ar * p.lda + k_off);
+            if (!(ok && n_ok)) c = u32x2{0u, 0u};
+            if (!(ok && k_ok)) a = u32x2{0u, 0u};
+            c_nxt[r] = c;
+            a_nxt[r] = a;
+        }
+    };
+
+    load_step(m_begin);
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
+        u32x2 c_cur[8], a_cur[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { c_cur[r] = c_nxt[r]; a_cur[r] = a_nxt[r]; }
+        if (m0 + 16 < m_end) load_step(m0 + 16);
+
+        u32x4 opb[4];
+        opb[0] = pack_column<0>(a_cur);
+        opb[1] = pack_column<1>(a_cur);
+        opb[2] = pack_column<2>(a_cur);
+        opb[3] = pack_column<3>(a_cur);
+        u32x4 opa[4];
+        opa[0] = pack_column<0>(c_cur);
+        opa[1] = pack_column<1>(c_cur);
+        opa[2] = pack_column<2>(c_cur);
+        opa[3] = pack_column<3>(c_cur);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8_t, opa[e]), __builtin_bit_cast(bf16x8_t, opb[f]),
+                    acc[e][f], 0, 0, 0);
+    }
+
+    // epilogue: D[i][j] of MFMA (e, f) is dW[n_base + 4i + e][k_base + 4j + f]; lane l holds
+    // j = l & 31 and i = (r & 3) + 8 (r >> 2) + 4 (l >> 5): one float4 (f = 0..3) per (e, r).
+    float *slab = p.slabs + (int64_t)blockIdx.x * p.Ntot * p.ldk;
+    const int64_t k = k_base + 4 * ii;
+    if (k + 3 < p.ldk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int64_t n = n_base + 4 * i + e;
+                if (n < p.Ntot) {
+                    f32x4 v = {acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
+                    *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
+                }
+            }
+    }
+}
+
+// out_g[n_local * K + k] = sum_s slabs[s][g * n_per_group + n_local][k]
+__global__ void __launch_bounds__(256)
+k_reduce_slabs(const float *__restrict__ slabs, int32_t S, int64_t Ntot, int64_t K, int64_t ldk,
+               int64_t n_per_group, float *__restrict__ out, int64_t out_gstride)
+{
+    const int64_t total = Ntot * K;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t n = t / K;
+        const int64_t k = t - n * K;
+        const float *src = slabs + n * ldk + k;
+        float s = 0.f;
+        for (int i = 0; i < S; ++i) s += src[(int64_t)i * Ntot * ldk];
+        const int64_t g = n / n_per_group;
+        out[g * out_gstride + (n - g * n_per_group) * K + k] = s;
+    }
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split)
+{
+    return (int)ceil_div(M, rows_per_split);
+}
+
+int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, const int64_t *a_rows,
+                int a_rows_group0_only, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
+                int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
+                int64_t out_gstride, void *stream)
+{
+    GSAGE_REQUIRE(dC && A && slabs && out, "wgrad: null pointer");
+    GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
+    GSAGE_REQUIRE(ldc % 4 == 0 && lda % 4 == 0 && ldk % 4 == 0, "wgrad: ldc, lda, ldk must be multiples of 4");
+    GSAGE_REQUIRE(Ntot % 4 == 0 && Ntot <= ldc, "wgrad: Ntot must be a multiple of 4 and <= ldc");
+    GSAGE_REQUIRE(ldk >= K && ldk <= lda + 3, "wgrad: need K <= ldk <= lda");
+    GSAGE_REQUIRE(n_per_group > 0 && (n_per_group % 128 == 0 || n_per_group >= Ntot),
+                  "wgrad: n_per_group must be a multiple of 128 (or a single group)");
+    GSAGE_REQUIRE(rows_per_split >= 16 && rows_per_split % 16 == 0, "wgrad: rows_per_split must be a multiple of 16");
+    GSAGE_REQUIRE(((uintptr_t)dC % 8) == 0 && ((uintptr_t)A % 8) == 0 && ((uintptr_t)slabs % 16) == 0,
+                  "wgrad: misaligned pointer");
+    WgradParams p;
+    p.dC = (const uint16_t *)dC; p.A = (const uint16_t *)A; p.a_rows = a_rows; p.slabs = slabs;
+    p.ldc = ldc; p.lda = lda; p.a_gstride = a_gstride; p.M = M; p.Ntot = Ntot; p.K = K;
+    p.n_per_group = n_per_group; p.ldk = ldk; p.rows_per_split = rows_per_split;
+    p.a_rows_group0_only = a_rows_group0_only;
+    const int S = (int)ceil_div(M, rows_per_split);
+    dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
+    hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
+    int rc = check_launch("wgrad");
+    if (rc != GSAGE_OK) return rc;
+    int64_t blocks = ceil_div(Ntot * K, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)slabs, S, Ntot, K, ldk, n_per_group, out, out_gstride);
+    return check_launch("wgrad_reduce");
+}
+
+}  // extern "C"

@@ -133,3 +133,303 @@ class CapturedTrainStep(object):
             torch.distributed.all_reduce(self.flat)
             self.g_back.replay()
         return self.preds
+
+
+# =================================================================================================
+# Fused engine: the SAGE layers without autograd
+# =================================================================================================
+import ctypes
+
+from . import ops
+from .nn_modules import IdentityPrep, MeanAggregator, SparseUniformNeighborSampler, \
+    _split_activation, concat_combine
+from .store import FeatureStore
+
+
+class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/gsage.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_ld", ctypes.c_int32),
+                ("dst_t_ld", ctypes.c_int32)]
+
+
+def _r8(v):
+    return (v + 7) // 8 * 8
+
+
+class FusedMeanTrainStep(object):
+    """train_step (reference models.py:97-104) for the north-star configuration -- sparse sampler,
+    identity prep over a bf16 FeatureStore, mean aggregators (ReLU on all but the last layer) --
+    as ~20 kernel launches replayed from a hipGraph:
+
+        K-prep   fp32 weights -> bf16 operand copies (one launch)
+        K1       one launch per hop, ids written straight into the concatenated frontier
+        K2       gather+mean per hop (level 0 from the feature table, upper levels in order)
+        K5       ONE grouped MFMA GEMM per level (x | agg against Wx | Wn, gather fused for level 0)
+        head     normalize + fc + loss and their gradients (stock torch: 0.01 % of the work)
+        K5b      ONE MFMA weight-gradient launch per level (+ deterministic slab reduce)
+        K5/merge input gradients of upper levels: grouped GEMM against W^T, ReLU mask + hop routing
+        [RCCL]   one all-reduce of the flat gradient bucket (between the two graphs, DP only)
+        Adam     grad-norm partials + clip + Adam over the flat bucket (3 launches)
+
+    The arithmetic is that of GSSupervised.train_step; autograd is not involved below the head, so
+    nothing is saved per op and no framework glue kernels (casts, fills, masks) remain.
+    Parameters and gradients live in flat fp32 buckets; the model's Parameters become views of
+    them, so `model.state_dict()`, evaluation and checkpointing keep working.
+    """
+
+    @staticmethod
+    def supports(model, feats):
+        layers = list(model.agg_layers.children())
+        if not layers or not all(type(l) is MeanAggregator and l.combine_fn is concat_combine for l in layers):
+            return False
+        codes = [_split_activation(l.activation)[0] for l in layers]
+        if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
+            return False
+        if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
+            return False
+        if feats.dtype != torch.bfloat16 or not feats.is_cuda:
+            return False
+        if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
+            return False
+        return all(l.output_dim_ % 8 == 0 for l in layers)
+
+    def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
+                 warmup=2):
+        assert FusedMeanTrainStep.supports(model, feats), "configuration not covered by the fused engine"
+        self.model, self.store, self.loss_fn, self.ddp = model, feats, loss_fn, ddp
+        dev = feats.device
+        self.dev = dev
+        self.layers = list(model.agg_layers.children())
+        L = self.L = len(self.layers)
+        self.post = _split_activation(self.layers[-1].activation)[1]
+        self.fan = [1] + [fn.keywords["n_samples"] for fn in model.train_sample_fns]
+        B = self.B = int(example_ids.shape[0])
+        self.size = [B]
+        for k in range(1, L + 1):
+            self.size.append(self.size[-1] * self.fan[k])
+        self.off = [0]
+        for k in range(L + 1):
+            self.off.append(self.off[-1] + self.size[k])          # off[k] = first row of hop k
+        self.sampler = model.train_sampler
+        self.csr = self.sampler.csr(dev)
+
+        # ---- flat parameter / gradient / Adam buckets; Parameters become views ----------------
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        sizes = [p.numel() for p in self.params]
+        self.poff = [0]
+        for n in sizes:
+            self.poff.append(self.poff[-1] + n)
+        total = self.poff[-1]
+        self.flat_p = torch.cat([p.detach().reshape(-1).float() for p in self.params]).contiguous()
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros_like(self.flat_g)
+        self.flat_v = torch.zeros_like(self.flat_g)
+        for p, o, n in zip(self.params, self.poff, sizes):
+            p.data = self.flat_p[o:o + n].view_as(p)
+            p.grad = self.flat_g[o:o + n].view_as(p)
+        self.pidx = {id(p): i for i, p in enumerate(self.params)}
+        self.step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr = torch.tensor([float(model.lr)], dtype=torch.float32, device=dev)
+        self.wd = float(model.optimizer.param_groups[0].get("weight_decay", 0.0))
+        self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+        # ---- per-level shapes, operand copies and work buffers ------------------------------
+        self.h = [l.output_dim_ for l in self.layers]
+        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
+        self.rows = [self.off[L - l] for l in range(L)]           # R_l = rows of level l
+        self.w2, self.w2t, descs = [], [], []
+        for l, layer in enumerate(self.layers):
+            h, din = self.h[l], self.din[l]
+            assert tuple(layer.fc_x.weight.shape) == (h, din) == tuple(layer.fc_neib.weight.shape)
+            ix, inb = self.pidx[id(layer.fc_x.weight)], self.pidx[id(layer.fc_neib.weight)]
+            assert inb == ix + 1, "fc_x / fc_neib must be adjacent in the parameter order"
+            w2 = torch.zeros(2, h, _r8(din), dtype=torch.bfloat16, device=dev)
+            w2t = torch.zeros(2, din, _r8(h), dtype=torch.bfloat16, device=dev) if l > 0 else None
+            self.w2.append(w2)
+            self.w2t.append(w2t)
+            for g, prm in enumerate((layer.fc_x.weight, layer.fc_neib.weight)):
+                descs.append(_PrepDesc(prm.data_ptr(), w2[g].data_ptr(),
+                                       w2t[g].data_ptr() if w2t is not None else None,
+                                       h, din, w2.shape[2], w2t.shape[2] if w2t is not None else 0))
+        raw = bytes((_PrepDesc * len(descs))(*descs))
+        self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n_desc = len(descs)
+        self.max_elems = max(h * d for h, d in zip(self.h, self.din))
+
+        self.all_ids = torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev)
+        self.targets = example_targets.clone()
+        bf, f32 = torch.bfloat16, torch.float32
+        self.agg, self.hout, self.dc, self.dg = [], [], [], []
+        for l in range(L):
+            R = self.rows[l]
+            ld = feats.ld if l == 0 else self.din[l]
+            assert ld % 8 == 0
+            self.agg.append(torch.zeros(R, ld, dtype=bf, device=dev))
+            last = l == L - 1
+            self.hout.append(torch.zeros(R, 2 * self.h[l], dtype=f32 if last else bf, device=dev))
+            self.dc.append(torch.zeros(R, 2 * self.h[l], dtype=bf, device=dev))
+            self.dg.append(torch.zeros(R, 2 * self.din[l], dtype=f32, device=dev) if l > 0 else None)
+        self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
+        self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
+
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.preds = None
+        self.all_ids[:B].copy_(example_ids)
+
+        # warm-up (library handles, allocator) with state restored afterwards, then capture
+        saved = self.flat_p.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._front()
+                if ddp is not None:
+                    torch.distributed.all_reduce(self.flat_g)
+                self._back()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.flat_p.copy_(saved)
+        for t in (self.flat_m, self.flat_v, self.step, self.counter):
+            t.zero_()
+        torch.cuda.synchronize()
+        self.graphs = None
+        if capture:
+            g1 = torch.cuda.CUDAGraph()
+            if ddp is None:
+                with torch.cuda.graph(g1):
+                    self._front()
+                    self._back()
+                self.graphs = (g1, None)
+            else:
+                with torch.cuda.graph(g1):
+                    self._front()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._back()
+                self.graphs = (g1, g2)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _grad_slice(self, prm):
+        i = self.pidx[id(prm)]
+        return self.flat_g[self.poff[i]:self.poff[i + 1]]
+
+    def _linear(self, A, lda, a_rows, a_g0, W, ldw, C, c_dtype, ldc, M, N, K, act, a_gs, w_gs, c_gs):
+        ops._linear_launch(A, lda, a_rows, a_g0, W, ldw, None, C, ldc, M, N, K, act, 2, a_gs, w_gs,
+                           c_gs, nat.BF16, c_dtype)
+
+    # ---- graph bodies ------------------------------------------------------------------------
+    def _front(self):
+        L, B, st, lib = self.L, self.B, self.store, nat.lib()
+        stream = ops._stream()
+        nat.check(lib.gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems, stream),
+                  "prep_weights")
+        # K1: frontier, written in place into the concatenated id buffer
+        rank = self.sampler.shard[0]
+        for k in range(1, L + 1):
+            src = self.all_ids[self.off[k - 1]:self.off[k]]
+            dst = self.all_ids[self.off[k]:self.off[k + 1]]
+            ops.sample_csr(self.csr, src, self.fan[k],
+                           philox={"seed": self.sampler.seed, "call_ctr": self.counter,
+                                   "call_base": k - 1, "g0": rank * self.size[k]}, out=dst)
+        esz = 2
+        for l in range(L):
+            R, h, din = self.rows[l], self.h[l], self.din[l]
+            agg = self.agg[l]
+            if l == 0:
+                xbuf, lda, a_rows = st.data, st.ld, self.all_ids
+                for k in range(L):                       # hop k rows <- mean of hop k+1 table rows
+                    ops._gather_mean_raw(st.data, st.ld, self.all_ids[self.off[k + 1]:self.off[k + 2]],
+                                         self.size[k], self.fan[k + 1], torch.bfloat16, st.ld,
+                                         out=agg[self.off[k]:self.off[k + 1]])
+            else:
+                xbuf, lda, a_rows = self.hout[l - 1], din, None
+                for k in range(L - l):                   # in-order segment means of the level below
+                    ops._gather_mean_raw(xbuf[self.off[k + 1]:self.off[k + 2]], din, None, self.size[k],
+                                         self.fan[k + 1], torch.bfloat16, din,
+                                         out=agg[self.off[k]:self.off[k + 1]])
+            delta = agg.data_ptr() - xbuf.data_ptr()
+            assert delta % esz == 0 and agg.stride(0) == lda
+            last = l == L - 1
+            self._linear(xbuf.data_ptr(), lda, a_rows.data_ptr() if a_rows is not None else None, 1,
+                         self.w2[l].data_ptr(), self.w2[l].shape[2], self.hout[l].data_ptr(),
+                         nat.F32 if last else nat.BF16, 2 * h, R, h, din,
+                         nat.ACT_NONE if last else nat.ACT_RELU, delta // esz,
+                         h * self.w2[l].shape[2], h)
+
+        # head: normalize + fc + loss (stock torch, autograd confined to these few ops)
+        m = self.model
+        emb = self.hout[L - 1].detach().requires_grad_(True)
+        z = self.post(emb) if self.post is not None else emb
+        preds = m.fc(torch.nn.functional.normalize(z, dim=1))
+        loss = self.loss_fn(preds, self.targets.squeeze())
+        d_emb, d_w, d_b = torch.autograd.grad(loss, [emb, m.fc.weight, m.fc.bias])
+        self._grad_slice(m.fc.weight).copy_(d_w.reshape(-1))
+        self._grad_slice(m.fc.bias).copy_(d_b.reshape(-1))
+        self.dc[L - 1].copy_(d_emb)
+        if self.preds is None:
+            self.preds = torch.empty_like(preds)
+        self.preds.copy_(preds.detach())
+
+        # backward through the levels
+        for l in range(L - 1, -1, -1):
+            R, h, din = self.rows[l], self.h[l], self.din[l]
+            dc = self.dc[l]
+            if l == 0:
+                xbuf, lda, a_rows = st.data, st.ld, self.all_ids
+            else:
+                xbuf, lda, a_rows = self.hout[l - 1], din, None
+            delta = (self.agg[l].data_ptr() - xbuf.data_ptr()) // esz
+            ix = self.pidx[id(self.layers[l].fc_x.weight)]               # fc_neib is ix + 1
+            if h % 128 == 0:
+                ops.wgrad(dc, xbuf, lda, a_rows, 1, delta, R, 2 * h, din, h,
+                          out=self.flat_g[self.poff[ix]:self.poff[ix + 2]].view(2, h, din))
+            else:
+                for g in range(2):
+                    src = xbuf if g == 0 else self.agg[l]
+                    ops.wgrad(dc[:, g * h:], src, lda, a_rows if g == 0 else None, 1, 0, R, h, din, h,
+                              out=self.flat_g[self.poff[ix + g]:self.poff[ix + g + 1]].view(1, h, din))
+            if l > 0:
+                w2t = self.w2t[l]
+                # (dX | dAgg) = dC_g @ W_g : NT GEMM against the transposed operand copies
+                self._linear(dc.data_ptr(), 2 * h, None, 0, w2t.data_ptr(), w2t.shape[2],
+                             self.dg[l].data_ptr(), nat.F32, 2 * din, R, din, h, nat.ACT_NONE, h,
+                             din * w2t.shape[2], din)
+                below = self.hout[l - 1]
+                nat.check(lib.gsage_bwd_merge(below.data_ptr(), below.stride(0), self.dg[l].data_ptr(),
+                                              2 * din, din, self.dc[l - 1].data_ptr(),
+                                              self.dc[l - 1].stride(0), self.rows[l - 1], R, din,
+                                              L - l + 1, self.off_host, self.fan_host, stream),
+                          "bwd_merge")
+        if self.ddp is not None:
+            self.flat_g.div_(self.ddp.world)
+
+    def _back(self):
+        lib = nat.lib()
+        n = self.flat_p.numel()
+        nat.check(lib.gsage_clip_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
+                                           self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
+                                           self.partial.data_ptr(), self.lr.data_ptr(),
+                                           self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
+                                           self.gnorm.data_ptr(), ops._stream()), "clip_adam_step")
+        nat.check(lib.gsage_counter_add(self.counter.data_ptr(), self.L, ops._stream()), "counter_add")
+
+    # ---- per-batch entry --------------------------------------------------------------------------
+    def set_progress(self, progress):
+        self.model.lr = self.model.lr_scheduler(progress)
+        self.lr.fill_(float(self.model.lr))
+
+    def __call__(self, ids, targets):
+        self.all_ids[:self.B].copy_(ids, non_blocking=True)
+        self.targets.copy_(targets, non_blocking=True)
+        if self.graphs is None:
+            self._front()
+            if self.ddp is not None:
+                torch.distributed.all_reduce(self.flat_g)
+            self._back()
+        else:
+            self.graphs[0].replay()
+            if self.graphs[1] is not None:
+                torch.distributed.all_reduce(self.flat_g)
+                self.graphs[1].replay()
+        return self.preds

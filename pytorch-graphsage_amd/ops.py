@@ -112,7 +112,7 @@ def _philox_host(seed, call, g0, count, max_deg):
     return ((words * np.uint64(max_deg)) >> np.uint64(32)).astype(np.int64)
 
 
-def sample_csr(csr, ids, n, sel=None, philox=None):
+def sample_csr(csr, ids, n, sel=None, philox=None, out=None):
     """SparseUniformNeighborSampler.__call__ (nn_modules.py:80-101).
 
     ids: LongTensor [M] on csr.device.  Exactly one of
@@ -124,7 +124,9 @@ def sample_csr(csr, ids, n, sel=None, philox=None):
     M = int(ids.shape[0])
     if ids.is_cuda:
         L = nat.lib()
-        out = torch.empty(M * n, dtype=torch.int64, device=ids.device)
+        if out is None:
+            out = torch.empty(M * n, dtype=torch.int64, device=ids.device)
+        assert out.dtype == torch.int64 and out.numel() == M * n and out.is_contiguous()
         if sel is not None:
             sel = sel.contiguous().view(-1)
             assert sel.dtype == torch.int32 and sel.shape[0] == M * n and sel.is_cuda
@@ -162,13 +164,17 @@ def sample_csr(csr, ids, n, sel=None, philox=None):
 # =============================================================================================
 # K2 / K6  gather + mean, segment mean, scatter-add
 # =============================================================================================
-def _gather_mean_raw(table, D, ids, M, n, out_dtype, out_ld=None):
-    """out[i] = mean_j table[ids[i*n+j]] (ids None: rows i*n+j).  table: [R, ld] tensor."""
+def _gather_mean_raw(table, D, ids, M, n, out_dtype, out_ld=None, out=None):
+    """out[i] = mean_j table[ids[i*n+j]] (ids None: rows i*n+j).  table: [R, ld] tensor.
+    `out`: optional preallocated [M, out_ld] destination (a row slice of a larger buffer)."""
     if out_ld is None:
         out_ld = D
     if table.is_cuda:
-        out = (torch.zeros if out_ld != D else torch.empty)(M, out_ld, dtype=out_dtype,
-                                                            device=table.device)
+        if out is None:
+            out = (torch.zeros if out_ld != D else torch.empty)(M, out_ld, dtype=out_dtype,
+                                                                device=table.device)
+        else:
+            assert out.dtype == out_dtype and out.stride(0) == out_ld and out.shape[0] == M
         nat.check(nat.lib().gsage_gather_mean(_ptr(table), _code(table.dtype), table.stride(0),
                                               _ptr(ids), M, n, D, _ptr(out), _code(out_dtype),
                                               out_ld, _stream()), "gather_mean")
@@ -272,6 +278,24 @@ def _prep_weight(W, cdt, epc):
     return _pad_cast(W.detach(), cdt, epc)
 
 
+def wgrad(dC, A, lda, a_rows, a_g0, a_gstride, M, Ntot, K, n_per_group, out=None):
+    """dW_g = dC_g^T @ A_g on the matrix cores (K5b), bf16 operands, fp32 result
+    [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 tensor (table or rows)."""
+    groups = (Ntot + n_per_group - 1) // n_per_group
+    ldk = _round_up(K, 4)
+    nblk = (Ntot + 127) // 128
+    kblk = (ldk + 127) // 128
+    rps = min(1024, max(64, _round_up((M * nblk * kblk + 511) // 512, 16)))
+    S = (M + rps - 1) // rps
+    slabs = torch.empty(S, Ntot, ldk, dtype=torch.float32, device=dC.device)
+    if out is None:
+        out = torch.empty(groups, n_per_group, K, dtype=torch.float32, device=dC.device)
+    nat.check(nat.lib().gsage_wgrad(_ptr(dC), dC.stride(0), _ptr(A), lda, _ptr(a_rows), a_g0,
+                                    a_gstride, M, Ntot, K, n_per_group, rps, _ptr(slabs), ldk,
+                                    _ptr(out), n_per_group * K, _stream()), "wgrad")
+    return out
+
+
 class _Linear(torch.autograd.Function):
     """act(x @ W^T + b) on the matrix cores; backward contractions are plain library GEMMs."""
 
@@ -372,6 +396,7 @@ class _SageProject(torch.autograd.Function):
                            _vp(out.data_ptr() + h * out.element_size()), 2 * h, M, h, Dn, act, 1,
                            0, 0, 0, _code(cdt), _code(out_dtype))
         ctx.save_for_backward(xa, a_rows, an, wxa, wna, out if act == nat.ACT_RELU else None)
+        ctx.grouped = (delta // esz) if grouped else None
         ctx.meta = (act, h, Dx, Dn, x.dtype if x is not None else None, agg.dtype, Wx.dtype, cdt, epc)
         return out
 
@@ -385,14 +410,21 @@ class _SageProject(torch.autograd.Function):
         gc = g.to(cdt)
         gx, gn = gc[:, :h], gc[:, h:]
         dx = dagg = dwx = dwn = None
-        if ctx.needs_input_grad[2]:
+        fused_w = (cdt == torch.bfloat16 and ctx.grouped is not None and h % 128 == 0 and
+                   xa.stride(0) % 4 == 0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
+        if fused_w:
+            # both weight gradients in one MFMA launch; x rows are gathered inside the kernel
+            dw = wgrad(gc.contiguous(), xa, xa.stride(0), a_rows, 1, ctx.grouped, an.shape[0], 2 * h,
+                       Dx, h)
+            dwx, dwn = dw[0].to(wdt), dw[1].to(wdt)
+        if ctx.needs_input_grad[2] and not fused_w:
             if a_rows is not None:
                 M = an.shape[0]
                 xm = _gather_mean_raw(xa, Dx, a_rows, M, 1, cdt, _round_up(Dx, epc))
             else:
                 xm = xa
             dwx = _mm_f32(gx.t(), xm)[:, :Dx].to(wdt)
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and not fused_w:
             dwn = _mm_f32(gn.t(), an)[:, :Dn].to(wdt)
         if ctx.needs_input_grad[0]:
             dx = _mm_f32(gx, wxa)[:, :Dx].to(xdt)

@@ -1,0 +1,128 @@
+"""-m gpu: the hipGraph engines (engine.py) against the eager autograd path and the oracle.
+Both engines draw the same Philox samples as the eager product path for the same seed, so
+predictions / gradients / updated weights are directly comparable."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+from torch.nn import functional as F
+
+from conftest import pkg
+from util import close, close_fro
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+DEV = "cuda"
+
+
+def _problem(n=600, D=40, C=5, seed=0, max_deg=30):
+    rng = np.random.RandomState(seed)
+    deg = rng.randint(0, max_deg, size=n + 1)
+    deg[0], deg[7], deg[n] = 0, 0, 3
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    data = rng.randint(1, n + 1, size=int(indptr[-1]))
+    adj = sparse.csr_matrix((data, gs.store.row_positions(indptr), indptr), shape=(n + 1, int(deg.max())))
+    feats = rng.normal(size=(n + 1, D)).astype(np.float32)
+    feats[0] = 0
+    return adj, feats, rng
+
+
+def _model(adj, D, C, dims, fans, seed=3):
+    torch.manual_seed(seed)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": (lambda x: x) if i == len(dims) - 1 else F.relu}
+             for i, (h, f) in enumerate(zip(dims, fans))]
+    m = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj,
+                        train_adj=adj, prep_class=gs.prep_lookup["identity"],
+                        aggregator_class=gs.aggregator_lookup["mean"], input_dim=D,
+                        n_nodes=adj.shape[0], n_classes=C, layer_specs=specs, lr_init=0.01,
+                        weight_decay=1e-4)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    m.train_sampler.seed = m.val_sampler.seed = 77
+    return m.to(DEV)
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    yield
+    ops.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((16, 8), (5, 3), 33),
+                                         ((32, 16, 8), (4, 3, 2), 20)])
+@pytest.mark.parametrize("capture", [False, True])
+def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
+    adj, feats, rng = _problem()
+    D, C = feats.shape[1], 5
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ref_model = _model(adj, D, C, dims, fans)
+    eng_model = _model(adj, D, C, dims, fans)
+    eng_model.load_state_dict(ref_model.state_dict())
+    ref_model.optimizer = torch.optim.Adam(ref_model.parameters(), lr=0.01, weight_decay=1e-4)
+    loss_fn = gs.ProblemLosses.classification
+    assert gs.engine.FusedMeanTrainStep.supports(eng_model, store)
+    batches = [(torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV),
+                torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)) for _ in range(3)]
+    eng = gs.engine.FusedMeanTrainStep(eng_model, store, loss_fn, batches[0][0], batches[0][1], capture=capture)
+    for step, (ids, tg) in enumerate(batches):
+        # every step is checked from identical weights (Adam's sign-like first updates would
+        # otherwise amplify bf16 round-off into O(lr) weight differences)
+        ref_model.load_state_dict(eng_model.state_dict())
+        p_ref = ref_model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn).detach().float().cpu().numpy()
+        p_eng = eng(ids, tg).detach().float().cpu().numpy()
+        # same samples, same forward kernels: predictions agree to bf16 round-off of the weights
+        close(p_eng, p_ref, ("preds", step), 3e-2, 3e-2)
+        for (k, a), (_, b) in zip(eng_model.named_parameters(), ref_model.named_parameters()):
+            close_fro(a.grad.cpu().numpy(), b.grad.cpu().numpy(), ("grad", step, k), 0.1)
+            if step == 0:
+                close_fro(a.detach().cpu().numpy(), b.detach().cpu().numpy(), ("weight", k), 0.05)
+    # the Parameters are views of the flat bucket: state_dict stays usable, eval path still works
+    ev = eng_model(batches[0][0], store, train=False)
+    assert ev.shape == (B, C) and torch.isfinite(ev).all()
+    eng_model.train_sampler.csr(DEV).check()
+
+
+def test_fused_engine_first_step_against_oracle():
+    """One engine step vs the fp32 CPU oracle fed the same Philox sel (bf16 tolerance)."""
+    from oracle import cpu as ocpu
+    from oracle import torch_ref as tref
+    adj, feats, rng = _problem(seed=5)
+    D, C, B, fans, dims = feats.shape[1], 5, 48, (6, 4), (128, 128)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    model = _model(adj, D, C, dims, fans)
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ids = rng.randint(1, adj.shape[0], size=B)
+    tg = rng.randint(0, C, size=(B, 1))
+    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification,
+                                       torch.from_numpy(ids).to(DEV), torch.from_numpy(tg).to(DEV))
+    preds = eng(torch.from_numpy(ids).to(DEV), torch.from_numpy(tg).to(DEV)).cpu().numpy()
+    sels = [ocpu.philox_sel(77, 0, 0, B * fans[0], adj.shape[1]).reshape(B, fans[0]),
+            ocpu.philox_sel(77, 1, 0, B * fans[0] * fans[1], adj.shape[1]).reshape(-1, fans[1])]
+    fb = store.dense().cpu()                                  # the bf16-rounded table, as fp32
+    ref = tref.train_step(w0, tref.Adam(weight_decay=1e-4), 0.01, "classification", ids, fb,
+                          torch.from_numpy(tg), adj.indptr.astype(np.int64), adj.data.astype(np.int64),
+                          fans, sels, "mean", "identity", adj.shape[0])
+    close(preds, ref["preds"].numpy(), "preds vs oracle", 3e-2, 3e-2)
+    assert abs(float(eng.gnorm.item()) - ref["gradnorm"]) < 0.05 * max(1.0, ref["gradnorm"])
+    for k, v in model.named_parameters():
+        close_fro(v.grad.cpu().numpy(), ref["clipped"][k].numpy(), ("grad vs oracle", k), 0.1)
+
+
+def test_captured_autograd_engine_runs_and_advances_samples():
+    adj, feats, rng = _problem(seed=9)
+    D, C, B = feats.shape[1], 5, 32
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    model = _model(adj, D, C, (16, 16), (5, 3))
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)
+    eng = gs.engine.CapturedTrainStep(model, store, gs.ProblemLosses.classification, ids, tg)
+    a = eng(ids, tg).clone()
+    b = eng(ids, tg).clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)     # new samples + updated weights
+    assert int(eng.counter.item()) == 4

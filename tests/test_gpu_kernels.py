@@ -275,3 +275,26 @@ def test_attn_aggregate_forward_backward():
         close(na.grad.cpu().numpy(), na_c.grad.numpy(), "dna", 1e-4, 1e-5)
         close(xa.grad.cpu().numpy(), xa_c.grad.numpy(), "dxa", 1e-4, 1e-5)
         close(nb.grad.cpu().numpy(), nb_c.grad.numpy(), "dnb", 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,groups,gather", [(16, 128, 8, 1, False), (100, 128, 602, 2, True),
+                                                 (513, 128, 256, 2, False), (1300, 4, 70, 1, False),
+                                                 (3000, 128, 1433, 2, True), (64, 128, 128, 1, True)])
+def test_wgrad_mfma_vs_fp64(M, N, K, groups, gather):
+    """dW_g = dC_g^T @ A_g (K5b): exact in fp32 up to summation order on bf16-rounded operands."""
+    rng = np.random.RandomState(M + N + K)
+    ld = ((K + 63) // 64) * 64
+    R = max(M, 700) if gather else M
+    tab = np.zeros((groups, R, ld), dtype=np.float32)
+    tab[:, :, :K] = bf16_round(rng.normal(size=(groups, R, K)))
+    dC = bf16_round(rng.normal(size=(M, groups * N)))
+    rows = rng.randint(0, R, size=M) if gather else np.arange(M)
+    tabt = torch.from_numpy(tab).to(DEV).bfloat16().contiguous()
+    dCt = torch.from_numpy(dC).to(DEV).bfloat16().contiguous()
+    a_rows = torch.from_numpy(rows).to(DEV) if gather else None
+    out = ops.wgrad(dCt, tabt, ld, a_rows, 1, R * ld, M, groups * N, K, N)
+    assert out.shape == (groups, N, K) and out.dtype == torch.float32
+    for g in range(groups):
+        src = tab[g][rows] if (gather and g == 0) else tab[g][:M]
+        ref = dC[:, g * N:(g + 1) * N].astype(np.float64).T @ src[:, :K].astype(np.float64)
+        close(out[g].cpu().numpy(), ref, ("wgrad", M, N, K, g), 2e-5, 2e-6)
