@@ -108,6 +108,14 @@ int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *i
                       int32_t n, int64_t D, void *out, int out_dtype, int64_t out_ld,
                       void *stream);
 
+/* Up to 8 gather+mean problems (e.g. all hops of one level) in one launch; bf16 in / bf16 out.
+ * tables / ids / outs / M / n are HOST arrays of n_seg entries holding DEVICE pointers and sizes;
+ * segment s computes outs[s][i] = mean_j tables[s][ rows(i, j) ] exactly like gsage_gather_mean
+ * (ids[s] == NULL: rows i*n+j of tables[s]).  All segments share ld, D, out_ld. */
+int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
+                            void *const *outs, const int64_t *M, const int32_t *n, int dtype,
+                            int64_t ld, int64_t D, int out_dtype, int64_t out_ld, void *stream);
+
 /* Backward of the segment mean w.r.t. contiguous neighbour rows (autograd of nn_modules.py:198):
  *     dneibs[i*n+j, c] = dagg[i, c] / n          (fp32 in, fp32 out) */
 int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, int64_t D,
@@ -146,14 +154,13 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
  *     weights (autograd of nn_modules.py:189-190,200 under loss.backward(), models.py:100)
  *
  *     out[g*out_gstride + n*K + k] = sum_m dC[m, g*n_per_group + n] * A_g[m, k]
- *         A_g row m = (a_rows ? A + a_rows[m]*lda : A + m*lda) + g*a_gstride   (a_rows: group 0
- *         only when a_rows_group0_only)            dC, A: bf16;  out: fp32 [groups, n_per_group, K]
+ *         A_g = A + g*a_gstride  ([M, lda] row-major)      dC, A: bf16;  out: fp32 [groups, n_per_group, K]
  *     The reduction over M is split into ceil(M / rows_per_split) slices whose partial tiles are
  *     written to `slabs` (fp32 [slices, Ntot, ldk], caller-allocated) and summed deterministically.
  *     Needs ldc, lda, ldk % 4 == 0, Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0,
  *     n_per_group % 128 == 0 unless there is a single group. */
-int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, const int64_t *a_rows,
-                int a_rows_group0_only, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
+int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
+                int64_t Ntot, int64_t K,
                 int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
                 int64_t out_gstride, void *stream);
 /* [host] number of slabs gsage_wgrad writes for (M, rows_per_split). */
@@ -188,6 +195,19 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Classification head, forward + backward   replaces F.normalize(dim=1) -> fc -> F.cross_entropy
+ *                                            (models.py:90-91, problem.py:34) and their autograd
+ *
+ *     z = E / max(||E||_2, 1e-12) (row-wise);  preds = z W^T + bias;  loss = mean CE(preds, targets)
+ *     dE (bf16 or fp32, [B, ldd]), dW [C, D], db [C] = gradients of loss;  loss may be NULL.
+ *     C <= 64, D <= 1024.  scratch: fp32, gsage_head_ce_scratch(B, C, D) elements. */
+int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias,
+                  const int64_t *targets, int32_t B, int32_t C, int32_t D, float *preds, void *dE,
+                  int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
+                  void *stream);
+int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
+
+/* ------------------------------------------------------------------------------------------
  * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86
  * under autograd), used by the hipGraph engine.
  * ---------------------------------------------------------------------------------------- */
@@ -195,25 +215,30 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
 /* clip_grad_norm(params, max_norm) + Adam(betas, eps, L2 weight_decay) over FLAT fp32 buckets of n
  * elements: p (parameters), g (gradients; overwritten with the clipped gradient), m, v (Adam
  * moments).  lr and step are DEVICE scalars (float / int64) so a captured graph follows the LR
- * schedule and counts steps; step is incremented by one.  partial: fp32 scratch of
- * gsage_adam_partials(n) elements.  norm_out (may be NULL) receives the pre-clip gradient norm. */
+ * schedule and counts steps.  step_is_current == 0: this call is update number *step + 1 and
+ * increments *step afterwards; != 0: *step was already advanced for this update (by
+ * gsage_prep_weights' tick) and is left alone.  partial: fp32 scratch of gsage_adam_partials(n)
+ * elements.  norm_out (may be NULL) receives the pre-clip gradient norm. */
 int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
-                         float weight_decay, float max_norm, float *norm_out, void *stream);
+                         float weight_decay, float max_norm, float *norm_out, int step_is_current,
+                         void *stream);
 int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
  * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy
  * dst_t[c, r] (leading dimension dst_t_ld).  `descs` is a DEVICE array of n_desc descriptors;
  * padding columns of dst / dst_t are not written (allocate them zeroed).
- * max_elems = max rows*cols over the descriptors. */
+ * max_elems = max rows*cols over the descriptors.  Being the first launch of a step it can also
+ * advance two device counters: *tick0 += inc0, *tick1 += inc1 (either pointer may be NULL). */
 typedef struct {
     const float *src;
     uint16_t *dst;
     uint16_t *dst_t;
     int32_t rows, cols, dst_ld, dst_t_ld;
 } gsage_prep_desc;
-int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, void *stream);
+int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int64_t *tick0,
+                       int64_t inc0, int64_t *tick1, int64_t inc1, void *stream);
 
 /* Gradient of a level's ReLU output H (bf16 [R, ldh], rows = hops concatenated, hop k starting at
  * row off[k] with fan-out fan[k] relative to hop k-1):

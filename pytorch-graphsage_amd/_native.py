@@ -40,17 +40,21 @@ SIGNATURES = {
     "gsage_mt_choice_i32": (_i64, [_vp, _i64, _i64, _vp]),
     "gsage_mt_permutation": (None, [_vp, _i64, _vp]),
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
+    "gsage_gather_mean_multi": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64, _vp]),
     "gsage_segment_mean_bwd": (_int, [_vp, _i64, _i64, _i32, _i64, _vp, _i64, _vp]),
     "gsage_scatter_add_rows": (_int, [_vp, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _i64, _vp]),
     "gsage_linear_nt": (_int, [_vp, _int, _i64, _vp, _int, _vp, _i64, _vp, _vp, _int, _i64, _i64,
                                _i64, _i64, _int, _int, _i64, _i64, _i64, _vp]),
-    "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _vp,
-                           _i64, _vp, _i64, _vp]),
+    "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
+                           _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
+    "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
+                             _vp, _vp, _vp]),
+    "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
-                                    _f32, _vp, _vp]),
+                                    _f32, _vp, _int, _vp]),
     "gsage_adam_partials": (_int, [_i64]),
-    "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp]),
+    "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
     "gsage_bwd_merge": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp,
                                _vp, _vp]),
     "gsage_pool_mlp": (_int, [_vp, _int, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _int,

@@ -55,55 +55,99 @@ struct chunk_io<float, VEC> {
     }
 };
 
+// One work item: 16-byte column chunk c0 of output row `row` = mean of n table rows.
 // TI = table element type, TO = output element type, VEC elements per chunk (both sides).
 template <typename TI, typename TO, int VEC>
-__global__ void __launch_bounds__(256)
-k_gather_mean(const TI *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M,
-              int32_t n, int32_t D, int32_t chunks, TO *__restrict__ out, int64_t out_ld)
+__device__ __forceinline__ void gather_mean_chunk(const TI *__restrict__ table, int64_t ld,
+                                                  const int64_t *__restrict__ ids, int64_t row,
+                                                  int32_t n, int32_t D, int32_t c0,
+                                                  TO *__restrict__ out, int64_t out_ld)
 {
     using in_io = chunk_io<TI, VEC>;
     using out_io = chunk_io<TO, VEC>;
     using in_raw = typename in_io::raw;
     using out_raw = typename out_io::raw;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const int64_t base = row * (int64_t)n;
+    int32_t j = 0;
+    // 8 then 4 independent 16-byte loads in flight per lane (HBM latency ~ 1-2 us under load)
+    for (; j + 8 <= n; j += 8) {
+        int64_t r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = ids ? ids[base + j + u] : base + j + u;
+        in_raw v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + r[u] * ld + c0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) in_io::accumulate(v[u], acc);
+    }
+    for (; j + 4 <= n; j += 4) {
+        int64_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = ids ? ids[base + j + u] : base + j + u;
+        in_raw v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + r[u] * ld + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) in_io::accumulate(v[u], acc);
+    }
+    for (; j < n; ++j) {
+        const int64_t r = ids ? ids[base + j] : base + j;
+        const in_raw a = *reinterpret_cast<const in_raw *>(table + r * ld + c0);
+        in_io::accumulate(a, acc);
+    }
+    const float fn = (float)n;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = (c0 + e < D) ? acc[e] / fn : 0.f;   // n == 1: exact
+    *reinterpret_cast<out_raw *>(out + row * out_ld + c0) = out_io::pack(acc);
+}
 
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather_mean(const TI *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M,
+              int32_t n, int32_t D, int32_t chunks, TO *__restrict__ out, int64_t out_ld)
+{
     const int64_t total = M * (int64_t)chunks;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    const float fn = (float)n;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
         const int64_t row = (total <= 0xffffffffLL) ? (int64_t)((uint32_t)t / (uint32_t)chunks)
                                                     : t / chunks;
         const int32_t c0 = (int32_t)(t - row * chunks) * VEC;
-        float acc[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        gather_mean_chunk<TI, TO, VEC>(table, ld, ids, row, n, D, c0, out, out_ld);
+    }
+}
 
-        const int64_t base = row * (int64_t)n;
-        int32_t j = 0;
-        // 4 independent loads in flight per lane
-        for (; j + 4 <= n; j += 4) {
-            int64_t r0, r1, r2, r3;
-            if (ids) {
-                r0 = ids[base + j]; r1 = ids[base + j + 1]; r2 = ids[base + j + 2]; r3 = ids[base + j + 3];
-            } else {
-                r0 = base + j; r1 = r0 + 1; r2 = r0 + 2; r3 = r0 + 3;
-            }
-            const in_raw a = *reinterpret_cast<const in_raw *>(table + r0 * ld + c0);
-            const in_raw b = *reinterpret_cast<const in_raw *>(table + r1 * ld + c0);
-            const in_raw c = *reinterpret_cast<const in_raw *>(table + r2 * ld + c0);
-            const in_raw d = *reinterpret_cast<const in_raw *>(table + r3 * ld + c0);
-            in_io::accumulate(a, acc);
-            in_io::accumulate(b, acc);
-            in_io::accumulate(c, acc);
-            in_io::accumulate(d, acc);
-        }
-        for (; j < n; ++j) {
-            const int64_t r = ids ? ids[base + j] : base + j;
-            const in_raw a = *reinterpret_cast<const in_raw *>(table + r * ld + c0);
-            in_io::accumulate(a, acc);
-        }
+// Several gather+mean problems in ONE launch (all the hops of a level): segment s covers work
+// items [first[s], first[s+1]).  Small segments ride along with the big one instead of paying
+// their own launch + tail.
+struct MultiSeg {
+    const void *table[8];
+    const int64_t *ids[8];
+    void *out[8];
+    int64_t M[8];
+    int64_t first[9];
+    int32_t n[8];
+    int32_t n_seg;
+};
+
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld)
+{
+    const int64_t total = q.first[q.n_seg];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        int s = 0;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = (c0 + e < D) ? acc[e] / fn : 0.f;   // n == 1: exact
-        *reinterpret_cast<out_raw *>(out + row * out_ld + c0) = out_io::pack(acc);
+        for (int j = 1; j < 8; ++j)
+            if (j < q.n_seg && t >= q.first[j]) s = j;
+        const int64_t u = t - q.first[s];
+        const int64_t row = u / chunks;
+        const int32_t c0 = (int32_t)(u - row * chunks) * VEC;
+        gather_mean_chunk<TI, TO, VEC>((const TI *)q.table[s], ld, q.ids[s], row, q.n[s], D, c0,
+                                       (TO *)q.out[s], out_ld);
     }
 }
 
@@ -214,6 +258,40 @@ int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *i
         return dispatch_vec<float, uint16_t>(table, ld, ids, M, n, D, out, out_ld, s);
     set_error("gather_mean: unsupported dtype pair %d -> %d", dtype, out_dtype);
     return GSAGE_EINVAL;
+}
+
+int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
+                            void *const *outs, const int64_t *M, const int32_t *n, int dtype,
+                            int64_t ld, int64_t D, int out_dtype, int64_t out_ld, void *stream)
+{
+    GSAGE_REQUIRE(n_seg >= 1 && n_seg <= 8, "gather_mean_multi: 1..8 segments");
+    GSAGE_REQUIRE(tables && ids && outs && M && n, "gather_mean_multi: null pointer");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 && out_dtype == GSAGE_BF16,
+                  "gather_mean_multi: bf16 tables and outputs only");
+    GSAGE_REQUIRE(D > 0 && ld % 8 == 0 && out_ld % 8 == 0 && ceil_div(D, 8) * 8 <= ld &&
+                  ceil_div(D, 8) * 8 <= out_ld, "gather_mean_multi: needs 16-byte row chunks");
+    const int32_t chunks = (int32_t)ceil_div(D, 8);
+    MultiSeg q;
+    q.n_seg = n_seg;
+    q.first[0] = 0;
+    for (int s = 0; s < 8; ++s) {
+        const bool live = s < n_seg;
+        q.table[s] = live ? tables[s] : nullptr;
+        q.ids[s] = live ? ids[s] : nullptr;
+        q.out[s] = live ? outs[s] : nullptr;
+        q.M[s] = live ? M[s] : 0;
+        q.n[s] = live ? n[s] : 1;
+        if (live) {
+            GSAGE_REQUIRE(q.table[s] && q.out[s] && q.M[s] >= 0 && q.n[s] > 0 &&
+                          aligned_to(q.table[s], 16) && aligned_to(q.out[s], 16),
+                          "gather_mean_multi: bad segment %d", s);
+        }
+        q.first[s + 1] = q.first[s] + q.M[s] * chunks;
+    }
+    if (q.first[n_seg] == 0) return GSAGE_OK;
+    hipLaunchKernelGGL((k_gather_mean_multi<uint16_t, uint16_t, 8>), dim3(grid_for(q.first[n_seg])),
+                       dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
+    return check_launch("gather_mean_multi");
 }
 
 int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, int64_t D,

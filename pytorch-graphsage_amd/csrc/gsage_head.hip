@@ -1,0 +1,285 @@
+// gsage_head.hip -- the classification head of GSSupervised, forward AND backward, in two launches.
+//
+// Replaces (reference models.py:90-91, problem.py:34 and their autograd under models.py:100):
+//     out   = F.normalize(emb, p=2, dim=1, eps=1e-12)
+//     preds = fc(out)                               nn.Linear(2h, n_classes)
+//     loss  = F.cross_entropy(preds, targets)       (mean over the batch)
+//     loss.backward() -> d emb, d fc.weight, d fc.bias
+// which stock PyTorch runs as ~35 sub-5-microsecond kernels (normalise, addmm, log_softmax, nll,
+// their backwards, a 41x512x256 GEMM through hipBLASLt, reductions, fills).  The work is tiny
+// (B x 2h x C = 512 x 256 x 41), so the cost is launches, not flops: here a workgroup keeps
+// fc.weight in LDS and walks its rows, a second tiny kernel sums the per-workgroup partial
+// weight gradients deterministically.
+#include "gsage_common.h"
+
+namespace gsage {
+
+constexpr int HEAD_CMAX = 64;      // classes handled per lane pass
+constexpr int HEAD_DMAX = 1024;    // max embedding width (2h)
+
+struct HeadParams {
+    const float *E;          // [B, lde] fp32 embedding (last SAGE layer output)
+    const float *W;          // [C, D] fc.weight
+    const float *bias;       // [C]
+    const int64_t *targets;  // [B] class ids
+    float *preds;            // [B, C] logits
+    void *dE;                // [B, ldd] gradient w.r.t. E (bf16 or fp32)
+    float *partial;          // [grid, C*D + C + 1] per-workgroup dW | db | loss
+    int64_t lde, ldd;
+    int32_t B, C, D, rows_per_wg, dE_dtype;
+};
+
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum over 256 threads (4 waves) through a 4-float LDS scratch
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    v = wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int KPT>
+__global__ void __launch_bounds__(256)
+k_head_ce(const HeadParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int C = p.C, D = p.D;
+    const int ldw = D + 1;                        // +1 float: conflict-free column walks
+    float *Ws = lds;                              // [C][ldw]
+    float *zs = Ws + C * ldw;                     // [D] normalised row
+    float *part = zs + D;                         // [4][HEAD_CMAX] partial logits
+    float *dls = part + 4 * HEAD_CMAX;            // [HEAD_CMAX] d logits
+    float *red = dls + HEAD_CMAX;                 // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // fc.weight -> LDS, 8 independent loads in flight per thread before the stores
+    for (int k = tid; k < D; k += 256) {
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = p.W[(int64_t)(c + u) * D + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Ws[(c + u) * ldw + k] = w[u];
+        }
+        for (; c < C; ++c) Ws[c * ldw + k] = p.W[(int64_t)c * D + k];
+    }
+
+    float accW[HEAD_CMAX][KPT];                   // dW partial for this thread's KPT columns
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c)
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) accW[c][j] = 0.f;
+    float acc_db = 0.f, acc_loss = 0.f;
+    __syncthreads();
+
+    const int row0 = blockIdx.x * p.rows_per_wg;
+    const float invB = 1.f / (float)p.B;
+    for (int r = 0; r < p.rows_per_wg; ++r) {
+        const int i = row0 + r;
+        if (i >= p.B) break;                      // block-uniform
+        // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12))
+        float e[KPT], ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            e[j] = (k < D) ? p.E[(int64_t)i * p.lde + k] : 0.f;
+            ss += e[j] * e[j];
+        }
+        const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+        float z[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            z[j] = e[j] / nrm;
+            if (k < D) zs[k] = z[j];
+        }
+        __syncthreads();
+        // 2. logits: lane c of wave w sums its quarter of the columns
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains (LDS latency)
+            if (lane < C) {
+                const int k0 = wave * ((D + 3) / 4), k1 = min(D, k0 + (D + 3) / 4);
+                const float *wr = Ws + lane * ldw;
+                int k = k0;
+                for (; k + 4 <= k1; k += 4) {
+                    s0 += zs[k] * wr[k];
+                    s1 += zs[k + 1] * wr[k + 1];
+                    s2 += zs[k + 2] * wr[k + 2];
+                    s3 += zs[k + 3] * wr[k + 3];
+                }
+                for (; k < k1; ++k) s0 += zs[k] * wr[k];
+            }
+            part[wave * HEAD_CMAX + lane] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        // 3. softmax / loss / d logits (wave 0)
+        if (wave == 0) {
+            const bool ok = lane < C;
+            float logit = -INFINITY;
+            if (ok)
+                logit = part[lane] + part[HEAD_CMAX + lane] + part[2 * HEAD_CMAX + lane] +
+                        part[3 * HEAD_CMAX + lane] + p.bias[lane];
+            const float mx = wave_max64(logit);
+            const float ex = ok ? expf(logit - mx) : 0.f;
+            const float den = wave_sum64(ex);
+            const int64_t t = p.targets[i];
+            const float prob = ex / den;
+            const float dl = ok ? (prob - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
+            dls[lane] = dl;
+            if (ok) p.preds[(int64_t)i * C + lane] = logit;
+            if ((int64_t)lane == t) acc_loss += -(logit - mx - logf(den));
+            acc_db += dl;
+        }
+        __syncthreads();
+        // 4. d z, d emb, dW accumulation (thread <-> columns)
+        float dz[KPT], zdz = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (k < D) {
+                int c = 0;
+                for (; c + 4 <= C; c += 4) {
+                    s0 += dls[c] * Ws[c * ldw + k];
+                    s1 += dls[c + 1] * Ws[(c + 1) * ldw + k];
+                    s2 += dls[c + 2] * Ws[(c + 2) * ldw + k];
+                    s3 += dls[c + 3] * Ws[(c + 3) * ldw + k];
+                }
+                for (; c < C; ++c) s0 += dls[c] * Ws[c * ldw + k];
+            }
+            const float s = (s0 + s1) + (s2 + s3);
+            dz[j] = s;
+            zdz += z[j] * s;
+        }
+        zdz = block_sum(zdz, red);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            if (k < D) {
+                const float g = (dz[j] - z[j] * zdz) / nrm;
+                if (p.dE_dtype == GSAGE_BF16)
+                    ((uint16_t *)p.dE)[(int64_t)i * p.ldd + k] = f32_to_bf16(g);
+                else
+                    ((float *)p.dE)[(int64_t)i * p.ldd + k] = g;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HEAD_CMAX; ++c) {
+            if (c < C) {
+                const float dl = dls[c];
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) accW[c][j] += dl * z[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    float *out = p.partial + (int64_t)blockIdx.x * ((int64_t)C * D + C + 1);
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c)
+        if (c < C)
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int k = tid + 256 * j;
+                if (k < D) out[c * D + k] = accW[c][j];
+            }
+    if (wave == 0) {
+        if (lane < C) out[C * D + lane] = acc_db;
+        const float l = wave_sum64(acc_loss);
+        if (lane == 0) out[C * D + C] = l;
+    }
+}
+
+// dW | db | loss = sum over workgroups of the partials (deterministic order).  64 outputs per
+// block; the 4 waves each sum a quarter of the workgroup range with 8 loads in flight.
+__global__ void __launch_bounds__(256)
+k_head_reduce(const float *__restrict__ partial, int32_t n_wg, int64_t width, int64_t cd, int32_t C,
+              float *__restrict__ dW, float *__restrict__ db, float *__restrict__ loss, float inv_b)
+{
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+    const int per = (n_wg + 3) / 4;
+    const int g0 = q * per, g1 = min(n_wg, g0 + per);
+    float s = 0.f;
+    if (t < width) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(g + u) * width + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < g1; ++g) s += partial[(int64_t)g * width + t];
+    }
+    red[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && t < width) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (t < cd) dW[t] = s;
+        else if (t < cd + C) db[t - cd] = s;
+        else if (loss) *loss = s * inv_b;
+    }
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D)
+{
+    const int rows_per_wg = 2;
+    const int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+    return n_wg * ((int64_t)C * D + C + 1);
+}
+
+int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias,
+                  const int64_t *targets, int32_t B, int32_t C, int32_t D, float *preds, void *dE,
+                  int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
+                  void *stream)
+{
+    GSAGE_REQUIRE(E && W && bias && targets && preds && dE && dW && db && scratch, "head_ce: null pointer");
+    GSAGE_REQUIRE(B > 0 && C > 0 && C <= HEAD_CMAX && D > 0 && D <= HEAD_DMAX,
+                  "head_ce: needs 1 <= n_classes <= %d and 1 <= width <= %d", HEAD_CMAX, HEAD_DMAX);
+    GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
+    HeadParams p;
+    p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.preds = preds; p.dE = dE;
+    p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = 2;
+    p.dE_dtype = dE_dtype;
+    const int n_wg = (B + p.rows_per_wg - 1) / p.rows_per_wg;
+    const size_t lds = sizeof(float) * ((size_t)C * (D + 1) + D + 4 * HEAD_CMAX + HEAD_CMAX + 4);
+    GSAGE_REQUIRE(lds <= 160 * 1024, "head_ce: fc.weight does not fit in LDS");
+    if (D <= 256)
+        hipLaunchKernelGGL(k_head_ce<1>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+    else if (D <= 512)
+        hipLaunchKernelGGL(k_head_ce<2>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_head_ce<4>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+    int rc = check_launch("head_ce");
+    if (rc != GSAGE_OK) return rc;
+    const int64_t width = (int64_t)C * D + C + 1;
+    hipLaunchKernelGGL(k_head_reduce, dim3((unsigned)ceil_div(width, 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const float *)scratch, n_wg, width, (int64_t)C * D, C, dW,
+                       db, loss, 1.f / (float)B);
+    return check_launch("head_reduce");
+}
+
+}  // extern "C"

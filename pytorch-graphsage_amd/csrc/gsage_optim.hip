@@ -47,7 +47,7 @@ struct AdamParams {
     int64_t *step;              // device step counter; this launch uses *step + 1
     float *norm_out;            // optional: total gradient norm before clipping
     int64_t n;
-    int32_t n_partial;
+    int32_t n_partial, step_off;
     float beta1, beta2, eps, weight_decay, max_norm;
 };
 
@@ -61,7 +61,7 @@ k_adam_clip(const AdamParams a)
     const float total = sqrtf(sq);
     float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
     coef = coef < 1.f ? coef : 1.f;
-    const float t = (float)(*a.step + 1);
+    const float t = (float)(*a.step + a.step_off);
     const float bc1 = 1.f - powf(a.beta1, t);
     const float bc2 = 1.f - powf(a.beta2, t);
     const float step_size = *a.lr / bc1;
@@ -94,8 +94,14 @@ struct PrepDesc {
 };
 
 __global__ void __launch_bounds__(256)
-k_prep_weights(const PrepDesc *__restrict__ descs)
+k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0, int64_t *tick1,
+               int64_t inc1)
 {
+    // first kernel of a step: also advances the step's device counters (Adam step, Philox call)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (tick0) *tick0 += inc0;
+        if (tick1) *tick1 += inc1;
+    }
     const PrepDesc d = descs[blockIdx.y];
     const int64_t total = (int64_t)d.rows * d.cols;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -174,7 +180,8 @@ int gsage_adam_partials(int64_t n)
 
 int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
-                         float weight_decay, float max_norm, float *norm_out, void *stream)
+                         float weight_decay, float max_norm, float *norm_out, int step_is_current,
+                         void *stream)
 {
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0, "clip_adam_step: empty bucket");
@@ -186,19 +193,23 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     AdamParams a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
     a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.weight_decay = weight_decay; a.max_norm = max_norm;
+    a.weight_decay = weight_decay; a.max_norm = max_norm; a.step_off = step_is_current ? 0 : 1;
     hipLaunchKernelGGL(k_adam_clip, dim3(grid_for(n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;
-    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, step);
-    return check_launch("step_inc");
+    if (!step_is_current) {
+        hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, step);
+        rc = check_launch("step_inc");
+    }
+    return rc;
 }
 
-int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, void *stream)
+int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int64_t *tick0,
+                       int64_t inc0, int64_t *tick1, int64_t inc1, void *stream)
 {
     GSAGE_REQUIRE(descs && n_desc > 0 && max_elems > 0, "prep_weights: bad arguments");
     hipLaunchKernelGGL(k_prep_weights, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
-                       (hipStream_t)stream, (const PrepDesc *)descs);
+                       (hipStream_t)stream, (const PrepDesc *)descs, tick0, inc0, tick1, inc1);
     return check_launch("prep_weights");
 }
 

@@ -17,7 +17,6 @@
 // a workgroup = 4 waves on 4 adjacent k-tiles sharing the dC rows through L1; the reduction over
 // M is split across grid.x into `rows_per_split` slices whose partial tiles go to fp32 slabs
 // (deterministic; summed by k_reduce_slabs -- no atomics).  MFMA-bound per wave, L2-bound overall.
-// A rows may be gathered through a_rows (feats[ids] is never materialised for the backward).
 #include "gsage_common.h"
 
 namespace gsage {
@@ -27,15 +26,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
 
 struct WgradParams {
     const uint16_t *dC;
     const uint16_t *A;
-    const int64_t *a_rows;
     float *slabs;
     int64_t ldc, lda, a_gstride;
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
-    int32_t a_rows_group0_only;
 };
 
 // operand for column residue E out of eight 8-byte row segments
@@ -50,6 +48,79 @@ __device__ __forceinline__ u32x4 pack_column(const u32x2 (&v)[8])
     return o;
 }
 
+__device__ __forceinline__ void mma_step(const u32x2 (&c_cur)[8], const u32x2 (&a_cur)[8],
+                                         f32x16_t (&acc)[4][4])
+{
+    u32x4 opb[4], opa[4];
+    opb[0] = pack_column<0>(a_cur);
+    opb[1] = pack_column<1>(a_cur);
+    opb[2] = pack_column<2>(a_cur);
+    opb[3] = pack_column<3>(a_cur);
+    opa[0] = pack_column<0>(c_cur);
+    opa[1] = pack_column<1>(c_cur);
+    opa[2] = pack_column<2>(c_cur);
+    opa[3] = pack_column<3>(c_cur);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, opa[e]), __builtin_bit_cast(bf16x8_t, opb[f]),
+                acc[e][f], 0, 0, 0);
+}
+
+// Software pipeline (one wave per SIMD has nothing else to hide latency with): phase s issues the
+// 16 loads of step s+2, then runs the 16 MFMAs of step s -- two steps (16 KiB per wave) stay in
+// flight.  3 register slots with static numbering (loop unrolled x3); vmcnt retires in order, so
+// a phase only waits for loads issued two phases earlier.  No selects on loaded data in here
+// (see the column-validity note in the kernel), so hipcc does not wait right after issue.
+__device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint16_t *A,
+                                               int64_t m_begin, int64_t m_end, int64_t n_off,
+                                               int64_t k_off, int half, f32x16_t (&acc)[4][4])
+{
+    u32x2 cb[3][8], ab[3][8];
+    const int64_t nfull = (m_end - m_begin) / 16;            // steps with 16 valid rows
+    const uint16_t *c_base = p.dC + (m_begin + 8 * half) * p.ldc + n_off;
+    const uint16_t *a_base = A + (m_begin + 8 * half) * p.lda + k_off;
+    auto load_data = [&](u32x2 (&cdst)[8], u32x2 (&adst)[8], int64_t step) {
+        const uint16_t *cp = c_base + step * 16 * p.ldc;
+        const uint16_t *ap = a_base + step * 16 * p.lda;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            cdst[r] = *reinterpret_cast<const u32x2 *>(cp + r * p.ldc);
+            adst[r] = *reinterpret_cast<const u32x2 *>(ap + r * p.lda);
+        }
+    };
+    if (nfull > 0) load_data(cb[0], ab[0], 0);
+    if (nfull > 1) load_data(cb[1], ab[1], 1);
+    for (int64_t s0 = 0; s0 < nfull; s0 += 3) {
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int64_t sidx = s0 + ph;
+            if (sidx < nfull) {                                      // wave-uniform
+                if (sidx + 2 < nfull) load_data(cb[(ph + 2) % 3], ab[(ph + 2) % 3], sidx + 2);
+                mma_step(cb[ph], ab[ph], acc);
+            }
+        }
+    }
+    // ragged tail (< 16 rows, last slice only): rows past the end contribute zeros
+    const int64_t m_tail = m_begin + nfull * 16;
+    if (m_tail < m_end) {
+        u32x2 ct[8], at[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t m = m_tail + 8 * half + r;
+            const bool ok = m < m_end;
+            const int64_t mm = ok ? m : m_begin;
+            u32x2 c = *reinterpret_cast<const u32x2 *>(p.dC + mm * p.ldc + n_off);
+            u32x2 a = *reinterpret_cast<const u32x2 *>(A + mm * p.lda + k_off);
+            ct[r] = ok ? c : u32x2{0u, 0u};
+            at[r] = ok ? a : u32x2{0u, 0u};
+        }
+        mma_step(ct, at, acc);
+    }
+}
+
 __global__ void __launch_bounds__(256, 1)
 k_wgrad_bf16(const WgradParams p)
 {
@@ -62,12 +133,14 @@ k_wgrad_bf16(const WgradParams p)
     if (k_base >= p.ldk) return;                                   // wave-uniform; no barriers below
     const int g = (int)(n_base / p.n_per_group);
     const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
-    const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
 
     const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
 
-    // column validity is loop invariant; invalid columns read column 0 and are zeroed
+    // Column validity is lane invariant: a lane whose columns fall outside the matrices reads
+    // column 0 instead and its (garbage) accumulators are simply never stored -- output (n, k)
+    // depends on column n of dC and column k of A only.  So the steady-state loop has no selects
+    // on loaded data, and hipcc keeps the loads in flight instead of waiting right after issue.
     const bool n_ok = n_base + 4 * ii + 3 < p.ldc && n_base + 4 * ii < p.Ntot;
     const bool k_ok = k_base + 4 * ii + 3 < p.lda;
     const int64_t n_off = n_ok ? n_base + 4 * ii : 0;
@@ -81,48 +154,7 @@ k_wgrad_bf16(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
 
-    u32x2 c_nxt[8], a_nxt[8];
-    auto load_step = [&](int64_t m0) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int64_t m = m0 + 8 * half + r;
-            const bool ok = m < m_end;
-            const int64_t mm = ok ? m : m_begin;
-            const int64_t ar = a_rows ? a_rows[mm] : mm;
-            u32x2 c = *reinterpret_cast<const u32x2 *>(p.dC + mm * p.ldc + n_off);
-            u32x2 a = *reinterpret_cast<const u32x2 *>(A + ar * p.lda + k_off);
-            if (!(ok && n_ok)) c = u32x2{0u, 0u};
-            if (!(ok && k_ok)) a = u32x2{0u, 0u};
-            c_nxt[r] = c;
-            a_nxt[r] = a;
-        }
-    };
-
-    load_step(m_begin);
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
-        u32x2 c_cur[8], a_cur[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { c_cur[r] = c_nxt[r]; a_cur[r] = a_nxt[r]; }
-        if (m0 + 16 < m_end) load_step(m0 + 16);
-
-        u32x4 opb[4];
-        opb[0] = pack_column<0>(a_cur);
-        opb[1] = pack_column<1>(a_cur);
-        opb[2] = pack_column<2>(a_cur);
-        opb[3] = pack_column<3>(a_cur);
-        u32x4 opa[4];
-        opa[0] = pack_column<0>(c_cur);
-        opa[1] = pack_column<1>(c_cur);
-        opa[2] = pack_column<2>(c_cur);
-        opa[3] = pack_column<3>(c_cur);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8_t, opa[e]), __builtin_bit_cast(bf16x8_t, opb[f]),
-                    acc[e][f], 0, 0, 0);
-    }
+    wgrad_mainloop(p, A, m_begin, m_end, n_off, k_off, half, acc);
 
     // epilogue: D[i][j] of MFMA (e, f) is dW[n_base + 4i + e][k_base + 4j + f]; lane l holds
     // j = l & 31 and i = (r & 3) + 8 (r >> 2) + 4 (l >> 5): one float4 (f = 0..3) per (e, r).
@@ -172,8 +204,7 @@ int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split)
     return (int)ceil_div(M, rows_per_split);
 }
 
-int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, const int64_t *a_rows,
-                int a_rows_group0_only, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
+int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
                 int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
                 int64_t out_gstride, void *stream)
 {
@@ -188,10 +219,9 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, const i
     GSAGE_REQUIRE(((uintptr_t)dC % 8) == 0 && ((uintptr_t)A % 8) == 0 && ((uintptr_t)slabs % 16) == 0,
                   "wgrad: misaligned pointer");
     WgradParams p;
-    p.dC = (const uint16_t *)dC; p.A = (const uint16_t *)A; p.a_rows = a_rows; p.slabs = slabs;
+    p.dC = (const uint16_t *)dC; p.A = (const uint16_t *)A; p.slabs = slabs;
     p.ldc = ldc; p.lda = lda; p.a_gstride = a_gstride; p.M = M; p.Ntot = Ntot; p.K = K;
     p.n_per_group = n_per_group; p.ldk = ldk; p.rows_per_split = rows_per_split;
-    p.a_rows_group0_only = a_rows_group0_only;
     const int S = (int)ceil_div(M, rows_per_split);
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
     hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -261,11 +261,14 @@ class FusedMeanTrainStep(object):
         self.targets = example_targets.clone()
         bf, f32 = torch.bfloat16, torch.float32
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
+        # level 0 operands: [x rows | neighbour means] gathered ONCE per step into one buffer, so the
+        # forward GEMM and the weight-gradient kernel both read plain row-major operands
+        self.xa0 = torch.zeros(2, self.rows[0], feats.ld, dtype=bf, device=dev)
         for l in range(L):
             R = self.rows[l]
             ld = feats.ld if l == 0 else self.din[l]
             assert ld % 8 == 0
-            self.agg.append(torch.zeros(R, ld, dtype=bf, device=dev))
+            self.agg.append(self.xa0[1] if l == 0 else torch.zeros(R, ld, dtype=bf, device=dev))
             last = l == L - 1
             self.hout.append(torch.zeros(R, 2 * self.h[l], dtype=f32 if last else bf, device=dev))
             self.dc.append(torch.zeros(R, 2 * self.h[l], dtype=bf, device=dev))
@@ -273,9 +276,22 @@ class FusedMeanTrainStep(object):
         self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
         self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
 
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.counter = torch.full((1,), -L, dtype=torch.int64, device=dev)
         self.preds = None
         self.all_ids[:B].copy_(example_ids)
+
+        # classification head as one fused kernel pair when it applies (else stock torch autograd)
+        from .problem import ProblemLosses
+        C, D2 = model.fc.weight.shape
+        probe = torch.randn(3, 4, device=dev)
+        ident = self.post is None or torch.equal(self.post(probe), probe)
+        self.fused_head = (loss_fn is ProblemLosses.classification and ident and C <= 64 and
+                           D2 <= 1024 and self.targets.dtype == torch.int64)
+        if self.fused_head:
+            self.head_scratch = torch.zeros(nat.lib().gsage_head_ce_scratch(B, C, D2),
+                                            dtype=torch.float32, device=dev)
+            self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.preds = torch.zeros(B, C, dtype=torch.float32, device=dev)
 
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
@@ -290,8 +306,9 @@ class FusedMeanTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.flat_p.copy_(saved)
-        for t in (self.flat_m, self.flat_v, self.step, self.counter):
+        for t in (self.flat_m, self.flat_v, self.step):
             t.zero_()
+        self.counter.fill_(-self.L)
         torch.cuda.synchronize()
         self.graphs = None
         if capture:
@@ -322,8 +339,11 @@ class FusedMeanTrainStep(object):
     def _front(self):
         L, B, st, lib = self.L, self.B, self.store, nat.lib()
         stream = ops._stream()
-        nat.check(lib.gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems, stream),
-                  "prep_weights")
+        # first launch of the step: operand copies + tick (Adam step += 1, Philox call index += L;
+        # the call counter starts at -L so the first step samples with call indices 0..L-1)
+        nat.check(lib.gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems,
+                                         self.step.data_ptr(), 1, self.counter.data_ptr(), self.L,
+                                         stream), "prep_weights")
         # K1: frontier, written in place into the concatenated id buffer
         rank = self.sampler.shard[0]
         for k in range(1, L + 1):
@@ -337,28 +357,44 @@ class FusedMeanTrainStep(object):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             agg = self.agg[l]
             if l == 0:
-                xbuf, lda, a_rows = st.data, st.ld, self.all_ids
-                for k in range(L):                       # hop k rows <- mean of hop k+1 table rows
-                    ops._gather_mean_raw(st.data, st.ld, self.all_ids[self.off[k + 1]:self.off[k + 2]],
-                                         self.size[k], self.fan[k + 1], torch.bfloat16, st.ld,
-                                         out=agg[self.off[k]:self.off[k + 1]])
+                # one launch: x rows of every hop + the mean of each hop's sampled neighbours
+                xbuf, lda = self.xa0[0], st.ld
+                segs = [(st.data, self.all_ids[:R], xbuf, R, 1)]
+                for k in range(L):
+                    segs.append((st.data, self.all_ids[self.off[k + 1]:self.off[k + 2]],
+                                 agg[self.off[k]:self.off[k + 1]], self.size[k], self.fan[k + 1]))
+                ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
             else:
-                xbuf, lda, a_rows = self.hout[l - 1], din, None
-                for k in range(L - l):                   # in-order segment means of the level below
-                    ops._gather_mean_raw(xbuf[self.off[k + 1]:self.off[k + 2]], din, None, self.size[k],
-                                         self.fan[k + 1], torch.bfloat16, din,
-                                         out=agg[self.off[k]:self.off[k + 1]])
+                xbuf, lda = self.hout[l - 1], din
+                segs = [(xbuf[self.off[k + 1]:self.off[k + 2]], None, agg[self.off[k]:self.off[k + 1]],
+                         self.size[k], self.fan[k + 1]) for k in range(L - l)]
+                ops.gather_mean_multi(segs, din, din, din)
             delta = agg.data_ptr() - xbuf.data_ptr()
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
-            self._linear(xbuf.data_ptr(), lda, a_rows.data_ptr() if a_rows is not None else None, 1,
-                         self.w2[l].data_ptr(), self.w2[l].shape[2], self.hout[l].data_ptr(),
-                         nat.F32 if last else nat.BF16, 2 * h, R, h, din,
+            self._linear(xbuf.data_ptr(), lda, None, 0, self.w2[l].data_ptr(), self.w2[l].shape[2],
+                         self.hout[l].data_ptr(), nat.F32 if last else nat.BF16, 2 * h, R, h, din,
                          nat.ACT_NONE if last else nat.ACT_RELU, delta // esz,
                          h * self.w2[l].shape[2], h)
 
-        # head: normalize + fc + loss (stock torch, autograd confined to these few ops)
         m = self.model
+        if self.fused_head:
+            C, D2 = m.fc.weight.shape
+            tg = self.targets.view(-1)
+            nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
+                                        m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), tg.data_ptr(),
+                                        B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
+                                        nat.BF16, self.dc[L - 1].stride(0),
+                                        self._grad_slice(m.fc.weight).data_ptr(),
+                                        self._grad_slice(m.fc.bias).data_ptr(), self.loss.data_ptr(),
+                                        self.head_scratch.data_ptr(), stream), "head_ce")
+        else:
+            self._torch_head()
+        self._backward_levels()
+
+    def _torch_head(self):
+        # head: normalize + fc + loss (stock torch, autograd confined to these few ops)
+        m, L = self.model, self.L
         emb = self.hout[L - 1].detach().requires_grad_(True)
         z = self.post(emb) if self.post is not None else emb
         preds = m.fc(torch.nn.functional.normalize(z, dim=1))
@@ -371,23 +407,23 @@ class FusedMeanTrainStep(object):
             self.preds = torch.empty_like(preds)
         self.preds.copy_(preds.detach())
 
-        # backward through the levels
+    def _backward_levels(self):
+        L, st, lib = self.L, self.store, nat.lib()
+        stream = ops._stream()
+        esz = 2
         for l in range(L - 1, -1, -1):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             dc = self.dc[l]
-            if l == 0:
-                xbuf, lda, a_rows = st.data, st.ld, self.all_ids
-            else:
-                xbuf, lda, a_rows = self.hout[l - 1], din, None
+            xbuf, lda = (self.xa0[0], st.ld) if l == 0 else (self.hout[l - 1], din)
             delta = (self.agg[l].data_ptr() - xbuf.data_ptr()) // esz
             ix = self.pidx[id(self.layers[l].fc_x.weight)]               # fc_neib is ix + 1
             if h % 128 == 0:
-                ops.wgrad(dc, xbuf, lda, a_rows, 1, delta, R, 2 * h, din, h,
+                ops.wgrad(dc, xbuf, lda, delta, R, 2 * h, din, h,
                           out=self.flat_g[self.poff[ix]:self.poff[ix + 2]].view(2, h, din))
             else:
                 for g in range(2):
                     src = xbuf if g == 0 else self.agg[l]
-                    ops.wgrad(dc[:, g * h:], src, lda, a_rows if g == 0 else None, 1, 0, R, h, din, h,
+                    ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h,
                               out=self.flat_g[self.poff[ix + g]:self.poff[ix + g + 1]].view(1, h, din))
             if l > 0:
                 w2t = self.w2t[l]
@@ -411,8 +447,7 @@ class FusedMeanTrainStep(object):
                                            self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
                                            self.partial.data_ptr(), self.lr.data_ptr(),
                                            self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
-                                           self.gnorm.data_ptr(), ops._stream()), "clip_adam_step")
-        nat.check(lib.gsage_counter_add(self.counter.data_ptr(), self.L, ops._stream()), "counter_add")
+                                           self.gnorm.data_ptr(), 1, ops._stream()), "clip_adam_step")
 
     # ---- per-batch entry --------------------------------------------------------------------------
     def set_progress(self, progress):

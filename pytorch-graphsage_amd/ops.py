@@ -278,9 +278,22 @@ def _prep_weight(W, cdt, epc):
     return _pad_cast(W.detach(), cdt, epc)
 
 
-def wgrad(dC, A, lda, a_rows, a_g0, a_gstride, M, Ntot, K, n_per_group, out=None):
+def gather_mean_multi(segments, ld, D, out_ld):
+    """All hops of a level in one K2 launch.  segments: list of (table, ids|None, out, M, n) with
+    bf16 row-major tensors sharing ld / out_ld."""
+    k = len(segments)
+    T = (ctypes.c_void_p * k)(*[s[0].data_ptr() for s in segments])
+    I = (ctypes.c_void_p * k)(*[(s[1].data_ptr() if s[1] is not None else None) for s in segments])
+    O = (ctypes.c_void_p * k)(*[s[2].data_ptr() for s in segments])
+    Ms = (ctypes.c_int64 * k)(*[int(s[3]) for s in segments])
+    ns = (ctypes.c_int32 * k)(*[int(s[4]) for s in segments])
+    nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16, out_ld,
+                                                _stream()), "gather_mean_multi")
+
+
+def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None):
     """dW_g = dC_g^T @ A_g on the matrix cores (K5b), bf16 operands, fp32 result
-    [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 tensor (table or rows)."""
+    [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 [M, lda] row-major."""
     groups = (Ntot + n_per_group - 1) // n_per_group
     ldk = _round_up(K, 4)
     nblk = (Ntot + 127) // 128
@@ -290,9 +303,9 @@ def wgrad(dC, A, lda, a_rows, a_g0, a_gstride, M, Ntot, K, n_per_group, out=None
     slabs = torch.empty(S, Ntot, ldk, dtype=torch.float32, device=dC.device)
     if out is None:
         out = torch.empty(groups, n_per_group, K, dtype=torch.float32, device=dC.device)
-    nat.check(nat.lib().gsage_wgrad(_ptr(dC), dC.stride(0), _ptr(A), lda, _ptr(a_rows), a_g0,
-                                    a_gstride, M, Ntot, K, n_per_group, rps, _ptr(slabs), ldk,
-                                    _ptr(out), n_per_group * K, _stream()), "wgrad")
+    nat.check(nat.lib().gsage_wgrad(_ptr(dC), dC.stride(0), _ptr(A), lda, a_gstride, M, Ntot, K,
+                                    n_per_group, rps, _ptr(slabs), ldk, _ptr(out), n_per_group * K,
+                                    _stream()), "wgrad")
     return out
 
 
@@ -413,9 +426,11 @@ class _SageProject(torch.autograd.Function):
         fused_w = (cdt == torch.bfloat16 and ctx.grouped is not None and h % 128 == 0 and
                    xa.stride(0) % 4 == 0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         if fused_w:
-            # both weight gradients in one MFMA launch; x rows are gathered inside the kernel
-            dw = wgrad(gc.contiguous(), xa, xa.stride(0), a_rows, 1, ctx.grouped, an.shape[0], 2 * h,
-                       Dx, h)
+            # both weight gradients in one MFMA launch (x rows re-gathered when they were lazy)
+            xm = xa if a_rows is None else _gather_mean_raw(xa, an.stride(0), a_rows, an.shape[0], 1,
+                                                            cdt, an.stride(0))
+            dw = wgrad(gc.contiguous(), xm, xm.stride(0), (an.data_ptr() - xm.data_ptr()) // 2,
+                       an.shape[0], 2 * h, Dx, h)
             dwx, dwn = dw[0].to(wdt), dw[1].to(wdt)
         if ctx.needs_input_grad[2] and not fused_w:
             if a_rows is not None:

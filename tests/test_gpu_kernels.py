@@ -277,24 +277,66 @@ def test_attn_aggregate_forward_backward():
         close(nb.grad.cpu().numpy(), nb_c.grad.numpy(), "dnb", 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("M,N,K,groups,gather", [(16, 128, 8, 1, False), (100, 128, 602, 2, True),
-                                                 (513, 128, 256, 2, False), (1300, 4, 70, 1, False),
-                                                 (3000, 128, 1433, 2, True), (64, 128, 128, 1, True)])
-def test_wgrad_mfma_vs_fp64(M, N, K, groups, gather):
+@pytest.mark.parametrize("M,N,K,groups", [(16, 128, 8, 1), (100, 128, 602, 2), (513, 128, 256, 2),
+                                          (1300, 4, 70, 1), (3000, 128, 1433, 2), (64, 128, 128, 1)])
+def test_wgrad_mfma_vs_fp64(M, N, K, groups):
     """dW_g = dC_g^T @ A_g (K5b): exact in fp32 up to summation order on bf16-rounded operands."""
     rng = np.random.RandomState(M + N + K)
     ld = ((K + 63) // 64) * 64
-    R = max(M, 700) if gather else M
-    tab = np.zeros((groups, R, ld), dtype=np.float32)
-    tab[:, :, :K] = bf16_round(rng.normal(size=(groups, R, K)))
+    tab = np.zeros((groups, M, ld), dtype=np.float32)
+    tab[:, :, :K] = bf16_round(rng.normal(size=(groups, M, K)))
     dC = bf16_round(rng.normal(size=(M, groups * N)))
-    rows = rng.randint(0, R, size=M) if gather else np.arange(M)
     tabt = torch.from_numpy(tab).to(DEV).bfloat16().contiguous()
     dCt = torch.from_numpy(dC).to(DEV).bfloat16().contiguous()
-    a_rows = torch.from_numpy(rows).to(DEV) if gather else None
-    out = ops.wgrad(dCt, tabt, ld, a_rows, 1, R * ld, M, groups * N, K, N)
+    out = ops.wgrad(dCt, tabt, ld, M * ld, M, groups * N, K, N)
     assert out.shape == (groups, N, K) and out.dtype == torch.float32
     for g in range(groups):
-        src = tab[g][rows] if (gather and g == 0) else tab[g][:M]
-        ref = dC[:, g * N:(g + 1) * N].astype(np.float64).T @ src[:, :K].astype(np.float64)
+        ref = dC[:, g * N:(g + 1) * N].astype(np.float64).T @ tab[g][:, :K].astype(np.float64)
         close(out[g].cpu().numpy(), ref, ("wgrad", M, N, K, g), 2e-5, 2e-6)
+
+
+def test_gather_mean_multi_equals_single_launches():
+    rng = np.random.RandomState(4)
+    store = gs.FeatureStore.from_array(rng.normal(size=(900, 602)).astype(np.float32), torch.device(DEV), "bf16")
+    specs = [(300, 1), (12, 25), (300, 10)]
+    segs, refs = [], []
+    for M, n in specs:
+        ids = torch.from_numpy(rng.randint(0, 900, size=M * n)).to(DEV)
+        out = torch.zeros(M, store.ld, dtype=torch.bfloat16, device=DEV)
+        segs.append((store.data, ids, out, M, n))
+        refs.append(ops.gather_mean(store, ids, M, n, out_dtype=torch.bfloat16, out_ld=store.ld))
+    h = torch.from_numpy(rng.normal(size=(120, 256)).astype(np.float32)).to(DEV).bfloat16()
+    o2 = torch.zeros(40, 256, dtype=torch.bfloat16, device=DEV)
+    ops.gather_mean_multi(segs, store.ld, store.ld, store.ld)
+    ops.gather_mean_multi([(h, None, o2, 40, 3)], 256, 256, 256)
+    for (t, i, o, M, n), r in zip(segs, refs):
+        assert torch.equal(o, r)
+    assert torch.equal(o2, ops._gather_mean_raw(h, 256, None, 40, 3, torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,C,D", [(512, 41, 256), (33, 7, 32), (5, 64, 600), (100, 2, 1024)])
+def test_head_ce_forward_backward_vs_torch(B, C, D):
+    """normalize + fc + cross-entropy and all three gradients in two launches (fp32: 1e-5)."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(B + C + D)
+    E = torch.from_numpy(rng.normal(size=(B, D)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.normal(size=(C, D)) * 0.3).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.normal(size=(C,)).astype(np.float32)).to(DEV)
+    t = torch.from_numpy(rng.randint(0, C, size=B)).to(DEV)
+    L = nat.lib()
+    preds = torch.empty(B, C, device=DEV)
+    dE = torch.empty(B, D, device=DEV)
+    dW, db, loss = torch.empty(C, D, device=DEV), torch.empty(C, device=DEV), torch.empty(1, device=DEV)
+    scratch = torch.empty(L.gsage_head_ce_scratch(B, C, D), device=DEV)
+    nat.check(L.gsage_head_ce(E.data_ptr(), D, W.data_ptr(), b.data_ptr(), t.data_ptr(), B, C, D,
+                              preds.data_ptr(), dE.data_ptr(), nat.F32, D, dW.data_ptr(), db.data_ptr(),
+                              loss.data_ptr(), scratch.data_ptr(), None))
+    Ed, Wd, bd = [v.detach().double().cpu().requires_grad_(True) for v in (E, W, b)]
+    pr = F.normalize(Ed, dim=1) @ Wd.t() + bd
+    ls = F.cross_entropy(pr, t.cpu())
+    ls.backward()
+    close(preds.cpu().numpy(), pr.detach().numpy(), "preds", 1e-5, 1e-6)
+    assert abs(float(loss.item()) - float(ls)) < 1e-5 * max(1.0, float(ls))
+    close(dE.cpu().numpy(), Ed.grad.numpy(), "dE", 1e-5, 1e-7)
+    close(dW.cpu().numpy(), Wd.grad.numpy(), "dW", 1e-5, 1e-7)
+    close(db.cpu().numpy(), bd.grad.numpy(), "db", 1e-5, 1e-7)
