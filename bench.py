@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"],
                     help="fused: engine.FusedMeanTrainStep (no autograd below the head); "
                          "autograd: GSSupervised.train_step (captured unless --no-graph)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="fused engine: do not overlap batch k+1's sampling/gathers with batch k's compute")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -228,7 +230,7 @@ def main():
         engine = "autograd"
     if engine == "fused":
         step_fn = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
-                                               capture=use_graph)
+                                               capture=use_graph, pipelined=not args.no_pipeline)
     elif use_graph:
         try:
             step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
@@ -254,6 +256,9 @@ def main():
         step_fn(ids_all[k], tg_all[k])
     sync()
     elapsed = time.perf_counter() - t0
+    if hasattr(step_fn, "flush"):
+        step_fn.flush()          # pipelined engine: the timed region ran exactly K sample/gather
+        torch.cuda.synchronize()  # stages and K compute stages; this drains the last compute stage
     if ddp is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -271,7 +276,8 @@ def main():
             "config": {"workload": "Reddit-shaped %s-aggregator 2-layer fanout 25/10 hidden 128 "
                                    "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
-                       "engine": engine, "hip_graph": use_graph, "parallelism": "dp%d" % world,
+                       "engine": engine, "hip_graph": use_graph,
+                       "pipelined": bool(engine == "fused" and not args.no_pipeline), "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
                        if not use_graph else None},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),

@@ -273,6 +273,145 @@ k_linear_nt(const LinearParams p)
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// K5, LDS-DMA pipelined variant (the fast path whenever operand rows are whole 128-byte lines).
+//
+// Same tile, same LDS image and same MFMA loop as k_linear_nt, but the tiles travel global -> LDS
+// with `global_load_lds_dwordx4` (no staging VGPRs, no ds_write pass) through a 3-buffer ring:
+//     wait vmcnt(6) -> s_barrier -> issue tile kt+2 -> MFMAs on tile kt
+// i.e. ONE barrier per K-tile and two tiles (48 KiB per workgroup) in flight across it.  hipcc
+// cannot express "wait for the older of two in-flight tiles" across a barrier by itself (it drains
+// to vmcnt(0)), hence the raw s_barrier + explicit counted waits (CDNA guide, "Pipelining across
+// barriers").  The DMA writes LDS linearly (wave-uniform base + lane*16), so the conflict-free
+// swizzle is applied on the SOURCE side: the lane that fills LDS slot (R, c') fetches global
+// (row = swap03(R), chunk = c' ^ (row & 7)) -- still one full 128-byte line per 8 lanes.
+// Out-of-range rows are clamped (their outputs are never stored); the K tail relies on the
+// operands' zero padding, which is why rows must be whole lines (lda, ldw % (8*EPC) == 0).
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256)
+k_linear_nt_dma(const LinearParams p)
+{
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int TILE = (BM + BN) * CH;                 // vec16 slots per buffer (24 KiB)
+    __shared__ vec16 smem[3 * TILE];                     // single LDS object: 72 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = blockIdx.z;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t n0 = (int64_t)blockIdx.y * BN;
+    const T *A = (const T *)p.A + (int64_t)g * p.a_gstride;
+    const T *W = (const T *)p.W + (int64_t)g * p.w_gstride;
+    const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
+
+    const int kchunks = (int)((p.K + EPC - 1) / EPC);
+    const int nk = (kchunks + CH - 1) / CH;
+
+    // ---- DMA assignment: wave w, instruction s fills LDS rows R = 32*s + 8*w + (lane >> 3),
+    //      slot c' = lane & 7 (1 KiB contiguous per instruction) from the swizzled source
+    const int cdst = lane & 7;
+    const T *a_src[2];
+    const T *w_src[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int R = 32 * s2 + 8 * wave + (lane >> 3);
+        const int row = (R & ~9) | ((R & 1) << 3) | ((R >> 3) & 1);
+        int64_t m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        const int64_t r = a_rows ? a_rows[m] : m;
+        a_src[s2] = A + r * p.lda + (cdst ^ (row & 7)) * EPC;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int R = 32 * s4 + 8 * wave + (lane >> 3);
+        const int row = (R & ~9) | ((R & 1) << 3) | ((R >> 3) & 1);
+        int64_t j = n0 + row;
+        if (j >= p.N) j = p.N - 1;
+        w_src[s4] = W + j * p.ldw + (cdst ^ (row & 7)) * EPC;
+    }
+    // wave-uniform LDS destinations (slot index of the instruction's first lane)
+    const int a_dst0 = (8 * wave) * CH, a_dst1 = (32 + 8 * wave) * CH;
+    const int w_dst0 = BM * CH + (8 * wave) * CH;
+
+    auto issue_tile = [&](int kt, int buf) {
+        vec16 *base = smem + buf * TILE;
+        const int64_t ko = (int64_t)kt * CH * EPC;
+        __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[0] + ko), (lds_void_t *)(base + a_dst0), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[1] + ko), (lds_void_t *)(base + a_dst1), 16, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+            __builtin_amdgcn_global_load_lds((global_void_t *)(w_src[s4] + ko),
+                                             (lds_void_t *)(base + w_dst0 + 32 * s4 * CH), 16, 0, 0);
+    };
+
+    const int wm = wave & 1;
+    const int wn = wave >> 1;
+    f32x16_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int arow = wm * 32 + (lane & 31);
+    const int wrow0 = wn * 64 + (lane & 31), wrow1 = wrow0 + 32;
+
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // my own DMAs of tile kt have landed (tile kt+1 may still be in flight) ...
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and after the barrier so have everybody's; it also proves every wave is done
+        // reading the buffer tile kt+2 is about to overwrite (it was tile kt-1's)
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
+        const vec16 *sA = smem + buf * TILE;
+        const vec16 *sW = sA + BM * CH;
+        // all 12 fragment reads of the tile first (one LDS latency per tile instead of one per
+        // MFMA pair), then the 8 MFMAs back to back
+        vec16 fa[4], fb0[4], fb1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = kk * 2 + (lane >> 5);
+            fa[kk] = sA[lds_slot(arow, ch)];
+            fb0[kk] = sW[lds_slot(wrow0, ch)];
+            fb1[kk] = sW[lds_slot(wrow1, ch)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done: this buffer may be
+        __builtin_amdgcn_sched_barrier(0);                       // overwritten after the next barrier
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
+            mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16_t &acc = t ? acc1 : acc0;
+        const int64_t j = n0 + wn * 64 + t * 32 + (lane & 31);
+        const float bj = (bias && j < p.N) ? bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t m = m0 + wm * 32 + i;
+            if (m < p.M && j < p.N) {
+                const float v = apply_act(acc[r] + bj, ACT);
+                const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
+                if (p.c_dtype == GSAGE_BF16)
+                    ((uint16_t *)p.C)[off] = f32_to_bf16(v);
+                else
+                    ((float *)p.C)[off] = v;
+            }
+        }
+    }
+}
+
 static int check_operands(const char *who, const void *A, int dtype, int64_t lda, const void *W,
                           int64_t ldw, int64_t M, int64_t N, int64_t K)
 {
@@ -316,6 +455,27 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     p.argmax = nullptr;
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
+    // whole-line operand rows -> LDS-DMA pipelined kernel
+    const int64_t epc = dtype == GSAGE_BF16 ? 8 : 4;
+    const int64_t kpad = ceil_div(K, 8 * epc) * 8 * epc;
+    const bool dma = lda % (8 * epc) == 0 && ldw % (8 * epc) == 0 && kpad <= lda && kpad <= ldw;
+#define GSAGE_LAUNCH_DMA(T)                                                                       \
+    do {                                                                                          \
+        if (act == ACT_RELU)                                                                      \
+            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_RELU>), grid, dim3(256), 0, s, p);         \
+        else if (act == ACT_TANH)                                                                 \
+            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_TANH>), grid, dim3(256), 0, s, p);         \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_NONE>), grid, dim3(256), 0, s, p);         \
+    } while (0)
+    if (dma) {
+        if (dtype == GSAGE_BF16)
+            GSAGE_LAUNCH_DMA(uint16_t);
+        else
+            GSAGE_LAUNCH_DMA(float);
+        return check_launch("linear_nt_dma");
+    }
+#undef GSAGE_LAUNCH_DMA
 #define GSAGE_LAUNCH_LINEAR(T)                                                                    \
     do {                                                                                          \
         if (act == ACT_RELU)                                                                      \

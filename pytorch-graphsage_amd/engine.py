@@ -153,7 +153,7 @@ class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/
 
 
 def _r8(v):
-    return (v + 7) // 8 * 8
+    return (v + 63) // 64 * 64          # whole 128-byte bf16 lines: enables the LDS-DMA GEMM path
 
 
 class FusedMeanTrainStep(object):
@@ -194,9 +194,14 @@ class FusedMeanTrainStep(object):
         return all(l.output_dim_ % 8 == 0 for l in layers)
 
     def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
-                 warmup=2):
+                 warmup=2, pipelined=False):
         assert FusedMeanTrainStep.supports(model, feats), "configuration not covered by the fused engine"
         self.model, self.store, self.loss_fn, self.ddp = model, feats, loss_fn, ddp
+        # pipelined: batch k+1's sampling + gathers (which do not depend on the weights) run on a
+        # second graph branch WHILE batch k's GEMMs / backward / Adam run; results are identical
+        # to the sequential order, `__call__` then returns the predictions of the previous batch.
+        self.pipelined = bool(pipelined)
+        self.nset = 2 if self.pipelined else 1
         dev = feats.device
         self.dev = dev
         self.layers = list(model.agg_layers.children())
@@ -257,18 +262,20 @@ class FusedMeanTrainStep(object):
         self.n_desc = len(descs)
         self.max_elems = max(h * d for h, d in zip(self.h, self.din))
 
-        self.all_ids = torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev)
-        self.targets = example_targets.clone()
         bf, f32 = torch.bfloat16, torch.float32
+        # per-batch inputs of the compute stage, one set per batch in flight:
+        #   ids   the concatenated frontier [hop 0 | hop 1 | ... | hop L]
+        #   xa0   level-0 operands [x rows | neighbour means], gathered ONCE per step so the forward
+        #         GEMM and the weight-gradient kernel both read plain row-major operands
+        self.ids_set = [torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev) for _ in range(self.nset)]
+        self.tg_set = [example_targets.clone() for _ in range(self.nset)]
+        self.xa0_set = [torch.zeros(2, self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
-        # level 0 operands: [x rows | neighbour means] gathered ONCE per step into one buffer, so the
-        # forward GEMM and the weight-gradient kernel both read plain row-major operands
-        self.xa0 = torch.zeros(2, self.rows[0], feats.ld, dtype=bf, device=dev)
         for l in range(L):
             R = self.rows[l]
             ld = feats.ld if l == 0 else self.din[l]
             assert ld % 8 == 0
-            self.agg.append(self.xa0[1] if l == 0 else torch.zeros(R, ld, dtype=bf, device=dev))
+            self.agg.append(None if l == 0 else torch.zeros(R, ld, dtype=bf, device=dev))
             last = l == L - 1
             self.hout.append(torch.zeros(R, 2 * self.h[l], dtype=f32 if last else bf, device=dev))
             self.dc.append(torch.zeros(R, 2 * self.h[l], dtype=bf, device=dev))
@@ -276,9 +283,10 @@ class FusedMeanTrainStep(object):
         self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
         self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
 
-        self.counter = torch.full((1,), -L, dtype=torch.int64, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.preds = None
-        self.all_ids[:B].copy_(example_ids)
+        self.ids_set[0][:B].copy_(example_ids)
+        self.n_calls = 0
 
         # classification head as one fused kernel pair when it applies (else stock torch autograd)
         from .problem import ProblemLosses
@@ -286,7 +294,7 @@ class FusedMeanTrainStep(object):
         probe = torch.randn(3, 4, device=dev)
         ident = self.post is None or torch.equal(self.post(probe), probe)
         self.fused_head = (loss_fn is ProblemLosses.classification and ident and C <= 64 and
-                           D2 <= 1024 and self.targets.dtype == torch.int64)
+                           D2 <= 1024 and example_targets.dtype == torch.int64)
         if self.fused_head:
             self.head_scratch = torch.zeros(nat.lib().gsage_head_ce_scratch(B, C, D2),
                                             dtype=torch.float32, device=dev)
@@ -299,32 +307,46 @@ class FusedMeanTrainStep(object):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._front()
-                if ddp is not None:
-                    torch.distributed.all_reduce(self.flat_g)
-                self._back()
+                self._run_sequential(0)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.flat_p.copy_(saved)
-        for t in (self.flat_m, self.flat_v, self.step):
+        for t in (self.flat_m, self.flat_v, self.step, self.counter):
             t.zero_()
-        self.counter.fill_(-self.L)
         torch.cuda.synchronize()
-        self.graphs = None
+        self.g_main, self.g_opt, self.g_front = None, None, None
+        # pipelined mode runs the two stages on two streams (two hardware queues): parallel
+        # branches inside ONE hipGraph were measured to be serialised by the runtime.
+        self.s_front = torch.cuda.Stream() if self.pipelined else None
+        self.s_back = torch.cuda.Stream() if self.pipelined else None
+        self.ev_front = [torch.cuda.Event() for _ in range(self.nset)]
+        self.ev_back = [torch.cuda.Event() for _ in range(self.nset)]
         if capture:
-            g1 = torch.cuda.CUDAGraph()
-            if ddp is None:
-                with torch.cuda.graph(g1):
-                    self._front()
-                    self._back()
-                self.graphs = (g1, None)
-            else:
-                with torch.cuda.graph(g1):
-                    self._front()
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g1.pool()):
-                    self._back()
-                self.graphs = (g1, g2)
+            pool = None
+            self.g_main = []
+            if self.pipelined:
+                self.g_front = []
+                for st_ in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=self.s_front):
+                        self._stage_sample_gather(st_)
+                    pool = g.pool()
+                    self.g_front.append(g)
+            for st_ in range(self.nset):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=self.s_back if self.pipelined else None):
+                    if not self.pipelined:
+                        self._stage_sample_gather(0)
+                    self._stage_compute(st_)
+                    if ddp is None:
+                        self._stage_opt()
+                pool = g.pool()
+                self.g_main.append(g)
+            if ddp is not None:
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, pool=pool, stream=self.s_back if self.pipelined else None):
+                    self._stage_opt()
+        torch.cuda.synchronize()
 
     # ---- helpers ------------------------------------------------------------------------------
     def _grad_slice(self, prm):
@@ -335,37 +357,42 @@ class FusedMeanTrainStep(object):
         ops._linear_launch(A, lda, a_rows, a_g0, W, ldw, None, C, ldc, M, N, K, act, 2, a_gs, w_gs,
                            c_gs, nat.BF16, c_dtype)
 
-    # ---- graph bodies ------------------------------------------------------------------------
-    def _front(self):
+    # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
+    def _stage_sample_gather(self, s):
+        """K1 for every hop + the level-0 gathers of batch set `s`; independent of the weights."""
+        L, st = self.L, self.store
+        ids = self.ids_set[s]
+        rank = self.sampler.shard[0]
+        for k in range(1, L + 1):          # frontier written in place into the concatenated ids
+            ops.sample_csr(self.csr, ids[self.off[k - 1]:self.off[k]], self.fan[k],
+                           philox={"seed": self.sampler.seed, "call_ctr": self.counter,
+                                   "call_base": k - 1, "g0": rank * self.size[k]},
+                           out=ids[self.off[k]:self.off[k + 1]])
+        # one launch: x rows of every hop + the mean of each hop's sampled neighbours
+        R = self.rows[0]
+        xa = self.xa0_set[s]
+        segs = [(st.data, ids[:R], xa[0], R, 1)]
+        for k in range(L):
+            segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
+                         self.size[k], self.fan[k + 1]))
+        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
+        # the next batch's samples use the next L Philox call indices
+        nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), L, ops._stream()), "counter_add")
+
+    def _stage_compute(self, s):
+        """Forward GEMMs, head, backward; everything that needs the current weights."""
         L, B, st, lib = self.L, self.B, self.store, nat.lib()
         stream = ops._stream()
-        # first launch of the step: operand copies + tick (Adam step += 1, Philox call index += L;
-        # the call counter starts at -L so the first step samples with call indices 0..L-1)
+        # operand copies of the weights + Adam step tick
         nat.check(lib.gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems,
-                                         self.step.data_ptr(), 1, self.counter.data_ptr(), self.L,
-                                         stream), "prep_weights")
-        # K1: frontier, written in place into the concatenated id buffer
-        rank = self.sampler.shard[0]
-        for k in range(1, L + 1):
-            src = self.all_ids[self.off[k - 1]:self.off[k]]
-            dst = self.all_ids[self.off[k]:self.off[k + 1]]
-            ops.sample_csr(self.csr, src, self.fan[k],
-                           philox={"seed": self.sampler.seed, "call_ctr": self.counter,
-                                   "call_base": k - 1, "g0": rank * self.size[k]}, out=dst)
+                                         self.step.data_ptr(), 1, None, 0, stream), "prep_weights")
         esz = 2
         for l in range(L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
-            agg = self.agg[l]
             if l == 0:
-                # one launch: x rows of every hop + the mean of each hop's sampled neighbours
-                xbuf, lda = self.xa0[0], st.ld
-                segs = [(st.data, self.all_ids[:R], xbuf, R, 1)]
-                for k in range(L):
-                    segs.append((st.data, self.all_ids[self.off[k + 1]:self.off[k + 2]],
-                                 agg[self.off[k]:self.off[k + 1]], self.size[k], self.fan[k + 1]))
-                ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
+                xbuf, agg, lda = self.xa0_set[s][0], self.xa0_set[s][1], st.ld
             else:
-                xbuf, lda = self.hout[l - 1], din
+                xbuf, agg, lda = self.hout[l - 1], self.agg[l], din
                 segs = [(xbuf[self.off[k + 1]:self.off[k + 2]], None, agg[self.off[k]:self.off[k + 1]],
                          self.size[k], self.fan[k + 1]) for k in range(L - l)]
                 ops.gather_mean_multi(segs, din, din, din)
@@ -380,7 +407,7 @@ class FusedMeanTrainStep(object):
         m = self.model
         if self.fused_head:
             C, D2 = m.fc.weight.shape
-            tg = self.targets.view(-1)
+            tg = self.tg_set[s].view(-1)
             nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
                                         m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), tg.data_ptr(),
                                         B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
@@ -389,16 +416,16 @@ class FusedMeanTrainStep(object):
                                         self._grad_slice(m.fc.bias).data_ptr(), self.loss.data_ptr(),
                                         self.head_scratch.data_ptr(), stream), "head_ce")
         else:
-            self._torch_head()
-        self._backward_levels()
+            self._torch_head(s)
+        self._backward_levels(s)
 
-    def _torch_head(self):
+    def _torch_head(self, s):
         # head: normalize + fc + loss (stock torch, autograd confined to these few ops)
         m, L = self.model, self.L
         emb = self.hout[L - 1].detach().requires_grad_(True)
         z = self.post(emb) if self.post is not None else emb
         preds = m.fc(torch.nn.functional.normalize(z, dim=1))
-        loss = self.loss_fn(preds, self.targets.squeeze())
+        loss = self.loss_fn(preds, self.tg_set[s].squeeze())
         d_emb, d_w, d_b = torch.autograd.grad(loss, [emb, m.fc.weight, m.fc.bias])
         self._grad_slice(m.fc.weight).copy_(d_w.reshape(-1))
         self._grad_slice(m.fc.bias).copy_(d_b.reshape(-1))
@@ -407,22 +434,23 @@ class FusedMeanTrainStep(object):
             self.preds = torch.empty_like(preds)
         self.preds.copy_(preds.detach())
 
-    def _backward_levels(self):
+    def _backward_levels(self, s):
         L, st, lib = self.L, self.store, nat.lib()
         stream = ops._stream()
         esz = 2
         for l in range(L - 1, -1, -1):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             dc = self.dc[l]
-            xbuf, lda = (self.xa0[0], st.ld) if l == 0 else (self.hout[l - 1], din)
-            delta = (self.agg[l].data_ptr() - xbuf.data_ptr()) // esz
+            xbuf, lda = (self.xa0_set[s][0], st.ld) if l == 0 else (self.hout[l - 1], din)
+            aggl = self.xa0_set[s][1] if l == 0 else self.agg[l]
+            delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
             ix = self.pidx[id(self.layers[l].fc_x.weight)]               # fc_neib is ix + 1
             if h % 128 == 0:
                 ops.wgrad(dc, xbuf, lda, delta, R, 2 * h, din, h,
                           out=self.flat_g[self.poff[ix]:self.poff[ix + 2]].view(2, h, din))
             else:
                 for g in range(2):
-                    src = xbuf if g == 0 else self.agg[l]
+                    src = xbuf if g == 0 else aggl
                     ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h,
                               out=self.flat_g[self.poff[ix + g]:self.poff[ix + g + 1]].view(1, h, din))
             if l > 0:
@@ -440,31 +468,88 @@ class FusedMeanTrainStep(object):
         if self.ddp is not None:
             self.flat_g.div_(self.ddp.world)
 
-    def _back(self):
-        lib = nat.lib()
+    def _stage_opt(self):
+        """clip_grad_norm(5) + Adam over the flat bucket."""
         n = self.flat_p.numel()
-        nat.check(lib.gsage_clip_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
-                                           self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
-                                           self.partial.data_ptr(), self.lr.data_ptr(),
-                                           self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
-                                           self.gnorm.data_ptr(), 1, ops._stream()), "clip_adam_step")
+        nat.check(nat.lib().gsage_clip_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
+                                                 self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
+                                                 self.partial.data_ptr(), self.lr.data_ptr(),
+                                                 self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
+                                                 self.gnorm.data_ptr(), 1, ops._stream()),
+                  "clip_adam_step")
+
+    def _run_sequential(self, s):
+        self._stage_sample_gather(s)
+        self._stage_compute(s)
+        if self.ddp is not None:
+            torch.distributed.all_reduce(self.flat_g)
+        self._stage_opt()
 
     # ---- per-batch entry --------------------------------------------------------------------------
     def set_progress(self, progress):
         self.model.lr = self.model.lr_scheduler(progress)
         self.lr.fill_(float(self.model.lr))
 
+    def _load(self, s, ids, targets):
+        self.ids_set[s][:self.B].copy_(ids, non_blocking=True)
+        self.tg_set[s].copy_(targets, non_blocking=True)
+
     def __call__(self, ids, targets):
-        self.all_ids[:self.B].copy_(ids, non_blocking=True)
-        self.targets.copy_(targets, non_blocking=True)
-        if self.graphs is None:
-            self._front()
-            if self.ddp is not None:
-                torch.distributed.all_reduce(self.flat_g)
-            self._back()
-        else:
-            self.graphs[0].replay()
-            if self.graphs[1] is not None:
-                torch.distributed.all_reduce(self.flat_g)
-                self.graphs[1].replay()
+        """Sequential mode: same contract as GSSupervised.train_step -> preds of THIS batch.
+        Pipelined mode: submits this batch (its sampling/gathers start now), finishes the previous
+        one and returns ITS preds (None on the very first call); call flush() after the last batch."""
+        k = self.n_calls
+        self.n_calls += 1
+        if not self.pipelined:
+            self._load(0, ids, targets)
+            if self.g_main is None:
+                self._run_sequential(0)
+            else:
+                self.g_main[0].replay()
+                if self.g_opt is not None:
+                    torch.distributed.all_reduce(self.flat_g)
+                    self.g_opt.replay()
+            return self.preds
+        s = k % 2
+        cur = torch.cuda.current_stream()
+        # front stream: wait until the compute stage that last used buffer set s is done, load the
+        # batch, sample + gather
+        self.s_front.wait_stream(cur)
+        with torch.cuda.stream(self.s_front):
+            self.s_front.wait_event(self.ev_back[s])
+            self._load(s, ids, targets)
+            if self.g_front is None:
+                self._stage_sample_gather(s)
+            else:
+                self.g_front[s].replay()
+            self.ev_front[s].record(self.s_front)
+        if k == 0:
+            return None                              # pipeline primed
+        self._launch_back((k - 1) % 2)
+        cur.wait_event(self.ev_back[(k - 1) % 2])    # whoever reads preds on this stream sees them
+        return self.preds
+
+    def _launch_back(self, par):
+        with torch.cuda.stream(self.s_back):
+            self.s_back.wait_event(self.ev_front[par])
+            if self.g_main is None:
+                self._stage_compute(par)
+                if self.ddp is not None:
+                    torch.distributed.all_reduce(self.flat_g)
+                self._stage_opt()
+            else:
+                self.g_main[par].replay()
+                if self.g_opt is not None:
+                    torch.distributed.all_reduce(self.flat_g)
+                    self.g_opt.replay()
+            self.ev_back[par].record(self.s_back)
+
+    def flush(self):
+        """Pipelined mode: finish the last submitted batch; returns its preds."""
+        if not self.pipelined or self.n_calls == 0:
+            return self.preds
+        self._launch_back((self.n_calls - 1) % 2)
+        torch.cuda.current_stream().wait_stream(self.s_back)
+        torch.cuda.current_stream().wait_stream(self.s_front)
+        self.n_calls = 0                              # the next call primes a fresh pipeline
         return self.preds

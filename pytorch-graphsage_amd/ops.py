@@ -318,8 +318,8 @@ class _Linear(torch.autograd.Function):
         epc = 8 if cdt == torch.bfloat16 else 4
         M, K = x.shape
         N = W.shape[0]
-        xa = _pad_cast(x.detach(), cdt, epc)
-        wa = _prep_weight(W, cdt, epc)
+        xa = _pad_cast(x.detach(), cdt, 8 * epc)          # whole 128-byte rows: LDS-DMA GEMM path
+        wa = _prep_weight(W, cdt, 8 * epc)
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
         bf = b.detach().float().contiguous() if b is not None else None
         _linear_launch(_ptr(xa), xa.stride(0), None, 0, _ptr(wa), wa.stride(0), _ptr(bf),
@@ -373,7 +373,7 @@ class _SageProject(torch.autograd.Function):
         h = Wx.shape[0]
         M = agg.shape[0]
         Dn = Wn.shape[1]
-        an = _pad_cast(agg.detach(), cdt, epc)
+        an = _pad_cast(agg.detach(), cdt, 8 * epc)
         if x_ids is not None:
             Dx = x_dim
             if x_table.dtype != cdt or x_table.stride(0) % epc != 0:
@@ -383,7 +383,7 @@ class _SageProject(torch.autograd.Function):
                 xa, a_rows = x_table, x_ids
         else:
             Dx = x.shape[1]
-            xa, a_rows = _pad_cast(x.detach(), cdt, epc), None
+            xa, a_rows = _pad_cast(x.detach(), cdt, 8 * epc), None
         out = torch.empty(M, 2 * h, dtype=out_dtype, device=agg.device)
         esz = xa.element_size()
         delta = an.data_ptr() - xa.data_ptr()
@@ -391,7 +391,7 @@ class _SageProject(torch.autograd.Function):
         # operand is addressed as A + a_gstride, i.e. the agg buffer relative to the x operand
         grouped = (Dx == Dn and delta % esz == 0 and xa.stride(0) == an.stride(0))
         if grouped:
-            ldw = _round_up(Dx, epc)
+            ldw = _round_up(Dx, 8 * epc)
             w2 = torch.zeros(2, h, ldw, dtype=cdt, device=agg.device)
             w2[0, :, :Dx] = Wx.detach()
             w2[1, :, :Dn] = Wn.detach()
@@ -401,8 +401,8 @@ class _SageProject(torch.autograd.Function):
                            _code(out_dtype))
             wxa, wna = w2[0], w2[1]
         else:
-            wxa = _prep_weight(Wx, cdt, epc)
-            wna = _prep_weight(Wn, cdt, epc)
+            wxa = _prep_weight(Wx, cdt, 8 * epc)
+            wna = _prep_weight(Wn, cdt, 8 * epc)
             _linear_launch(_ptr(xa), xa.stride(0), _ptr(a_rows), 1, _ptr(wxa), wxa.stride(0), None,
                            _ptr(out), 2 * h, M, h, Dx, act, 1, 0, 0, 0, _code(cdt), _code(out_dtype))
             _linear_launch(_ptr(an), an.stride(0), None, 0, _ptr(wna), wna.stride(0), None,

@@ -88,6 +88,34 @@ def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
     eng_model.train_sampler.csr(DEV).check()
 
 
+@pytest.mark.parametrize("capture", [False, True])
+def test_pipelined_engine_is_bit_identical_to_sequential(capture):
+    """Overlapping batch k+1's sampling/gathers with batch k's compute must not change anything:
+    sampling does not depend on the weights and every kernel is deterministic."""
+    adj, feats, rng = _problem(seed=2)
+    D, C, B, dims, fans = feats.shape[1], 5, 40, (128, 128), (6, 4)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    batches = [(torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV),
+                torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)) for _ in range(5)]
+    outs = {}
+    for mode in (False, True):
+        model = _model(adj, D, C, dims, fans)
+        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, batches[0][0],
+                                           batches[0][1], capture=capture, pipelined=mode)
+        preds = []
+        for ids, tg in batches:
+            r = eng(ids, tg)
+            if r is not None:
+                preds.append(r.clone())
+        if mode:
+            preds.append(eng.flush().clone())
+        torch.cuda.synchronize()
+        outs[mode] = (torch.stack(preds), eng.flat_p.clone(), int(eng.counter.item()), int(eng.step.item()))
+    assert outs[False][2] == outs[True][2] == 10 and outs[False][3] == outs[True][3] == 5
+    assert torch.equal(outs[False][0], outs[True][0])
+    assert torch.equal(outs[False][1], outs[True][1])
+
+
 def test_fused_engine_first_step_against_oracle():
     """One engine step vs the fp32 CPU oracle fed the same Philox sel (bf16 tolerance)."""
     from oracle import cpu as ocpu

@@ -1,0 +1,98 @@
+"""Per-kernel micro-benchmarks at the Reddit config-2 shapes (run on the GPU box)."""
+import importlib, sys, ctypes
+sys.path.insert(0, '.')
+import numpy as np, torch
+gs = importlib.import_module('pytorch-graphsage_amd')
+ops, nat = gs.ops, gs._native
+dev = torch.device('cuda')
+ops.warmup(dev)
+L = nat.lib()
+
+def timeit(fn, reps=40, warm=3):
+    """GPU time per call: `reps` launches captured in one hipGraph (no host launch overhead)."""
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5): g.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / (5 * reps) * 1e3
+
+B, f1, f2, D, ld, h = 512, 25, 10, 602, 640, 128
+R0 = B * (1 + f1)
+N = 232966
+torch.manual_seed(0)
+table = torch.zeros(N, ld, dtype=torch.bfloat16, device=dev); table[:, :D] = torch.randn(N, D, device=dev).bfloat16()
+which = sys.argv[1:] or ['wgrad', 'linear', 'head', 'gather']
+
+if 'wgrad' in which:
+    dC = torch.randn(R0, 2 * h, device=dev).bfloat16()
+    XA = torch.randn(2, R0, ld, device=dev).bfloat16()
+    out = torch.empty(2, h, D, device=dev)
+    for rps in (128, 256, 272, 512, 1024, 2048):
+        S = (R0 + rps - 1) // rps
+        slabs = torch.empty(S, 2 * h, 604, device=dev)
+        def f():
+            nat.check(L.gsage_wgrad(dC.data_ptr(), 2 * h, XA.data_ptr(), ld, R0 * ld, R0, 2 * h, D, h, rps,
+                                    slabs.data_ptr(), 604, out.data_ptr(), h * D, None))
+        print('wgrad L0 rps=%d S=%d: %.1f us' % (rps, S, timeit(f)))
+
+if 'linear' in which:
+    XA = torch.randn(2, R0, ld, device=dev).bfloat16()
+    H = torch.empty(R0, 2 * h, dtype=torch.bfloat16, device=dev)
+    for ldw in (608, 640):
+        W2 = torch.randn(2, h, ldw, device=dev).bfloat16()
+        for M in (R0, R0 // 4, 512):
+            def f():
+                ops._linear_launch(XA.data_ptr(), ld, None, 0, W2.data_ptr(), ldw, None, H.data_ptr(), 2 * h, M, h, D,
+                                   1, 2, R0 * ld, h * ldw, h, nat.BF16, nat.BF16)
+            t = timeit(f)
+            print('linear L0 grouped ldw=%d (%s) M=%d: %.1f us  (%.0f TF/s)' % (ldw, 'dma' if ldw == 640 else 'reg', M, t, 2 * 2 * M * 640 * h / t / 1e6))
+
+if 'linK' in which:
+    XA = torch.randn(2, R0, ld, device=dev).bfloat16()
+    H = torch.empty(R0, 2 * h, dtype=torch.bfloat16, device=dev)
+    W2 = torch.randn(2, h, 640, device=dev).bfloat16()
+    for M in (512, R0):
+        for K in (64, 128, 256, 384, 640):
+            def f():
+                ops._linear_launch(XA.data_ptr(), ld, None, 0, W2.data_ptr(), 640, None, H.data_ptr(), 2 * h, M, h, K,
+                                   1, 2, R0 * ld, h * 640, h, nat.BF16, nat.BF16)
+            print('linear dma M=%d K=%d: %.1f us' % (M, K, timeit(f)))
+
+if 'head' in which:
+    E = torch.randn(B, 2 * h, device=dev); W = torch.randn(41, 2 * h, device=dev) * 0.1; b = torch.zeros(41, device=dev)
+    tg = torch.randint(0, 41, (B,), device=dev)
+    preds = torch.empty(B, 41, device=dev); dE = torch.empty(B, 2 * h, dtype=torch.bfloat16, device=dev)
+    dW = torch.empty(41, 2 * h, device=dev); db = torch.empty(41, device=dev); loss = torch.empty(1, device=dev)
+    scr = torch.empty(L.gsage_head_ce_scratch(B, 41, 2 * h), device=dev)
+    def f():
+        nat.check(L.gsage_head_ce(E.data_ptr(), 2 * h, W.data_ptr(), b.data_ptr(), tg.data_ptr(), B, 41, 2 * h,
+                                  preds.data_ptr(), dE.data_ptr(), nat.BF16, 2 * h, dW.data_ptr(), db.data_ptr(),
+                                  loss.data_ptr(), scr.data_ptr(), None))
+    print('head (2 launches): %.1f us' % timeit(f))
+
+if 'gather' in which:
+    store = gs.FeatureStore(table, D)
+    ids = [torch.randint(1, N, (B * f1 * f2,), device=dev) for _ in range(8)]
+    i = [0]
+    def f():
+        i[0] += 1
+        ops.gather_mean(store, ids[i[0] % 8], B * f1, f2, out_dtype=torch.bfloat16, out_ld=ld)
+    t = timeit(f)
+    print('gather hop2: %.1f us (%.2f TB/s alg)' % (t, B * f1 * f2 * D * 2 / t / 1e6))
+
+if 'sample' in which:
+    import bench
+    data = bench.synthetic_reddit(seed=0)
+    csr = gs.DeviceCSR.from_scipy(data['adj'], dev)
+    ids0 = torch.randint(1, N, (B,), device=dev)
+    o1 = torch.empty(B * f1, dtype=torch.int64, device=dev); o2 = torch.empty(B * f1 * f2, dtype=torch.int64, device=dev)
+    def f():
+        ops.sample_csr(csr, ids0, f1, philox={"seed": 1, "call_base": 0}, out=o1)
+        ops.sample_csr(csr, o1, f2, philox={"seed": 1, "call_base": 1}, out=o2)
+    print('sample 2 hops: %.1f us' % timeit(f))
