@@ -156,7 +156,8 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
  *     out[g*out_gstride + n*K + k] = sum_m dC[m, g*n_per_group + n] * A_g[m, k]
  *         A_g = A + g*a_gstride  ([M, lda] row-major)      dC, A: bf16;  out: fp32 [groups, n_per_group, K]
  *     The reduction over M is split into ceil(M / rows_per_split) slices whose partial tiles are
- *     written to `slabs` (fp32 [slices, Ntot, ldk], caller-allocated) and summed deterministically.
+ *     written to `slabs` (fp32 [slices, Ntot, ldk], caller-allocated) and summed deterministically
+ *     into `out` (out == NULL: the slabs are left for gsage_finalize_grads).
  *     Needs ldc, lda, ldk % 4 == 0, Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0,
  *     n_per_group % 128 == 0 unless there is a single group. */
 int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
@@ -200,7 +201,8 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
  *
  *     z = E / max(||E||_2, 1e-12) (row-wise);  preds = z W^T + bias;  loss = mean CE(preds, targets)
  *     dE (bf16 or fp32, [B, ldd]), dW [C, D], db [C] = gradients of loss;  loss may be NULL.
- *     C <= 64, D <= 1024.  scratch: fp32, gsage_head_ce_scratch(B, C, D) elements. */
+ *     C <= 64, D <= 1024.  scratch: fp32, gsage_head_ce_scratch(B, C, D) elements = per-workgroup
+ *     partials [n_wg][C*D + C + 1] (dW | db | loss); dW == NULL leaves them for gsage_finalize_grads. */
 int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias,
                   const int64_t *targets, int32_t B, int32_t C, int32_t D, float *preds, void *dE,
                   int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
@@ -217,12 +219,34 @@ int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
  * moments).  lr and step are DEVICE scalars (float / int64) so a captured graph follows the LR
  * schedule and counts steps.  step_is_current == 0: this call is update number *step + 1 and
  * increments *step afterwards; != 0: *step was already advanced for this update (by
- * gsage_prep_weights' tick) and is left alone.  partial: fp32 scratch of gsage_adam_partials(n)
- * elements.  norm_out (may be NULL) receives the pre-clip gradient norm. */
+ * gsage_prep_weights' / gsage_finalize_grads' tick) and is left alone.  partial: fp32 scratch of
+ * gsage_adam_partials(n) elements.  norm_out (may be NULL) receives the pre-clip gradient norm.
+ * n_partial_ready > 0: `partial` already holds that many squared-norm partials (written by
+ * gsage_finalize_grads) and the norm pass is skipped.  prep_descs (DEVICE array of n_prep
+ * gsage_prep_desc whose src point into p; may be NULL): the bf16 operand copies of the updated
+ * weights are refreshed in the same launch.
+ */
 int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
                          float weight_decay, float max_norm, float *norm_out, int step_is_current,
+                         int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
                          void *stream);
+
+/* Sums partial gradient buffers into the flat bucket and emits the squared-norm partials the
+ * clip needs, in one launch: for descriptor d, flat_g[out_off + r*cols + c] =
+ * sum_{s<S} src[s*stride + r*ld + c].  Covers the K5b slabs (call gsage_wgrad with out == NULL)
+ * and the head partials (gsage_head_ce with dW == NULL: one row of C*D + C columns, ld = stride
+ * = C*D + C + 1).  descs: DEVICE array.  partial_sq: gsage_finalize_partials(n_desc, max_elems)
+ * floats.  tick (may be NULL): *tick += 1 (the Adam step counter). */
+typedef struct {
+    const float *src;
+    int64_t stride;
+    int64_t out_off;
+    int32_t S, rows, cols, ld;
+} gsage_reduce_desc;
+int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
+                         float *partial_sq, int64_t *tick, void *stream);
+int gsage_finalize_partials(int32_t n_desc, int64_t max_elems);
 int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:

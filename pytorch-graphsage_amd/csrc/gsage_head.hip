@@ -256,7 +256,7 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
                   int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
                   void *stream)
 {
-    GSAGE_REQUIRE(E && W && bias && targets && preds && dE && dW && db && scratch, "head_ce: null pointer");
+    GSAGE_REQUIRE(E && W && bias && targets && preds && dE && scratch, "head_ce: null pointer");
     GSAGE_REQUIRE(B > 0 && C > 0 && C <= HEAD_CMAX && D > 0 && D <= HEAD_DMAX,
                   "head_ce: needs 1 <= n_classes <= %d and 1 <= width <= %d", HEAD_CMAX, HEAD_DMAX);
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
@@ -274,7 +274,7 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
     else
         hipLaunchKernelGGL(k_head_ce<4>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     int rc = check_launch("head_ce");
-    if (rc != GSAGE_OK) return rc;
+    if (rc != GSAGE_OK || dW == nullptr || db == nullptr) return rc;   // caller reduces the partials
     const int64_t width = (int64_t)C * D + C + 1;
     hipLaunchKernelGGL(k_head_reduce, dim3((unsigned)ceil_div(width, 64)), dim3(256), 0,
                        (hipStream_t)stream, (const float *)scratch, n_wg, width, (int64_t)C * D, C, dW,

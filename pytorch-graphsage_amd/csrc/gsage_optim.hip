@@ -40,6 +40,14 @@ k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partia
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// ---- weight operand copies ------------------------------------------------------------------------
+struct PrepDesc {
+    const float *src;      // [rows, cols] fp32, contiguous
+    uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
+    uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
+    int32_t rows, cols, dst_ld, dst_t_ld;
+};
+
 struct AdamParams {
     float *p, *g, *m, *v;
     const float *partial;       // per-block squared-norm partials of g
@@ -49,6 +57,8 @@ struct AdamParams {
     int64_t n;
     int32_t n_partial, step_off;
     float beta1, beta2, eps, weight_decay, max_norm;
+    const struct PrepDesc *prep;   // optional: refresh the bf16 operand copies of the new weights
+    int32_t n_prep;
 };
 
 __global__ void __launch_bounds__(256)
@@ -79,19 +89,62 @@ k_adam_clip(const AdamParams a)
         a.m[i] = m;
         a.v[i] = v;
         const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
-        a.p[i] = p - step_size * (m / denom);
+        const float pn = p - step_size * (m / denom);
+        a.p[i] = pn;
+        // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
+        for (int d = 0; d < a.n_prep; ++d) {
+            const PrepDesc &q = a.prep[d];
+            const int64_t o = i - (q.src - a.p);
+            if (o >= 0 && o < (int64_t)q.rows * q.cols) {
+                const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
+                const uint16_t b = f32_to_bf16(pn);
+                if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
+                if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
+                break;
+            }
+        }
     }
 }
 
-__global__ void k_step_inc(int64_t *step) { *step += 1; }
-
-// ---- weight operand copies ------------------------------------------------------------------------
-struct PrepDesc {
-    const float *src;      // [rows, cols] fp32, contiguous
-    uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
-    uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
-    int32_t rows, cols, dst_ld, dst_t_ld;
+// ---- gradient finalisation: sum partial buffers into the flat bucket + squared-norm partials ------
+struct ReduceDesc {
+    const float *src;       // S partial buffers, `stride` floats apart, each [rows, ld]
+    int64_t stride;
+    int64_t out_off;        // destination offset in the flat gradient bucket ([rows, cols] contiguous)
+    int32_t S, rows, cols, ld;
 };
+
+__global__ void __launch_bounds__(256)
+k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
+                 float *__restrict__ partial_sq, int64_t *tick)
+{
+    __shared__ float red[4];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && tick) *tick += 1;
+    const ReduceDesc d = descs[blockIdx.y];
+    const int64_t total = (int64_t)d.rows * d.cols;
+    const int64_t gstride = (int64_t)gridDim.x * 256;
+    float sq = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += gstride) {
+        const int64_t r = t / d.cols;
+        const float *src = d.src + r * d.ld + (t - r * d.cols);
+        float s = 0.f;
+        int i = 0;
+        for (; i + 8 <= d.S; i += 8) {                 // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < d.S; ++i) s += src[(int64_t)i * d.stride];
+        flat_g[d.out_off + t] = s;
+        sq += s * s;
+    }
+    const float tot = block_sum_256(sq, red);
+    if (threadIdx.x == 0) partial_sq[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ void k_step_inc(int64_t *step) { *step += 1; }
 
 __global__ void __launch_bounds__(256)
 k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0, int64_t *tick1,
@@ -181,16 +234,22 @@ int gsage_adam_partials(int64_t n)
 int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, float *partial,
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
                          float weight_decay, float max_norm, float *norm_out, int step_is_current,
+                         int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
                          void *stream)
 {
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
-    GSAGE_REQUIRE(n > 0, "clip_adam_step: empty bucket");
+    GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = grid_for(n, 1024);
-    hipLaunchKernelGGL(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
-    int rc = check_launch("grad_sqnorm");
-    if (rc != GSAGE_OK) return rc;
+    int nb = n_partial_ready;
+    int rc = GSAGE_OK;
+    if (nb == 0) {          // no gsage_finalize_grads before us: compute the norm partials here
+        nb = grid_for(n, 1024);
+        hipLaunchKernelGGL(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
+        rc = check_launch("grad_sqnorm");
+        if (rc != GSAGE_OK) return rc;
+    }
     AdamParams a;
+    a.prep = (const PrepDesc *)prep_descs; a.n_prep = prep_descs ? n_prep : 0;
     a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
     a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.weight_decay = weight_decay; a.max_norm = max_norm; a.step_off = step_is_current ? 0 : 1;
@@ -211,6 +270,20 @@ int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int
     hipLaunchKernelGGL(k_prep_weights, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
                        (hipStream_t)stream, (const PrepDesc *)descs, tick0, inc0, tick1, inc1);
     return check_launch("prep_weights");
+}
+
+int gsage_finalize_partials(int32_t n_desc, int64_t max_elems)
+{
+    return grid_for(max_elems, 256) * n_desc;
+}
+
+int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
+                         float *partial_sq, int64_t *tick, void *stream)
+{
+    GSAGE_REQUIRE(descs && flat_g && partial_sq && n_desc > 0 && max_elems > 0, "finalize_grads: bad arguments");
+    hipLaunchKernelGGL(k_finalize_grads, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
+                       (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick);
+    return check_launch("finalize_grads");
 }
 
 int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,

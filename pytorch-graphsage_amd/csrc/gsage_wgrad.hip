@@ -208,7 +208,7 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
                 int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
                 int64_t out_gstride, void *stream)
 {
-    GSAGE_REQUIRE(dC && A && slabs && out, "wgrad: null pointer");
+    GSAGE_REQUIRE(dC && A && slabs, "wgrad: null pointer");
     GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
     GSAGE_REQUIRE(ldc % 4 == 0 && lda % 4 == 0 && ldk % 4 == 0, "wgrad: ldc, lda, ldk must be multiples of 4");
     GSAGE_REQUIRE(Ntot % 4 == 0 && Ntot <= ldc, "wgrad: Ntot must be a multiple of 4 and <= ldc");
@@ -226,7 +226,7 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
     hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
     int rc = check_launch("wgrad");
-    if (rc != GSAGE_OK) return rc;
+    if (rc != GSAGE_OK || out == nullptr) return rc;      // out == NULL: caller reduces the slabs
     int64_t blocks = ceil_div(Ntot * K, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,

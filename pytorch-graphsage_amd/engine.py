@@ -146,6 +146,12 @@ from .nn_modules import IdentityPrep, MeanAggregator, SparseUniformNeighborSampl
 from .store import FeatureStore
 
 
+class _ReduceDesc(ctypes.Structure):         # mirrors gsage_reduce_desc (include/gsage.h)
+    _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("out_off", ctypes.c_int64),
+                ("S", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("ld", ctypes.c_int32)]
+
+
 class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/gsage.h)
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_ld", ctypes.c_int32),
@@ -301,6 +307,40 @@ class FusedMeanTrainStep(object):
             self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
             self.preds = torch.zeros(B, C, dtype=torch.float32, device=dev)
 
+        # ---- gradient partial buffers + the descriptor table gsage_finalize_grads sums them with
+        rdesc, self.slabs = [], []
+        for l in range(L):
+            h, din, R = self.h[l], self.din[l], self.rows[l]
+            ix = self.pidx[id(self.layers[l].fc_x.weight)]
+            parts = [(2 * h, 0)] if h % 128 == 0 else [(h, 0), (h, 1)]
+            bufs = []
+            for ntot, g in parts:
+                rps, S, ldk = ops.wgrad_plan(R, ntot, din)
+                buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
+                bufs.append(buf)
+                rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[ix + g], S, ntot, din, ldk))
+            self.slabs.append(bufs)
+        Cc, D2c = model.fc.weight.shape
+        ifc = self.pidx[id(model.fc.weight)]
+        assert self.pidx[id(model.fc.bias)] == ifc + 1
+        if self.fused_head:
+            width = Cc * D2c + Cc + 1
+            rdesc.append(_ReduceDesc(self.head_scratch.data_ptr(), width, self.poff[ifc],
+                                     self.head_scratch.numel() // width, 1, Cc * D2c + Cc, width))
+        else:
+            self.head_stage = torch.zeros(Cc * D2c + Cc, dtype=f32, device=dev)
+            rdesc.append(_ReduceDesc(self.head_stage.data_ptr(), 0, self.poff[ifc], 1, 1, Cc * D2c + Cc,
+                                     Cc * D2c + Cc))
+        covered = sum(d.rows * d.cols for d in rdesc)
+        assert covered == self.flat_p.numel(), "every parameter must be covered by a gradient source"
+        self.rdescs = torch.frombuffer(bytearray(bytes((_ReduceDesc * len(rdesc))(*rdesc))),
+                                       dtype=torch.uint8).to(dev)
+        self.n_rdesc = len(rdesc)
+        self.r_max = max(d.rows * d.cols for d in rdesc)
+        self.n_partial = nat.lib().gsage_finalize_partials(self.n_rdesc, self.r_max)
+        self.partial = torch.zeros(max(self.n_partial, self.partial.numel()), dtype=f32, device=dev)
+        self.refresh_weights()
+
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
         side = torch.cuda.Stream()
@@ -313,6 +353,7 @@ class FusedMeanTrainStep(object):
         self.flat_p.copy_(saved)
         for t in (self.flat_m, self.flat_v, self.step, self.counter):
             t.zero_()
+        self.refresh_weights()
         torch.cuda.synchronize()
         self.g_main, self.g_opt, self.g_front = None, None, None
         # pipelined mode runs the two stages on two streams (two hardware queues): parallel
@@ -349,6 +390,12 @@ class FusedMeanTrainStep(object):
         torch.cuda.synchronize()
 
     # ---- helpers ------------------------------------------------------------------------------
+    def refresh_weights(self):
+        """Rebuild the bf16 operand copies from the fp32 Parameters.  Adam keeps them current;
+        call this after changing the weights from outside (load_state_dict, manual edits)."""
+        nat.check(nat.lib().gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems,
+                                               None, 0, None, 0, ops._stream()), "prep_weights")
+
     def _grad_slice(self, prm):
         i = self.pidx[id(prm)]
         return self.flat_g[self.poff[i]:self.poff[i + 1]]
@@ -383,9 +430,6 @@ class FusedMeanTrainStep(object):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
         L, B, st, lib = self.L, self.B, self.store, nat.lib()
         stream = ops._stream()
-        # operand copies of the weights + Adam step tick
-        nat.check(lib.gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems,
-                                         self.step.data_ptr(), 1, None, 0, stream), "prep_weights")
         esz = 2
         for l in range(L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
@@ -411,9 +455,7 @@ class FusedMeanTrainStep(object):
             nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
                                         m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), tg.data_ptr(),
                                         B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
-                                        nat.BF16, self.dc[L - 1].stride(0),
-                                        self._grad_slice(m.fc.weight).data_ptr(),
-                                        self._grad_slice(m.fc.bias).data_ptr(), self.loss.data_ptr(),
+                                        nat.BF16, self.dc[L - 1].stride(0), None, None, None,
                                         self.head_scratch.data_ptr(), stream), "head_ce")
         else:
             self._torch_head(s)
@@ -427,8 +469,9 @@ class FusedMeanTrainStep(object):
         preds = m.fc(torch.nn.functional.normalize(z, dim=1))
         loss = self.loss_fn(preds, self.tg_set[s].squeeze())
         d_emb, d_w, d_b = torch.autograd.grad(loss, [emb, m.fc.weight, m.fc.bias])
-        self._grad_slice(m.fc.weight).copy_(d_w.reshape(-1))
-        self._grad_slice(m.fc.bias).copy_(d_b.reshape(-1))
+        nw = d_w.numel()
+        self.head_stage[:nw].copy_(d_w.reshape(-1))
+        self.head_stage[nw:].copy_(d_b.reshape(-1))
         self.dc[L - 1].copy_(d_emb)
         if self.preds is None:
             self.preds = torch.empty_like(preds)
@@ -446,13 +489,12 @@ class FusedMeanTrainStep(object):
             delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
             ix = self.pidx[id(self.layers[l].fc_x.weight)]               # fc_neib is ix + 1
             if h % 128 == 0:
-                ops.wgrad(dc, xbuf, lda, delta, R, 2 * h, din, h,
-                          out=self.flat_g[self.poff[ix]:self.poff[ix + 2]].view(2, h, din))
+                ops.wgrad(dc, xbuf, lda, delta, R, 2 * h, din, h, slabs=self.slabs[l][0], reduce=False)
             else:
                 for g in range(2):
                     src = xbuf if g == 0 else aggl
-                    ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h,
-                              out=self.flat_g[self.poff[ix + g]:self.poff[ix + g + 1]].view(1, h, din))
+                    ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h, slabs=self.slabs[l][g],
+                              reduce=False)
             if l > 0:
                 w2t = self.w2t[l]
                 # (dX | dAgg) = dC_g @ W_g : NT GEMM against the transposed operand copies
@@ -465,6 +507,10 @@ class FusedMeanTrainStep(object):
                                               self.dc[l - 1].stride(0), self.rows[l - 1], R, din,
                                               L - l + 1, self.off_host, self.fan_host, stream),
                           "bwd_merge")
+        # every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick
+        nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
+                                           self.flat_g.data_ptr(), self.partial.data_ptr(),
+                                           self.step.data_ptr(), stream), "finalize_grads")
         if self.ddp is not None:
             self.flat_g.div_(self.ddp.world)
 
@@ -475,7 +521,9 @@ class FusedMeanTrainStep(object):
                                                  self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
                                                  self.partial.data_ptr(), self.lr.data_ptr(),
                                                  self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
-                                                 self.gnorm.data_ptr(), 1, ops._stream()),
+                                                 self.gnorm.data_ptr(), 1,
+                                                 0 if self.ddp is not None else self.n_partial,
+                                                 self.descs.data_ptr(), self.n_desc, ops._stream()),
                   "clip_adam_step")
 
     def _run_sequential(self, s):

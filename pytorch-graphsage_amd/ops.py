@@ -291,22 +291,30 @@ def gather_mean_multi(segments, ld, D, out_ld):
                                                 _stream()), "gather_mean_multi")
 
 
-def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None):
-    """dW_g = dC_g^T @ A_g on the matrix cores (K5b), bf16 operands, fp32 result
-    [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 [M, lda] row-major."""
-    groups = (Ntot + n_per_group - 1) // n_per_group
+def wgrad_plan(M, Ntot, K):
+    """(rows_per_split, n_slabs, ldk) used by wgrad: enough M-slices to occupy the chip."""
     ldk = _round_up(K, 4)
     nblk = (Ntot + 127) // 128
     kblk = (ldk + 127) // 128
     rps = min(1024, max(64, _round_up((M * nblk * kblk + 511) // 512, 16)))
-    S = (M + rps - 1) // rps
-    slabs = torch.empty(S, Ntot, ldk, dtype=torch.float32, device=dC.device)
-    if out is None:
+    return rps, (M + rps - 1) // rps, ldk
+
+
+def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None, slabs=None, reduce=True):
+    """dW_g = dC_g^T @ A_g on the matrix cores (K5b), bf16 operands, fp32 result
+    [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 [M, lda] row-major.
+    reduce=False leaves the per-slice partial tiles in `slabs` ([S, Ntot, ldk]) for
+    gsage_finalize_grads and returns the slabs."""
+    groups = (Ntot + n_per_group - 1) // n_per_group
+    rps, S, ldk = wgrad_plan(M, Ntot, K)
+    if slabs is None:
+        slabs = torch.empty(S, Ntot, ldk, dtype=torch.float32, device=dC.device)
+    if reduce and out is None:
         out = torch.empty(groups, n_per_group, K, dtype=torch.float32, device=dC.device)
     nat.check(nat.lib().gsage_wgrad(_ptr(dC), dC.stride(0), _ptr(A), lda, a_gstride, M, Ntot, K,
-                                    n_per_group, rps, _ptr(slabs), ldk, _ptr(out), n_per_group * K,
-                                    _stream()), "wgrad")
-    return out
+                                    n_per_group, rps, _ptr(slabs), ldk, _ptr(out) if reduce else None,
+                                    n_per_group * K, _stream()), "wgrad")
+    return out if reduce else slabs
 
 
 class _Linear(torch.autograd.Function):
