@@ -186,8 +186,9 @@ def main():
     ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"],
                     help="fused: engine.FusedMeanTrainStep (no autograd below the head); "
                          "autograd: GSSupervised.train_step (captured unless --no-graph)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="fused engine: do not overlap batch k+1's sampling/gathers with batch k's compute")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="fused engine: overlap batch k+1's sampling/gathers with batch k's compute "
+                         "on a second stream (bit-identical results; currently no faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -230,7 +231,7 @@ def main():
         engine = "autograd"
     if engine == "fused":
         step_fn = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
-                                               capture=use_graph, pipelined=not args.no_pipeline)
+                                               capture=use_graph, pipelined=args.pipeline)
     elif use_graph:
         try:
             step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
@@ -277,7 +278,7 @@ def main():
                                    "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
                        "engine": engine, "hip_graph": use_graph,
-                       "pipelined": bool(engine == "fused" and not args.no_pipeline), "parallelism": "dp%d" % world,
+                       "pipelined": bool(engine == "fused" and args.pipeline), "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
                        if not use_graph else None},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),

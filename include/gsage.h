@@ -83,6 +83,16 @@ int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n
                             uint64_t g0, int64_t *out, int32_t *sel_out, int32_t *err_flag,
                             void *stream);
 
+/* Every hop of a frontier in one launch (counter mode).  `ids` is the concatenated frontier
+ * [hop 0 (B seeds, filled by the caller) | hop 1 (B*fan[0]) | hop 2 (B*fan[0]*fan[1]) | ...];
+ * hop k is sampled exactly as gsage_sample_csr_philox would with call index call_base + k - 1 and
+ * g0 = rank * |hop k| -- results are bit-identical to n_hops separate launches.  fan: HOST array
+ * of n_hops (<= 5) fan-outs. */
+int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t *ids,
+                             int64_t B, int32_t n_hops, const int32_t *fan, uint32_t max_deg,
+                             uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
+                             uint64_t rank, int32_t *err_flag, void *stream);
+
 /* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
 

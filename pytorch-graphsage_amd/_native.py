@@ -33,6 +33,8 @@ SIGNATURES = {
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
                                        _vp, _vp, _vp, _vp]),
+    "gsage_sample_hops_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _u32, _u64, _vp, _u64, _u64,
+                                        _vp, _vp]),
     "gsage_counter_add": (_int, [_vp, _u64, _vp]),
     "gsage_mt_create": (_vp, [_u32]),
     "gsage_mt_destroy": (None, [_vp]),

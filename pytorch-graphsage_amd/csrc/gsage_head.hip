@@ -52,7 +52,11 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
-template <int KPT>
+// R rows are processed TOGETHER by the workgroup: every phase (normalise, logits, softmax,
+// d z, dW accumulation) handles all R rows between two barriers, so a workgroup pays ~6 barriers
+// for R rows instead of ~9 per row, fc.weight is read from LDS once per R rows, and the R
+// independent dot products give the LDS latency some ILP.  Thread t owns columns t + 256 j.
+template <int KPT, int R>
 __global__ void __launch_bounds__(256)
 k_head_ce(const HeadParams p)
 {
@@ -60,10 +64,10 @@ k_head_ce(const HeadParams p)
     const int C = p.C, D = p.D;
     const int ldw = D + 1;                        // +1 float: conflict-free column walks
     float *Ws = lds;                              // [C][ldw]
-    float *zs = Ws + C * ldw;                     // [D] normalised row
-    float *part = zs + D;                         // [4][HEAD_CMAX] partial logits
-    float *dls = part + 4 * HEAD_CMAX;            // [HEAD_CMAX] d logits
-    float *red = dls + HEAD_CMAX;                 // [4]
+    float *zs = Ws + C * ldw;                     // [R][D] normalised rows
+    float *part = zs + R * D;                     // [4 waves][R][HEAD_CMAX] partial logits
+    float *dls = part + 4 * R * HEAD_CMAX;        // [R][HEAD_CMAX] d logits
+    float *red = dls + R * HEAD_CMAX;             // [4][R]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // fc.weight -> LDS, 8 independent loads in flight per thread before the stores
@@ -79,114 +83,135 @@ k_head_ce(const HeadParams p)
         for (; c < C; ++c) Ws[c * ldw + k] = p.W[(int64_t)c * D + k];
     }
 
-    float accW[HEAD_CMAX][KPT];                   // dW partial for this thread's KPT columns
+    auto block_sum_rows = [&](float (&v)[R]) {     // sums each v[r] over the 256 threads
 #pragma unroll
-    for (int c = 0; c < HEAD_CMAX; ++c)
+        for (int r = 0; r < R; ++r) v[r] = wave_sum64(v[r]);
+        __syncthreads();
+        if (lane == 0)
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) accW[c][j] = 0.f;
-    float acc_db = 0.f, acc_loss = 0.f;
-    __syncthreads();
+            for (int r = 0; r < R; ++r) red[wave * R + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = (red[r] + red[R + r]) + (red[2 * R + r] + red[3 * R + r]);
+    };
 
-    const int row0 = blockIdx.x * p.rows_per_wg;
+    const int row0 = blockIdx.x * R;
     const float invB = 1.f / (float)p.B;
-    for (int r = 0; r < p.rows_per_wg; ++r) {
+    // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12)); rows past B behave as zero rows
+    float z[R][KPT], ss[R], nrm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ss[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            const float e = (k < D && row0 + r < p.B) ? p.E[(int64_t)(row0 + r) * p.lde + k] : 0.f;
+            z[r][j] = e;
+            ss[r] += e * e;
+        }
+    }
+    block_sum_rows(ss);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nrm[r] = fmaxf(sqrtf(ss[r]), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            z[r][j] = z[r][j] / nrm[r];
+            if (k < D) zs[r * D + k] = z[r][j];
+        }
+    }
+    __syncthreads();
+    // 2. logits: lane c of wave w sums its quarter of the columns, for all R rows at once
+    {
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = 0.f;
+        if (lane < C) {
+            const int k0 = wave * ((D + 3) / 4), k1 = min(D, k0 + (D + 3) / 4);
+            const float *wr = Ws + lane * ldw;
+            for (int k = k0; k < k1; ++k) {
+                const float w = wr[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) s[r] += zs[r * D + k] * w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) part[(wave * R + r) * HEAD_CMAX + lane] = s[r];
+    }
+    __syncthreads();
+    // 3. softmax / loss / d logits: wave r handles row r (extra rows loop when R > 4)
+    float acc_db = 0.f, acc_loss = 0.f;
+    for (int r = wave; r < R; r += 4) {
         const int i = row0 + r;
-        if (i >= p.B) break;                      // block-uniform
-        // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12))
-        float e[KPT], ss = 0.f;
+        const bool ok = lane < C && i < p.B;
+        float logit = -INFINITY;
+        if (lane < C)
+            logit = part[(0 * R + r) * HEAD_CMAX + lane] + part[(1 * R + r) * HEAD_CMAX + lane] +
+                    part[(2 * R + r) * HEAD_CMAX + lane] + part[(3 * R + r) * HEAD_CMAX + lane] + p.bias[lane];
+        const float mx = wave_max64(logit);
+        const float ex = (lane < C) ? expf(logit - mx) : 0.f;
+        const float den = wave_sum64(ex);
+        const int64_t t = (i < p.B) ? p.targets[i] : -1;
+        const float dl = ok ? (ex / den - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
+        dls[r * HEAD_CMAX + lane] = dl;
+        if (ok) p.preds[(int64_t)i * C + lane] = logit;
+        if (i < p.B && (int64_t)lane == t) acc_loss += -(logit - mx - logf(den));
+        acc_db += dl;                                   // lane c accumulates db[c] over its rows
+    }
+    __syncthreads();
+    // 4. d z, d emb, dW accumulation (thread <-> columns)
+    float dz[R][KPT], zdz[R];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int k = tid + 256 * j;
-            e[j] = (k < D) ? p.E[(int64_t)i * p.lde + k] : 0.f;
-            ss += e[j] * e[j];
-        }
-        const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
-        float z[KPT];
+    for (int r = 0; r < R; ++r) {
+        zdz[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int k = tid + 256 * j;
-            z[j] = e[j] / nrm;
-            if (k < D) zs[k] = z[j];
-        }
-        __syncthreads();
-        // 2. logits: lane c of wave w sums its quarter of the columns
-        {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains (LDS latency)
-            if (lane < C) {
-                const int k0 = wave * ((D + 3) / 4), k1 = min(D, k0 + (D + 3) / 4);
-                const float *wr = Ws + lane * ldw;
-                int k = k0;
-                for (; k + 4 <= k1; k += 4) {
-                    s0 += zs[k] * wr[k];
-                    s1 += zs[k + 1] * wr[k + 1];
-                    s2 += zs[k + 2] * wr[k + 2];
-                    s3 += zs[k + 3] * wr[k + 3];
+        for (int j = 0; j < KPT; ++j) dz[r][j] = 0.f;
+    }
+    float accW[HEAD_CMAX][KPT];
+#pragma unroll
+    for (int c = 0; c < HEAD_CMAX; ++c) {
+        if (c < C) {                                    // block-uniform
+            float dl[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) dl[r] = dls[r * HEAD_CMAX + c];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int k = tid + 256 * j;
+                const float w = (k < D) ? Ws[c * ldw + k] : 0.f;
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    dz[r][j] += dl[r] * w;
+                    a += dl[r] * z[r][j];
                 }
-                for (; k < k1; ++k) s0 += zs[k] * wr[k];
+                accW[c][j] = a;
             }
-            part[wave * HEAD_CMAX + lane] = (s0 + s1) + (s2 + s3);
-        }
-        __syncthreads();
-        // 3. softmax / loss / d logits (wave 0)
-        if (wave == 0) {
-            const bool ok = lane < C;
-            float logit = -INFINITY;
-            if (ok)
-                logit = part[lane] + part[HEAD_CMAX + lane] + part[2 * HEAD_CMAX + lane] +
-                        part[3 * HEAD_CMAX + lane] + p.bias[lane];
-            const float mx = wave_max64(logit);
-            const float ex = ok ? expf(logit - mx) : 0.f;
-            const float den = wave_sum64(ex);
-            const int64_t t = p.targets[i];
-            const float prob = ex / den;
-            const float dl = ok ? (prob - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
-            dls[lane] = dl;
-            if (ok) p.preds[(int64_t)i * C + lane] = logit;
-            if ((int64_t)lane == t) acc_loss += -(logit - mx - logf(den));
-            acc_db += dl;
-        }
-        __syncthreads();
-        // 4. d z, d emb, dW accumulation (thread <-> columns)
-        float dz[KPT], zdz = 0.f;
+        } else {
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int k = tid + 256 * j;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            if (k < D) {
-                int c = 0;
-                for (; c + 4 <= C; c += 4) {
-                    s0 += dls[c] * Ws[c * ldw + k];
-                    s1 += dls[c + 1] * Ws[(c + 1) * ldw + k];
-                    s2 += dls[c + 2] * Ws[(c + 2) * ldw + k];
-                    s3 += dls[c + 3] * Ws[(c + 3) * ldw + k];
-                }
-                for (; c < C; ++c) s0 += dls[c] * Ws[c * ldw + k];
-            }
-            const float s = (s0 + s1) + (s2 + s3);
-            dz[j] = s;
-            zdz += z[j] * s;
+            for (int j = 0; j < KPT; ++j) accW[c][j] = 0.f;
         }
-        zdz = block_sum(zdz, red);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) zdz[r] += z[r][j] * dz[r][j];
+    block_sum_rows(zdz);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = row0 + r;
+        if (i >= p.B) continue;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const int k = tid + 256 * j;
             if (k < D) {
-                const float g = (dz[j] - z[j] * zdz) / nrm;
+                const float g = (dz[r][j] - z[r][j] * zdz[r]) / nrm[r];
                 if (p.dE_dtype == GSAGE_BF16)
                     ((uint16_t *)p.dE)[(int64_t)i * p.ldd + k] = f32_to_bf16(g);
                 else
                     ((float *)p.dE)[(int64_t)i * p.ldd + k] = g;
             }
         }
-#pragma unroll
-        for (int c = 0; c < HEAD_CMAX; ++c) {
-            if (c < C) {
-                const float dl = dls[c];
-#pragma unroll
-                for (int j = 0; j < KPT; ++j) accW[c][j] += dl * z[j];
-            }
-        }
-        __syncthreads();
     }
 
     float *out = p.partial + (int64_t)blockIdx.x * ((int64_t)C * D + C + 1);
@@ -198,10 +223,16 @@ k_head_ce(const HeadParams p)
                 const int k = tid + 256 * j;
                 if (k < D) out[c * D + k] = accW[c][j];
             }
+    // db[c]: lane c of every wave holds its rows' share; loss likewise
+    __syncthreads();
+    part[wave * HEAD_CMAX + lane] = acc_db;
+    const float l = wave_sum64(acc_loss);
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
     if (wave == 0) {
-        if (lane < C) out[C * D + lane] = acc_db;
-        const float l = wave_sum64(acc_loss);
-        if (lane == 0) out[C * D + C] = l;
+        if (lane < C)
+            out[C * D + lane] = (part[lane] + part[HEAD_CMAX + lane]) + (part[2 * HEAD_CMAX + lane] + part[3 * HEAD_CMAX + lane]);
+        if (lane == 0) out[C * D + C] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -246,7 +277,7 @@ extern "C" {
 
 int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D)
 {
-    const int rows_per_wg = 2;
+    const int rows_per_wg = D <= 256 ? 4 : 1;
     const int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
     return n_wg * ((int64_t)C * D + C + 1);
 }
@@ -262,17 +293,18 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
     HeadParams p;
     p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.preds = preds; p.dE = dE;
-    p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = 2;
+    p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = D <= 256 ? 4 : 1;
     p.dE_dtype = dE_dtype;
     const int n_wg = (B + p.rows_per_wg - 1) / p.rows_per_wg;
-    const size_t lds = sizeof(float) * ((size_t)C * (D + 1) + D + 4 * HEAD_CMAX + HEAD_CMAX + 4);
+    const int R = p.rows_per_wg;
+    const size_t lds = sizeof(float) * ((size_t)C * (D + 1) + (size_t)R * D + 4 * R * HEAD_CMAX + R * HEAD_CMAX + 4 * R + 16);
     GSAGE_REQUIRE(lds <= 160 * 1024, "head_ce: fc.weight does not fit in LDS");
     if (D <= 256)
-        hipLaunchKernelGGL(k_head_ce<1>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_head_ce<1, 4>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     else if (D <= 512)
-        hipLaunchKernelGGL(k_head_ce<2>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_head_ce<2, 1>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_head_ce<4>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_head_ce<4, 1>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     int rc = check_launch("head_ce");
     if (rc != GSAGE_OK || dW == nullptr || db == nullptr) return rc;   // caller reduces the partials
     const int64_t width = (int64_t)C * D + C + 1;

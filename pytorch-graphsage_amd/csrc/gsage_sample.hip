@@ -86,6 +86,67 @@ k_sample_philox(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ 
 
 __global__ void k_counter_add(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
+// All hops of a frontier in ONE launch.  A workgroup owns SPW consecutive seeds and walks their
+// whole sub-tree: the children of hop k are produced by the same workgroup that consumes them at
+// hop k+1, so the only synchronisation is __syncthreads() and the previous hop's ids sit in LDS.
+// Sample (hop k, global index g) uses exactly the Philox word the per-hop kernel would use
+// (call index call_base + k - 1, counter g), so results are identical to L separate launches.
+struct HopsParams {
+    const int64_t *rowptr;
+    const int32_t *col;
+    int64_t *ids;                 // [hop 0 | hop 1 | ... | hop L], hop 0 filled by the caller
+    const uint64_t *call_ctr;
+    int32_t *err_flag;
+    int64_t n_rows;
+    int64_t off[6];               // first element of hop k in ids
+    uint64_t g0[6];               // global sample index of this rank's first sample of hop k
+    uint64_t call_base;
+    int32_t fan[6];               // fan[k]: samples per parent at hop k (k >= 1)
+    int32_t n_hops, B;
+    uint32_t max_deg, seed_lo, seed_hi;
+};
+
+constexpr int HOPS_SPW = 4;       // seeds per workgroup
+
+__global__ void __launch_bounds__(256)
+k_sample_hops(const HopsParams p)
+{
+    extern __shared__ int64_t frontier[];            // two ping-pong buffers of the widest hop
+    const int seed0 = blockIdx.x * HOPS_SPW;
+    const int nseed = min(HOPS_SPW, p.B - seed0);
+    if (nseed <= 0) return;
+    int width = 1, widest = 1;
+    for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
+    int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
+    for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
+    __syncthreads();
+    const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
+    int64_t per_seed = 1;                            // nodes of hop k per seed
+    for (int k = 1; k <= p.n_hops; ++k) {
+        const uint32_t n = (uint32_t)p.fan[k];
+        const int64_t parents = per_seed * nseed;
+        per_seed *= n;
+        const int64_t count = per_seed * nseed;
+        const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
+        const int64_t local0 = (int64_t)seed0 * per_seed;             // first sample of this WG in hop k
+        for (int64_t t = threadIdx.x; t < count; t += 256) {
+            const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
+            const uint64_t blk = g >> 2;
+            const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
+                                            (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
+            const uint32_t w = r.v[g & 3];
+            const uint32_t s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
+            const int64_t parent = cur[(uint32_t)t / n];
+            const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
+            nxt[t] = v;
+            p.ids[p.off[k] + local0 + t] = v;
+        }
+        (void)parents;
+        __syncthreads();
+        int64_t *tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
 static inline int grid_for(int64_t work_items)
 {
     int64_t blocks = ceil_div(work_items, 256);
@@ -215,6 +276,42 @@ int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n
                        (uint32_t)seed, (uint32_t)(seed >> 32), call_ctr, call_base, g0, out,
                        sel_out, err_flag);
     return check_launch("sample_csr_philox");
+}
+
+int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t *ids,
+                             int64_t B, int32_t n_hops, const int32_t *fan, uint32_t max_deg,
+                             uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
+                             uint64_t rank, int32_t *err_flag, void *stream)
+{
+    GSAGE_REQUIRE(rowptr && col && ids && fan, "sample_hops_philox: null pointer");
+    GSAGE_REQUIRE(n_hops >= 1 && n_hops <= 5, "sample_hops_philox: 1..5 hops");
+    GSAGE_REQUIRE(B >= 0 && B < (1LL << 31) && max_deg > 0, "sample_hops_philox: bad sizes");
+    if (B == 0) return GSAGE_OK;
+    HopsParams p;
+    p.rowptr = rowptr; p.col = col; p.ids = ids; p.call_ctr = call_ctr; p.err_flag = err_flag;
+    p.n_rows = n_rows; p.call_base = call_base; p.n_hops = n_hops; p.B = (int32_t)B; p.max_deg = max_deg;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    int64_t size = B, off = 0, widest = 1, width = 1;
+    p.fan[0] = 1;
+    for (int k = 0; k <= 5; ++k) {
+        if (k >= 1 && k <= n_hops) {
+            GSAGE_REQUIRE(fan[k - 1] > 0, "sample_hops_philox: n_samples must be > 0");
+            p.fan[k] = fan[k - 1];
+            size *= fan[k - 1];
+            width *= fan[k - 1];
+            if (width > widest) widest = width;
+        } else if (k > n_hops) {
+            p.fan[k] = 1;
+        }
+        p.off[k] = off;
+        p.g0[k] = rank * (uint64_t)size;
+        if (k <= n_hops) off += size;
+    }
+    const size_t lds = sizeof(int64_t) * 2 * HOPS_SPW * (size_t)widest;
+    GSAGE_REQUIRE(lds <= 160 * 1024, "sample_hops_philox: fan-out product too large for the fused kernel");
+    hipLaunchKernelGGL(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds,
+                       (hipStream_t)stream, p);
+    return check_launch("sample_hops_philox");
 }
 
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream)

@@ -410,11 +410,12 @@ class FusedMeanTrainStep(object):
         L, st = self.L, self.store
         ids = self.ids_set[s]
         rank = self.sampler.shard[0]
-        for k in range(1, L + 1):          # frontier written in place into the concatenated ids
-            ops.sample_csr(self.csr, ids[self.off[k - 1]:self.off[k]], self.fan[k],
-                           philox={"seed": self.sampler.seed, "call_ctr": self.counter,
-                                   "call_base": k - 1, "g0": rank * self.size[k]},
-                           out=ids[self.off[k]:self.off[k + 1]])
+        # K1: every hop in one launch, frontier written in place into the concatenated ids
+        fan = (ctypes.c_int32 * L)(*[int(v) for v in self.fan[1:]])
+        nat.check(nat.lib().gsage_sample_hops_philox(
+            self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows, ids.data_ptr(),
+            self.B, L, fan, self.csr.max_deg, self.sampler.seed, self.counter.data_ptr(), 0, rank,
+            self.csr.err_flag.data_ptr(), ops._stream()), "sample_hops_philox")
         # one launch: x rows of every hop + the mean of each hop's sampled neighbours
         R = self.rows[0]
         xa = self.xa0_set[s]

@@ -340,3 +340,31 @@ def test_head_ce_forward_backward_vs_torch(B, C, D):
     close(dE.cpu().numpy(), Ed.grad.numpy(), "dE", 1e-5, 1e-7)
     close(dW.cpu().numpy(), Wd.grad.numpy(), "dW", 1e-5, 1e-7)
     close(db.cpu().numpy(), bd.grad.numpy(), "db", 1e-5, 1e-7)
+
+
+@pytest.mark.parametrize("B,fans", [(512, (25, 10)), (33, (5, 3)), (7, (4, 3, 2)), (1, (1,)), (130, (15, 10, 5))])
+def test_fused_multi_hop_sampler_equals_per_hop_launches(B, fans):
+    import ctypes
+    g = load_golden("sampler_kat.npz")
+    adj = csr_of(g, "g2_")
+    csr = dcsr(adj)
+    rng = np.random.RandomState(B)
+    seeds = torch.from_numpy(rng.randint(0, adj.shape[0], size=B)).to(DEV)
+    sizes = [B]
+    for f in fans:
+        sizes.append(sizes[-1] * f)
+    ids = torch.zeros(sum(sizes), dtype=torch.int64, device=DEV)
+    ids[:B] = seeds
+    ctr = torch.full((1,), 6, dtype=torch.int64, device=DEV)
+    rank = 3
+    fan = (ctypes.c_int32 * len(fans))(*fans)
+    nat.check(nat.lib().gsage_sample_hops_philox(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.n_rows,
+                                                 ids.data_ptr(), B, len(fans), fan, csr.max_deg, 99,
+                                                 ctr.data_ptr(), 1, rank, csr.err_flag.data_ptr(), None))
+    cur, off = seeds, B
+    for k, f in enumerate(fans):
+        nxt = ops.sample_csr(csr, cur, f, philox={"seed": 99, "call_ctr": ctr, "call_base": 1 + k,
+                                                  "g0": rank * sizes[k + 1]})
+        assert torch.equal(ids[off:off + sizes[k + 1]], nxt), (B, fans, k)
+        cur, off = nxt, off + sizes[k + 1]
+    csr.check()
