@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="fused engine: overlap batch k+1's sampling/gathers with batch k's compute "
                          "on a second stream (bit-identical results; currently no faster)")
+    ap.add_argument("--per-step-copy", action="store_true",
+                    help="copy each batch into the engine's static buffers per step instead of walking "
+                         "a device-resident batch queue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -242,6 +245,14 @@ def main():
     if step_fn is None:
         def step_fn(ids, tg):
             return model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+    queued = engine == "fused" and not args.pipeline and not args.per_step_copy
+    if queued:
+        # the whole run's seed batches live in HBM (as the task's timing rule prescribes) and the
+        # graph walks them through a device-side batch index: no per-step copies
+        step_fn.load_epoch(ids_all, tg_all)
+        run_step = lambda k: step_fn.step_queue()
+    else:
+        run_step = lambda k: step_fn(ids_all[k], tg_all[k])
 
     def sync():
         if ddp is not None:
@@ -250,11 +261,11 @@ def main():
 
     launches0 = gs._native.launch_count()
     for k in range(args.warmup):
-        step_fn(ids_all[k], tg_all[k])
+        run_step(k)
     sync()
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
-        step_fn(ids_all[k], tg_all[k])
+        run_step(k)
     sync()
     elapsed = time.perf_counter() - t0
     if hasattr(step_fn, "flush"):
@@ -278,7 +289,7 @@ def main():
                                    "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
                        "engine": engine, "hip_graph": use_graph,
-                       "pipelined": bool(engine == "fused" and args.pipeline), "parallelism": "dp%d" % world,
+                       "pipelined": bool(engine == "fused" and args.pipeline), "batch_queue": bool(queued), "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
                        if not use_graph else None},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),

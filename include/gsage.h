@@ -87,11 +87,14 @@ int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n
  * [hop 0 (B seeds, filled by the caller) | hop 1 (B*fan[0]) | hop 2 (B*fan[0]*fan[1]) | ...];
  * hop k is sampled exactly as gsage_sample_csr_philox would with call index call_base + k - 1 and
  * g0 = rank * |hop k| -- results are bit-identical to n_hops separate launches.  fan: HOST array
- * of n_hops (<= 5) fan-outs. */
+ * of n_hops (<= 5) fan-outs.  seed_queue (may be NULL): device-resident [n_batches, B] seed
+ * batches; the batch *batch_idx % n_batches is copied into hop 0 by the kernel itself, so a
+ * captured graph can walk an epoch without per-step host copies. */
 int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t *ids,
                              int64_t B, int32_t n_hops, const int32_t *fan, uint32_t max_deg,
                              uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
-                             uint64_t rank, int32_t *err_flag, void *stream);
+                             uint64_t rank, const int64_t *seed_queue, const int64_t *batch_idx,
+                             int64_t n_batches, int32_t *err_flag, void *stream);
 
 /* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
@@ -212,11 +215,12 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
  *     z = E / max(||E||_2, 1e-12) (row-wise);  preds = z W^T + bias;  loss = mean CE(preds, targets)
  *     dE (bf16 or fp32, [B, ldd]), dW [C, D], db [C] = gradients of loss;  loss may be NULL.
  *     C <= 64, D <= 1024.  scratch: fp32, gsage_head_ce_scratch(B, C, D) elements = per-workgroup
- *     partials [n_wg][C*D + C + 1] (dW | db | loss); dW == NULL leaves them for gsage_finalize_grads. */
+ *     partials [n_wg][C*D + C + 1] (dW | db | loss); dW == NULL leaves them for gsage_finalize_grads.
+ *     batch_idx (may be NULL): targets is a queue [n_batches, B], batch *batch_idx % n_batches is used. */
 int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias,
                   const int64_t *targets, int32_t B, int32_t C, int32_t D, float *preds, void *dE,
                   int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
-                  void *stream);
+                  const int64_t *batch_idx, int64_t n_batches, void *stream);
 int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
 
 /* ------------------------------------------------------------------------------------------
@@ -247,7 +251,8 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
  * sum_{s<S} src[s*stride + r*ld + c].  Covers the K5b slabs (call gsage_wgrad with out == NULL)
  * and the head partials (gsage_head_ce with dW == NULL: one row of C*D + C columns, ld = stride
  * = C*D + C + 1).  descs: DEVICE array.  partial_sq: gsage_finalize_partials(n_desc, max_elems)
- * floats.  tick (may be NULL): *tick += 1 (the Adam step counter). */
+ * floats.  tick (may be NULL): *tick += 1 (the Adam step counter); tick1 / tick2 (may be NULL):
+ * *tick1 += inc1, *tick2 += inc2 (Philox call index, batch-queue index). */
 typedef struct {
     const float *src;
     int64_t stride;
@@ -255,7 +260,8 @@ typedef struct {
     int32_t S, rows, cols, ld;
 } gsage_reduce_desc;
 int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
-                         float *partial_sq, int64_t *tick, void *stream);
+                         float *partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
+                         int64_t *tick2, int64_t inc2, void *stream);
 int gsage_finalize_partials(int32_t n_desc, int64_t max_elems);
 int gsage_adam_partials(int64_t n);
 

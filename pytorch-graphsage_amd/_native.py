@@ -34,7 +34,7 @@ SIGNATURES = {
     "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
                                        _vp, _vp, _vp, _vp]),
     "gsage_sample_hops_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _u32, _u64, _vp, _u64, _u64,
-                                        _vp, _vp]),
+                                        _vp, _vp, _i64, _vp, _vp]),
     "gsage_counter_add": (_int, [_vp, _u64, _vp]),
     "gsage_mt_create": (_vp, [_u32]),
     "gsage_mt_destroy": (None, [_vp]),
@@ -51,11 +51,11 @@ SIGNATURES = {
                            _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
-                             _vp, _vp, _vp]),
+                             _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp]),
-    "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_partials": (_int, [_i32, _i64]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),

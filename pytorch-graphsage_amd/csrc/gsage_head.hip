@@ -21,7 +21,9 @@ struct HeadParams {
     const float *E;          // [B, lde] fp32 embedding (last SAGE layer output)
     const float *W;          // [C, D] fc.weight
     const float *bias;       // [C]
-    const int64_t *targets;  // [B] class ids
+    const int64_t *targets;  // [B] class ids (or [n_batches, B] with batch_idx)
+    const int64_t *batch_idx;
+    int64_t n_batches;
     float *preds;            // [B, C] logits
     void *dE;                // [B, ldd] gradient w.r.t. E (bf16 or fp32)
     float *partial;          // [grid, C*D + C + 1] per-workgroup dW | db | loss
@@ -95,6 +97,7 @@ k_head_ce(const HeadParams p)
         for (int r = 0; r < R; ++r) v[r] = (red[r] + red[R + r]) + (red[2 * R + r] + red[3 * R + r]);
     };
 
+    const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * p.B : 0);
     const int row0 = blockIdx.x * R;
     const float invB = 1.f / (float)p.B;
     // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12)); rows past B behave as zero rows
@@ -152,7 +155,7 @@ k_head_ce(const HeadParams p)
         const float mx = wave_max64(logit);
         const float ex = (lane < C) ? expf(logit - mx) : 0.f;
         const float den = wave_sum64(ex);
-        const int64_t t = (i < p.B) ? p.targets[i] : -1;
+        const int64_t t = (i < p.B) ? tgt[i] : -1;
         const float dl = ok ? (ex / den - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
         dls[r * HEAD_CMAX + lane] = dl;
         if (ok) p.preds[(int64_t)i * C + lane] = logit;
@@ -285,14 +288,15 @@ int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D)
 int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias,
                   const int64_t *targets, int32_t B, int32_t C, int32_t D, float *preds, void *dE,
                   int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
-                  void *stream)
+                  const int64_t *batch_idx, int64_t n_batches, void *stream)
 {
+    GSAGE_REQUIRE(!batch_idx || n_batches > 0, "head_ce: bad target queue");
     GSAGE_REQUIRE(E && W && bias && targets && preds && dE && scratch, "head_ce: null pointer");
     GSAGE_REQUIRE(B > 0 && C > 0 && C <= HEAD_CMAX && D > 0 && D <= HEAD_DMAX,
                   "head_ce: needs 1 <= n_classes <= %d and 1 <= width <= %d", HEAD_CMAX, HEAD_DMAX);
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
     HeadParams p;
-    p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.preds = preds; p.dE = dE;
+    p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches; p.preds = preds; p.dE = dE;
     p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = D <= 256 ? 4 : 1;
     p.dE_dtype = dE_dtype;
     const int n_wg = (B + p.rows_per_wg - 1) / p.rows_per_wg;

@@ -116,10 +116,15 @@ struct ReduceDesc {
 
 __global__ void __launch_bounds__(256)
 k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
-                 float *__restrict__ partial_sq, int64_t *tick)
+                 float *__restrict__ partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
+                 int64_t *tick2, int64_t inc2)
 {
     __shared__ float red[4];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && tick) *tick += 1;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (tick) *tick += 1;
+        if (tick1) *tick1 += inc1;
+        if (tick2) *tick2 += inc2;
+    }
     const ReduceDesc d = descs[blockIdx.y];
     const int64_t total = (int64_t)d.rows * d.cols;
     const int64_t gstride = (int64_t)gridDim.x * 256;
@@ -278,11 +283,13 @@ int gsage_finalize_partials(int32_t n_desc, int64_t max_elems)
 }
 
 int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
-                         float *partial_sq, int64_t *tick, void *stream)
+                         float *partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
+                         int64_t *tick2, int64_t inc2, void *stream)
 {
     GSAGE_REQUIRE(descs && flat_g && partial_sq && n_desc > 0 && max_elems > 0, "finalize_grads: bad arguments");
     hipLaunchKernelGGL(k_finalize_grads, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
-                       (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick);
+                       (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, tick1, inc1,
+                       tick2, inc2);
     return check_launch("finalize_grads");
 }
 

@@ -97,6 +97,9 @@ struct HopsParams {
     int64_t *ids;                 // [hop 0 | hop 1 | ... | hop L], hop 0 filled by the caller
     const uint64_t *call_ctr;
     int32_t *err_flag;
+    const int64_t *seed_queue;    // optional [n_batches, B] device-resident seed batches ...
+    const int64_t *batch_idx;     // ... and the device word selecting the current one
+    int64_t n_batches;
     int64_t n_rows;
     int64_t off[6];               // first element of hop k in ids
     uint64_t g0[6];               // global sample index of this rank's first sample of hop k
@@ -118,7 +121,16 @@ k_sample_hops(const HopsParams p)
     int width = 1, widest = 1;
     for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
     int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
-    for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
+    if (p.seed_queue) {           // take the seeds from the queue (and publish them as hop 0)
+        const int64_t b = (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches);
+        for (int t = threadIdx.x; t < nseed; t += 256) {
+            const int64_t v = p.seed_queue[b * p.B + seed0 + t];
+            cur[t] = v;
+            p.ids[p.off[0] + seed0 + t] = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
+    }
     __syncthreads();
     const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
     int64_t per_seed = 1;                            // nodes of hop k per seed
@@ -281,14 +293,17 @@ int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n
 int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t *ids,
                              int64_t B, int32_t n_hops, const int32_t *fan, uint32_t max_deg,
                              uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
-                             uint64_t rank, int32_t *err_flag, void *stream)
+                             uint64_t rank, const int64_t *seed_queue, const int64_t *batch_idx,
+                             int64_t n_batches, int32_t *err_flag, void *stream)
 {
     GSAGE_REQUIRE(rowptr && col && ids && fan, "sample_hops_philox: null pointer");
+    GSAGE_REQUIRE(!seed_queue || (batch_idx && n_batches > 0), "sample_hops_philox: bad seed queue");
     GSAGE_REQUIRE(n_hops >= 1 && n_hops <= 5, "sample_hops_philox: 1..5 hops");
     GSAGE_REQUIRE(B >= 0 && B < (1LL << 31) && max_deg > 0, "sample_hops_philox: bad sizes");
     if (B == 0) return GSAGE_OK;
     HopsParams p;
     p.rowptr = rowptr; p.col = col; p.ids = ids; p.call_ctr = call_ctr; p.err_flag = err_flag;
+    p.seed_queue = seed_queue; p.batch_idx = batch_idx; p.n_batches = n_batches;
     p.n_rows = n_rows; p.call_base = call_base; p.n_hops = n_hops; p.B = (int32_t)B; p.max_deg = max_deg;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     int64_t size = B, off = 0, widest = 1, width = 1;

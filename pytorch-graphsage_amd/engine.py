@@ -293,6 +293,9 @@ class FusedMeanTrainStep(object):
         self.preds = None
         self.ids_set[0][:B].copy_(example_ids)
         self.n_calls = 0
+        # optional device-resident batch queue (load_epoch): the graph then needs no per-step copies
+        self.queue = None
+        self.batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
 
         # classification head as one fused kernel pair when it applies (else stock torch autograd)
         from .problem import ProblemLosses
@@ -415,6 +418,8 @@ class FusedMeanTrainStep(object):
         nat.check(nat.lib().gsage_sample_hops_philox(
             self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows, ids.data_ptr(),
             self.B, L, fan, self.csr.max_deg, self.sampler.seed, self.counter.data_ptr(), 0, rank,
+            self.queue[0].data_ptr() if self.queue else None,
+            self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
             self.csr.err_flag.data_ptr(), ops._stream()), "sample_hops_philox")
         # one launch: x rows of every hop + the mean of each hop's sampled neighbours
         R = self.rows[0]
@@ -424,8 +429,10 @@ class FusedMeanTrainStep(object):
             segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
                          self.size[k], self.fan[k + 1]))
         ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
-        # the next batch's samples use the next L Philox call indices
-        nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), L, ops._stream()), "counter_add")
+        # the next batch's samples use the next L Philox call indices (sequential mode: ticked by
+        # gsage_finalize_grads instead of a launch of its own)
+        if self.pipelined:
+            nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), L, ops._stream()), "counter_add")
 
     def _stage_compute(self, s):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
@@ -452,12 +459,14 @@ class FusedMeanTrainStep(object):
         m = self.model
         if self.fused_head:
             C, D2 = m.fc.weight.shape
-            tg = self.tg_set[s].view(-1)
+            tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
             nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
                                         m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), tg.data_ptr(),
                                         B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
                                         nat.BF16, self.dc[L - 1].stride(0), None, None, None,
-                                        self.head_scratch.data_ptr(), stream), "head_ce")
+                                        self.head_scratch.data_ptr(),
+                                        self.batch_idx.data_ptr() if self.queue else None,
+                                        self.queue[2] if self.queue else 0, stream), "head_ce")
         else:
             self._torch_head(s)
         self._backward_levels(s)
@@ -511,7 +520,10 @@ class FusedMeanTrainStep(object):
         # every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick
         nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
                                            self.flat_g.data_ptr(), self.partial.data_ptr(),
-                                           self.step.data_ptr(), stream), "finalize_grads")
+                                           self.step.data_ptr(),
+                                           None if self.pipelined else self.counter.data_ptr(), L,
+                                           self.batch_idx.data_ptr() if self.queue else None, 1,
+                                           stream), "finalize_grads")
         if self.ddp is not None:
             self.flat_g.div_(self.ddp.world)
 
@@ -538,6 +550,42 @@ class FusedMeanTrainStep(object):
     def set_progress(self, progress):
         self.model.lr = self.model.lr_scheduler(progress)
         self.lr.fill_(float(self.model.lr))
+
+    def load_epoch(self, ids_epoch, targets_epoch):
+        """Device-resident batch queue: ids_epoch int64 [n_batches, B], targets_epoch int64
+        [n_batches, B(,1)] on the GPU.  Afterwards `step_queue()` runs one train_step on the next batch
+        of the queue (wrapping around) with no host->device or device->device copies at all.
+        Needs the fused classification head and the sequential (non-pipelined) mode; the graph is
+        re-captured because its kernels now read the queue."""
+        assert self.fused_head and not self.pipelined and self.ddp is None or self.fused_head and not self.pipelined
+        n_batches = int(ids_epoch.shape[0])
+        assert tuple(ids_epoch.shape) == (n_batches, self.B) and ids_epoch.dtype == torch.int64
+        tq = targets_epoch.reshape(n_batches, self.B).contiguous()
+        assert tq.dtype == torch.int64
+        self.queue = (ids_epoch.contiguous(), tq, n_batches)
+        self.batch_idx.zero_()
+        if self.g_main is not None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.g_main[0].pool()):
+                self._stage_sample_gather(0)
+                self._stage_compute(0)
+                if self.ddp is None:
+                    self._stage_opt()
+            self.g_main = [g]
+        return self
+
+    def step_queue(self):
+        """One train_step on the next batch of the loaded epoch queue -> preds (static buffer)."""
+        assert self.queue is not None, "call load_epoch() first"
+        if self.g_main is None:
+            self._run_sequential(0)
+        else:
+            self.g_main[0].replay()
+            if self.g_opt is not None:
+                torch.distributed.all_reduce(self.flat_g)
+                self.g_opt.replay()
+        return self.preds
 
     def _load(self, s, ids, targets):
         self.ids_set[s][:self.B].copy_(ids, non_blocking=True)

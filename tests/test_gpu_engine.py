@@ -116,6 +116,28 @@ def test_pipelined_engine_is_bit_identical_to_sequential(capture):
     assert torch.equal(outs[False][1], outs[True][1])
 
 
+def test_batch_queue_equals_per_step_copies():
+    adj, feats, rng = _problem(seed=4)
+    D, C, B, dims, fans = feats.shape[1], 5, 24, (128, 128), (5, 3)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
+    tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
+    res = []
+    for queued in (False, True):
+        model = _model(adj, D, C, dims, fans)
+        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0], tg_all[0])
+        preds = []
+        if queued:
+            eng.load_epoch(ids_all, tg_all)
+            for k in range(5):                       # wraps around the 3-batch queue
+                preds.append(eng.step_queue().clone())
+        else:
+            for k in range(5):
+                preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
+        res.append((torch.stack(preds), eng.flat_p.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_fused_engine_first_step_against_oracle():
     """One engine step vs the fp32 CPU oracle fed the same Philox sel (bf16 tolerance)."""
     from oracle import cpu as ocpu

@@ -330,7 +330,7 @@ def test_head_ce_forward_backward_vs_torch(B, C, D):
     scratch = torch.empty(L.gsage_head_ce_scratch(B, C, D), device=DEV)
     nat.check(L.gsage_head_ce(E.data_ptr(), D, W.data_ptr(), b.data_ptr(), t.data_ptr(), B, C, D,
                               preds.data_ptr(), dE.data_ptr(), nat.F32, D, dW.data_ptr(), db.data_ptr(),
-                              loss.data_ptr(), scratch.data_ptr(), None))
+                              loss.data_ptr(), scratch.data_ptr(), None, 0, None))
     Ed, Wd, bd = [v.detach().double().cpu().requires_grad_(True) for v in (E, W, b)]
     pr = F.normalize(Ed, dim=1) @ Wd.t() + bd
     ls = F.cross_entropy(pr, t.cpu())
@@ -360,7 +360,7 @@ def test_fused_multi_hop_sampler_equals_per_hop_launches(B, fans):
     fan = (ctypes.c_int32 * len(fans))(*fans)
     nat.check(nat.lib().gsage_sample_hops_philox(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.n_rows,
                                                  ids.data_ptr(), B, len(fans), fan, csr.max_deg, 99,
-                                                 ctr.data_ptr(), 1, rank, csr.err_flag.data_ptr(), None))
+                                                 ctr.data_ptr(), 1, rank, None, None, 0, csr.err_flag.data_ptr(), None))
     cur, off = seeds, B
     for k, f in enumerate(fans):
         nxt = ops.sample_csr(csr, cur, f, philox={"seed": 99, "call_ctr": ctr, "call_base": 1 + k,

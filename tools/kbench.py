@@ -73,7 +73,7 @@ if 'head' in which:
     def f():
         nat.check(L.gsage_head_ce(E.data_ptr(), 2 * h, W.data_ptr(), b.data_ptr(), tg.data_ptr(), B, 41, 2 * h,
                                   preds.data_ptr(), dE.data_ptr(), nat.BF16, 2 * h, dW.data_ptr(), db.data_ptr(),
-                                  loss.data_ptr(), scr.data_ptr(), None))
+                                  loss.data_ptr(), scr.data_ptr(), None, 0, ops._stream()))
     print('head (2 launches): %.1f us' % timeit(f))
 
 if 'gather' in which:
