@@ -27,6 +27,8 @@
 // activations of the reference never reach HBM.
 #include "gsage_common.h"
 
+#include <stdlib.h>
+
 namespace gsage {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -53,6 +55,7 @@ struct LinearParams {
     float *pooled;
     int64_t pooled_ld;
     int32_t *argmax;
+    int32_t dbg;           // GSAGE_DBG ablation switches (tools/kbench.py only): 1 no MFMA, 2 no DMA, 4 no stores
 };
 
 constexpr int BM = 64;
@@ -100,13 +103,83 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
+// Epilogue shared by both K5 kernels: bias + activation, then the 64x128 tile goes through LDS
+// so that global memory sees full 16-byte row chunks (256 B contiguous per 16 lanes) instead of the
+// MFMA layout's 2-byte column-per-lane scatter -- the scatter alone cost ~5.5 us per launch at the
+// layer-0 shape (ablation: tools/kbench.py linK with GSAGE_DBG=4).  Falls back to per-element
+// stores when the output rows are not 16-byte chunk aligned or the tile is ragged in N.
+// C/D layout of the 32x32 MFMA: lane l, register r -> column (l & 31),
+// row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+template <int ACT>
+__device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t &acc0,
+                                           const f32x16_t &acc1, int g, int64_t m0, int64_t n0,
+                                           int wm, int wn, int lane, int tid, void *lds_raw)
+{
+    const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
+    const int esz = p.c_dtype == GSAGE_BF16 ? 2 : 4;
+    const int epc = 16 / esz;                                    // output elements per 16-byte chunk
+    const int64_t cbase = (int64_t)g * p.c_gstride + n0;         // first output column of the tile
+    const bool wide = n0 + BN <= p.N && p.ldc % epc == 0 && cbase % epc == 0 &&
+                      ((uintptr_t)p.C % 16) == 0 && !(p.dbg & 8);
+    if (wide) {
+        __syncthreads();                                         // operand buffers are free now
+        const int ldt = BN + epc;                                // padded row, still 16-byte aligned
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x16_t &acc = t ? acc1 : acc0;
+            const int jl = wn * 64 + t * 32 + (lane & 31);
+            const float bj = bias ? bias[n0 + jl] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = apply_act(acc[r] + bj, ACT);
+                if (p.c_dtype == GSAGE_BF16)
+                    ((uint16_t *)lds_raw)[i * ldt + jl] = f32_to_bf16(v);
+                else
+                    ((float *)lds_raw)[i * ldt + jl] = v;
+            }
+        }
+        __syncthreads();
+        const int cpr = BN / epc;                                // chunks per tile row
+        for (int q = tid; q < BM * cpr; q += 256) {
+            const int row = q / cpr, ch = q - row * cpr;
+            const int64_t m = m0 + row;
+            if (m < p.M) {
+                const vec16 v = *reinterpret_cast<const vec16 *>((const char *)lds_raw +
+                                                                 ((size_t)row * ldt + ch * epc) * esz);
+                *reinterpret_cast<vec16 *>((char *)p.C + ((size_t)m * p.ldc + cbase + ch * epc) * esz) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16_t &acc = t ? acc1 : acc0;
+        const int64_t j = n0 + wn * 64 + t * 32 + (lane & 31);
+        const float bj = (bias && j < p.N) ? bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t m = m0 + wm * 32 + i;
+            if (m < p.M && j < p.N && !((p.dbg & 4) && acc[r] != 12345.f)) {
+                const float v = apply_act(acc[r] + bj, ACT);
+                const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
+                if (p.c_dtype == GSAGE_BF16)
+                    ((uint16_t *)p.C)[off] = f32_to_bf16(v);
+                else
+                    ((float *)p.C)[off] = v;
+            }
+        }
+    }
+}
+
 template <typename T, bool POOL, int ACT>
 __global__ void __launch_bounds__(256)
 k_linear_nt(const LinearParams p)
 {
     constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-byte chunk
     // one raw LDS array (keeps the compiler from serialising waits across objects)
-    __shared__ vec16 smem[POOL ? (BM * BN * 4 / 16) : ((BM + BN) * CH)];
+    __shared__ vec16 smem[POOL ? (BM * BN * 4 / 16) : (BM * (BN + 4) * 4 / 16)];   // >= operand tiles (24 KiB) and the fp32 output staging tile
     vec16 *sA = smem;
     vec16 *sW = smem + BM * CH;
 
@@ -212,26 +285,7 @@ k_linear_nt(const LinearParams p)
     // C/D layout of the 32x32 MFMA: lane l, register r -> column (l & 31),
     // row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
     if (!POOL) {
-        const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x16_t &acc = t ? acc1 : acc0;
-            const int64_t j = n0 + wn * 64 + t * 32 + (lane & 31);
-            const float bj = (bias && j < p.N) ? bias[j] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int64_t m = m0 + wm * 32 + i;
-                if (m < p.M && j < p.N) {
-                    const float v = apply_act(acc[r] + bj, ACT);
-                    const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
-                    if (p.c_dtype == GSAGE_BF16)
-                        ((uint16_t *)p.C)[off] = f32_to_bf16(v);
-                    else
-                        ((float *)p.C)[off] = v;
-                }
-            }
-        }
+        store_tile<ACT>(p, acc0, acc1, g, m0, n0, wm, wn, lane, tid, smem);
     } else {
         // bias + ReLU'd tile -> LDS [64][128] fp32, then segment max / mean down the rows
         float *tile = reinterpret_cast<float *>(smem);
@@ -367,7 +421,7 @@ k_linear_nt_dma(const LinearParams p)
         // ... and after the barrier so have everybody's; it also proves every wave is done
         // reading the buffer tile kt+2 is about to overwrite (it was tile kt-1's)
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
+        if (kt + 2 < nk && !(p.dbg & 2)) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
         const vec16 *sA = smem + buf * TILE;
         const vec16 *sW = sA + BM * CH;
         // all 12 fragment reads of the tile first (one LDS latency per tile instead of one per
@@ -382,34 +436,20 @@ k_linear_nt_dma(const LinearParams p)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done: this buffer may be
         __builtin_amdgcn_sched_barrier(0);                       // overwritten after the next barrier
+        if (!(p.dbg & 1)) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
-            mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
+            for (int kk = 0; kk < 4; ++kk) {
+                mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
+                mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { acc0[kk] += __uint_as_float(fa[kk][0] ^ fb0[kk][1]); acc1[kk] += __uint_as_float(fb1[kk][2]); }
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
 
-    const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x16_t &acc = t ? acc1 : acc0;
-        const int64_t j = n0 + wn * 64 + t * 32 + (lane & 31);
-        const float bj = (bias && j < p.N) ? bias[j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int64_t m = m0 + wm * 32 + i;
-            if (m < p.M && j < p.N) {
-                const float v = apply_act(acc[r] + bj, ACT);
-                const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
-                if (p.c_dtype == GSAGE_BF16)
-                    ((uint16_t *)p.C)[off] = f32_to_bf16(v);
-                else
-                    ((float *)p.C)[off] = v;
-            }
-        }
-    }
+    store_tile<ACT>(p, acc0, acc1, g, m0, n0, wm, wn, lane, tid, smem);
 }
 
 static int check_operands(const char *who, const void *A, int dtype, int64_t lda, const void *W,
@@ -453,6 +493,7 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     p.a_rows_group0_only = a_rows_group0_only; p.act = act; p.c_dtype = c_dtype;
     p.pool_n = 0; p.pool_groups = 0; p.pool_mode = 0; p.pooled = nullptr; p.pooled_ld = 0;
     p.argmax = nullptr;
+    { static const char *e = getenv("GSAGE_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
     // whole-line operand rows -> LDS-DMA pipelined kernel
@@ -509,7 +550,7 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     p.a_gstride = 0; p.w_gstride = 0; p.c_gstride = 0;
     p.a_rows_group0_only = 0; p.act = ACT_RELU; p.c_dtype = GSAGE_F32;
     p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled;
-    p.pooled_ld = pooled_ld; p.argmax = argmax;
+    p.pooled_ld = pooled_ld; p.argmax = argmax; p.dbg = 0;
     dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, BN), 1);
     if (dtype == GSAGE_BF16)
         hipLaunchKernelGGL((k_linear_nt<uint16_t, true, ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, p);
