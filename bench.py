@@ -168,9 +168,16 @@ def dominant_kernel_roofline(gs, model, store, data, dev, reps=40, n_frontiers=8
     elem = store.data.element_size()
     alg_bytes = BATCH * FANOUT[0] * FANOUT[1] * FEAT_DIM * elem
     achieved = alg_bytes / dur_s / 1e9
+    # HBM bytes per launch of the same kernel from the PMC pass committed under profiles/
+    # (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only valid for the default workload
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+    if os.path.exists(pmc) and elem == 2:
+        with open(pmc) as f:
+            traffic = json.load(f).get("hbm_read_bytes_per_launch")
     return {"bound": "hbm", "kernel": "k_gather_mean (hop 2: 250 of 276 rows/seed)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "alg_bytes_per_launch": alg_bytes, "avg_launch_us": dur_s * 1e6}
 
 

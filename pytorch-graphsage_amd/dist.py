@@ -80,8 +80,10 @@ def init_from_env(cuda=True):
     """Returns a DataParallel handle when launched by torch.distributed.run with WORLD_SIZE > 1,
     else None.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
-        return None
+    if world <= 1 and os.environ.get("GSAGE_FORCE_DDP", "0") != "1":
+        return None      # (GSAGE_FORCE_DDP=1: exercise the collective path with a 1-rank group)
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("MASTER_PORT", "29511")
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
