@@ -73,21 +73,28 @@ def synthetic_reddit(n_nodes=N_NODES, seed=0, feat_dim=FEAT_DIM, max_deg=MAX_DEG
             "targets": targets, "nnz": nnz}
 
 
-def build_model(gs, adj, aggregator="mean", rng="philox", seed=123):
+def build_model(gs, adj, aggregator="mean", rng="philox", seed=123, fanout=FANOUT, hidden=HIDDEN):
     from torch.nn import functional as F
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = rng
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": (lambda x: x) if i == len(fanout) - 1 else F.relu}
+             for i, (f, h) in enumerate(zip(fanout, hidden))]
     model = gs.GSSupervised(
         sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
         prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup[aggregator],
         input_dim=FEAT_DIM, n_nodes=adj.shape[0], n_classes=N_CLASSES,
-        layer_specs=[{"n_train_samples": FANOUT[0], "n_val_samples": FANOUT[0],
-                      "output_dim": HIDDEN[0], "activation": F.relu},
-                     {"n_train_samples": FANOUT[1], "n_val_samples": FANOUT[1],
-                      "output_dim": HIDDEN[1], "activation": lambda x: x}],
-        lr_init=0.01, lr_schedule="constant", weight_decay=0.0)
+        layer_specs=specs, lr_init=0.01, lr_schedule="constant", weight_decay=0.0)
     model.train_sampler.seed = seed
     model.val_sampler.seed = seed
     return model
+
+
+def rows_per_seed(fanout):
+    n, prod = 1, 1
+    for f in fanout:
+        prod *= f
+        n += prod
+    return n
 
 
 def cpu_baseline(data, budget_s=15.0, batch=BATCH):
@@ -188,6 +195,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-size", type=int, default=BATCH, help="seed nodes per GPU per step")
     ap.add_argument("--aggregator", type=str, default="mean")
+    ap.add_argument("--fanout", type=str, default="25,10", help="per-layer fan-outs (BASELINE: 25,10)")
+    ap.add_argument("--hidden", type=str, default="128,128", help="per-layer output dims")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"],
@@ -220,7 +229,11 @@ def main():
 
     data = synthetic_reddit(seed=0)
     store = data["feats"](dev, args.precision)
-    model = build_model(gs, data["adj"], aggregator=args.aggregator, rng="philox").to(dev)
+    fanout = tuple(int(v) for v in args.fanout.split(","))
+    hidden = tuple(int(v) for v in args.hidden.split(","))
+    assert len(fanout) == len(hidden)
+    model = build_model(gs, data["adj"], aggregator=args.aggregator, rng="philox", fanout=fanout,
+                        hidden=hidden).to(dev)
     if ddp is not None:
         gs.dist.attach(model, ddp, seed=123)
     model.train_sampler.csr(dev)                       # upload the CSR before timing
@@ -292,14 +305,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "Reddit-shaped %s-aggregator 2-layer fanout 25/10 hidden 128 "
-                                   "(BASELINE configs[1]); N=232965 D=602 nnz=%d" % (args.aggregator, data["nnz"]),
+            "config": {"workload": "Reddit-shaped %s-aggregator %d-layer fanout %s hidden %s "
+                                   "(BASELINE configs[1]%s); N=232965 D=602 nnz=%d"
+                                   % (args.aggregator, len(fanout), "/".join(map(str, fanout)),
+                                      "/".join(map(str, hidden)),
+                                      "" if (args.aggregator, fanout, hidden) == ("mean", FANOUT, HIDDEN)
+                                      else " variant", data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
                        "engine": engine, "hip_graph": use_graph,
                        "pipelined": bool(engine == "fused" and args.pipeline), "batch_queue": bool(queued), "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
                        if not use_graph else None},
-            "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (276 * FEAT_DIM * store.data.element_size())),
+            "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (
+                rows_per_seed(fanout) * FEAT_DIM * store.data.element_size())),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,25 @@ k_head_ce(const HeadParams p)
     float *red = dls + R * HEAD_CMAX;             // [4][R]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every global input is requested up front (one memory round trip on the critical path, not
+    // one per phase): this wave's row target, the bias, the R embedding rows, then fc.weight
+    const int row0 = blockIdx.x * R;
+    const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * p.B : 0);
+    int64_t my_target[(R + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (R + 3) / 4; ++q) {
+        const int i = row0 + wave + 4 * q;
+        my_target[q] = (wave + 4 * q < R && i < p.B) ? tgt[i] : -1;
+    }
+    const float my_bias = (lane < C) ? p.bias[lane] : 0.f;
+    float z[R][KPT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + 256 * j;
+            z[r][j] = (k < D && row0 + r < p.B) ? p.E[(int64_t)(row0 + r) * p.lde + k] : 0.f;
+        }
     // fc.weight -> LDS, 8 independent loads in flight per thread before the stores
     for (int k = tid; k < D; k += 256) {
         int c = 0;
@@ -97,21 +116,14 @@ k_head_ce(const HeadParams p)
         for (int r = 0; r < R; ++r) v[r] = (red[r] + red[R + r]) + (red[2 * R + r] + red[3 * R + r]);
     };
 
-    const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * p.B : 0);
-    const int row0 = blockIdx.x * R;
     const float invB = 1.f / (float)p.B;
     // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12)); rows past B behave as zero rows
-    float z[R][KPT], ss[R], nrm[R];
+    float ss[R], nrm[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         ss[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int k = tid + 256 * j;
-            const float e = (k < D && row0 + r < p.B) ? p.E[(int64_t)(row0 + r) * p.lde + k] : 0.f;
-            z[r][j] = e;
-            ss[r] += e * e;
-        }
+        for (int j = 0; j < KPT; ++j) ss[r] += z[r][j] * z[r][j];
     }
     block_sum_rows(ss);
 #pragma unroll
@@ -151,11 +163,11 @@ k_head_ce(const HeadParams p)
         float logit = -INFINITY;
         if (lane < C)
             logit = part[(0 * R + r) * HEAD_CMAX + lane] + part[(1 * R + r) * HEAD_CMAX + lane] +
-                    part[(2 * R + r) * HEAD_CMAX + lane] + part[(3 * R + r) * HEAD_CMAX + lane] + p.bias[lane];
+                    part[(2 * R + r) * HEAD_CMAX + lane] + part[(3 * R + r) * HEAD_CMAX + lane] + my_bias;
         const float mx = wave_max64(logit);
         const float ex = (lane < C) ? expf(logit - mx) : 0.f;
         const float den = wave_sum64(ex);
-        const int64_t t = (i < p.B) ? tgt[i] : -1;
+        const int64_t t = my_target[(r - wave) / 4];
         const float dl = ok ? (ex / den - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
         dls[r * HEAD_CMAX + lane] = dl;
         if (ok) p.preds[(int64_t)i * C + lane] = logit;

@@ -109,7 +109,9 @@ struct HopsParams {
     uint32_t max_deg, seed_lo, seed_hi;
 };
 
-constexpr int HOPS_SPW = 4;       // seeds per workgroup
+constexpr int HOPS_SPW = 1;       // seeds per workgroup: hop 2 of a 25x10 frontier is one pass of
+                                  // 250 lanes, so a seed's whole sub-tree costs two dependent
+                                  // (rowptr -> col) round trips
 
 __global__ void __launch_bounds__(256)
 k_sample_hops(const HopsParams p)
