@@ -223,6 +223,22 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
                   const int64_t *batch_idx, int64_t n_batches, void *stream);
 int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
 
+/* The whole seed level of a mean-aggregator model in one launch: segment mean of the n sampled
+ * neighbours (nn_modules.py:197-198), emb = cat[fc_x(x), fc_neib(agg)] (:200-202, identity
+ * activation), the classification head above (models.py:90-91, problem.py:34) and the backward down
+ * to the previous level's activations.  H: bf16 [B*(1+n), 256] = previous level output (seed rows,
+ * then their n neighbours each); w2 / w2t: bf16 operand copies [2,128,ldw2] / [2,256,ldw2t] of
+ * (fc_x | fc_neib) and their transposes.  Writes agg (bf16 [B,256]) and dE (bf16 [B,256]) -- the
+ * operands of this level's gsage_wgrad --, preds [B,C], dH (bf16 [B*(1+n),256], ReLU mask of H
+ * applied) and the fc.weight | fc.bias | loss partials (layout of gsage_head_ce, scratch size
+ * gsage_mean_tail_ce_scratch).  Fixed widths: previous level 256, this level 2h = 256; n <= 32;
+ * C <= 64. */
+int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int64_t ldw2,
+                       const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
+                       const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
+                       void *dE, float *preds, void *dH, float *partial, void *stream);
+int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
+
 /* ------------------------------------------------------------------------------------------
  * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86
  * under autograd), used by the hipGraph engine.

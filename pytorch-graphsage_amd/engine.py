@@ -139,6 +139,7 @@ class CapturedTrainStep(object):
 # Fused engine: the SAGE layers without autograd
 # =================================================================================================
 import ctypes
+import os
 
 from . import ops
 from .nn_modules import IdentityPrep, MeanAggregator, SparseUniformNeighborSampler, \
@@ -304,7 +305,13 @@ class FusedMeanTrainStep(object):
         ident = self.post is None or torch.equal(self.post(probe), probe)
         self.fused_head = (loss_fn is ProblemLosses.classification and ident and C <= 64 and
                            D2 <= 1024 and example_targets.dtype == torch.int64)
+        # the seed level (segment mean + GEMM + head + input gradients + mask/route) as ONE kernel
+        self.fused_tail = bool(self.fused_head and L >= 2 and self.din[L - 1] == 256 and
+                               2 * self.h[L - 1] == 256 and self.fan[1] <= 32 and
+                               os.environ.get("GSAGE_NO_FUSED_TAIL", "0") != "1")
         if self.fused_head:
+            assert nat.lib().gsage_head_ce_scratch(B, C, D2) == nat.lib().gsage_mean_tail_ce_scratch(B, C) \
+                or not self.fused_tail
             self.head_scratch = torch.zeros(nat.lib().gsage_head_ce_scratch(B, C, D2),
                                             dtype=torch.float32, device=dev)
             self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -439,7 +446,7 @@ class FusedMeanTrainStep(object):
         L, B, st, lib = self.L, self.B, self.store, nat.lib()
         stream = ops._stream()
         esz = 2
-        for l in range(L):
+        for l in range(L - 1 if self.fused_tail else L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             if l == 0:
                 xbuf, agg, lda = self.xa0_set[s][0], self.xa0_set[s][1], st.ld
@@ -457,7 +464,17 @@ class FusedMeanTrainStep(object):
                          h * self.w2[l].shape[2], h)
 
         m = self.model
-        if self.fused_head:
+        if self.fused_tail:
+            C = m.fc.weight.shape[0]
+            tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+            nat.check(lib.gsage_mean_tail_ce(
+                self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
+                self.w2[L - 1].shape[2], self.w2t[L - 1].data_ptr(), self.w2t[L - 1].shape[2],
+                m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), C, tg.data_ptr(),
+                self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
+                self.agg[L - 1].data_ptr(), self.dc[L - 1].data_ptr(), self.preds.data_ptr(),
+                self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(), stream), "mean_tail_ce")
+        elif self.fused_head:
             C, D2 = m.fc.weight.shape
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
             nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
@@ -505,7 +522,7 @@ class FusedMeanTrainStep(object):
                     src = xbuf if g == 0 else aggl
                     ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h, slabs=self.slabs[l][g],
                               reduce=False)
-            if l > 0:
+            if l > 0 and not (self.fused_tail and l == L - 1):
                 w2t = self.w2t[l]
                 # (dX | dAgg) = dC_g @ W_g : NT GEMM against the transposed operand copies
                 self._linear(dc.data_ptr(), 2 * h, None, 0, w2t.data_ptr(), w2t.shape[2],
