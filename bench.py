@@ -198,7 +198,10 @@ def main():
     ap.add_argument("--fanout", type=str, default="25,10", help="per-layer fan-outs (BASELINE: 25,10)")
     ap.add_argument("--hidden", type=str, default="128,128", help="per-layer output dims")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--launch", choices=["cmdlist", "graph", "eager"], default="cmdlist",
+                    help="how a step's kernels are issued: native command lists (default), hipGraph "
+                         "replay, or one Python call per kernel")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"],
                     help="fused: engine.FusedMeanTrainStep (no autograd below the head); "
                          "autograd: GSSupervised.train_step (captured unless --no-graph)")
@@ -247,14 +250,17 @@ def main():
     ids_all = torch.from_numpy(data["train_ids"][pick][:, rank * B:(rank + 1) * B]).to(dev)
     tg_all = torch.from_numpy(data["targets"][data["train_ids"][pick]][:, rank * B:(rank + 1) * B]).to(dev)
 
-    use_graph = not args.no_graph
+    if args.no_graph:
+        args.launch = "eager"
+    use_graph = args.launch != "eager"
     step_fn = None
     engine = args.engine
     if engine == "fused" and not gs.engine.FusedMeanTrainStep.supports(model, store):
         engine = "autograd"
     if engine == "fused":
         step_fn = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
-                                               capture=use_graph, pipelined=args.pipeline)
+                                               capture=args.launch if use_graph else False,
+                                               pipelined=args.pipeline)
     elif use_graph:
         try:
             step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
@@ -312,10 +318,11 @@ def main():
                                       "" if (args.aggregator, fanout, hidden) == ("mean", FANOUT, HIDDEN)
                                       else " variant", data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
-                       "engine": engine, "hip_graph": use_graph,
+                       "engine": engine,
+                       "launch": (getattr(step_fn, "capture_mode", None) or ("graph" if use_graph else "eager")),
                        "pipelined": bool(engine == "fused" and args.pipeline), "batch_queue": bool(queued), "parallelism": "dp%d" % world,
                        "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
-                       if not use_graph else None},
+                       if args.launch != "graph" else None},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (
                 rows_per_seed(fanout) * FEAT_DIM * store.data.element_size())),
             "roofline": roof,

@@ -57,6 +57,29 @@ uint64_t gsage_launch_count(void);
 int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
 
 /* ------------------------------------------------------------------------------------------
+ * Command lists.  No reference counterpart: the reference dispatches one PyTorch op per tensor
+ * expression from Python (models.py:71-104); here a train_step is ~9 kernels of 5-40 us and the
+ * way they are issued matters as much as the kernels.
+ *
+ *   gsage_cmdlist_begin()            [host] every gsage_* kernel call made by THIS thread from now
+ *                                    on is validated and recorded (kernel, geometry, by-value
+ *                                    arguments) instead of launched; `stream` arguments are ignored.
+ *   gsage_cmdlist_end(&list)         [host] stops recording, returns the list.
+ *   gsage_cmdlist_replay(list, s)    [host] issues the recorded kernels back to back on stream s
+ *                                    (one hipLaunchKernel each, no validation, no Python).  The
+ *                                    pointers recorded must still be valid: same rule as a hipGraph.
+ *   gsage_cmdlist_size / _destroy
+ * Unlike a hipGraph a list has no start-up gap on the device and can be cut anywhere (e.g.
+ * around an RCCL collective on another stream) at no cost.  Host-side calls (gsage_mt_*) and the
+ * one-time LDS-limit setup of a kernel are not recordable: run one un-recorded step first.
+ * ---------------------------------------------------------------------------------------- */
+int gsage_cmdlist_begin(void);
+int gsage_cmdlist_end(void **list);
+int64_t gsage_cmdlist_size(const void *list);
+int gsage_cmdlist_replay(const void *list, void *stream);
+void gsage_cmdlist_destroy(void *list);
+
+/* ------------------------------------------------------------------------------------------
  * K1  neighbour sampler     replaces SparseUniformNeighborSampler.__call__, nn_modules.py:80-101
  *     (and __init__, :72-78: degrees are rowptr differences, nothing is precomputed)
  *

@@ -30,6 +30,11 @@ SIGNATURES = {
     "gsage_last_error": (ctypes.c_char_p, []),
     "gsage_launch_count": (_u64, []),
     "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "gsage_cmdlist_begin": (_int, []),
+    "gsage_cmdlist_end": (_int, [ctypes.POINTER(_vp)]),
+    "gsage_cmdlist_size": (_i64, [_vp]),
+    "gsage_cmdlist_replay": (_int, [_vp, _vp]),
+    "gsage_cmdlist_destroy": (None, [_vp]),
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
                                        _vp, _vp, _vp, _vp]),
@@ -122,6 +127,47 @@ def check(rc, what=""):
 
 def launch_count():
     return int(lib().gsage_launch_count())
+
+
+class CommandList(object):
+    """Recorded gsage kernel launches, replayed back to back on a stream (include/gsage.h,
+    "Command lists").  Usage:  with CommandList.record() as cl: <gsage kernel calls>;  cl.replay(stream)"""
+
+    def __init__(self):
+        self._h = None
+
+    @classmethod
+    def record(cls):
+        return _Recorder(cls())
+
+    def __len__(self):
+        return int(lib().gsage_cmdlist_size(self._h)) if self._h else 0
+
+    def replay(self, stream):
+        check(lib().gsage_cmdlist_replay(self._h, stream), "cmdlist_replay")
+
+    def __del__(self):
+        if self._h and _LIB is not None:
+            _LIB.gsage_cmdlist_destroy(self._h)
+            self._h = None
+
+
+class _Recorder(object):
+    def __init__(self, cl):
+        self.cl = cl
+
+    def __enter__(self):
+        check(lib().gsage_cmdlist_begin(), "cmdlist_begin")
+        return self.cl
+
+    def __exit__(self, et, ev, tb):
+        h = _vp()
+        rc = lib().gsage_cmdlist_end(ctypes.byref(h))
+        if rc == 0:
+            self.cl._h = h.value
+        if et is None:
+            check(rc, "cmdlist_end")
+        return False
 
 
 def device_info():

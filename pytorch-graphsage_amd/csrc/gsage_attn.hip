@@ -91,11 +91,11 @@ extern "C" int gsage_attn_aggregate(const float *na, int64_t na_ld, const float 
     GSAGE_REQUIRE(na && xa && table && agg && ws, "attn_aggregate: null pointer");
     dim3 grid((unsigned)ceil_div(M, 4));
     if (dtype == GSAGE_F32)
-        hipLaunchKernelGGL((k_attn_aggregate<float>), grid, dim3(256), 0, (hipStream_t)stream, na,
+        launch(k_attn_aggregate<float>, grid, dim3(256), 0, (hipStream_t)stream, na,
                            na_ld, xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha,
                            (int32_t)D, agg, agg_ld, ws);
     else if (dtype == GSAGE_BF16)
-        hipLaunchKernelGGL((k_attn_aggregate<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream,
+        launch(k_attn_aggregate<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
                            na, na_ld, xa, xa_ld, (const uint16_t *)table, ld, ids, M, n,
                            (int32_t)Ha, (int32_t)D, agg, agg_ld, ws);
     else {

@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
+#include <functional>
+#include <tuple>
+#include <vector>
 
 #include "../../include/gsage.h"
 
@@ -34,6 +37,36 @@ inline int check_launch(const char *what)
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- command lists ------------------------------------------------------------------------------
+// Every kernel of this library is launched through launch().  While a command list is being
+// recorded on the calling thread (gsage_cmdlist_begin .. gsage_cmdlist_end) the launch is not
+// issued: the kernel, its geometry and a by-value copy of its arguments (already converted to the
+// kernel's parameter types) become a node of the list, and gsage_cmdlist_replay() later issues the
+// nodes back to back on a stream of the caller's choice.  Compared with a hipGraph of the same
+// kernels a replay costs the host one hipLaunchKernel per node (~2-3 us) instead of ~10-16 us per
+// graph launch PLUS an 8-15 us start-up gap on the device at every graph boundary, which matters
+// when a step has to be cut into several pieces around a collective (engine.py, data-parallel).
+struct CmdList {
+    std::vector<std::function<void(hipStream_t)>> nodes;
+};
+extern thread_local CmdList *t_recording;
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                   Args... args)
+{
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "launch: argument count mismatch");
+    if (t_recording) {
+        std::tuple<KArgs...> packed(static_cast<KArgs>(args)...);
+        t_recording->nodes.emplace_back([kernel, grid, block, lds, packed](hipStream_t s) {
+            std::apply([&](const KArgs &...a) { hipLaunchKernelGGL(kernel, grid, block, lds, s, a...); },
+                       packed);
+        });
+        return;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
+}
 
 // ---- bf16 <-> fp32 (bf16 = upper half of an IEEE fp32, round-to-nearest-even) ------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

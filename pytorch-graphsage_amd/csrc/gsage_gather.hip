@@ -209,7 +209,7 @@ static int launch_gather_mean(const void *table, int64_t ld, const int64_t *ids,
                               int32_t n, int64_t D, void *out, int64_t out_ld, hipStream_t s)
 {
     const int32_t chunks = (int32_t)ceil_div(D, VEC);
-    hipLaunchKernelGGL((k_gather_mean<TI, TO, VEC>), dim3(grid_for(M * chunks)), dim3(256), 0, s,
+    launch(k_gather_mean<TI, TO, VEC>, dim3(grid_for(M * chunks)), dim3(256), 0, s,
                        (const TI *)table, ld, ids, M, n, (int32_t)D, chunks, (TO *)out, out_ld);
     return check_launch("gather_mean");
 }
@@ -289,7 +289,7 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
         q.first[s + 1] = q.first[s] + q.M[s] * chunks;
     }
     if (q.first[n_seg] == 0) return GSAGE_OK;
-    hipLaunchKernelGGL((k_gather_mean_multi<uint16_t, uint16_t, 8>), dim3(grid_for(q.first[n_seg])),
+    launch(k_gather_mean_multi<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg])),
                        dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
     return check_launch("gather_mean_multi");
 }
@@ -306,10 +306,10 @@ int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, 
                     aligned_to(dneibs, 16);
     if (v4) {
         const int32_t chunks = (int32_t)(D / 4);
-        hipLaunchKernelGGL((k_segment_mean_bwd<4>), dim3(grid_for(M * n * chunks)), dim3(256), 0, s,
+        launch(k_segment_mean_bwd<4>, dim3(grid_for(M * n * chunks)), dim3(256), 0, s,
                            dagg, ld, M, n, (int32_t)D, chunks, dneibs, out_ld);
     } else {
-        hipLaunchKernelGGL((k_segment_mean_bwd<1>), dim3(grid_for(M * n * D)), dim3(256), 0, s,
+        launch(k_segment_mean_bwd<1>, dim3(grid_for(M * n * D)), dim3(256), 0, s,
                            dagg, ld, M, n, (int32_t)D, (int32_t)D, dneibs, out_ld);
     }
     return check_launch("segment_mean_bwd");
@@ -324,7 +324,7 @@ int gsage_scatter_add_rows(const float *rows, int64_t ld, const int64_t *ids, in
     if (M == 0) return GSAGE_OK;
     GSAGE_REQUIRE(rows && ids && table_grad, "scatter_add_rows: null pointer");
     const int64_t total_rows = M * (int64_t)n;
-    hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(total_rows * D)), dim3(256), 0,
+    launch(k_scatter_add_rows, dim3(grid_for(total_rows * D)), dim3(256), 0,
                        (hipStream_t)stream, rows, ld, ids, total_rows, n, (int32_t)D, scale,
                        table_grad, table_ld);
     return check_launch("scatter_add_rows");

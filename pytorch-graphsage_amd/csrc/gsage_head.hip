@@ -316,15 +316,15 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
     const size_t lds = sizeof(float) * ((size_t)C * (D + 1) + (size_t)R * D + 4 * R * HEAD_CMAX + R * HEAD_CMAX + 4 * R + 16);
     GSAGE_REQUIRE(lds <= 160 * 1024, "head_ce: fc.weight does not fit in LDS");
     if (D <= 256)
-        hipLaunchKernelGGL((k_head_ce<1, 4>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        launch(k_head_ce<1, 4>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     else if (D <= 512)
-        hipLaunchKernelGGL((k_head_ce<2, 1>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        launch(k_head_ce<2, 1>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((k_head_ce<4, 1>), dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
+        launch(k_head_ce<4, 1>, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, p);
     int rc = check_launch("head_ce");
     if (rc != GSAGE_OK || dW == nullptr || db == nullptr) return rc;   // caller reduces the partials
     const int64_t width = (int64_t)C * D + C + 1;
-    hipLaunchKernelGGL(k_head_reduce, dim3((unsigned)ceil_div(width, 64)), dim3(256), 0,
+    launch(k_head_reduce, dim3((unsigned)ceil_div(width, 64)), dim3(256), 0,
                        (hipStream_t)stream, (const float *)scratch, n_wg, width, (int64_t)C * D, C, dW,
                        db, loss, 1.f / (float)B);
     return check_launch("head_reduce");

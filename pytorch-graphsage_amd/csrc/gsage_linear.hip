@@ -503,11 +503,11 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
 #define GSAGE_LAUNCH_DMA(T)                                                                       \
     do {                                                                                          \
         if (act == ACT_RELU)                                                                      \
-            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_RELU>), grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_RELU>, grid, dim3(256), 0, s, p);         \
         else if (act == ACT_TANH)                                                                 \
-            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_TANH>), grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_TANH>, grid, dim3(256), 0, s, p);         \
         else                                                                                      \
-            hipLaunchKernelGGL((k_linear_nt_dma<T, ACT_NONE>), grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_NONE>, grid, dim3(256), 0, s, p);         \
     } while (0)
     if (dma) {
         if (dtype == GSAGE_BF16)
@@ -520,11 +520,11 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
 #define GSAGE_LAUNCH_LINEAR(T)                                                                    \
     do {                                                                                          \
         if (act == ACT_RELU)                                                                      \
-            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_RELU>), grid, dim3(256), 0, s, p);      \
+            launch(k_linear_nt<T, false, ACT_RELU>, grid, dim3(256), 0, s, p);      \
         else if (act == ACT_TANH)                                                                 \
-            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_TANH>), grid, dim3(256), 0, s, p);      \
+            launch(k_linear_nt<T, false, ACT_TANH>, grid, dim3(256), 0, s, p);      \
         else                                                                                      \
-            hipLaunchKernelGGL((k_linear_nt<T, false, ACT_NONE>), grid, dim3(256), 0, s, p);      \
+            launch(k_linear_nt<T, false, ACT_NONE>, grid, dim3(256), 0, s, p);      \
     } while (0)
     if (dtype == GSAGE_BF16)
         GSAGE_LAUNCH_LINEAR(uint16_t);
@@ -553,9 +553,9 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     p.pooled_ld = pooled_ld; p.argmax = argmax; p.dbg = 0;
     dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, BN), 1);
     if (dtype == GSAGE_BF16)
-        hipLaunchKernelGGL((k_linear_nt<uint16_t, true, ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch(k_linear_nt<uint16_t, true, ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((k_linear_nt<float, true, ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        launch(k_linear_nt<float, true, ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("pool_mlp");
 }
 

@@ -249,7 +249,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     int rc = GSAGE_OK;
     if (nb == 0) {          // no gsage_finalize_grads before us: compute the norm partials here
         nb = grid_for(n, 1024);
-        hipLaunchKernelGGL(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
+        launch(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
         rc = check_launch("grad_sqnorm");
         if (rc != GSAGE_OK) return rc;
     }
@@ -258,11 +258,11 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
     a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.weight_decay = weight_decay; a.max_norm = max_norm; a.step_off = step_is_current ? 0 : 1;
-    hipLaunchKernelGGL(k_adam_clip, dim3(grid_for(n, 2048)), dim3(256), 0, s, a);
+    launch(k_adam_clip, dim3(grid_for(n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;
     if (!step_is_current) {
-        hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, step);
+        launch(k_step_inc, dim3(1), dim3(1), 0, s, step);
         rc = check_launch("step_inc");
     }
     return rc;
@@ -272,7 +272,7 @@ int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int
                        int64_t inc0, int64_t *tick1, int64_t inc1, void *stream)
 {
     GSAGE_REQUIRE(descs && n_desc > 0 && max_elems > 0, "prep_weights: bad arguments");
-    hipLaunchKernelGGL(k_prep_weights, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
+    launch(k_prep_weights, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
                        (hipStream_t)stream, (const PrepDesc *)descs, tick0, inc0, tick1, inc1);
     return check_launch("prep_weights");
 }
@@ -287,7 +287,7 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                          int64_t *tick2, int64_t inc2, void *stream)
 {
     GSAGE_REQUIRE(descs && flat_g && partial_sq && n_desc > 0 && max_elems > 0, "finalize_grads: bad arguments");
-    hipLaunchKernelGGL(k_finalize_grads, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
+    launch(k_finalize_grads, dim3(grid_for(max_elems, 256), n_desc), dim3(256), 0,
                        (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, tick1, inc1,
                        tick2, inc2);
     return check_launch("finalize_grads");
@@ -306,7 +306,7 @@ int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, in
     q.H = (const uint16_t *)H; q.DG = DG; q.dH = (uint16_t *)dH; q.ldh = ldh; q.ldg = ldg; q.ldo = ldo;
     q.dagg_off = dagg_off; q.R = R; q.r_x = r_x; q.D = D; q.n_hops = n_hops;
     for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }
-    hipLaunchKernelGGL(k_bwd_merge, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0,
+    launch(k_bwd_merge, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0,
                        (hipStream_t)stream, q);
     return check_launch("bwd_merge");
 }

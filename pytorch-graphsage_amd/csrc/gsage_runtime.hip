@@ -1,0 +1,101 @@
+// gsage_runtime.hip -- library-wide host state of libgsage_hip.so: error text, launch counter,
+// device probe, and the command lists (recorded kernel launches replayed with one call).
+//
+// The reference has no counterpart (it is eager PyTorch: one Python-dispatched op per tensor
+// expression, models.py:71-104).  A train_step here is ~9 kernels of 5-40 us each, so how they are
+// issued decides the step time as much as the kernels do: see gsage_common.h launch().
+#include "gsage_common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+namespace gsage {
+
+static thread_local char t_err[512] = "";
+std::atomic<uint64_t> g_launches{0};
+thread_local CmdList *t_recording = nullptr;
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" {
+
+int gsage_abi_version(void) { return GSAGE_ABI_VERSION; }
+const char *gsage_last_error(void) { return t_err; }
+uint64_t gsage_launch_count(void) { return g_launches.load(); }
+
+int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size)
+{
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible");
+        return GSAGE_ENODEV;
+    }
+    if (arch && arch_len > 0) {
+        strncpy(arch, p.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_begin(void)
+{
+    GSAGE_REQUIRE(!t_recording, "cmdlist_begin: this thread is already recording");
+    t_recording = new CmdList();
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_end(void **list)
+{
+    GSAGE_REQUIRE(t_recording, "cmdlist_end: no recording in progress on this thread");
+    CmdList *l = t_recording;
+    t_recording = nullptr;
+    if (!list) {
+        delete l;
+        set_error("cmdlist_end: null output pointer");
+        return GSAGE_EINVAL;
+    }
+    *list = l;
+    return GSAGE_OK;
+}
+
+int64_t gsage_cmdlist_size(const void *list)
+{
+    return list ? (int64_t)((const CmdList *)list)->nodes.size() : -1;
+}
+
+int gsage_cmdlist_replay(const void *list, void *stream)
+{
+    GSAGE_REQUIRE(list, "cmdlist_replay: null list");
+    GSAGE_REQUIRE(!t_recording, "cmdlist_replay: cannot replay while recording");
+    const CmdList *l = (const CmdList *)list;
+    if (l->nodes.empty()) return GSAGE_OK;
+    for (const auto &node : l->nodes) node((hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("cmdlist_replay: %s", hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
+    g_launches.fetch_add(l->nodes.size(), std::memory_order_relaxed);
+    return GSAGE_OK;
+}
+
+void gsage_cmdlist_destroy(void *list)
+{
+    delete (CmdList *)list;
+}
+
+}  // extern "C"

@@ -11,22 +11,9 @@
 // read and one 8-byte write per sample.
 #include "gsage_common.h"
 
-#include <stdarg.h>
 #include <string.h>
 
 namespace gsage {
-
-// ---- library-wide state -------------------------------------------------------------------------
-static thread_local char t_err[512] = "";
-std::atomic<uint64_t> g_launches{0};
-
-void set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(t_err, sizeof(t_err), fmt, ap);
-    va_end(ap);
-}
 
 // ---- device code ----------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t pick_neighbor(const int64_t *__restrict__ rowptr,
@@ -237,28 +224,6 @@ using namespace gsage;
 
 extern "C" {
 
-int gsage_abi_version(void) { return GSAGE_ABI_VERSION; }
-const char *gsage_last_error(void) { return t_err; }
-uint64_t gsage_launch_count(void) { return g_launches.load(); }
-
-int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size)
-{
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
-        (void)hipGetLastError();
-        set_error("no HIP device visible");
-        return GSAGE_ENODEV;
-    }
-    if (arch && arch_len > 0) {
-        strncpy(arch, p.gcnArchName, (size_t)arch_len - 1);
-        arch[arch_len - 1] = 0;
-    }
-    if (cu_count) *cu_count = p.multiProcessorCount;
-    if (wave_size) *wave_size = p.warpSize;
-    return GSAGE_OK;
-}
-
 int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
                          const int64_t *ids, int64_t M, int32_t n, const int32_t *sel,
                          int64_t *out, int32_t *err_flag, void *stream)
@@ -268,7 +233,7 @@ int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_ro
     if (M == 0) return GSAGE_OK;
     GSAGE_REQUIRE(rowptr && col && ids && sel && out, "sample_csr_sel: null pointer");
     const int64_t total = M * (int64_t)n;
-    hipLaunchKernelGGL(k_sample_sel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+    launch(k_sample_sel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        rowptr, col, n_rows, ids, total, (uint32_t)n, sel, out, err_flag);
     return check_launch("sample_csr_sel");
 }
@@ -285,7 +250,7 @@ int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n
     if (M == 0) return GSAGE_OK;
     GSAGE_REQUIRE(rowptr && col && ids && out, "sample_csr_philox: null pointer");
     const int64_t total = M * (int64_t)n;
-    hipLaunchKernelGGL(k_sample_philox, dim3(grid_for(total / 4 + 2)), dim3(256), 0,
+    launch(k_sample_philox, dim3(grid_for(total / 4 + 2)), dim3(256), 0,
                        (hipStream_t)stream, rowptr, col, n_rows, ids, total, (uint32_t)n, max_deg,
                        (uint32_t)seed, (uint32_t)(seed >> 32), call_ctr, call_base, g0, out,
                        sel_out, err_flag);
@@ -326,7 +291,7 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
     }
     const size_t lds = sizeof(int64_t) * 2 * HOPS_SPW * (size_t)widest;
     GSAGE_REQUIRE(lds <= 160 * 1024, "sample_hops_philox: fan-out product too large for the fused kernel");
-    hipLaunchKernelGGL(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds,
+    launch(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds,
                        (hipStream_t)stream, p);
     return check_launch("sample_hops_philox");
 }
@@ -334,7 +299,7 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream)
 {
     GSAGE_REQUIRE(ctr, "counter_add: null pointer");
-    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    launch(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
     return check_launch("counter_add");
 }
 

@@ -489,7 +489,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
             raised[n <= 16] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((B + TAIL_R - 1) / TAIL_R), dim3(256), lds, (hipStream_t)stream, p);
+    launch(kern, dim3((B + TAIL_R - 1) / TAIL_R), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("mean_tail_ce");
 }
 

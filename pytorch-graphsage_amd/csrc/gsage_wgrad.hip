@@ -224,12 +224,12 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
     p.n_per_group = n_per_group; p.ldk = ldk; p.rows_per_split = rows_per_split;
     const int S = (int)ceil_div(M, rows_per_split);
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
-    hipLaunchKernelGGL(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
+    launch(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
     int rc = check_launch("wgrad");
     if (rc != GSAGE_OK || out == nullptr) return rc;      // out == NULL: caller reduces the slabs
     int64_t blocks = ceil_div(Ntot * K, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    launch(k_reduce_slabs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float *)slabs, S, Ntot, K, ldk, n_per_group, out, out_gstride);
     return check_launch("wgrad_reduce");
 }

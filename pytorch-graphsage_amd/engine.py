@@ -163,6 +163,16 @@ def _r8(v):
     return (v + 63) // 64 * 64          # whole 128-byte bf16 lines: enables the LDS-DMA GEMM path
 
 
+class _ListRunner(object):
+    """hipGraph-like handle over a native command list: replay() issues it on the current stream."""
+
+    def __init__(self, cl):
+        self.cl = cl
+
+    def replay(self):
+        self.cl.replay(ops._stream())
+
+
 class FusedMeanTrainStep(object):
     """train_step (reference models.py:97-104) for the north-star configuration -- sparse sampler,
     identity prep over a bf16 FeatureStore, mean aggregators (ReLU on all but the last layer) --
@@ -209,6 +219,19 @@ class FusedMeanTrainStep(object):
         # to the sequential order, `__call__` then returns the predictions of the previous batch.
         self.pipelined = bool(pipelined)
         self.nset = 2 if self.pipelined else 1
+        self._front_ready, self.g_qfront = False, None
+        self._reduce_op = None
+        if ddp is not None:
+            # averaging inside the collective saves a launch; fall back to divide-then-sum where
+            # the backend has no AVG
+            self._reduce_op = torch.distributed.ReduceOp.AVG
+            try:
+                probe = torch.ones(8, device=feats.device)
+                torch.distributed.all_reduce(probe, op=self._reduce_op)
+                if abs(float(probe[0]) - 1.0) > 1e-6:
+                    raise RuntimeError("AVG returned %r" % float(probe[0]))
+            except Exception:
+                self._reduce_op = torch.distributed.ReduceOp.SUM
         dev = feats.device
         self.dev = dev
         self.layers = list(model.agg_layers.children())
@@ -372,34 +395,47 @@ class FusedMeanTrainStep(object):
         self.s_back = torch.cuda.Stream() if self.pipelined else None
         self.ev_front = [torch.cuda.Event() for _ in range(self.nset)]
         self.ev_back = [torch.cuda.Event() for _ in range(self.nset)]
-        if capture:
-            pool = None
+        # capture: False = eager launches from Python; "cmdlist" (or True) = native command lists
+        # (include/gsage.h: recorded launches replayed by one C call, no device-side start-up gap);
+        # "graph" = hipGraphs.
+        self.capture_mode = {True: "cmdlist", False: None, None: None}.get(capture, capture)
+        assert self.capture_mode in (None, "cmdlist", "graph")
+        if self.capture_mode == "cmdlist" and not self.fused_head:
+            self.capture_mode = "graph"              # the stock-torch head cannot be recorded
+        self._pool = None
+        if self.capture_mode:
             self.g_main = []
             if self.pipelined:
-                self.g_front = []
-                for st_ in range(2):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, stream=self.s_front):
-                        self._stage_sample_gather(st_)
-                    pool = g.pool()
-                    self.g_front.append(g)
-            for st_ in range(self.nset):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=self.s_back if self.pipelined else None):
-                    if not self.pipelined:
-                        self._stage_sample_gather(0)
-                    self._stage_compute(st_)
-                    if ddp is None:
-                        self._stage_opt()
-                pool = g.pool()
-                self.g_main.append(g)
-            if ddp is not None:
-                self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=pool, stream=self.s_back if self.pipelined else None):
+                self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
+                                for st_ in range(2)]
+
+            def main(st_):
+                if not self.pipelined:
+                    self._stage_sample_gather(0)
+                self._stage_compute(st_)
+                if ddp is None:
                     self._stage_opt()
+            for st_ in range(self.nset):
+                self.g_main.append(self._record(lambda st_=st_: main(st_),
+                                                self.s_back if self.pipelined else None))
+            if ddp is not None:
+                self.g_opt = self._record(self._stage_opt, self.s_back if self.pipelined else None)
         torch.cuda.synchronize()
 
     # ---- helpers ------------------------------------------------------------------------------
+    def _record(self, fn, stream=None):
+        """Record the launches of fn() once; returns an object whose replay() re-issues them on the
+        current stream (command list) or on the capture stream (hipGraph)."""
+        if self.capture_mode == "cmdlist":
+            with nat.CommandList.record() as cl:
+                fn()
+            return _ListRunner(cl)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool, stream=stream):
+            fn()
+        self._pool = g.pool()
+        return g
+
     def refresh_weights(self):
         """Rebuild the bf16 operand copies from the fp32 Parameters.  Adam keeps them current;
         call this after changing the weights from outside (load_state_dict, manual edits)."""
@@ -541,8 +577,12 @@ class FusedMeanTrainStep(object):
                                            None if self.pipelined else self.counter.data_ptr(), L,
                                            self.batch_idx.data_ptr() if self.queue else None, 1,
                                            stream), "finalize_grads")
-        if self.ddp is not None:
+
+    def _all_reduce(self, async_op=False):
+        """The step's ONE exchange: average the flat fp32 gradient bucket over the ranks (RCCL)."""
+        if self._reduce_op == torch.distributed.ReduceOp.SUM:
             self.flat_g.div_(self.ddp.world)
+        return torch.distributed.all_reduce(self.flat_g, op=self._reduce_op, async_op=async_op)
 
     def _stage_opt(self):
         """clip_grad_norm(5) + Adam over the flat bucket."""
@@ -560,7 +600,7 @@ class FusedMeanTrainStep(object):
         self._stage_sample_gather(s)
         self._stage_compute(s)
         if self.ddp is not None:
-            torch.distributed.all_reduce(self.flat_g)
+            self._all_reduce()
         self._stage_opt()
 
     # ---- per-batch entry --------------------------------------------------------------------------
@@ -581,27 +621,52 @@ class FusedMeanTrainStep(object):
         assert tq.dtype == torch.int64
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
         self.batch_idx.zero_()
+        self._front_ready = False
         if self.g_main is not None:
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.g_main[0].pool()):
-                self._stage_sample_gather(0)
-                self._stage_compute(0)
-                if self.ddp is None:
+            if self.ddp is None:
+                def whole():
+                    self._stage_sample_gather(0)
+                    self._stage_compute(0)
                     self._stage_opt()
-            self.g_main = [g]
+                self.g_main = [self._record(whole)]
+            else:
+                # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
+                # sampling + gathers (see step_queue)
+                self.g_qfront = self._record(lambda: self._stage_sample_gather(0))
+                self.g_main = [self._record(lambda: self._stage_compute(0))]
         return self
 
     def step_queue(self):
-        """One train_step on the next batch of the loaded epoch queue -> preds (static buffer)."""
+        """One train_step on the next batch of the loaded epoch queue -> preds (static buffer).
+
+        Data-parallel runs are software-pipelined by one stage: sampling and the level-0 gathers do
+        not depend on the weights, so batch i+1's are issued while batch i's gradient all-reduce is
+        in flight on RCCL's stream, and Adam(i) follows both.  Every call still performs exactly one
+        sample/gather, one forward/backward, one exchange and one optimizer step; the first call
+        after load_epoch() additionally primes the pipeline."""
         assert self.queue is not None, "call load_epoch() first"
-        if self.g_main is None:
-            self._run_sequential(0)
-        else:
+        if self.ddp is None:
+            if self.g_main is None:
+                self._run_sequential(0)
+            else:
+                self.g_main[0].replay()
+            return self.preds
+        front = self.g_qfront.replay if self.g_main is not None else (lambda: self._stage_sample_gather(0))
+        if not self._front_ready:
+            front()
+            self._front_ready = True
+        if self.g_main is not None:
             self.g_main[0].replay()
-            if self.g_opt is not None:
-                torch.distributed.all_reduce(self.flat_g)
-                self.g_opt.replay()
+        else:
+            self._stage_compute(0)
+        work = self._all_reduce(async_op=True)
+        front()                                      # batch i+1: sample + gather, overlapping the exchange
+        work.wait()                                  # stream-level wait, the host does not block
+        if self.g_opt is not None:
+            self.g_opt.replay()
+        else:
+            self._stage_opt()
         return self.preds
 
     def _load(self, s, ids, targets):
@@ -621,7 +686,7 @@ class FusedMeanTrainStep(object):
             else:
                 self.g_main[0].replay()
                 if self.g_opt is not None:
-                    torch.distributed.all_reduce(self.flat_g)
+                    self._all_reduce()
                     self.g_opt.replay()
             return self.preds
         s = k % 2
@@ -649,12 +714,12 @@ class FusedMeanTrainStep(object):
             if self.g_main is None:
                 self._stage_compute(par)
                 if self.ddp is not None:
-                    torch.distributed.all_reduce(self.flat_g)
+                    self._all_reduce()
                 self._stage_opt()
             else:
                 self.g_main[par].replay()
                 if self.g_opt is not None:
-                    torch.distributed.all_reduce(self.flat_g)
+                    self._all_reduce()
                     self.g_opt.replay()
             self.ev_back[par].record(self.s_back)
 

@@ -48,6 +48,26 @@ def test_bad_arguments_return_einval_without_gpu():
     assert rc == -1 and b"lda" in L.gsage_last_error()
 
 
+def test_command_list_lifecycle_without_gpu():
+    """Recording state machine of the command lists (no kernel is recorded, so no GPU needed)."""
+    nat = pkg()._native
+    L = nat.lib()
+    h = ctypes.c_void_p()
+    assert L.gsage_cmdlist_end(ctypes.byref(h)) == -1 and b"no recording" in L.gsage_last_error()
+    assert L.gsage_cmdlist_begin() == 0
+    assert L.gsage_cmdlist_begin() == -1 and b"already recording" in L.gsage_last_error()
+    # argument validation still runs while recording, and a rejected call records nothing
+    assert L.gsage_gather_mean(None, 7, 8, None, 4, 1, 8, None, 0, 8, None) == -1
+    assert L.gsage_cmdlist_end(ctypes.byref(h)) == 0 and h.value
+    assert L.gsage_cmdlist_size(h) == 0
+    assert L.gsage_cmdlist_replay(h, None) == 0            # empty list: nothing to launch
+    L.gsage_cmdlist_destroy(h)
+    assert L.gsage_cmdlist_size(None) == -1
+    with nat.CommandList.record() as cl:
+        pass
+    assert len(cl) == 0
+
+
 @pytest.mark.parametrize("seed", [0, 123, 15129])
 def test_host_legacy_stream_equals_numpy(seed):
     L = pkg()._native.lib()

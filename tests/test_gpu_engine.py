@@ -56,7 +56,7 @@ def _setup():
 
 @pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((16, 8), (5, 3), 33),
                                          ((32, 16, 8), (4, 3, 2), 20)])
-@pytest.mark.parametrize("capture", [False, True])
+@pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
 def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
     adj, feats, rng = _problem()
     D, C = feats.shape[1], 5
@@ -88,7 +88,7 @@ def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
     eng_model.train_sampler.csr(DEV).check()
 
 
-@pytest.mark.parametrize("capture", [False, True])
+@pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
 def test_pipelined_engine_is_bit_identical_to_sequential(capture):
     """Overlapping batch k+1's sampling/gathers with batch k's compute must not change anything:
     sampling does not depend on the weights and every kernel is deterministic."""
@@ -136,6 +136,55 @@ def test_batch_queue_equals_per_step_copies():
                 preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
         res.append((torch.stack(preds), eng.flat_p.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
+def test_data_parallel_queue_order_matches_single_process(capture):
+    """dist.py + engine.step_queue with a ONE-rank RCCL group: the exchange is an identity, so the
+    software-pipelined order (next batch's sample/gather issued while the all-reduce is in flight,
+    Adam afterwards) must reproduce the plain sequential engine.  The clip norm comes from a
+    different kernel in this mode (k_grad_sqnorm), hence a tolerance instead of torch.equal."""
+    import os
+    import torch.distributed as dist
+    adj, feats, rng = _problem(seed=6)
+    D, C, B, dims, fans = feats.shape[1], 5, 24, (128, 128), (5, 3)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
+    tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
+
+    def run(ddp):
+        model = _model(adj, D, C, dims, fans)
+        if ddp is not None:
+            gs.dist.attach(model, ddp, seed=77)
+        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0],
+                                           tg_all[0], ddp=ddp, capture=capture)
+        eng.load_epoch(ids_all, tg_all)
+        preds = [eng.step_queue().clone() for _ in range(5)]
+        torch.cuda.synchronize()
+        return torch.stack(preds), eng.flat_p.clone()
+
+    ref = run(None)
+    env = {"GSAGE_FORCE_DDP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
+           "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    ddp = None
+    try:
+        ddp = gs.dist.init_from_env(cuda=True)
+        assert ddp is not None and ddp.world == 1
+        got = run(ddp)
+    finally:
+        if ddp is not None:
+            ddp.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    close(got[0].cpu().numpy(), ref[0].cpu().numpy(), "preds of 5 queue steps", rtol=2e-3, atol=2e-3)
+    close(got[1].cpu().numpy(), ref[1].cpu().numpy(), "weights after 5 queue steps", rtol=2e-3, atol=2e-3)
 
 
 def test_fused_engine_first_step_against_oracle():

@@ -368,3 +368,40 @@ def test_fused_multi_hop_sampler_equals_per_hop_launches(B, fans):
         assert torch.equal(ids[off:off + sizes[k + 1]], nxt), (B, fans, k)
         cur, off = nxt, off + sizes[k + 1]
     csr.check()
+
+
+def test_command_list_replay_equals_direct_launches():
+    """include/gsage.h "Command lists": recorded launches do not run until replayed, replay
+    re-issues them (on any stream) with the recorded arguments, and the launch counter counts them."""
+    nat = gs._native
+    rng = np.random.RandomState(5)
+    R, D, ld, M, n = 300, 40, 64, 50, 7
+    table = torch.zeros(R, ld, dtype=torch.bfloat16, device=DEV)
+    table[:, :D] = torch.from_numpy(rng.normal(size=(R, D)).astype(np.float32)).to(DEV).bfloat16()
+    store = gs.FeatureStore(table, D)
+    ids = torch.from_numpy(rng.randint(0, R, size=M * n)).to(DEV)
+    ref1 = ops.gather_mean(store, ids, M, n, out_dtype=torch.float32)
+    ref2 = ops.gather_mean(store, ids[:M], M, 1, out_dtype=torch.bfloat16, out_ld=ld)
+    out1 = torch.full_like(ref1, -7.0)
+    out2 = torch.full_like(ref2, -7.0)
+    torch.cuda.synchronize()
+    with nat.CommandList.record() as cl:
+        ops._gather_mean_raw(store.data, store.dim, ids, M, n, torch.float32, None, out=out1)
+        ops._gather_mean_raw(store.data, store.ld, ids[:M], M, 1, torch.bfloat16, ld, out=out2)
+    assert len(cl) == 2
+    torch.cuda.synchronize()
+    assert float(out1.min()) == -7.0 and float(out2.float().min()) == -7.0     # nothing ran yet
+    before = nat.launch_count()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    cl.replay(side.cuda_stream)
+    side.synchronize()
+    assert nat.launch_count() == before + 2
+    assert torch.equal(out1, ref1) and torch.equal(out2, ref2)
+    # a list replays any number of times and tracks the DATA behind the recorded pointers
+    table[:, :D] *= 2
+    out1.fill_(-7.0)
+    torch.cuda.synchronize()
+    cl.replay(ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out1, ops.gather_mean(store, ids, M, n, out_dtype=torch.float32))
