@@ -202,6 +202,18 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
                 int64_t out_gstride, void *stream);
 /* [host] number of slabs gsage_wgrad writes for (M, rows_per_split). */
 int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split);
+/* Up to 8 weight-gradient problems (all the levels of one backward pass) in ONE launch; the partial
+ * tiles stay in each problem's slabs for gsage_finalize_grads.  Each problem alone fills a fraction
+ * of the chip for the length of its M-slice, so side by side they cost the longest, not the sum.
+ * `probs` is a HOST array (copied into the kernel arguments).  Field meaning as in gsage_wgrad. */
+typedef struct gsage_wgrad_desc {
+    const void *dC;
+    const void *A;
+    float *slabs;
+    int64_t ldc, lda, a_gstride;
+    int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
+} gsage_wgrad_desc;
+int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3  pooling MLP           replaces mlp(neibs) -> view(M,-1,H) -> max/mean over the fanout

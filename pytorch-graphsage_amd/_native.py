@@ -55,6 +55,7 @@ SIGNATURES = {
     "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
                            _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
+    "gsage_wgrad_multi": (_int, [_i32, _vp, _vp]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
                              _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
@@ -127,6 +128,12 @@ def check(rc, what=""):
 
 def launch_count():
     return int(lib().gsage_launch_count())
+
+
+class WgradDesc(ctypes.Structure):            # mirrors gsage_wgrad_desc (include/gsage.h)
+    _fields_ = [("dC", _vp), ("A", _vp), ("slabs", _vp), ("ldc", _i64), ("lda", _i64),
+                ("a_gstride", _i64), ("M", _i64), ("Ntot", _i64), ("K", _i64), ("n_per_group", _i64),
+                ("ldk", _i64), ("rows_per_split", _i64)]
 
 
 class CommandList(object):

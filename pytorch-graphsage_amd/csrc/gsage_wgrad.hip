@@ -121,20 +121,20 @@ __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint1
     }
 }
 
-__global__ void __launch_bounds__(256, 1)
-k_wgrad_bf16(const WgradParams p)
+// one workgroup's share of problem p: M-slice bx, 128-row n tile by, 512-column k block bz
+__device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx, int64_t by, int64_t bz)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ii = lane & 31;
     const int half = lane >> 5;
-    const int64_t n_base = (int64_t)blockIdx.y * 128;
-    const int64_t k_base = ((int64_t)blockIdx.z * 4 + wave) * 128;
+    const int64_t n_base = by * 128;
+    const int64_t k_base = (bz * 4 + wave) * 128;
     if (k_base >= p.ldk) return;                                   // wave-uniform; no barriers below
     const int g = (int)(n_base / p.n_per_group);
     const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
 
-    const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_split;
+    const int64_t m_begin = bx * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
 
     // Column validity is lane invariant: a lane whose columns fall outside the matrices reads
@@ -158,7 +158,7 @@ k_wgrad_bf16(const WgradParams p)
 
     // epilogue: D[i][j] of MFMA (e, f) is dW[n_base + 4i + e][k_base + 4j + f]; lane l holds
     // j = l & 31 and i = (r & 3) + 8 (r >> 2) + 4 (l >> 5): one float4 (f = 0..3) per (e, r).
-    float *slab = p.slabs + (int64_t)blockIdx.x * p.Ntot * p.ldk;
+    float *slab = p.slabs + bx * p.Ntot * p.ldk;
     const int64_t k = k_base + 4 * ii;
     if (k + 3 < p.ldk) {
 #pragma unroll
@@ -173,6 +173,36 @@ k_wgrad_bf16(const WgradParams p)
                 }
             }
     }
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_wgrad_bf16(const WgradParams p)
+{
+    wgrad_workgroup(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient problems in ONE launch (all levels of a backward pass).  Each problem
+// alone occupies a fraction of the chip for the length of its M-slice (Reddit shapes: 196 and 16
+// workgroups on 256 CUs), so side by side they cost the longest one instead of the sum.
+constexpr int WGRAD_MAX_PROBLEMS = 8;
+struct WgradMulti {
+    WgradParams p[WGRAD_MAX_PROBLEMS];
+    int32_t first[WGRAD_MAX_PROBLEMS + 1];     // workgroups [first[s], first[s+1]) belong to problem s
+    int32_t S[WGRAD_MAX_PROBLEMS], ny[WGRAD_MAX_PROBLEMS];
+    int32_t n_prob;
+};
+
+__global__ void __launch_bounds__(256, 1)
+k_wgrad_multi(const WgradMulti q)
+{
+    int s = 0;
+#pragma unroll
+    for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
+        if (j < q.n_prob && (int)blockIdx.x >= q.first[j]) s = j;
+    const int local = (int)blockIdx.x - q.first[s];
+    const int bx = local % q.S[s];
+    const int rest = local / q.S[s];
+    wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s]);
 }
 
 // out_g[n_local * K + k] = sum_s slabs[s][g * n_per_group + n_local][k]
@@ -197,16 +227,14 @@ k_reduce_slabs(const float *__restrict__ slabs, int32_t S, int64_t Ntot, int64_t
 
 using namespace gsage;
 
-extern "C" {
-
-int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split)
+extern "C" int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split)
 {
     return (int)ceil_div(M, rows_per_split);
 }
 
-int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
-                int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
-                int64_t out_gstride, void *stream)
+static int wgrad_fill(WgradParams &p, const void *dC, int64_t ldc, const void *A, int64_t lda,
+                      int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K, int64_t n_per_group,
+                      int64_t rows_per_split, float *slabs, int64_t ldk)
 {
     GSAGE_REQUIRE(dC && A && slabs, "wgrad: null pointer");
     GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
@@ -218,10 +246,47 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
     GSAGE_REQUIRE(rows_per_split >= 16 && rows_per_split % 16 == 0, "wgrad: rows_per_split must be a multiple of 16");
     GSAGE_REQUIRE(((uintptr_t)dC % 8) == 0 && ((uintptr_t)A % 8) == 0 && ((uintptr_t)slabs % 16) == 0,
                   "wgrad: misaligned pointer");
-    WgradParams p;
     p.dC = (const uint16_t *)dC; p.A = (const uint16_t *)A; p.slabs = slabs;
     p.ldc = ldc; p.lda = lda; p.a_gstride = a_gstride; p.M = M; p.Ntot = Ntot; p.K = K;
     p.n_per_group = n_per_group; p.ldk = ldk; p.rows_per_split = rows_per_split;
+    return GSAGE_OK;
+}
+
+extern "C" {
+
+int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *stream)
+{
+    GSAGE_REQUIRE(probs && n_prob >= 1 && n_prob <= WGRAD_MAX_PROBLEMS, "wgrad_multi: 1..%d problems",
+                  WGRAD_MAX_PROBLEMS);
+    WgradMulti q;
+    q.n_prob = n_prob;
+    q.first[0] = 0;
+    for (int s = 0; s < WGRAD_MAX_PROBLEMS; ++s) {
+        if (s < n_prob) {
+            const gsage_wgrad_desc &d = probs[s];
+            int rc = wgrad_fill(q.p[s], d.dC, d.ldc, d.A, d.lda, d.a_gstride, d.M, d.Ntot, d.K,
+                                d.n_per_group, d.rows_per_split, d.slabs, d.ldk);
+            if (rc != GSAGE_OK) return rc;
+            q.S[s] = (int32_t)ceil_div(d.M, d.rows_per_split);
+            q.ny[s] = (int32_t)ceil_div(d.Ntot, 128);
+            q.first[s + 1] = q.first[s] + q.S[s] * q.ny[s] * (int32_t)ceil_div(d.ldk, 512);
+        } else {
+            q.p[s] = q.p[0];
+            q.S[s] = q.ny[s] = 1;
+            q.first[s + 1] = q.first[s];
+        }
+    }
+    launch(k_wgrad_multi, dim3((unsigned)q.first[n_prob]), dim3(256), 0, (hipStream_t)stream, q);
+    return check_launch("wgrad_multi");
+}
+
+int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
+                int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
+                int64_t out_gstride, void *stream)
+{
+    WgradParams p;
+    int rc0 = wgrad_fill(p, dC, ldc, A, lda, a_gstride, M, Ntot, K, n_per_group, rows_per_split, slabs, ldk);
+    if (rc0 != GSAGE_OK) return rc0;
     const int S = (int)ceil_div(M, rows_per_split);
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
     launch(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -544,32 +544,38 @@ class FusedMeanTrainStep(object):
         L, st, lib = self.L, self.store, nat.lib()
         stream = ops._stream()
         esz = 2
+        # (1) the chain of input gradients down the levels: dC[l] -> (dX | dAgg) -> mask/route -> dC[l-1]
+        for l in range(L - 1, 0, -1):
+            if self.fused_tail and l == L - 1:
+                continue                                  # k_mean_tail_ce wrote dC[L-2] already
+            R, h, din = self.rows[l], self.h[l], self.din[l]
+            w2t = self.w2t[l]
+            # NT GEMM against the transposed operand copies
+            self._linear(self.dc[l].data_ptr(), 2 * h, None, 0, w2t.data_ptr(), w2t.shape[2],
+                         self.dg[l].data_ptr(), nat.F32, 2 * din, R, din, h, nat.ACT_NONE, h,
+                         din * w2t.shape[2], din)
+            below = self.hout[l - 1]
+            nat.check(lib.gsage_bwd_merge(below.data_ptr(), below.stride(0), self.dg[l].data_ptr(),
+                                          2 * din, din, self.dc[l - 1].data_ptr(),
+                                          self.dc[l - 1].stride(0), self.rows[l - 1], R, din,
+                                          L - l + 1, self.off_host, self.fan_host, stream),
+                      "bwd_merge")
+        # (2) every level's weight gradient in ONE launch: each alone fills a fraction of the chip
+        probs = []
         for l in range(L - 1, -1, -1):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             dc = self.dc[l]
             xbuf, lda = (self.xa0_set[s][0], st.ld) if l == 0 else (self.hout[l - 1], din)
             aggl = self.xa0_set[s][1] if l == 0 else self.agg[l]
             delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
-            ix = self.pidx[id(self.layers[l].fc_x.weight)]               # fc_neib is ix + 1
             if h % 128 == 0:
-                ops.wgrad(dc, xbuf, lda, delta, R, 2 * h, din, h, slabs=self.slabs[l][0], reduce=False)
+                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0]))
             else:
                 for g in range(2):
-                    src = xbuf if g == 0 else aggl
-                    ops.wgrad(dc[:, g * h:], src, lda, 0, R, h, din, h, slabs=self.slabs[l][g],
-                              reduce=False)
-            if l > 0 and not (self.fused_tail and l == L - 1):
-                w2t = self.w2t[l]
-                # (dX | dAgg) = dC_g @ W_g : NT GEMM against the transposed operand copies
-                self._linear(dc.data_ptr(), 2 * h, None, 0, w2t.data_ptr(), w2t.shape[2],
-                             self.dg[l].data_ptr(), nat.F32, 2 * din, R, din, h, nat.ACT_NONE, h,
-                             din * w2t.shape[2], din)
-                below = self.hout[l - 1]
-                nat.check(lib.gsage_bwd_merge(below.data_ptr(), below.stride(0), self.dg[l].data_ptr(),
-                                              2 * din, din, self.dc[l - 1].data_ptr(),
-                                              self.dc[l - 1].stride(0), self.rows[l - 1], R, din,
-                                              L - l + 1, self.off_host, self.fan_host, stream),
-                          "bwd_merge")
+                    probs.append((dc[:, g * h:], xbuf if g == 0 else aggl, lda, 0, R, h, din, h,
+                                  self.slabs[l][g]))
+        for i in range(0, len(probs), 8):
+            ops.wgrad_multi(probs[i:i + 8])
         # every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick
         nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
                                            self.flat_g.data_ptr(), self.partial.data_ptr(),

@@ -317,6 +317,21 @@ def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None, slabs=None, 
     return out if reduce else slabs
 
 
+def wgrad_multi(problems):
+    """Several K5b problems in one launch; partial tiles stay in each problem's slabs
+    (gsage_finalize_grads sums them).  problems: list of (dC, A, lda, a_gstride, M, Ntot, K,
+    n_per_group, slabs) with the meaning of wgrad()."""
+    descs = (nat.WgradDesc * len(problems))()
+    for d, (dC, A, lda, a_gs, M, Ntot, K, npg, slabs) in zip(descs, problems):
+        rps, S, ldk = wgrad_plan(M, Ntot, K)
+        assert tuple(slabs.shape) == (S, Ntot, ldk) and slabs.is_contiguous()
+        d.dC, d.A, d.slabs = _ptr(dC), _ptr(A), _ptr(slabs)
+        d.ldc, d.lda, d.a_gstride = dC.stride(0), lda, a_gs
+        d.M, d.Ntot, d.K, d.n_per_group, d.ldk, d.rows_per_split = M, Ntot, K, npg, ldk, rps
+    nat.check(nat.lib().gsage_wgrad_multi(len(problems), ctypes.cast(descs, ctypes.c_void_p), _stream()),
+              "wgrad_multi")
+
+
 class _Linear(torch.autograd.Function):
     """act(x @ W^T + b) on the matrix cores; backward contractions are plain library GEMMs."""
 

@@ -405,3 +405,27 @@ def test_command_list_replay_equals_direct_launches():
     cl.replay(ops._stream())
     torch.cuda.synchronize()
     assert torch.equal(out1, ops.gather_mean(store, ids, M, n, out_dtype=torch.float32))
+
+
+def test_wgrad_multi_equals_single_launches():
+    """gsage_wgrad_multi: the partial tiles of every problem are bit-identical to one gsage_wgrad
+    launch per problem (same tiles, same summation order), whatever mix of shapes shares the launch."""
+    rng = np.random.RandomState(11)
+    shapes = [(1300, 256, 602, 128), (512, 256, 256, 128), (70, 16, 40, 16), (33, 8, 24, 8)]
+    probs, refs = [], []
+    for (M, Ntot, K, npg) in shapes:
+        lda = gs.store._round_up(K, 8)
+        groups = Ntot // npg
+        dC = torch.from_numpy(rng.normal(size=(M, Ntot)).astype(np.float32)).to(DEV).bfloat16()
+        A = torch.zeros(groups, M, lda, dtype=torch.bfloat16, device=DEV)
+        A[:, :, :K] = torch.from_numpy(rng.normal(size=(groups, M, K)).astype(np.float32)).to(DEV).bfloat16()
+        rps, S, ldk = ops.wgrad_plan(M, Ntot, K)
+        ref = ops.wgrad(dC, A, lda, M * lda, M, Ntot, K, npg, reduce=False).clone()
+        slabs = torch.full((S, Ntot, ldk), float("nan"), dtype=torch.float32, device=DEV)
+        probs.append((dC, A, lda, M * lda, M, Ntot, K, npg, slabs))
+        refs.append(ref)
+    ops.wgrad_multi(probs)
+    torch.cuda.synchronize()
+    for (M, Ntot, K, npg), pr, ref in zip(shapes, probs, refs):
+        got = pr[8]
+        assert torch.equal(got[:, :, :K], ref[:, :, :K]), (M, Ntot, K)
