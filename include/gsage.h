@@ -118,6 +118,28 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
                              uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
                              uint64_t rank, const int64_t *seed_queue, const int64_t *batch_idx,
                              int64_t n_batches, int32_t *err_flag, void *stream);
+/* The same arguments as a struct (HOST memory), for entry points that launch the sampler together
+ * with something else.  batch_base is added to *batch_idx before the modulo: with call_base it lets
+ * the sampler run AHEAD of the counters' tick (gsage_finalize_grads_sample). */
+typedef struct gsage_hops_desc {
+    const int64_t *rowptr;
+    const int32_t *col;
+    int64_t n_rows;
+    int64_t *ids;
+    int64_t B;
+    int32_t n_hops;
+    int32_t fan[5];
+    uint32_t max_deg;
+    uint64_t seed;
+    const uint64_t *call_ctr;
+    uint64_t call_base;
+    uint64_t rank;
+    const int64_t *seed_queue;
+    const int64_t *batch_idx;
+    int64_t batch_base;
+    int64_t n_batches;
+    int32_t *err_flag;
+} gsage_hops_desc;
 
 /* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
@@ -295,7 +317,10 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
                          float weight_decay, float max_norm, float *norm_out, int step_is_current,
                          int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
-                         void *stream);
+                         int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2, void *stream);
+/* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts -- the Philox
+ * call index and batch-queue index when the NEXT batch was sampled ahead of the tick by
+ * gsage_finalize_grads_sample (nothing in this kernel reads them). */
 
 /* Sums partial gradient buffers into the flat bucket and emits the squared-norm partials the
  * clip needs, in one launch: for descriptor d, flat_g[out_off + r*cols + c] =
@@ -314,6 +339,15 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                          float *partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
                          int64_t *tick2, int64_t inc2, void *stream);
 int gsage_finalize_partials(int32_t n_desc, int64_t max_elems);
+/* gsage_finalize_grads and gsage_sample_hops_philox for the NEXT batch in one launch: the two are
+ * independent (sampling does not read weights or gradients), both are latency-bound and neither
+ * fills the chip, so side by side they cost the longer one.  The sampler's workgroups must see
+ * the counters of the next batch while this launch is in flight, so nothing here ticks them:
+ * pass call_base = (calls per batch) and batch_base = 1 in `hops`, and tick the counters in the
+ * following gsage_clip_adam_step (tick1 / tick2).  `tick` (Adam step counter) as above. */
+int gsage_finalize_grads_sample(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
+                                float *partial_sq, int64_t *tick, const gsage_hops_desc *hops,
+                                void *stream);
 int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:

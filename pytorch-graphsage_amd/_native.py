@@ -63,8 +63,9 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsage_mean_tail_ce_scratch": (_i64, [_i32, _i32]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
-                                    _f32, _vp, _int, _i32, _vp, _i32, _vp]),
+                                    _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "gsage_finalize_grads_sample": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsage_finalize_partials": (_int, [_i32, _i64]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -128,6 +129,13 @@ def check(rc, what=""):
 
 def launch_count():
     return int(lib().gsage_launch_count())
+
+
+class HopsDesc(ctypes.Structure):             # mirrors gsage_hops_desc (include/gsage.h)
+    _fields_ = [("rowptr", _vp), ("col", _vp), ("n_rows", _i64), ("ids", _vp), ("B", _i64),
+                ("n_hops", _i32), ("fan", _i32 * 5), ("max_deg", _u32), ("seed", _u64),
+                ("call_ctr", _vp), ("call_base", _u64), ("rank", _u64), ("seed_queue", _vp),
+                ("batch_idx", _vp), ("batch_base", _i64), ("n_batches", _i64), ("err_flag", _vp)]
 
 
 class WgradDesc(ctypes.Structure):            # mirrors gsage_wgrad_desc (include/gsage.h)

@@ -9,6 +9,7 @@
 // Adam betas (0.9, 0.999), eps 1e-8, L2 weight decay as at models.py:69) and autograd's
 // relu / mean / index backward between layers (models.py:85-86).  All HBM-bound, 16-byte lanes.
 #include "gsage_common.h"
+#include "gsage_sample_dev.h"
 
 namespace gsage {
 
@@ -59,6 +60,8 @@ struct AdamParams {
     float beta1, beta2, eps, weight_decay, max_norm;
     const struct PrepDesc *prep;   // optional: refresh the bf16 operand copies of the new weights
     int32_t n_prep;
+    int64_t *tick1, *tick2;        // optional counters advanced at kernel start (not read here)
+    int64_t inc1, inc2;
 };
 
 __global__ void __launch_bounds__(256)
@@ -76,7 +79,11 @@ k_adam_clip(const AdamParams a)
     const float bc2 = 1.f - powf(a.beta2, t);
     const float step_size = *a.lr / bc1;
     const float rsqrt_bc2 = 1.f / sqrtf(bc2);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) *a.norm_out = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.norm_out) *a.norm_out = total;
+        if (a.tick1) *a.tick1 += a.inc1;
+        if (a.tick2) *a.tick2 += a.inc2;
+    }
 
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
@@ -114,22 +121,17 @@ struct ReduceDesc {
     int32_t S, rows, cols, ld;
 };
 
-__global__ void __launch_bounds__(256)
-k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
-                 float *__restrict__ partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
-                 int64_t *tick2, int64_t inc2)
+// one workgroup of the finalisation: descriptor `by`, grid-stride slice bx of gx
+__device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
+                                                   float *__restrict__ flat_g,
+                                                   float *__restrict__ partial_sq, int bx, int by, int gx,
+                                                   float *red)
 {
-    __shared__ float red[4];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        if (tick) *tick += 1;
-        if (tick1) *tick1 += inc1;
-        if (tick2) *tick2 += inc2;
-    }
-    const ReduceDesc d = descs[blockIdx.y];
+    const ReduceDesc d = descs[by];
     const int64_t total = (int64_t)d.rows * d.cols;
-    const int64_t gstride = (int64_t)gridDim.x * 256;
+    const int64_t gstride = (int64_t)gx * 256;
     float sq = 0.f;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += gstride) {
+    for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
         const int64_t r = t / d.cols;
         const float *src = d.src + r * d.ld + (t - r * d.cols);
         float s = 0.f;
@@ -146,7 +148,42 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
         sq += s * s;
     }
     const float tot = block_sum_256(sq, red);
-    if (threadIdx.x == 0) partial_sq[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (threadIdx.x == 0) partial_sq[by * gx + bx] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
+                 float *__restrict__ partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
+                 int64_t *tick2, int64_t inc2)
+{
+    __shared__ float red[4];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (tick) *tick += 1;
+        if (tick1) *tick1 += inc1;
+        if (tick2) *tick2 += inc2;
+    }
+    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red);
+}
+
+// Gradient finalisation of batch i and the frontier sampling of batch i+1 side by side: workgroups
+// [0, gx*n_desc) finalise, the rest sample.  Neither job fills the chip and both are bound by
+// dependent-load latency, so together they take the longer of the two (11 vs 8 us at Reddit
+// shapes) instead of the sum.  Nothing here may advance the sampler's counters (its workgroups
+// read them while this launch runs): HopsParams carries call_base / batch_base offsets instead and
+// the following k_adam_clip ticks.
+__global__ void __launch_bounds__(256)
+k_finalize_sample(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
+                  float *__restrict__ partial_sq, int64_t *tick, int gx, int n_desc, const HopsParams h)
+{
+    extern __shared__ int64_t frontier[];
+    __shared__ float red[4];
+    const int n_fin = gx * n_desc;
+    if ((int)blockIdx.x < n_fin) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tick) *tick += 1;
+        finalize_workgroup(descs, flat_g, partial_sq, (int)blockIdx.x % gx, (int)blockIdx.x / gx, gx, red);
+    } else {
+        sample_hops_workgroup(h, (int)blockIdx.x - n_fin, frontier);
+    }
 }
 
 __global__ void k_step_inc(int64_t *step) { *step += 1; }
@@ -240,7 +277,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
                          const float *lr, int64_t *step, float beta1, float beta2, float eps,
                          float weight_decay, float max_norm, float *norm_out, int step_is_current,
                          int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
-                         void *stream)
+                         int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2, void *stream)
 {
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
@@ -255,6 +292,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     }
     AdamParams a;
     a.prep = (const PrepDesc *)prep_descs; a.n_prep = prep_descs ? n_prep : 0;
+    a.tick1 = tick1; a.inc1 = inc1; a.tick2 = tick2; a.inc2 = inc2;
     a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
     a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.weight_decay = weight_decay; a.max_norm = max_norm; a.step_off = step_is_current ? 0 : 1;
@@ -291,6 +329,23 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                        (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, tick1, inc1,
                        tick2, inc2);
     return check_launch("finalize_grads");
+}
+
+int gsage_finalize_grads_sample(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
+                                float *partial_sq, int64_t *tick, const gsage_hops_desc *hops,
+                                void *stream)
+{
+    GSAGE_REQUIRE(descs && flat_g && partial_sq && n_desc > 0 && max_elems > 0 && hops,
+                  "finalize_grads_sample: bad arguments");
+    HopsParams h;
+    size_t lds = 0;
+    int rc = fill_hops(h, lds, *hops);
+    if (rc != GSAGE_OK) return rc;
+    const int gx = grid_for(max_elems, 256);
+    const int n_sample = (int)ceil_div(hops->B, HOPS_SPW);
+    launch(k_finalize_sample, dim3((unsigned)(gx * n_desc + n_sample)), dim3(256), lds,
+           (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, gx, (int)n_desc, h);
+    return check_launch("finalize_grads_sample");
 }
 
 int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,

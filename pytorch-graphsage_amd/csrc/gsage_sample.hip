@@ -10,27 +10,13 @@
 // parent hit the same two words (TA broadcast), the only scattered traffic is one 4-byte `col`
 // read and one 8-byte write per sample.
 #include "gsage_common.h"
+#include "gsage_sample_dev.h"
 
 #include <string.h>
 
 namespace gsage {
 
 // ---- device code ----------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t pick_neighbor(const int64_t *__restrict__ rowptr,
-                                                 const int32_t *__restrict__ col, int64_t n_rows,
-                                                 int64_t id, uint32_t s, int32_t *err_flag)
-{
-    if ((uint64_t)id >= (uint64_t)n_rows) {          // the reference raises IndexError here
-        if (err_flag) *err_flag = 1;
-        return 0;
-    }
-    const int64_t beg = rowptr[id];
-    const int64_t deg = rowptr[id + 1] - beg;
-    if (deg <= 0) return 0;                          // numpy: x % 0 == 0 -> column 0 of an empty row
-    const uint64_t off = (deg <= 0xffffffffLL) ? (uint64_t)(s % (uint32_t)deg) : (uint64_t)s;
-    return (int64_t)col[beg + (int64_t)off];
-}
-
 __global__ void __launch_bounds__(256)
 k_sample_sel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t n_rows,
              const int64_t *__restrict__ ids, int64_t total, uint32_t n,
@@ -73,79 +59,11 @@ k_sample_philox(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ 
 
 __global__ void k_counter_add(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
-// All hops of a frontier in ONE launch.  A workgroup owns SPW consecutive seeds and walks their
-// whole sub-tree: the children of hop k are produced by the same workgroup that consumes them at
-// hop k+1, so the only synchronisation is __syncthreads() and the previous hop's ids sit in LDS.
-// Sample (hop k, global index g) uses exactly the Philox word the per-hop kernel would use
-// (call index call_base + k - 1, counter g), so results are identical to L separate launches.
-struct HopsParams {
-    const int64_t *rowptr;
-    const int32_t *col;
-    int64_t *ids;                 // [hop 0 | hop 1 | ... | hop L], hop 0 filled by the caller
-    const uint64_t *call_ctr;
-    int32_t *err_flag;
-    const int64_t *seed_queue;    // optional [n_batches, B] device-resident seed batches ...
-    const int64_t *batch_idx;     // ... and the device word selecting the current one
-    int64_t n_batches;
-    int64_t n_rows;
-    int64_t off[6];               // first element of hop k in ids
-    uint64_t g0[6];               // global sample index of this rank's first sample of hop k
-    uint64_t call_base;
-    int32_t fan[6];               // fan[k]: samples per parent at hop k (k >= 1)
-    int32_t n_hops, B;
-    uint32_t max_deg, seed_lo, seed_hi;
-};
-
-constexpr int HOPS_SPW = 1;       // seeds per workgroup: hop 2 of a 25x10 frontier is one pass of
-                                  // 250 lanes, so a seed's whole sub-tree costs two dependent
-                                  // (rowptr -> col) round trips
-
 __global__ void __launch_bounds__(256)
 k_sample_hops(const HopsParams p)
 {
-    extern __shared__ int64_t frontier[];            // two ping-pong buffers of the widest hop
-    const int seed0 = blockIdx.x * HOPS_SPW;
-    const int nseed = min(HOPS_SPW, p.B - seed0);
-    if (nseed <= 0) return;
-    int width = 1, widest = 1;
-    for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
-    int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
-    if (p.seed_queue) {           // take the seeds from the queue (and publish them as hop 0)
-        const int64_t b = (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches);
-        for (int t = threadIdx.x; t < nseed; t += 256) {
-            const int64_t v = p.seed_queue[b * p.B + seed0 + t];
-            cur[t] = v;
-            p.ids[p.off[0] + seed0 + t] = v;
-        }
-    } else {
-        for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
-    }
-    __syncthreads();
-    const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
-    int64_t per_seed = 1;                            // nodes of hop k per seed
-    for (int k = 1; k <= p.n_hops; ++k) {
-        const uint32_t n = (uint32_t)p.fan[k];
-        const int64_t parents = per_seed * nseed;
-        per_seed *= n;
-        const int64_t count = per_seed * nseed;
-        const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
-        const int64_t local0 = (int64_t)seed0 * per_seed;             // first sample of this WG in hop k
-        for (int64_t t = threadIdx.x; t < count; t += 256) {
-            const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
-            const uint64_t blk = g >> 2;
-            const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
-                                            (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
-            const uint32_t w = r.v[g & 3];
-            const uint32_t s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
-            const int64_t parent = cur[(uint32_t)t / n];
-            const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
-            nxt[t] = v;
-            p.ids[p.off[k] + local0 + t] = v;
-        }
-        (void)parents;
-        __syncthreads();
-        int64_t *tmp = cur; cur = nxt; nxt = tmp;
-    }
+    extern __shared__ int64_t frontier[];
+    sample_hops_workgroup(p, blockIdx.x, frontier);
 }
 
 static inline int grid_for(int64_t work_items)
@@ -263,36 +181,18 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
                              uint64_t rank, const int64_t *seed_queue, const int64_t *batch_idx,
                              int64_t n_batches, int32_t *err_flag, void *stream)
 {
-    GSAGE_REQUIRE(rowptr && col && ids && fan, "sample_hops_philox: null pointer");
-    GSAGE_REQUIRE(!seed_queue || (batch_idx && n_batches > 0), "sample_hops_philox: bad seed queue");
-    GSAGE_REQUIRE(n_hops >= 1 && n_hops <= 5, "sample_hops_philox: 1..5 hops");
-    GSAGE_REQUIRE(B >= 0 && B < (1LL << 31) && max_deg > 0, "sample_hops_philox: bad sizes");
-    if (B == 0) return GSAGE_OK;
+    gsage_hops_desc d;
+    d.rowptr = rowptr; d.col = col; d.n_rows = n_rows; d.ids = ids; d.B = B; d.n_hops = n_hops;
+    for (int k = 0; k < 5; ++k) d.fan[k] = (fan && k < n_hops && n_hops <= 5) ? fan[k] : 1;
+    GSAGE_REQUIRE(fan, "sample_hops_philox: null pointer");
+    d.max_deg = max_deg; d.seed = seed; d.call_ctr = call_ctr; d.call_base = call_base; d.rank = rank;
+    d.seed_queue = seed_queue; d.batch_idx = batch_idx; d.batch_base = 0; d.n_batches = n_batches;
+    d.err_flag = err_flag;
     HopsParams p;
-    p.rowptr = rowptr; p.col = col; p.ids = ids; p.call_ctr = call_ctr; p.err_flag = err_flag;
-    p.seed_queue = seed_queue; p.batch_idx = batch_idx; p.n_batches = n_batches;
-    p.n_rows = n_rows; p.call_base = call_base; p.n_hops = n_hops; p.B = (int32_t)B; p.max_deg = max_deg;
-    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
-    int64_t size = B, off = 0, widest = 1, width = 1;
-    p.fan[0] = 1;
-    for (int k = 0; k <= 5; ++k) {
-        if (k >= 1 && k <= n_hops) {
-            GSAGE_REQUIRE(fan[k - 1] > 0, "sample_hops_philox: n_samples must be > 0");
-            p.fan[k] = fan[k - 1];
-            size *= fan[k - 1];
-            width *= fan[k - 1];
-            if (width > widest) widest = width;
-        } else if (k > n_hops) {
-            p.fan[k] = 1;
-        }
-        p.off[k] = off;
-        p.g0[k] = rank * (uint64_t)size;
-        if (k <= n_hops) off += size;
-    }
-    const size_t lds = sizeof(int64_t) * 2 * HOPS_SPW * (size_t)widest;
-    GSAGE_REQUIRE(lds <= 160 * 1024, "sample_hops_philox: fan-out product too large for the fused kernel");
-    launch(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds,
-                       (hipStream_t)stream, p);
+    size_t lds = 0;
+    int rc = fill_hops(p, lds, d);
+    if (rc != GSAGE_OK || d.B == 0) return rc;
+    launch(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("sample_hops_philox");
 }
 

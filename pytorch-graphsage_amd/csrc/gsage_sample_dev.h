@@ -1,0 +1,135 @@
+// gsage_sample_dev.h -- device body of the fused multi-hop sampler (K1), shared by the stand-alone
+// kernel (gsage_sample.hip) and by k_finalize_sample (gsage_optim.hip), which samples the NEXT
+// batch's frontier side by side with the gradient finalisation of the current one.
+#pragma once
+#include "gsage_common.h"
+
+namespace gsage {
+
+__device__ __forceinline__ int64_t pick_neighbor(const int64_t *__restrict__ rowptr,
+                                                 const int32_t *__restrict__ col, int64_t n_rows,
+                                                 int64_t id, uint32_t s, int32_t *err_flag)
+{
+    if ((uint64_t)id >= (uint64_t)n_rows) {          // the reference raises IndexError here
+        if (err_flag) *err_flag = 1;
+        return 0;
+    }
+    const int64_t beg = rowptr[id];
+    const int64_t deg = rowptr[id + 1] - beg;
+    if (deg <= 0) return 0;                          // numpy: x % 0 == 0 -> column 0 of an empty row
+    const uint64_t off = (deg <= 0xffffffffLL) ? (uint64_t)(s % (uint32_t)deg) : (uint64_t)s;
+    return (int64_t)col[beg + (int64_t)off];
+}
+
+
+// All hops of a frontier in ONE launch.  A workgroup owns SPW consecutive seeds and walks their
+// whole sub-tree: the children of hop k are produced by the same workgroup that consumes them at
+// hop k+1, so the only synchronisation is __syncthreads() and the previous hop's ids sit in LDS.
+// Sample (hop k, global index g) uses exactly the Philox word the per-hop kernel would use
+// (call index call_base + k - 1, counter g), so results are identical to L separate launches.
+struct HopsParams {
+    const int64_t *rowptr;
+    const int32_t *col;
+    int64_t *ids;                 // [hop 0 | hop 1 | ... | hop L], hop 0 filled by the caller
+    const uint64_t *call_ctr;
+    int32_t *err_flag;
+    const int64_t *seed_queue;    // optional [n_batches, B] device-resident seed batches ...
+    const int64_t *batch_idx;     // ... and the device word selecting the current one
+    int64_t n_batches;
+    int64_t batch_base;           // added to *batch_idx (sampling AHEAD of the tick, see k_finalize_sample)
+    int64_t n_rows;
+    int64_t off[6];               // first element of hop k in ids
+    uint64_t g0[6];               // global sample index of this rank's first sample of hop k
+    uint64_t call_base;
+    int32_t fan[6];               // fan[k]: samples per parent at hop k (k >= 1)
+    int32_t n_hops, B;
+    uint32_t max_deg, seed_lo, seed_hi;
+};
+
+constexpr int HOPS_SPW = 1;       // seeds per workgroup: hop 2 of a 25x10 frontier is one pass of
+                                  // 250 lanes, so a seed's whole sub-tree costs two dependent
+                                  // (rowptr -> col) round trips
+
+// frontier: two ping-pong LDS buffers of the widest hop; wg: which group of HOPS_SPW seeds
+__device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int wg, int64_t *frontier)
+{
+    const int seed0 = wg * HOPS_SPW;
+    const int nseed = min(HOPS_SPW, p.B - seed0);
+    if (nseed <= 0) return;
+    int width = 1, widest = 1;
+    for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
+    int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
+    if (p.seed_queue) {           // take the seeds from the queue (and publish them as hop 0)
+        const int64_t b = (int64_t)((uint64_t)(*p.batch_idx + p.batch_base) % (uint64_t)p.n_batches);
+        for (int t = threadIdx.x; t < nseed; t += 256) {
+            const int64_t v = p.seed_queue[b * p.B + seed0 + t];
+            cur[t] = v;
+            p.ids[p.off[0] + seed0 + t] = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
+    }
+    __syncthreads();
+    const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
+    int64_t per_seed = 1;                            // nodes of hop k per seed
+    for (int k = 1; k <= p.n_hops; ++k) {
+        const uint32_t n = (uint32_t)p.fan[k];
+        const int64_t parents = per_seed * nseed;
+        per_seed *= n;
+        const int64_t count = per_seed * nseed;
+        const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
+        const int64_t local0 = (int64_t)seed0 * per_seed;             // first sample of this WG in hop k
+        for (int64_t t = threadIdx.x; t < count; t += 256) {
+            const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
+            const uint64_t blk = g >> 2;
+            const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
+                                            (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
+            const uint32_t w = r.v[g & 3];
+            const uint32_t s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
+            const int64_t parent = cur[(uint32_t)t / n];
+            const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
+            nxt[t] = v;
+            p.ids[p.off[k] + local0 + t] = v;
+        }
+        (void)parents;
+        __syncthreads();
+        int64_t *tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+
+// [host] validate a gsage_hops_desc and turn it into kernel parameters + dynamic LDS bytes
+inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
+{
+    GSAGE_REQUIRE(d.rowptr && d.col && d.ids, "sample_hops_philox: null pointer");
+    GSAGE_REQUIRE(!d.seed_queue || (d.batch_idx && d.n_batches > 0), "sample_hops_philox: bad seed queue");
+    GSAGE_REQUIRE(d.n_hops >= 1 && d.n_hops <= 5, "sample_hops_philox: 1..5 hops");
+    GSAGE_REQUIRE(d.B >= 0 && d.B < (1LL << 31) && d.max_deg > 0, "sample_hops_philox: bad sizes");
+    p.rowptr = d.rowptr; p.col = d.col; p.ids = d.ids; p.call_ctr = d.call_ctr; p.err_flag = d.err_flag;
+    p.seed_queue = d.seed_queue; p.batch_idx = d.batch_idx; p.n_batches = d.n_batches;
+    p.batch_base = d.batch_base;
+    p.n_rows = d.n_rows; p.call_base = d.call_base; p.n_hops = d.n_hops; p.B = (int32_t)d.B;
+    p.max_deg = d.max_deg;
+    p.seed_lo = (uint32_t)d.seed; p.seed_hi = (uint32_t)(d.seed >> 32);
+    int64_t size = d.B, off = 0, widest = 1, width = 1;
+    p.fan[0] = 1;
+    for (int k = 0; k <= 5; ++k) {
+        if (k >= 1 && k <= d.n_hops) {
+            GSAGE_REQUIRE(d.fan[k - 1] > 0, "sample_hops_philox: n_samples must be > 0");
+            p.fan[k] = d.fan[k - 1];
+            size *= d.fan[k - 1];
+            width *= d.fan[k - 1];
+            if (width > widest) widest = width;
+        } else if (k > d.n_hops) {
+            p.fan[k] = 1;
+        }
+        p.off[k] = off;
+        p.g0[k] = d.rank * (uint64_t)size;
+        if (k <= d.n_hops) off += size;
+    }
+    lds = sizeof(int64_t) * 2 * HOPS_SPW * (size_t)widest;
+    GSAGE_REQUIRE(lds <= 160 * 1024, "sample_hops_philox: fan-out product too large for the fused kernel");
+    return GSAGE_OK;
+}
+
+}  // namespace gsage

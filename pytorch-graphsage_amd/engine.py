@@ -220,6 +220,7 @@ class FusedMeanTrainStep(object):
         self.pipelined = bool(pipelined)
         self.nset = 2 if self.pipelined else 1
         self._front_ready, self.g_qfront = False, None
+        self.prefetch = False                        # queue mode: batch i+1 is sampled during step i
         self._reduce_op = None
         if ddp is not None:
             # averaging inside the collective saves a launch; fall back to divide-then-sum where
@@ -451,19 +452,43 @@ class FusedMeanTrainStep(object):
                            c_gs, nat.BF16, c_dtype)
 
     # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
+    def _hops_desc(self, s, ahead):
+        """gsage_hops_desc of batch set s; ahead=True: sample the NEXT batch of the queue before the
+        counters are ticked (call_base / batch_base offsets)."""
+        L = self.L
+        d = nat.HopsDesc()
+        d.rowptr, d.col, d.n_rows = self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows
+        d.ids, d.B, d.n_hops = self.ids_set[s].data_ptr(), self.B, L
+        for k in range(5):
+            d.fan[k] = int(self.fan[k + 1]) if k < L else 1
+        d.max_deg, d.seed = self.csr.max_deg, self.sampler.seed
+        d.call_ctr, d.call_base, d.rank = self.counter.data_ptr(), (L if ahead else 0), self.sampler.shard[0]
+        d.seed_queue = self.queue[0].data_ptr() if self.queue else None
+        d.batch_idx = self.batch_idx.data_ptr() if self.queue else None
+        d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
+        d.err_flag = self.csr.err_flag.data_ptr()
+        return d
+
+    def _stage_sample(self, s):
+        """K1: every hop in one launch, frontier written in place into the concatenated ids."""
+        d = self._hops_desc(s, False)
+        nat.check(nat.lib().gsage_sample_hops_philox(
+            d.rowptr, d.col, d.n_rows, d.ids, d.B, d.n_hops, d.fan, d.max_deg, d.seed, d.call_ctr,
+            d.call_base, d.rank, d.seed_queue, d.batch_idx, d.n_batches, d.err_flag, ops._stream()),
+            "sample_hops_philox")
+
     def _stage_sample_gather(self, s):
         """K1 for every hop + the level-0 gathers of batch set `s`; independent of the weights."""
+        self._stage_sample(s)
+        self._stage_gather(s)
+        # the next batch's samples use the next L Philox call indices (sequential mode: ticked by
+        # gsage_finalize_grads instead of a launch of its own)
+        if self.pipelined:
+            nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), self.L, ops._stream()), "counter_add")
+
+    def _stage_gather(self, s):
         L, st = self.L, self.store
         ids = self.ids_set[s]
-        rank = self.sampler.shard[0]
-        # K1: every hop in one launch, frontier written in place into the concatenated ids
-        fan = (ctypes.c_int32 * L)(*[int(v) for v in self.fan[1:]])
-        nat.check(nat.lib().gsage_sample_hops_philox(
-            self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows, ids.data_ptr(),
-            self.B, L, fan, self.csr.max_deg, self.sampler.seed, self.counter.data_ptr(), 0, rank,
-            self.queue[0].data_ptr() if self.queue else None,
-            self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
-            self.csr.err_flag.data_ptr(), ops._stream()), "sample_hops_philox")
         # one launch: x rows of every hop + the mean of each hop's sampled neighbours
         R = self.rows[0]
         xa = self.xa0_set[s]
@@ -472,10 +497,6 @@ class FusedMeanTrainStep(object):
             segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
                          self.size[k], self.fan[k + 1]))
         ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
-        # the next batch's samples use the next L Philox call indices (sequential mode: ticked by
-        # gsage_finalize_grads instead of a launch of its own)
-        if self.pipelined:
-            nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), L, ops._stream()), "counter_add")
 
     def _stage_compute(self, s):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
@@ -577,12 +598,21 @@ class FusedMeanTrainStep(object):
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         # every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick
-        nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
-                                           self.flat_g.data_ptr(), self.partial.data_ptr(),
-                                           self.step.data_ptr(),
-                                           None if self.pipelined else self.counter.data_ptr(), L,
-                                           self.batch_idx.data_ptr() if self.queue else None, 1,
-                                           stream), "finalize_grads")
+        if self.prefetch:
+            # ... side by side with the sampling of the NEXT batch of the queue (counters are
+            # ticked by the Adam launch that follows)
+            d = self._hops_desc(s, True)
+            nat.check(lib.gsage_finalize_grads_sample(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
+                                                      self.flat_g.data_ptr(), self.partial.data_ptr(),
+                                                      self.step.data_ptr(), ctypes.addressof(d), stream),
+                      "finalize_grads_sample")
+        else:
+            nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
+                                               self.flat_g.data_ptr(), self.partial.data_ptr(),
+                                               self.step.data_ptr(),
+                                               None if self.pipelined else self.counter.data_ptr(), L,
+                                               self.batch_idx.data_ptr() if self.queue else None, 1,
+                                               stream), "finalize_grads")
 
     def _all_reduce(self, async_op=False):
         """The step's ONE exchange: average the flat fp32 gradient bucket over the ranks (RCCL)."""
@@ -599,7 +629,10 @@ class FusedMeanTrainStep(object):
                                                  self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
                                                  self.gnorm.data_ptr(), 1,
                                                  0 if self.ddp is not None else self.n_partial,
-                                                 self.descs.data_ptr(), self.n_desc, ops._stream()),
+                                                 self.descs.data_ptr(), self.n_desc,
+                                                 self.counter.data_ptr() if self.prefetch else None, self.L,
+                                                 self.batch_idx.data_ptr() if self.prefetch else None, 1,
+                                                 ops._stream()),
                   "clip_adam_step")
 
     def _run_sequential(self, s):
@@ -627,49 +660,65 @@ class FusedMeanTrainStep(object):
         assert tq.dtype == torch.int64
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
         self.batch_idx.zero_()
+        # From here on batch i+1's frontier is sampled DURING step i (side by side with the gradient
+        # finalisation, gsage_finalize_grads_sample) and the counters are ticked by Adam.
+        self.prefetch = True
         self._front_ready = False
         if self.g_main is not None:
             torch.cuda.synchronize()
+            self.g_prime = self._record(lambda: self._stage_sample(0))
             if self.ddp is None:
                 def whole():
-                    self._stage_sample_gather(0)
+                    self._stage_gather(0)
                     self._stage_compute(0)
                     self._stage_opt()
                 self.g_main = [self._record(whole)]
             else:
                 # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
-                # sampling + gathers (see step_queue)
-                self.g_qfront = self._record(lambda: self._stage_sample_gather(0))
+                # gathers (see step_queue)
+                self.g_qfront = self._record(lambda: self._stage_gather(0))
                 self.g_main = [self._record(lambda: self._stage_compute(0))]
+                self.g_opt = self._record(self._stage_opt)
         return self
 
     def step_queue(self):
         """One train_step on the next batch of the loaded epoch queue -> preds (static buffer).
 
-        Data-parallel runs are software-pipelined by one stage: sampling and the level-0 gathers do
-        not depend on the weights, so batch i+1's are issued while batch i's gradient all-reduce is
-        in flight on RCCL's stream, and Adam(i) follows both.  Every call still performs exactly one
-        sample/gather, one forward/backward, one exchange and one optimizer step; the first call
-        after load_epoch() additionally primes the pipeline."""
+        Software-pipelined by one stage, because sampling and the level-0 gathers do not depend on
+        the weights: batch i+1's frontier is sampled side by side with batch i's gradient
+        finalisation, and in data-parallel runs batch i+1's gathers are issued while batch i's
+        gradient all-reduce is in flight on RCCL's stream, Adam(i) following both.  Every call
+        performs exactly one sampling, one gather, one forward/backward, (one exchange) and one
+        optimizer step; the first call after load_epoch() additionally samples batch 0."""
         assert self.queue is not None, "call load_epoch() first"
-        if self.ddp is None:
-            if self.g_main is None:
-                self._run_sequential(0)
-            else:
-                self.g_main[0].replay()
-            return self.preds
-        front = self.g_qfront.replay if self.g_main is not None else (lambda: self._stage_sample_gather(0))
+        rec = self.g_main is not None
         if not self._front_ready:
-            front()
+            if rec:
+                self.g_prime.replay()
+            else:
+                self._stage_sample(0)
+            if self.ddp is not None:
+                self._stage_gather(0)
             self._front_ready = True
-        if self.g_main is not None:
+        if self.ddp is None:
+            if rec:
+                self.g_main[0].replay()
+            else:
+                self._stage_gather(0)
+                self._stage_compute(0)
+                self._stage_opt()
+            return self.preds
+        if rec:
             self.g_main[0].replay()
         else:
             self._stage_compute(0)
         work = self._all_reduce(async_op=True)
-        front()                                      # batch i+1: sample + gather, overlapping the exchange
+        if rec:                                      # batch i+1's gathers overlap the exchange
+            self.g_qfront.replay()
+        else:
+            self._stage_gather(0)
         work.wait()                                  # stream-level wait, the host does not block
-        if self.g_opt is not None:
+        if rec:
             self.g_opt.replay()
         else:
             self._stage_opt()
