@@ -84,6 +84,14 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
+// for every outstanding GLOBAL store to be acknowledged (1-2 us each time on gfx950) -- wasted when
+// the stores are results no wave of this launch reads back.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 16-byte vector of raw bits; the unit every kernel moves per lane.  A first-class vector type
 // (not a struct with an array member): hipcc keeps these in VGPRs, whereas the struct form was
 // observed to live in scratch memory when selected/zeroed conditionally.

@@ -47,6 +47,7 @@ struct TailParams {
     float *partial;          // out: [grid, C*256 + C + 1] fc.weight / fc.bias / loss partials
     int64_t ldw2, ldw2t;
     int32_t B, n, C;
+    long long *stamps;
 };
 
 __device__ __forceinline__ float tail_wave_sum(float v)
@@ -68,9 +69,13 @@ __device__ __forceinline__ float tail_elem(const vec16 v, int e)
     return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
 }
 
+// fc.weight rows in LDS are padded to a multiple of 8 classes (zero rows): 8-class chunks need no
+// per-class guards, and every buffer behind them stays 16-byte aligned for ds_read_b128
+constexpr int tail_cpad(int C) { return (C + 7) & ~7; }
+
 constexpr size_t tail_lds_floats(int C)
 {
-    return (size_t)C * (TAIL_D + 1) + 4 * TAIL_R * TAIL_D + 4 * TAIL_R * TAIL_CMAX + TAIL_R * TAIL_CMAX +
+    return (size_t)tail_cpad(C) * (TAIL_D + 1) + 4 * TAIL_R * TAIL_D + 4 * TAIL_R * TAIL_CMAX + TAIL_R * TAIL_CMAX +
            4 * TAIL_R + 2 * 8 * TAIL_R * TAIL_D;
 }
 
@@ -83,8 +88,9 @@ k_mean_tail_ce(const TailParams p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = p.C;
     const int ldw = D + 1;
-    float *Ws = lds;                              // [C][257] fc.weight
-    float *xs = Ws + C * ldw;                     // [R][256] seed rows
+    const int Cp = tail_cpad(C);
+    float *Ws = lds;                              // [Cp][257] fc.weight, rows >= C zero
+    float *xs = Ws + Cp * ldw;                    // [R][256] seed rows
     float *as = xs + R * D;                       // [R][256] neighbour means
     float *zs = as + R * D;                       // [R][256] normalised embeddings
     float *des = zs + R * D;                      // [R][256] d emb (bf16-rounded)
@@ -102,6 +108,7 @@ k_mean_tail_ce(const TailParams p)
     const int n = p.n;
     const int64_t B = p.B;
 
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 0] = wall_clock64();
     // ---- 0. every request that depends on nothing, all in flight together -------------------------
     const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * B : 0);
     const int64_t iw = row0 + wave;               // this wave's seed
@@ -139,6 +146,9 @@ k_mean_tail_ce(const TailParams p)
             }
         }
     }
+
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 1] = wall_clock64();
+    for (int q = t; q < (Cp - C) * ldw; q += 256) Ws[C * ldw + q] = 0.f;
 
     // ---- 1. neighbour mean of this wave's seed + ReLU masks of the rows this lane loaded -----------
     uint32_t mbits[(NBH + 3) / 4];
@@ -184,8 +194,9 @@ k_mean_tail_ce(const TailParams p)
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 2] = wall_clock64();
     // ---- 2. emb = [x Wx^T | agg Wn^T]: lane = 8 output columns, half-wave `slot` = 32 of the 256 k ---
     {
         float acc[R][8];
@@ -227,7 +238,8 @@ k_mean_tail_ce(const TailParams p)
             *(float4 *)(d + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 3] = wall_clock64();
     float e[R];                                   // from here to the end of the head: thread t = column t
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -240,11 +252,11 @@ k_mean_tail_ce(const TailParams p)
     auto block_sum_rows = [&](float (&v)[R]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = tail_wave_sum(v[r]);
-        __syncthreads();
+        lds_barrier();
         if (lane == 0)
 #pragma unroll
             for (int r = 0; r < R; ++r) red[wave * R + r] = v[r];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = (red[r] + red[R + r]) + (red[2 * R + r] + red[3 * R + r]);
     };
@@ -261,7 +273,7 @@ k_mean_tail_ce(const TailParams p)
         z[r] = e[r] / nrm[r];
         zs[r * D + t] = z[r];
     }
-    __syncthreads();
+    lds_barrier();
     {
         float s[R];
 #pragma unroll
@@ -269,16 +281,23 @@ k_mean_tail_ce(const TailParams p)
         if (lane < C) {
             const int k0 = wave * (D / 4), k1 = k0 + D / 4;
             const float *wr = Ws + lane * ldw;
-            for (int k = k0; k < k1; ++k) {
-                const float w = wr[k];
+            for (int k = k0; k < k1; k += 8) {            // 8 weights + 8 float4 of z per round trip
+                float w[8];
 #pragma unroll
-                for (int r = 0; r < R; ++r) s[r] += zs[r * D + k] * w;
+                for (int u = 0; u < 8; ++u) w[u] = wr[k + u];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 a = *(const float4 *)(zs + r * D + k);
+                    const float4 b = *(const float4 *)(zs + r * D + k + 4);
+                    s[r] += a.x * w[0] + a.y * w[1] + a.z * w[2] + a.w * w[3] +
+                            b.x * w[4] + b.y * w[5] + b.z * w[6] + b.w * w[7];
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) part[(wave * R + r) * TAIL_CMAX + lane] = s[r];
     }
-    __syncthreads();
+    lds_barrier();
     float acc_db = 0.f, acc_loss = 0.f;
     {
         const int r = wave;                                   // R == 4 waves: wave r <-> row r
@@ -297,25 +316,38 @@ k_mean_tail_ce(const TailParams p)
         if (i < B && (int64_t)lane == my_target) acc_loss += -(logit - mx - logf(den));
         acc_db += dl;
     }
-    __syncthreads();
+    lds_barrier();
     float dz[R], zdz[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) dz[r] = 0.f;
     float accW[TAIL_CMAX];
+    {
+        // d logits of the 4 rows: lane c keeps class c, v_readlane broadcasts them as scalars (the
+        // obvious dls[r][c] LDS reads are a dependent ~100-clock round trip each with one wave per SIMD)
+        int dlv[R];
 #pragma unroll
-    for (int c = 0; c < TAIL_CMAX; ++c) {
-        if (c < C) {
-            const float w = Ws[c * ldw + t];
-            float acc = 0.f;
+        for (int r = 0; r < R; ++r) dlv[r] = __float_as_int(dls[r * TAIL_CMAX + lane]);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float dl = dls[r * TAIL_CMAX + c];
-                dz[r] += dl * w;
-                acc += dl * z[r];
+        for (int c0 = 0; c0 < TAIL_CMAX; c0 += 8) {
+            if (c0 < C) {                                     // uniform; rows up to Cp exist (zeros)
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = Ws[(c0 + u) * ldw + t];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float dl = __int_as_float(__builtin_amdgcn_readlane(dlv[r], c0 + u));
+                        dz[r] += dl * w[u];
+                        acc += dl * z[r];
+                    }
+                    accW[c0 + u] = acc;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) accW[c0 + u] = 0.f;
             }
-            accW[c] = acc;
-        } else {
-            accW[c] = 0.f;
         }
     }
 #pragma unroll
@@ -334,8 +366,9 @@ k_mean_tail_ce(const TailParams p)
         for (int c = 0; c < TAIL_CMAX; ++c)
             if (c < C) out[c * D + t] = accW[c];
     }
-    __syncthreads();                                            // des complete; part / red free again
+    lds_barrier();                                            // des complete; part / red free again
 
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 4] = wall_clock64();
     // ---- 4. input gradients dX = dE[:, :128] Wx, dA = dE[:, 128:] Wn: lane = 8 columns of H,
     //         half-wave `slot` = 16 of the 128 rows of each weight ------------------------------------
     {
@@ -390,7 +423,8 @@ k_mean_tail_ce(const TailParams p)
             *(float4 *)(d + 4) = make_float4(aa[r][4], aa[r][5], aa[r][6], aa[r][7]);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 5] = wall_clock64();
     // ---- 5. previous level's gradient rows of this wave's seed, ReLU mask applied -------------------
     if (live) {
         const float inv_n = 1.f / (float)n;
@@ -432,17 +466,19 @@ k_mean_tail_ce(const TailParams p)
             }
         }
     }
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 6] = wall_clock64();
     // ---- 6. fc.bias / loss partials ----------------------------------------------------------------
     part[wave * TAIL_CMAX + lane] = acc_db;
     const float l = tail_wave_sum(acc_loss);
     if (lane == 0) red[wave] = l;
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {
         float *out = p.partial + (int64_t)blockIdx.x * ((int64_t)C * D + C + 1);
         if (lane < C)
             out[C * D + lane] = (part[lane] + part[TAIL_CMAX + lane]) + (part[2 * TAIL_CMAX + lane] + part[3 * TAIL_CMAX + lane]);
         if (lane == 0) out[C * D + C] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 7] = wall_clock64();
 }
 
 }  // namespace gsage
@@ -475,6 +511,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     p.H = (const uint16_t *)H; p.w2 = (const uint16_t *)w2; p.w2t = (const uint16_t *)w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
     p.agg = (uint16_t *)agg; p.dE = (uint16_t *)dE; p.preds = preds; p.dH = (uint16_t *)dH;
+    { const char *e = getenv("GSAGE_TAIL_STAMPS"); p.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
     auto kern = n <= 16 ? k_mean_tail_ce<8> : k_mean_tail_ce<16>;
