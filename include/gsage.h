@@ -318,9 +318,34 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
                          float weight_decay, float max_norm, float *norm_out, int step_is_current,
                          int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
                          int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2, void *stream);
+/* The same arguments as a struct (HOST memory), for gsage_gather_mean_multi_adam. */
+typedef struct gsage_adam_desc {
+    float *p, *g, *m, *v;
+    int64_t n;
+    float *partial;
+    const float *lr;
+    int64_t *step;
+    float beta1, beta2, eps, weight_decay, max_norm;
+    float *norm_out;
+    int32_t step_is_current, n_partial_ready;
+    const void *prep_descs;
+    int32_t n_prep;
+    int64_t *tick1;
+    int64_t inc1;
+    int64_t *tick2;
+    int64_t inc2;
+} gsage_adam_desc;
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts -- the Philox
  * call index and batch-queue index when the NEXT batch was sampled ahead of the tick by
  * gsage_finalize_grads_sample (nothing in this kernel reads them). */
+/* gsage_gather_mean_multi (the NEXT batch's level-0 gathers: they read features and ids only) and
+ * the clip + Adam update of the CURRENT batch in one launch.  The update is ~8 us of latency-bound
+ * work on a few hundred workgroups; next to the HBM-bound gather it is free.  adam->n_partial_ready
+ * must be > 0 (norm partials from gsage_finalize_grads[_sample]) and adam->step_is_current != 0. */
+int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
+                                 void *const *outs, const int64_t *M, const int32_t *n, int dtype,
+                                 int64_t ld, int64_t D, int out_dtype, int64_t out_ld,
+                                 const gsage_adam_desc *adam, void *stream);
 
 /* Sums partial gradient buffers into the flat bucket and emits the squared-norm partials the
  * clip needs, in one launch: for descriptor d, flat_g[out_off + r*cols + c] =

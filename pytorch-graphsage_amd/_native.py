@@ -48,6 +48,8 @@ SIGNATURES = {
     "gsage_mt_permutation": (None, [_vp, _i64, _vp]),
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
     "gsage_gather_mean_multi": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64, _vp]),
+    "gsage_gather_mean_multi_adam": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64,
+                                            _vp, _vp]),
     "gsage_segment_mean_bwd": (_int, [_vp, _i64, _i64, _i32, _i64, _vp, _i64, _vp]),
     "gsage_scatter_add_rows": (_int, [_vp, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _i64, _vp]),
     "gsage_linear_nt": (_int, [_vp, _int, _i64, _vp, _int, _vp, _i64, _vp, _vp, _int, _i64, _i64,
@@ -136,6 +138,14 @@ class HopsDesc(ctypes.Structure):             # mirrors gsage_hops_desc (include
                 ("n_hops", _i32), ("fan", _i32 * 5), ("max_deg", _u32), ("seed", _u64),
                 ("call_ctr", _vp), ("call_base", _u64), ("rank", _u64), ("seed_queue", _vp),
                 ("batch_idx", _vp), ("batch_base", _i64), ("n_batches", _i64), ("err_flag", _vp)]
+
+
+class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include/gsage.h)
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64), ("partial", _vp),
+                ("lr", _vp), ("step", _vp), ("beta1", _f32), ("beta2", _f32), ("eps", _f32),
+                ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
+                ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
+                ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64)]
 
 
 class WgradDesc(ctypes.Structure):            # mirrors gsage_wgrad_desc (include/gsage.h)

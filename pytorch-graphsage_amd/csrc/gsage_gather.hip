@@ -13,6 +13,7 @@
 // needed by exactly one output row); L2 / Infinity Cache absorb the duplicates that sampling
 // with replacement produces.
 #include "gsage_common.h"
+#include "gsage_optim_dev.h"
 
 namespace gsage {
 
@@ -133,12 +134,12 @@ struct MultiSeg {
 };
 
 template <typename TI, typename TO, int VEC>
-__global__ void __launch_bounds__(256)
-k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld)
+__device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_t ld, int32_t D,
+                                                       int32_t chunks, int64_t out_ld, int bx, int gx)
 {
     const int64_t total = q.first[q.n_seg];
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const int64_t stride = (int64_t)gx * 256;
+    for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += stride) {
         int s = 0;
 #pragma unroll
         for (int j = 1; j < 8; ++j)
@@ -149,6 +150,30 @@ k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
         gather_mean_chunk<TI, TO, VEC>((const TI *)q.table[s], ld, q.ids[s], row, q.n[s], D, c0,
                                        (TO *)q.out[s], out_ld);
     }
+}
+
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld)
+{
+    gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, blockIdx.x, gridDim.x);
+}
+
+// The level-0 gathers of batch i+1 and the clip + Adam update of batch i side by side: workgroups
+// [0, n_adam) update (they come first so the short job is done long before the gather drains),
+// the rest gather.  The two touch disjoint data: the gather reads features and ids, Adam reads and
+// writes the parameter / gradient / moment buckets and the bf16 operand copies.
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256)
+k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
+                    int n_adam, const AdamParams a)
+{
+    __shared__ float red[4];
+    if ((int)blockIdx.x < n_adam)
+        adam_workgroup(a, blockIdx.x, n_adam, red);
+    else
+        gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, (int)blockIdx.x - n_adam,
+                                            (int)gridDim.x - n_adam);
 }
 
 // dneibs[i*n+j, :] = dagg[i, :] / n     (fp32, 16-byte chunks when aligned)
@@ -260,9 +285,9 @@ int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *i
     return GSAGE_EINVAL;
 }
 
-int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
-                            void *const *outs, const int64_t *M, const int32_t *n, int dtype,
-                            int64_t ld, int64_t D, int out_dtype, int64_t out_ld, void *stream)
+static int fill_multi(MultiSeg &q, int32_t &chunks, int32_t n_seg, const void *const *tables,
+                      const int64_t *const *ids, void *const *outs, const int64_t *M, const int32_t *n,
+                      int dtype, int64_t ld, int64_t D, int out_dtype, int64_t out_ld)
 {
     GSAGE_REQUIRE(n_seg >= 1 && n_seg <= 8, "gather_mean_multi: 1..8 segments");
     GSAGE_REQUIRE(tables && ids && outs && M && n, "gather_mean_multi: null pointer");
@@ -270,8 +295,7 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
                   "gather_mean_multi: bf16 tables and outputs only");
     GSAGE_REQUIRE(D > 0 && ld % 8 == 0 && out_ld % 8 == 0 && ceil_div(D, 8) * 8 <= ld &&
                   ceil_div(D, 8) * 8 <= out_ld, "gather_mean_multi: needs 16-byte row chunks");
-    const int32_t chunks = (int32_t)ceil_div(D, 8);
-    MultiSeg q;
+    chunks = (int32_t)ceil_div(D, 8);
     q.n_seg = n_seg;
     q.first[0] = 0;
     for (int s = 0; s < 8; ++s) {
@@ -288,10 +312,41 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
         }
         q.first[s + 1] = q.first[s] + q.M[s] * chunks;
     }
+    return GSAGE_OK;
+}
+
+int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
+                            void *const *outs, const int64_t *M, const int32_t *n, int dtype,
+                            int64_t ld, int64_t D, int out_dtype, int64_t out_ld, void *stream)
+{
+    MultiSeg q;
+    int32_t chunks = 0;
+    int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
+    if (rc != GSAGE_OK) return rc;
     if (q.first[n_seg] == 0) return GSAGE_OK;
     launch(k_gather_mean_multi<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg])),
                        dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
     return check_launch("gather_mean_multi");
+}
+
+int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
+                                 void *const *outs, const int64_t *M, const int32_t *n, int dtype,
+                                 int64_t ld, int64_t D, int out_dtype, int64_t out_ld,
+                                 const gsage_adam_desc *adam, void *stream)
+{
+    MultiSeg q;
+    int32_t chunks = 0;
+    int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
+    if (rc != GSAGE_OK) return rc;
+    GSAGE_REQUIRE(adam && adam->step_is_current && q.first[n_seg] > 0,
+                  "gather_mean_multi_adam: needs an Adam descriptor with step_is_current and a non-empty gather");
+    AdamParams a;
+    rc = fill_adam(a, *adam);
+    if (rc != GSAGE_OK) return rc;
+    const int n_adam = adam_grid(adam->n, 2048);
+    launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam),
+           dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a);
+    return check_launch("gather_mean_multi_adam");
 }
 
 int gsage_segment_mean_bwd(const float *dagg, int64_t ld, int64_t M, int32_t n, int64_t D,

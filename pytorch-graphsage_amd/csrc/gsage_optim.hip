@@ -10,21 +10,11 @@
 // relu / mean / index backward between layers (models.py:85-86).  All HBM-bound, 16-byte lanes.
 #include "gsage_common.h"
 #include "gsage_sample_dev.h"
+#include "gsage_optim_dev.h"
 
 namespace gsage {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float block_sum_256(float v, float *red)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
 
 // partial[b] = sum over this block's grid-stride slice of g[i]^2
 __global__ void __launch_bounds__(256)
@@ -41,76 +31,11 @@ k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partia
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-// ---- weight operand copies ------------------------------------------------------------------------
-struct PrepDesc {
-    const float *src;      // [rows, cols] fp32, contiguous
-    uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
-    uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
-    int32_t rows, cols, dst_ld, dst_t_ld;
-};
-
-struct AdamParams {
-    float *p, *g, *m, *v;
-    const float *partial;       // per-block squared-norm partials of g
-    const float *lr;            // device scalar (a captured graph sees schedule changes)
-    int64_t *step;              // device step counter; this launch uses *step + 1
-    float *norm_out;            // optional: total gradient norm before clipping
-    int64_t n;
-    int32_t n_partial, step_off;
-    float beta1, beta2, eps, weight_decay, max_norm;
-    const struct PrepDesc *prep;   // optional: refresh the bf16 operand copies of the new weights
-    int32_t n_prep;
-    int64_t *tick1, *tick2;        // optional counters advanced at kernel start (not read here)
-    int64_t inc1, inc2;
-};
-
 __global__ void __launch_bounds__(256)
 k_adam_clip(const AdamParams a)
 {
     __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
-    const float sq = block_sum_256(s, red);
-    const float total = sqrtf(sq);
-    float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
-    coef = coef < 1.f ? coef : 1.f;
-    const float t = (float)(*a.step + a.step_off);
-    const float bc1 = 1.f - powf(a.beta1, t);
-    const float bc2 = 1.f - powf(a.beta2, t);
-    const float step_size = *a.lr / bc1;
-    const float rsqrt_bc2 = 1.f / sqrtf(bc2);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (a.norm_out) *a.norm_out = total;
-        if (a.tick1) *a.tick1 += a.inc1;
-        if (a.tick2) *a.tick2 += a.inc2;
-    }
-
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
-        float g = a.g[i] * coef;
-        a.g[i] = g;                                     // clipped gradient stays visible (p.grad)
-        float p = a.p[i];
-        if (a.weight_decay != 0.f) g += a.weight_decay * p;
-        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
-        const float pn = p - step_size * (m / denom);
-        a.p[i] = pn;
-        // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
-        for (int d = 0; d < a.n_prep; ++d) {
-            const PrepDesc &q = a.prep[d];
-            const int64_t o = i - (q.src - a.p);
-            if (o >= 0 && o < (int64_t)q.rows * q.cols) {
-                const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
-                const uint16_t b = f32_to_bf16(pn);
-                if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
-                if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
-                break;
-            }
-        }
-    }
+    adam_workgroup(a, blockIdx.x, gridDim.x, red);
 }
 
 // ---- gradient finalisation: sum partial buffers into the flat bucket + squared-norm partials ------
@@ -279,24 +204,26 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
                          int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
                          int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2, void *stream)
 {
+    gsage_adam_desc d;
+    d.p = p; d.g = g; d.m = m; d.v = v; d.n = n; d.partial = partial; d.lr = lr; d.step = step;
+    d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay; d.max_norm = max_norm;
+    d.norm_out = norm_out; d.step_is_current = step_is_current; d.n_partial_ready = n_partial_ready;
+    d.prep_descs = prep_descs; d.n_prep = n_prep; d.tick1 = tick1; d.inc1 = inc1; d.tick2 = tick2;
+    d.inc2 = inc2;
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    int nb = n_partial_ready;
     int rc = GSAGE_OK;
-    if (nb == 0) {          // no gsage_finalize_grads before us: compute the norm partials here
-        nb = grid_for(n, 1024);
-        launch(k_grad_sqnorm, dim3(nb), dim3(256), 0, s, (const float *)g, n, partial);
+    if (n_partial_ready == 0) {   // no gsage_finalize_grads before us: compute the norm partials here
+        d.n_partial_ready = adam_grid(n, 1024);
+        launch(k_grad_sqnorm, dim3(d.n_partial_ready), dim3(256), 0, s, (const float *)g, n, partial);
         rc = check_launch("grad_sqnorm");
         if (rc != GSAGE_OK) return rc;
     }
     AdamParams a;
-    a.prep = (const PrepDesc *)prep_descs; a.n_prep = prep_descs ? n_prep : 0;
-    a.tick1 = tick1; a.inc1 = inc1; a.tick2 = tick2; a.inc2 = inc2;
-    a.p = p; a.g = g; a.m = m; a.v = v; a.partial = partial; a.lr = lr; a.step = step;
-    a.norm_out = norm_out; a.n = n; a.n_partial = nb; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.weight_decay = weight_decay; a.max_norm = max_norm; a.step_off = step_is_current ? 0 : 1;
-    launch(k_adam_clip, dim3(grid_for(n, 2048)), dim3(256), 0, s, a);
+    rc = fill_adam(a, d);
+    if (rc != GSAGE_OK) return rc;
+    launch(k_adam_clip, dim3(adam_grid(n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;
     if (!step_is_current) {

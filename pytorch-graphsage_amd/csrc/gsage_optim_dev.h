@@ -1,0 +1,114 @@
+// gsage_optim_dev.h -- device body of the clip + Adam update, shared by k_adam_clip
+// (gsage_optim.hip) and k_gather_multi_adam (gsage_gather.hip), which applies the update of batch i
+// side by side with the level-0 gathers of batch i+1.
+#pragma once
+#include "gsage_common.h"
+
+namespace gsage {
+
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- weight operand copies ------------------------------------------------------------------------
+struct PrepDesc {
+    const float *src;      // [rows, cols] fp32, contiguous
+    uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
+    uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
+    int32_t rows, cols, dst_ld, dst_t_ld;
+};
+
+struct AdamParams {
+    float *p, *g, *m, *v;
+    const float *partial;       // per-block squared-norm partials of g
+    const float *lr;            // device scalar (a captured graph sees schedule changes)
+    int64_t *step;              // device step counter; this launch uses *step + 1
+    float *norm_out;            // optional: total gradient norm before clipping
+    int64_t n;
+    int32_t n_partial, step_off;
+    float beta1, beta2, eps, weight_decay, max_norm;
+    const struct PrepDesc *prep;   // optional: refresh the bf16 operand copies of the new weights
+    int32_t n_prep;
+    int64_t *tick1, *tick2;        // optional counters advanced at kernel start (not read here)
+    int64_t inc1, inc2;
+};
+
+// one workgroup of the clip + Adam update: grid-stride slice bx of gx
+__device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
+{
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
+    const float sq = block_sum_256(s, red);
+    const float total = sqrtf(sq);
+    float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+    coef = coef < 1.f ? coef : 1.f;
+    const float t = (float)(*a.step + a.step_off);
+    const float bc1 = 1.f - powf(a.beta1, t);
+    const float bc2 = 1.f - powf(a.beta2, t);
+    const float step_size = *a.lr / bc1;
+    const float rsqrt_bc2 = 1.f / sqrtf(bc2);
+    if (bx == 0 && threadIdx.x == 0) {
+        if (a.norm_out) *a.norm_out = total;
+        if (a.tick1) *a.tick1 += a.inc1;
+        if (a.tick2) *a.tick2 += a.inc2;
+    }
+
+    const int64_t stride = (int64_t)gx * 256;
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride) {
+        float g = a.g[i] * coef;
+        a.g[i] = g;                                     // clipped gradient stays visible (p.grad)
+        float p = a.p[i];
+        if (a.weight_decay != 0.f) g += a.weight_decay * p;
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
+        const float pn = p - step_size * (m / denom);
+        a.p[i] = pn;
+        // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
+        for (int d = 0; d < a.n_prep; ++d) {
+            const PrepDesc &q = a.prep[d];
+            const int64_t o = i - (q.src - a.p);
+            if (o >= 0 && o < (int64_t)q.rows * q.cols) {
+                const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
+                const uint16_t b = f32_to_bf16(pn);
+                if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
+                if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
+                break;
+            }
+        }
+    }
+}
+
+
+inline int adam_grid(int64_t items, int cap)
+{
+    int64_t b = ceil_div(items, 256);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// [host] validate a gsage_adam_desc (norm partials must be ready) and turn it into kernel parameters
+inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
+{
+    GSAGE_REQUIRE(d.p && d.g && d.m && d.v && d.partial && d.lr && d.step, "clip_adam_step: null pointer");
+    GSAGE_REQUIRE(d.n > 0 && d.n_partial_ready > 0 && d.n_prep >= 0, "clip_adam_step: bad sizes");
+    a.prep = (const PrepDesc *)d.prep_descs; a.n_prep = d.prep_descs ? d.n_prep : 0;
+    a.tick1 = d.tick1; a.inc1 = d.inc1; a.tick2 = d.tick2; a.inc2 = d.inc2;
+    a.p = d.p; a.g = d.g; a.m = d.m; a.v = d.v; a.partial = d.partial; a.lr = d.lr; a.step = d.step;
+    a.norm_out = d.norm_out; a.n = d.n; a.n_partial = d.n_partial_ready; a.beta1 = d.beta1;
+    a.beta2 = d.beta2; a.eps = d.eps; a.weight_decay = d.weight_decay; a.max_norm = d.max_norm;
+    a.step_off = d.step_is_current ? 0 : 1;
+    return GSAGE_OK;
+}
+
+}  // namespace gsage

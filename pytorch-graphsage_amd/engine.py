@@ -486,7 +486,23 @@ class FusedMeanTrainStep(object):
         if self.pipelined:
             nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), self.L, ops._stream()), "counter_add")
 
-    def _stage_gather(self, s):
+    def _adam_desc(self):
+        d = nat.AdamDesc()
+        d.p, d.g, d.m, d.v = (self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                              self.flat_v.data_ptr())
+        d.n, d.partial, d.lr, d.step = (self.flat_p.numel(), self.partial.data_ptr(), self.lr.data_ptr(),
+                                        self.step.data_ptr())
+        d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
+        d.norm_out, d.step_is_current = self.gnorm.data_ptr(), 1
+        d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
+        d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
+        d.tick1, d.inc1 = (self.counter.data_ptr() if self.prefetch else None), self.L
+        d.tick2, d.inc2 = (self.batch_idx.data_ptr() if self.prefetch else None), 1
+        return d
+
+    def _stage_gather(self, s, with_adam=False):
+        """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
+        launch; with_adam: the clip + Adam update of the batch just finished rides along."""
         L, st = self.L, self.store
         ids = self.ids_set[s]
         # one launch: x rows of every hop + the mean of each hop's sampled neighbours
@@ -496,7 +512,7 @@ class FusedMeanTrainStep(object):
         for k in range(L):
             segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
                          self.size[k], self.fan[k + 1]))
-        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld)
+        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None)
 
     def _stage_compute(self, s):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
@@ -622,17 +638,11 @@ class FusedMeanTrainStep(object):
 
     def _stage_opt(self):
         """clip_grad_norm(5) + Adam over the flat bucket."""
-        n = self.flat_p.numel()
-        nat.check(nat.lib().gsage_clip_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
-                                                 self.flat_m.data_ptr(), self.flat_v.data_ptr(), n,
-                                                 self.partial.data_ptr(), self.lr.data_ptr(),
-                                                 self.step.data_ptr(), 0.9, 0.999, 1e-8, self.wd, 5.0,
-                                                 self.gnorm.data_ptr(), 1,
-                                                 0 if self.ddp is not None else self.n_partial,
-                                                 self.descs.data_ptr(), self.n_desc,
-                                                 self.counter.data_ptr() if self.prefetch else None, self.L,
-                                                 self.batch_idx.data_ptr() if self.prefetch else None, 1,
-                                                 ops._stream()),
+        d = self._adam_desc()
+        nat.check(nat.lib().gsage_clip_adam_step(d.p, d.g, d.m, d.v, d.n, d.partial, d.lr, d.step, d.beta1,
+                                                 d.beta2, d.eps, d.weight_decay, d.max_norm, d.norm_out,
+                                                 d.step_is_current, d.n_partial_ready, d.prep_descs,
+                                                 d.n_prep, d.tick1, d.inc1, d.tick2, d.inc2, ops._stream()),
                   "clip_adam_step")
 
     def _run_sequential(self, s):
@@ -669,9 +679,8 @@ class FusedMeanTrainStep(object):
             self.g_prime = self._record(lambda: self._stage_sample(0))
             if self.ddp is None:
                 def whole():
-                    self._stage_gather(0)
                     self._stage_compute(0)
-                    self._stage_opt()
+                    self._stage_gather(0, with_adam=True)     # Adam(i) || gathers of batch i+1
                 self.g_main = [self._record(whole)]
             else:
                 # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
@@ -686,10 +695,11 @@ class FusedMeanTrainStep(object):
 
         Software-pipelined by one stage, because sampling and the level-0 gathers do not depend on
         the weights: batch i+1's frontier is sampled side by side with batch i's gradient
-        finalisation, and in data-parallel runs batch i+1's gathers are issued while batch i's
-        gradient all-reduce is in flight on RCCL's stream, Adam(i) following both.  Every call
-        performs exactly one sampling, one gather, one forward/backward, (one exchange) and one
-        optimizer step; the first call after load_epoch() additionally samples batch 0."""
+        finalisation, and its gathers run side by side with Adam(i) (one launch) -- or, in
+        data-parallel runs, while batch i's gradient all-reduce is in flight on RCCL's stream, Adam(i)
+        following both.  Every call performs exactly one sampling, one gather, one forward/backward,
+        (one exchange) and one optimizer step, and the weights are up to date when it returns; the
+        first call after load_epoch() additionally samples and gathers batch 0."""
         assert self.queue is not None, "call load_epoch() first"
         rec = self.g_main is not None
         if not self._front_ready:
@@ -697,16 +707,14 @@ class FusedMeanTrainStep(object):
                 self.g_prime.replay()
             else:
                 self._stage_sample(0)
-            if self.ddp is not None:
-                self._stage_gather(0)
+            self._stage_gather(0)
             self._front_ready = True
         if self.ddp is None:
             if rec:
                 self.g_main[0].replay()
             else:
-                self._stage_gather(0)
                 self._stage_compute(0)
-                self._stage_opt()
+                self._stage_gather(0, with_adam=True)
             return self.preds
         if rec:
             self.g_main[0].replay()
