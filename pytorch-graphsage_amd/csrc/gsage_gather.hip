@@ -163,8 +163,10 @@ k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
 // [0, n_adam) update (they come first so the short job is done long before the gather drains),
 // the rest gather.  The two touch disjoint data: the gather reads features and ids, Adam reads and
 // writes the parameter / gradient / moment buckets and the bf16 operand copies.
+// (waves_per_eu: the Adam role's powf/sqrtf would otherwise raise the register count and cost the
+// HBM-bound gather role two of its seven waves per SIMD)
 template <typename TI, typename TO, int VEC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
                     int n_adam, const AdamParams a)
 {

@@ -13,10 +13,12 @@
 // interleave of the output, undone for free in the epilogue's addressing).  Same trick on the A
 // side.  Every global load is a full, coalesced row segment (32 lanes x 8 B = 256 B).
 //
-// Decomposition: wave tile = 128 (n) x 128 (k) = 16 accumulators (256 AGPRs, one wave per SIMD);
-// a workgroup = 4 waves on 4 adjacent k-tiles sharing the dC rows through L1; the reduction over
-// M is split across grid.x into `rows_per_split` slices whose partial tiles go to fp32 slabs
-// (deterministic; summed by k_reduce_slabs -- no atomics).  MFMA-bound per wave, L2-bound overall.
+// Decomposition: workgroup tile = wave tile = 128 (n) x 128 (k) = 16 accumulators (256 AGPRs, one
+// wave per SIMD, one workgroup per CU).  The reduction over M is split across grid.x into
+// `rows_per_split` slices; inside a workgroup the four waves quarter the slice, then sum their tiles
+// through LDS (wave E reduces and stores residue block E), so one fp32 partial tile per workgroup
+// goes to the slabs (deterministic; summed by k_reduce_slabs / gsage_finalize_grads -- no atomics).
+// MFMA-bound per wave, L2-bound overall.
 #include "gsage_common.h"
 
 namespace gsage {
@@ -121,21 +123,62 @@ __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint1
     }
 }
 
-// one workgroup's share of problem p: M-slice bx, 128-row n tile by, 512-column k block bz
-__device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx, int64_t by, int64_t bz)
+// ---- in-workgroup reduction of the four waves' partial tiles (residue block E of the output) ------
+// D[i][j] of MFMA (E, f) is dW[n_base + 4i + E][k_base + 4j + f]; lane l holds j = l & 31 and
+// i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), so (f = 0..3) of one r is a float4 of the output row.
+// LDS slot of wave w: [r][lane] float4 -- consecutive lanes, consecutive 16-byte words.
+template <int E>
+__device__ __forceinline__ void park_block(const f32x16_t (&acc)[4][4], float *lds, int wave, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f32x4 v = {acc[E][0][r], acc[E][1][r], acc[E][2][r], acc[E][3][r]};
+        *reinterpret_cast<f32x4 *>(lds + (((wave * 16 + r) * 64 + lane) << 2)) = v;
+    }
+}
+
+// wave E adds the other three waves' shares to its own (fixed order: deterministic) and stores
+template <int E>
+__device__ __forceinline__ void reduce_store_block(const f32x16_t (&acc)[4][4], const float *lds,
+                                                   const WgradParams &p, float *slab, int64_t n_base,
+                                                   int64_t k, int half, int lane)
+{
+    const bool k_in = k + 3 < p.ldk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        f32x4 v = {acc[E][0][r], acc[E][1][r], acc[E][2][r], acc[E][3][r]};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w != E) v += *reinterpret_cast<const f32x4 *>(lds + (((w * 16 + r) * 64 + lane) << 2));
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int64_t n = n_base + 4 * i + E;
+        if (k_in && n < p.Ntot) *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
+    }
+}
+
+// One workgroup's share of problem p: M-slice bx, 128 x 128 output tile (by, bz).  The four waves
+// take a quarter of the slice each (whole 16-row steps), then meet in LDS: residue block E of the
+// tile is summed and stored by wave E.  Compared with one wave per tile and slice this quarters the
+// number of partial tiles that travel through HBM to gsage_finalize_grads for the same number of
+// busy SIMDs.
+__device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx, int64_t by, int64_t bz,
+                                                float *lds)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int ii = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the per-wave branches
+    const int ii = lane & 31;                                            // below must not become selects
     const int half = lane >> 5;
     const int64_t n_base = by * 128;
-    const int64_t k_base = (bz * 4 + wave) * 128;
-    if (k_base >= p.ldk) return;                                   // wave-uniform; no barriers below
+    const int64_t k_base = bz * 128;
     const int g = (int)(n_base / p.n_per_group);
     const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
 
     const int64_t m_begin = bx * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
+    const int64_t quarter = ((m_end - m_begin + 63) / 64) * 16;     // rows per wave, whole steps
+    int64_t w_begin = m_begin + wave * quarter, w_end = w_begin + quarter;
+    if (w_begin > m_end) w_begin = m_end;
+    if (w_end > m_end) w_end = m_end;
 
     // Column validity is lane invariant: a lane whose columns fall outside the matrices reads
     // column 0 instead and its (garbage) accumulators are simply never stored -- output (n, k)
@@ -154,31 +197,33 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
 
-    wgrad_mainloop(p, A, m_begin, m_end, n_off, k_off, half, acc);
+    wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, half, acc);
 
-    // epilogue: D[i][j] of MFMA (e, f) is dW[n_base + 4i + e][k_base + 4j + f]; lane l holds
-    // j = l & 31 and i = (r & 3) + 8 (r >> 2) + 4 (l >> 5): one float4 (f = 0..3) per (e, r).
+    // four rounds, one residue block each (16 KiB per wave -> 64 KiB of LDS)
     float *slab = p.slabs + bx * p.Ntot * p.ldk;
     const int64_t k = k_base + 4 * ii;
-    if (k + 3 < p.ldk) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int64_t n = n_base + 4 * i + e;
-                if (n < p.Ntot) {
-                    f32x4 v = {acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
-                    *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
-                }
-            }
-    }
+    if (wave != 0) park_block<0>(acc, lds, wave, lane);
+    lds_barrier();
+    if (wave == 0) reduce_store_block<0>(acc, lds, p, slab, n_base, k, half, lane);
+    lds_barrier();
+    if (wave != 1) park_block<1>(acc, lds, wave, lane);
+    lds_barrier();
+    if (wave == 1) reduce_store_block<1>(acc, lds, p, slab, n_base, k, half, lane);
+    lds_barrier();
+    if (wave != 2) park_block<2>(acc, lds, wave, lane);
+    lds_barrier();
+    if (wave == 2) reduce_store_block<2>(acc, lds, p, slab, n_base, k, half, lane);
+    lds_barrier();
+    if (wave != 3) park_block<3>(acc, lds, wave, lane);
+    lds_barrier();
+    if (wave == 3) reduce_store_block<3>(acc, lds, p, slab, n_base, k, half, lane);
 }
 
 __global__ void __launch_bounds__(256, 1)
 k_wgrad_bf16(const WgradParams p)
 {
-    wgrad_workgroup(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 4 * 64 * 4];
+    wgrad_workgroup(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // Several weight-gradient problems in ONE launch (all levels of a backward pass).  Each problem
@@ -202,7 +247,8 @@ k_wgrad_multi(const WgradMulti q)
     const int local = (int)blockIdx.x - q.first[s];
     const int bx = local % q.S[s];
     const int rest = local / q.S[s];
-    wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s]);
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 4 * 64 * 4];
+    wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds);
 }
 
 // out_g[n_local * K + k] = sum_s slabs[s][g * n_per_group + n_local][k]
@@ -269,7 +315,7 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
             if (rc != GSAGE_OK) return rc;
             q.S[s] = (int32_t)ceil_div(d.M, d.rows_per_split);
             q.ny[s] = (int32_t)ceil_div(d.Ntot, 128);
-            q.first[s + 1] = q.first[s] + q.S[s] * q.ny[s] * (int32_t)ceil_div(d.ldk, 512);
+            q.first[s + 1] = q.first[s] + q.S[s] * q.ny[s] * (int32_t)ceil_div(d.ldk, 128);
         } else {
             q.p[s] = q.p[0];
             q.S[s] = q.ny[s] = 1;
@@ -288,7 +334,7 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
     int rc0 = wgrad_fill(p, dC, ldc, A, lda, a_gstride, M, Ntot, K, n_per_group, rows_per_split, slabs, ldk);
     if (rc0 != GSAGE_OK) return rc0;
     const int S = (int)ceil_div(M, rows_per_split);
-    dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 512));
+    dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 128));
     launch(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
     int rc = check_launch("wgrad");
     if (rc != GSAGE_OK || out == nullptr) return rc;      // out == NULL: caller reduces the slabs

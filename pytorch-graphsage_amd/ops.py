@@ -298,11 +298,14 @@ def gather_mean_multi(segments, ld, D, out_ld, adam=None):
 
 
 def wgrad_plan(M, Ntot, K):
-    """(rows_per_split, n_slabs, ldk) used by wgrad: enough M-slices to occupy the chip."""
+    """(rows_per_split, n_slabs, ldk) used by wgrad.  A workgroup owns one 128 x 128 output tile and
+    one M-slice (its four waves quarter the slice and meet in LDS), one workgroup fits per CU, and
+    every slice costs a partial tile in HBM: so aim at ~240 workgroups (MI355X: 256 CUs, the rest is
+    left to the small problems sharing a gsage_wgrad_multi launch) and never below 64 rows per wave."""
     ldk = _round_up(K, 4)
-    nblk = (Ntot + 127) // 128
-    kblk = (ldk + 127) // 128
-    rps = min(1024, max(64, _round_up((M * nblk * kblk + 511) // 512, 16)))
+    tiles = ((Ntot + 127) // 128) * ((ldk + 127) // 128)
+    s_target = max(1, 240 // tiles)
+    rps = max(256, _round_up((M + s_target - 1) // s_target, 16))
     return rps, (M + rps - 1) // rps, ldk
 
 
