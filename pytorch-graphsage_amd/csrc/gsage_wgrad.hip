@@ -16,7 +16,7 @@
 // Decomposition: workgroup tile = wave tile = 128 (n) x 128 (k) = 16 accumulators (256 AGPRs, one
 // wave per SIMD, one workgroup per CU).  The reduction over M is split across grid.x into
 // `rows_per_split` slices; inside a workgroup the four waves quarter the slice, then sum their tiles
-// through LDS (wave E reduces and stores residue block E), so one fp32 partial tile per workgroup
+// through LDS (every wave parks its tile, then sums and stores an eighth of the output), so one fp32 partial tile per workgroup
 // goes to the slabs (deterministic; summed by k_reduce_slabs / gsage_finalize_grads -- no atomics).
 // MFMA-bound per wave, L2-bound overall.
 #include "gsage_common.h"
@@ -127,29 +127,40 @@ __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint1
 // D[i][j] of MFMA (E, f) is dW[n_base + 4i + E][k_base + 4j + f]; lane l holds j = l & 31 and
 // i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), so (f = 0..3) of one r is a float4 of the output row.
 // LDS slot of wave w: [r][lane] float4 -- consecutive lanes, consecutive 16-byte words.
+// LDS: two residue blocks per round, one parked copy per wave: slot (E & 1) * 4 + wave; a slot is
+// [r][lane] float4 -- consecutive lanes, consecutive 16-byte words.  Branch-free on purpose: every
+// wave parks both blocks of the round (with per-wave `if (wave == E)` special cases hipcc spilled
+// accumulators to scratch), then every wave sums and stores half of one block straight from LDS.
+constexpr int WGRAD_SLOT = 16 * 64 * 4;                     // floats per parked block
+constexpr size_t WGRAD_LDS_BYTES = 8 * WGRAD_SLOT * sizeof(float);
+
 template <int E>
 __device__ __forceinline__ void park_block(const f32x16_t (&acc)[4][4], float *lds, int wave, int lane)
 {
+    float *slot = lds + ((E & 1) * 4 + wave) * WGRAD_SLOT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const f32x4 v = {acc[E][0][r], acc[E][1][r], acc[E][2][r], acc[E][3][r]};
-        *reinterpret_cast<f32x4 *>(lds + (((wave * 16 + r) * 64 + lane) << 2)) = v;
+        *reinterpret_cast<f32x4 *>(slot + ((r * 64 + lane) << 2)) = v;
     }
 }
 
-// wave E adds the other three waves' shares to its own (fixed order: deterministic) and stores
-template <int E>
-__device__ __forceinline__ void reduce_store_block(const f32x16_t (&acc)[4][4], const float *lds,
-                                                   const WgradParams &p, float *slab, int64_t n_base,
-                                                   int64_t k, int half, int lane)
+// wave w sums the four parked copies of residue block E = 2 * round + (w & 1), accumulator rows
+// r in [8 * (w >> 1), +8), in wave order (deterministic), and stores them
+__device__ __forceinline__ void reduce_store_half(const float *lds, int round, int wave, const WgradParams &p,
+                                                  float *slab, int64_t n_base, int64_t k, int half, int lane)
 {
+    const int E = 2 * round + (wave & 1);
     const bool k_in = k + 3 < p.ldk;
+    const float *slot = lds + (wave & 1) * 4 * WGRAD_SLOT;
+    const int r0 = 8 * (wave >> 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        f32x4 v = {acc[E][0][r], acc[E][1][r], acc[E][2][r], acc[E][3][r]};
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = r0 + rr;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(slot + ((r * 64 + lane) << 2));
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-            if (w != E) v += *reinterpret_cast<const f32x4 *>(lds + (((w * 16 + r) * 64 + lane) << 2));
+        for (int q = 1; q < 4; ++q)
+            v += *reinterpret_cast<const f32x4 *>(slot + q * WGRAD_SLOT + ((r * 64 + lane) << 2));
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int64_t n = n_base + 4 * i + E;
         if (k_in && n < p.Ntot) *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
@@ -199,30 +210,24 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 
     wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, half, acc);
 
-    // four rounds, one residue block each (16 KiB per wave -> 64 KiB of LDS)
+    // two rounds of two residue blocks (8 x 16 KiB of LDS)
     float *slab = p.slabs + bx * p.Ntot * p.ldk;
     const int64_t k = k_base + 4 * ii;
-    if (wave != 0) park_block<0>(acc, lds, wave, lane);
+    park_block<0>(acc, lds, wave, lane);
+    park_block<1>(acc, lds, wave, lane);
     lds_barrier();
-    if (wave == 0) reduce_store_block<0>(acc, lds, p, slab, n_base, k, half, lane);
+    reduce_store_half(lds, 0, wave, p, slab, n_base, k, half, lane);
     lds_barrier();
-    if (wave != 1) park_block<1>(acc, lds, wave, lane);
+    park_block<2>(acc, lds, wave, lane);
+    park_block<3>(acc, lds, wave, lane);
     lds_barrier();
-    if (wave == 1) reduce_store_block<1>(acc, lds, p, slab, n_base, k, half, lane);
-    lds_barrier();
-    if (wave != 2) park_block<2>(acc, lds, wave, lane);
-    lds_barrier();
-    if (wave == 2) reduce_store_block<2>(acc, lds, p, slab, n_base, k, half, lane);
-    lds_barrier();
-    if (wave != 3) park_block<3>(acc, lds, wave, lane);
-    lds_barrier();
-    if (wave == 3) reduce_store_block<3>(acc, lds, p, slab, n_base, k, half, lane);
+    reduce_store_half(lds, 1, wave, p, slab, n_base, k, half, lane);
 }
 
 __global__ void __launch_bounds__(256, 1)
 k_wgrad_bf16(const WgradParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 4 * 64 * 4];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     wgrad_workgroup(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
@@ -247,7 +252,7 @@ k_wgrad_multi(const WgradMulti q)
     const int local = (int)blockIdx.x - q.first[s];
     const int bx = local % q.S[s];
     const int rest = local / q.S[s];
-    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 4 * 64 * 4];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds);
 }
 
@@ -276,6 +281,21 @@ using namespace gsage;
 extern "C" int gsage_wgrad_slabs(int64_t M, int64_t rows_per_split)
 {
     return (int)ceil_div(M, rows_per_split);
+}
+
+// 128 KiB of dynamic LDS: above the 64 KiB a kernel gets by default (gfx950 has 160 KiB per CU)
+template <typename K>
+static int wgrad_raise_lds(K kernel, bool &done)
+{
+    if (done) return GSAGE_OK;
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)WGRAD_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("wgrad: cannot raise the dynamic LDS limit");
+        return GSAGE_ELAUNCH;
+    }
+    done = true;
+    return GSAGE_OK;
 }
 
 static int wgrad_fill(WgradParams &p, const void *dC, int64_t ldc, const void *A, int64_t lda,
@@ -322,7 +342,10 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
             q.first[s + 1] = q.first[s];
         }
     }
-    launch(k_wgrad_multi, dim3((unsigned)q.first[n_prob]), dim3(256), 0, (hipStream_t)stream, q);
+    static bool raised = false;
+    int rc2 = wgrad_raise_lds(k_wgrad_multi, raised);
+    if (rc2 != GSAGE_OK) return rc2;
+    launch(k_wgrad_multi, dim3((unsigned)q.first[n_prob]), dim3(256), WGRAD_LDS_BYTES, (hipStream_t)stream, q);
     return check_launch("wgrad_multi");
 }
 
@@ -335,7 +358,10 @@ int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t
     if (rc0 != GSAGE_OK) return rc0;
     const int S = (int)ceil_div(M, rows_per_split);
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 128));
-    launch(k_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, p);
+    static bool raised = false;
+    int rc1 = wgrad_raise_lds(k_wgrad_bf16, raised);
+    if (rc1 != GSAGE_OK) return rc1;
+    launch(k_wgrad_bf16, grid, dim3(256), WGRAD_LDS_BYTES, (hipStream_t)stream, p);
     int rc = check_launch("wgrad");
     if (rc != GSAGE_OK || out == nullptr) return rc;      // out == NULL: caller reduces the slabs
     int64_t blocks = ceil_div(Ntot * K, 256);
