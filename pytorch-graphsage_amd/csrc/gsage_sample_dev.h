@@ -69,7 +69,7 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
     } else {
         for (int t = threadIdx.x; t < nseed; t += 256) cur[t] = p.ids[p.off[0] + seed0 + t];
     }
-    __syncthreads();
+    lds_barrier();              // LDS only: the ids stored to HBM are not read back in this launch
     const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
     int64_t per_seed = 1;                            // nodes of hop k per seed
     for (int k = 1; k <= p.n_hops; ++k) {
@@ -84,7 +84,8 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
             const uint64_t blk = g >> 2;
             const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
                                             (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
-            const uint32_t w = r.v[g & 3];
+            const uint32_t sel4 = (uint32_t)g & 3u;              // selects, not r.v[g & 3]: no scratch
+            const uint32_t w = sel4 == 0 ? r.v[0] : sel4 == 1 ? r.v[1] : sel4 == 2 ? r.v[2] : r.v[3];
             const uint32_t s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
             const int64_t parent = cur[(uint32_t)t / n];
             const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
@@ -92,7 +93,7 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
             p.ids[p.off[k] + local0 + t] = v;
         }
         (void)parents;
-        __syncthreads();
+        lds_barrier();
         int64_t *tmp = cur; cur = nxt; nxt = tmp;
     }
 }

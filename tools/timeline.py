@@ -6,9 +6,10 @@ n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 anchor = sys.argv[3] if len(sys.argv) > 3 else None
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-if anchor:                      # start at the n-th last launch of the anchor kernel
+if anchor:                      # window = two consecutive launches of the anchor kernel
     idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
-    rows = rows[idx[-3]:idx[-1]] if len(idx) >= 3 else rows[-n_last:]
+    mid = len(idx) // 2             # two steps from the middle of the run (steady state)
+    rows = rows[idx[mid]:idx[mid + 2]] if len(idx) >= 4 else rows[-n_last:]
 else:
     rows = rows[-n_last:]
 t0 = int(rows[0]["Start_Timestamp"])
