@@ -47,7 +47,6 @@ struct TailParams {
     float *partial;          // out: [grid, C*256 + C + 1] fc.weight / fc.bias / loss partials
     int64_t ldw2, ldw2t;
     int32_t B, n, C;
-    long long *stamps;
 };
 
 __device__ __forceinline__ float tail_wave_sum(float v)
@@ -108,7 +107,6 @@ k_mean_tail_ce(const TailParams p)
     const int n = p.n;
     const int64_t B = p.B;
 
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 0] = wall_clock64();
     // ---- 0. every request that depends on nothing, all in flight together -------------------------
     const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * B : 0);
     const int64_t iw = row0 + wave;               // this wave's seed
@@ -147,7 +145,6 @@ k_mean_tail_ce(const TailParams p)
         }
     }
 
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 1] = wall_clock64();
     for (int q = t; q < (Cp - C) * ldw; q += 256) Ws[C * ldw + q] = 0.f;
 
     // ---- 1. neighbour mean of this wave's seed + ReLU masks of the rows this lane loaded -----------
@@ -196,7 +193,6 @@ k_mean_tail_ce(const TailParams p)
     }
     lds_barrier();
 
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 2] = wall_clock64();
     // ---- 2. emb = [x Wx^T | agg Wn^T]: lane = 8 output columns, half-wave `slot` = 32 of the 256 k ---
     {
         float acc[R][8];
@@ -239,7 +235,6 @@ k_mean_tail_ce(const TailParams p)
         }
     }
     lds_barrier();
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 3] = wall_clock64();
     float e[R];                                   // from here to the end of the head: thread t = column t
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -368,7 +363,6 @@ k_mean_tail_ce(const TailParams p)
     }
     lds_barrier();                                            // des complete; part / red free again
 
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 4] = wall_clock64();
     // ---- 4. input gradients dX = dE[:, :128] Wx, dA = dE[:, 128:] Wn: lane = 8 columns of H,
     //         half-wave `slot` = 16 of the 128 rows of each weight ------------------------------------
     {
@@ -424,7 +418,6 @@ k_mean_tail_ce(const TailParams p)
         }
     }
     lds_barrier();
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 5] = wall_clock64();
     // ---- 5. previous level's gradient rows of this wave's seed, ReLU mask applied -------------------
     if (live) {
         const float inv_n = 1.f / (float)n;
@@ -466,7 +459,6 @@ k_mean_tail_ce(const TailParams p)
             }
         }
     }
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 6] = wall_clock64();
     // ---- 6. fc.bias / loss partials ----------------------------------------------------------------
     part[wave * TAIL_CMAX + lane] = acc_db;
     const float l = tail_wave_sum(acc_loss);
@@ -478,7 +470,6 @@ k_mean_tail_ce(const TailParams p)
             out[C * D + lane] = (part[lane] + part[TAIL_CMAX + lane]) + (part[2 * TAIL_CMAX + lane] + part[3 * TAIL_CMAX + lane]);
         if (lane == 0) out[C * D + C] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x < 8) p.stamps[blockIdx.x * 16 + 7] = wall_clock64();
 }
 
 }  // namespace gsage
@@ -511,7 +502,6 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     p.H = (const uint16_t *)H; p.w2 = (const uint16_t *)w2; p.w2t = (const uint16_t *)w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
     p.agg = (uint16_t *)agg; p.dE = (uint16_t *)dE; p.preds = preds; p.dH = (uint16_t *)dH;
-    { const char *e = getenv("GSAGE_TAIL_STAMPS"); p.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
     auto kern = n <= 16 ? k_mean_tail_ce<8> : k_mean_tail_ce<16>;

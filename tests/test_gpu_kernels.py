@@ -429,3 +429,59 @@ def test_wgrad_multi_equals_single_launches():
     for (M, Ntot, K, npg), pr, ref in zip(shapes, probs, refs):
         got = pr[8]
         assert torch.equal(got[:, :, :K], ref[:, :, :K]), (M, Ntot, K)
+
+
+@pytest.mark.parametrize("B,n,C", [(512, 25, 41), (13, 7, 5), (6, 32, 64), (4, 1, 2), (33, 16, 41), (35, 17, 3)])
+def test_seed_level_kernel_vs_fp64(B, n, C):
+    """gsage_mean_tail_ce = segment mean + both projections + normalize/fc/CE + every gradient down to
+    the previous level, against fp64 torch autograd on the same bf16-rounded operands (ragged last
+    workgroup, both neighbour-register variants, 1..64 classes)."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(B * 131 + n * 7 + C)
+    L = nat.lib()
+    Hf = np.maximum(rng.normal(size=(B * (1 + n), 256)), 0).astype(np.float32)       # post-ReLU rows
+    H = torch.from_numpy(Hf).to(DEV).bfloat16()
+    w2 = torch.from_numpy((rng.normal(size=(2, 128, 256)) * 0.08).astype(np.float32)).to(DEV).bfloat16()
+    w2t = w2.transpose(1, 2).contiguous()
+    Wfc = torch.from_numpy((rng.normal(size=(C, 256)) * 0.3).astype(np.float32)).to(DEV)
+    bfc = torch.from_numpy(rng.normal(size=(C,)).astype(np.float32)).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=B)).to(DEV)
+    agg = torch.full((B, 256), 7.0, device=DEV, dtype=torch.bfloat16)
+    dE = torch.full((B, 256), 7.0, device=DEV, dtype=torch.bfloat16)
+    preds = torch.empty(B, C, device=DEV)
+    dH = torch.full_like(H, 7.0)
+    n_wg = (B + 3) // 4
+    part = torch.empty(L.gsage_mean_tail_ce_scratch(B, C), device=DEV)
+    assert part.numel() == n_wg * (C * 256 + C + 1)
+    nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
+                                   Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
+                                   agg.data_ptr(), dE.data_ptr(), preds.data_ptr(), dH.data_ptr(),
+                                   part.data_ptr(), None), "mean_tail_ce")
+    torch.cuda.synchronize()
+    Hd = H.double().cpu()
+    x, nb = Hd[:B], Hd[B:].view(B, n, 256)
+    mean = nb.mean(1)
+    close(agg.float().cpu().numpy(), mean.numpy(), "agg", 2 ** -8, 2 ** -8)           # one bf16 rounding
+    aggd = agg.double().cpu()                                                          # what the GEMM sees
+    Wx, Wn = w2[0].double().cpu(), w2[1].double().cpu()
+    emb = torch.cat([x @ Wx.t(), aggd @ Wn.t()], 1).requires_grad_(True)
+    Wd, bd = Wfc.double().cpu().requires_grad_(True), bfc.double().cpu().requires_grad_(True)
+    pr = F.normalize(emb, dim=1) @ Wd.t() + bd
+    ls = F.cross_entropy(pr, tg.cpu())
+    ls.backward()
+    close(preds.cpu().numpy(), pr.detach().numpy(), "preds", 2e-5, 2e-5)
+    scale = float(emb.grad.abs().max())
+    assert float((dE.double().cpu() - emb.grad).abs().max()) <= 2 ** -8 * scale, "dE beyond one bf16 rounding"
+    p3 = part.view(n_wg, C * 256 + C + 1).double().sum(0).cpu()
+    close(p3[:C * 256].view(C, 256).numpy(), Wd.grad.numpy(), "d fc.weight", 2e-5, 1e-6)
+    close(p3[C * 256:C * 256 + C].numpy(), bd.grad.numpy(), "d fc.bias", 2e-5, 1e-6)
+    assert abs(float(p3[-1]) / B - float(ls)) < 1e-5 * max(1.0, float(ls))            # loss partials are sums
+    # input gradients from the dE the kernel itself rounded to bf16 (that is what K5b consumes too)
+    dEd = dE.double().cpu()
+    dX = (dEd[:, :128] @ Wx) * (x > 0)
+    dA = (dEd[:, 128:] @ Wn) / n
+    ref = torch.cat([dX, (dA[:, None, :] * (nb > 0)).reshape(B * n, 256)], 0)
+    got = dH.double().cpu()
+    sc = max(float(ref.abs().max()), 1e-30)
+    assert float((got - ref).abs().max()) <= 2 ** -8 * sc + 1e-12, "dH beyond one bf16 rounding"
+    assert bool(((got == 0) == (ref == 0)).all()) or float((got - ref).abs().max()) <= 2 ** -8 * sc

@@ -111,13 +111,4 @@ if 'tail' in which:
                                        bfc.data_ptr(), C, tg.data_ptr(), None, 0, agg.data_ptr(), dE.data_ptr(),
                                        preds.data_ptr(), dH.data_ptr(), part.data_ptr(), ops._stream()))
     print('tail (B=%d n=%d): %.1f us' % (B, n, timeit(f)))
-    import os
-    st = torch.zeros(8 * 16, dtype=torch.int64, device=dev)
-    os.environ['GSAGE_TAIL_STAMPS'] = str(st.data_ptr())
-    for _ in range(3):
-        f(); torch.cuda.synchronize()
-    v = st.cpu().view(8, 16)[:, :8].double() * 10e-3       # 100 MHz ticks -> us
-    d = (v[:, 1:] - v[:, :-1])
-    print('phases us (issue, rows+mean, proj, head, dgrad, dH stores, partials) per WG:')
-    for r in d.tolist(): print('  ' + ' '.join('%5.2f' % x for x in r), ' total %.2f' % sum(r))
-    del os.environ['GSAGE_TAIL_STAMPS']
+
