@@ -250,6 +250,15 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
                    int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *stream);
 
+/* Backward routing of the max pool: the bf16 [M*n, ldo] gradient of the hidden activations,
+ *     out[i*n + j, c] = (argmax[i, c] == j && pooled[i, c] > 0) ? g[i, c] : 0
+ * (autograd of nn_modules.py:224-226,240: max picks one row per (segment, channel), ReLU passes
+ * positive maxima only) -- the dC operand of gsage_wgrad for the MLP's weight gradient.
+ * H, ldo % 8 == 0. */
+int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
+                         const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
+                         int64_t ldo, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K4  attention aggregation  replaces AttentionAggregator.forward's weighting,
  *                            nn_modules.py:307-315 (scores, softmax over the fanout, weighted

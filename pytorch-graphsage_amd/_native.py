@@ -57,6 +57,7 @@ SIGNATURES = {
     "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
                            _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
+    "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "gsage_wgrad_multi": (_int, [_i32, _vp, _vp]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
                              _vp, _vp, _vp, _i64, _vp]),

@@ -179,6 +179,39 @@ k_bwd_merge(const MergeParams q)
     }
 }
 
+// ---- backward routing of the max pool (K3) ------------------------------------------------------
+// hidden[i*n + j, c] receives g[i, c] iff row j won the max of (segment i, channel c) and the max
+// is positive (ReLU), else 0 -- autograd of nn_modules.py:224-226,240.  One thread = 8 channels of
+// one segment: reads 8 (g, pooled, argmax), writes n rows x 16 bytes of the bf16 operand of K5b.
+__global__ void __launch_bounds__(256)
+k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restrict__ pooled, int64_t ldp,
+                 const int32_t *__restrict__ argmax, int64_t lda, int64_t M, int32_t n, int32_t H,
+                 uint16_t *__restrict__ out, int64_t ldo)
+{
+    const int chunks = H / 8;
+    const int64_t total = M * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / chunks;
+        const int c0 = (int)(t - i * chunks) * 8;
+        uint16_t gb[8];
+        int32_t am[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool on = pooled[i * ldp + c0 + e] > 0.f;
+            gb[e] = on ? f32_to_bf16(g[i * ldg + c0 + e]) : (uint16_t)0;
+            am[e] = argmax[i * lda + c0 + e];
+        }
+        for (int j = 0; j < n; ++j) {
+            vec16 o;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+                o[e >> 1] = (am[e] == j ? (uint32_t)gb[e] : 0u) | ((am[e + 1] == j ? (uint32_t)gb[e + 1] : 0u) << 16);
+            *reinterpret_cast<vec16 *>(out + (i * n + j) * ldo + c0) = o;
+        }
+    }
+}
+
 static inline int grid_for(int64_t items, int cap)
 {
     int64_t b = ceil_div(items, 256);
@@ -273,6 +306,20 @@ int gsage_finalize_grads_sample(const void *descs, int32_t n_desc, int64_t max_e
     launch(k_finalize_sample, dim3((unsigned)(gx * n_desc + n_sample)), dim3(256), lds,
            (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, gx, (int)n_desc, h);
     return check_launch("finalize_grads_sample");
+}
+
+int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
+                         const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
+                         int64_t ldo, void *stream)
+{
+    GSAGE_REQUIRE(g && pooled && argmax && out, "pool_route_bwd: null pointer");
+    GSAGE_REQUIRE(M >= 0 && n > 0 && H > 0 && H % 8 == 0 && ldo % 8 == 0 && ldo >= H &&
+                  ((uintptr_t)out % 16) == 0, "pool_route_bwd: H and ldo must be multiples of 8, out 16-byte aligned");
+    GSAGE_REQUIRE(ldg >= H && ldp >= H && lda >= H, "pool_route_bwd: leading dimension smaller than H");
+    if (M == 0) return GSAGE_OK;
+    launch(k_pool_route_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+           pooled, ldp, argmax, lda, M, n, H, (uint16_t *)out, ldo);
+    return check_launch("pool_route_bwd");
 }
 
 int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,

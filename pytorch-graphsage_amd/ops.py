@@ -534,21 +534,33 @@ class _PoolMLP(torch.autograd.Function):
         g = g.float()
         rows = A if a_rows is None else _gather_mean_raw(A, K, a_rows, M * n, 1, cdt,
                                                          _round_up(K, epc))
-        if mode == nat.POOL_MAX:
-            gh = torch.zeros(M, n, H, dtype=torch.float32, device=g.device)
-            gh.scatter_(1, argmax.long().unsqueeze(1), (g * (pooled > 0)).unsqueeze(1))
-            gh = gh.view(M * n, H)
-        else:
-            hid = torch.relu(_mm_f32(rows, wa.t()) + bf)             # recompute (mean pool only)
-            gh = (g / n).repeat_interleave(n, dim=0) * (hid > 0)
-        ghc = gh.to(cdt)
         dn = dw = db = None
+        fast = mode == nat.POOL_MAX and cdt == torch.bfloat16 and H % 128 == 0 and g.is_cuda
+        if fast:
+            # routed gradient written once as the bf16 operand K5b wants (no fp32 [M, n, H] scatter)
+            g = g.contiguous()
+            ghc = torch.empty(M * n, H, dtype=torch.bfloat16, device=g.device)
+            nat.check(nat.lib().gsage_pool_route_bwd(_ptr(g), H, _ptr(pooled), H, _ptr(argmax), H, M, n, H,
+                                                     _ptr(ghc), H, _stream()), "pool_route_bwd")
+            if ctx.needs_input_grad[2]:
+                db = (g * (pooled > 0)).sum(dim=0)
+            if ctx.needs_input_grad[1]:
+                dw = wgrad(ghc, rows, rows.stride(0), 0, M * n, H, K, H)[0].to(wdt)
+        else:
+            if mode == nat.POOL_MAX:
+                gh = torch.zeros(M, n, H, dtype=torch.float32, device=g.device)
+                gh.scatter_(1, argmax.long().unsqueeze(1), (g * (pooled > 0)).unsqueeze(1))
+                gh = gh.view(M * n, H)
+            else:
+                hid = torch.relu(_mm_f32(rows, wa.t()) + bf)             # recompute (mean pool only)
+                gh = (g / n).repeat_interleave(n, dim=0) * (hid > 0)
+            ghc = gh.to(cdt)
+            if ctx.needs_input_grad[1]:
+                dw = _mm_f32(ghc.t(), rows)[:, :K].to(wdt)
+            if ctx.needs_input_grad[2]:
+                db = gh.sum(dim=0)
         if ctx.needs_input_grad[0]:
             dn = _mm_f32(ghc, wa)[:, :K].to(ndt)
-        if ctx.needs_input_grad[1]:
-            dw = _mm_f32(ghc.t(), rows)[:, :K].to(wdt)
-        if ctx.needs_input_grad[2]:
-            db = gh.sum(dim=0)
         return dn, dw, db, None, None, None, None, None, None, None
 
 
