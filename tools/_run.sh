@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "pool or model" 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8
-python bench.py --no-cpu-baseline --aggregator max_pool --steps 30 --warmup 5 2>&1 | grep metric | cut -c1-200
+rm -rf gpurun_out/prof_mp
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_mp -o r --output-format csv -- python bench.py --aggregator max_pool --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_mp.log 2>&1
+find gpurun_out/prof_mp -name "*kernel_trace*.csv" -size +20M -delete
