@@ -91,7 +91,9 @@ def init_from_env(cuda=True):
     if cuda:
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-        backend = "nccl"
+        # "nccl" is RCCL on ROCm.  GSAGE_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL
+        # refuses duplicate devices): tests/test_gpu_dist.py runs the data-parallel engine that way.
+        backend = os.environ.get("GSAGE_DIST_BACKEND", "nccl")
     else:
         device = torch.device("cpu")
         backend = "gloo"
