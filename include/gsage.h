@@ -248,7 +248,10 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
  * ---------------------------------------------------------------------------------------- */
 int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
-                   int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *stream);
+                   int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
+                   int64_t pooled_bf16_ld, void *stream);
+/* pooled_bf16 (may be NULL): the same result rounded to bf16, [M, pooled_bf16_ld] -- the operand
+ * copy the following projection (gsage_linear_nt) and its weight gradient (gsage_wgrad) read. */
 
 /* Backward routing of the max pool: the bf16 [M*n, ldo] gradient of the hidden activations,
  *     out[i*n + j, c] = (argmax[i, c] == j && pooled[i, c] > 0) ? g[i, c] : 0
@@ -258,6 +261,21 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
 int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
                          const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
                          int64_t ldo, void *stream);
+
+/* Bias gradient of the pooling MLP under the max pool: column sums of g * (pooled > 0) over the M
+ * segments, as `n_part` deterministic partial rows part[b, c] (b < n_part; summed by
+ * gsage_finalize_grads with S = n_part, stride = H).  n_part <= 1024. */
+int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, int64_t ldp, int64_t M,
+                             int32_t H, float *part, int32_t n_part, void *stream);
+
+/* Input gradient of a pool-aggregator level, merged and masked (autograd of nn_modules.py:224-230
+ * w.r.t. the previous level's post-ReLU output Hprev [R, ldh] bf16):
+ *     dH[m, c] = (Hprev[m, c] > 0) * ( (m < r_x ? DX[m, c] : 0) + (m >= r0 ? DN[m - r0, c] : 0) )
+ * DX fp32 [r_x, ldx] = gradient through fc_x of the rows that were "x", DN fp32 [R - r0, ldn] =
+ * gradient through the pooling MLP of the rows that were neighbours.  D % 4 == 0. */
+int gsage_pool_merge_bwd(const void *Hprev, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
+                         const float *DN, int64_t ldn, int64_t r0, void *dH, int64_t ldo, int64_t R,
+                         int32_t D, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4  attention aggregation  replaces AttentionAggregator.forward's weighting,

@@ -319,9 +319,11 @@ k_linear_nt(const LinearParams p)
             }
             if (p.pool_mode == GSAGE_POOL_MAX) {
                 p.pooled[seg * p.pooled_ld + j] = best;
+                if (p.C) ((uint16_t *)p.C)[seg * p.ldc + j] = f32_to_bf16(best);   // operand copy for K5 / K5b
                 if (p.argmax) p.argmax[seg * p.N + j] = arg;
             } else {
                 p.pooled[seg * p.pooled_ld + j] = sum / (float)p.pool_n;
+                if (p.C) ((uint16_t *)p.C)[seg * p.ldc + j] = f32_to_bf16(sum / (float)p.pool_n);
             }
         }
     }
@@ -536,17 +538,19 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
 
 int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
-                   int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *stream)
+                   int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
+                   int64_t pooled_bf16_ld, void *stream)
 {
     GSAGE_REQUIRE(n >= 1 && n <= BM, "pool_mlp: fanout must be in [1, %d]", BM);
+    GSAGE_REQUIRE(!pooled_bf16 || pooled_bf16_ld >= H, "pool_mlp: bad bf16 output");
     int rc = check_operands("pool_mlp", A, dtype, lda, W, ldw, M * (int64_t)n, H, K);
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(pooled && pooled_ld >= H, "pool_mlp: bad output");
     GSAGE_REQUIRE(pool == GSAGE_POOL_MAX || pool == GSAGE_POOL_MEAN, "pool_mlp: bad pool mode");
     if (M == 0) return GSAGE_OK;
     LinearParams p;
-    p.A = A; p.W = W; p.bias = bias; p.a_rows = a_rows; p.C = nullptr;
-    p.lda = lda; p.ldw = ldw; p.ldc = 0; p.M = M * (int64_t)n; p.N = H; p.K = K;
+    p.A = A; p.W = W; p.bias = bias; p.a_rows = a_rows; p.C = pooled_bf16;
+    p.lda = lda; p.ldw = ldw; p.ldc = pooled_bf16_ld; p.M = M * (int64_t)n; p.N = H; p.K = K;
     p.a_gstride = 0; p.w_gstride = 0; p.c_gstride = 0;
     p.a_rows_group0_only = 0; p.act = ACT_RELU; p.c_dtype = GSAGE_F32;
     p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled;

@@ -212,6 +212,43 @@ k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restri
     }
 }
 
+// part[b, c] = sum over rows i = b, b + n_part, ... of g[i, c] * (pooled[i, c] > 0)
+__global__ void __launch_bounds__(256)
+k_pool_bias_partials(const float *__restrict__ g, int64_t ldg, const float *__restrict__ pooled, int64_t ldp,
+                     int64_t M, int32_t H, float *__restrict__ part)
+{
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float s = 0.f;
+        for (int64_t i = blockIdx.x; i < M; i += gridDim.x)
+            s += pooled[i * ldp + c] > 0.f ? g[i * ldg + c] : 0.f;
+        part[(int64_t)blockIdx.x * H + c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_pool_merge_bwd(const uint16_t *__restrict__ Hp, int64_t ldh, const float *__restrict__ DX, int64_t ldx,
+                 int64_t r_x, const float *__restrict__ DN, int64_t ldn, int64_t r0,
+                 uint16_t *__restrict__ dH, int64_t ldo, int64_t R, int32_t D)
+{
+    const int chunks = D / 4;
+    const int64_t total = R * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t m = t / chunks;
+        const int c = (int)(t - m * chunks) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < r_x) v = *reinterpret_cast<const f32x4 *>(DX + m * ldx + c);
+        if (m >= r0) v += *reinterpret_cast<const f32x4 *>(DN + (m - r0) * ldn + c);
+        const uint2 h = *reinterpret_cast<const uint2 *>(Hp + m * ldh + c);
+        const float h0 = bf16_to_f32((uint16_t)(h.x & 0xffff)), h1 = bf16_to_f32((uint16_t)(h.x >> 16));
+        const float h2 = bf16_to_f32((uint16_t)(h.y & 0xffff)), h3 = bf16_to_f32((uint16_t)(h.y >> 16));
+        uint2 o;
+        o.x = pack_bf16x2(h0 > 0.f ? v[0] : 0.f, h1 > 0.f ? v[1] : 0.f);
+        o.y = pack_bf16x2(h2 > 0.f ? v[2] : 0.f, h3 > 0.f ? v[3] : 0.f);
+        *reinterpret_cast<uint2 *>(dH + m * ldo + c) = o;
+    }
+}
+
 static inline int grid_for(int64_t items, int cap)
 {
     int64_t b = ceil_div(items, 256);
@@ -320,6 +357,31 @@ int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64
     launch(k_pool_route_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
            pooled, ldp, argmax, lda, M, n, H, (uint16_t *)out, ldo);
     return check_launch("pool_route_bwd");
+}
+
+int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, int64_t ldp, int64_t M,
+                             int32_t H, float *part, int32_t n_part, void *stream)
+{
+    GSAGE_REQUIRE(g && pooled && part, "pool_bias_partials: null pointer");
+    GSAGE_REQUIRE(M >= 0 && H > 0 && ldg >= H && ldp >= H && n_part >= 1 && n_part <= 1024,
+                  "pool_bias_partials: bad sizes");
+    launch(k_pool_bias_partials, dim3((unsigned)n_part), dim3(256), 0, (hipStream_t)stream, g, ldg, pooled,
+           ldp, M, H, part);
+    return check_launch("pool_bias_partials");
+}
+
+int gsage_pool_merge_bwd(const void *Hprev, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
+                         const float *DN, int64_t ldn, int64_t r0, void *dH, int64_t ldo, int64_t R,
+                         int32_t D, void *stream)
+{
+    GSAGE_REQUIRE(Hprev && DX && DN && dH, "pool_merge_bwd: null pointer");
+    GSAGE_REQUIRE(D > 0 && D % 4 == 0 && ldh % 4 == 0 && ldx % 4 == 0 && ldn % 4 == 0 && ldo % 4 == 0,
+                  "pool_merge_bwd: D and leading dimensions must be multiples of 4");
+    GSAGE_REQUIRE(R >= 0 && r_x >= 0 && r_x <= R && r0 >= 0 && r0 <= R, "pool_merge_bwd: bad row ranges");
+    if (R == 0) return GSAGE_OK;
+    launch(k_pool_merge_bwd, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
+           (const uint16_t *)Hprev, ldh, DX, ldx, r_x, DN, ldn, r0, (uint16_t *)dH, ldo, R, D);
+    return check_launch("pool_merge_bwd");
 }
 
 int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,

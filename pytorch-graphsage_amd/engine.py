@@ -212,7 +212,17 @@ class FusedMeanTrainStep(object):
 
     def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
                  warmup=2, pipelined=False):
-        assert FusedMeanTrainStep.supports(model, feats), "configuration not covered by the fused engine"
+        assert type(self).supports(model, feats), "configuration not covered by this fused engine"
+        self._init_common(model, feats, loss_fn, example_ids, example_targets, ddp, pipelined)
+        self._init_levels(example_ids, example_targets)
+        self._init_head(loss_fn, example_targets)
+        self._init_reduce()
+        self._finish_init(capture, warmup)
+
+    # ---- construction, in five steps (subclasses override the aggregator-specific ones) -----------
+    def _init_common(self, model, feats, loss_fn, example_ids, example_targets, ddp, pipelined):
+        """Everything that does not depend on the aggregator: exchange op, frontier geometry, flat
+        parameter / gradient / Adam buckets (Parameters become views), device counters."""
         self.model, self.store, self.loss_fn, self.ddp = model, feats, loss_fn, ddp
         # pipelined: batch k+1's sampling + gathers (which do not depend on the weights) run on a
         # second graph branch WHILE batch k's GEMMs / backward / Adam run; results are identical
@@ -270,6 +280,20 @@ class FusedMeanTrainStep(object):
         self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
 
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.preds = None
+        self.n_calls = 0
+        # optional device-resident batch queue (load_epoch): the graph then needs no per-step copies
+        self.queue = None
+        self.batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.ids_set = [torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev) for _ in range(self.nset)]
+        self.tg_set = [example_targets.clone() for _ in range(self.nset)]
+        self.ids_set[0][:B].copy_(example_ids)
+
+    def _init_levels(self, example_ids, example_targets):
+        """Mean aggregator: per-level shapes, bf16 operand copies (+ their refresh descriptors) and
+        work buffers."""
+        model, feats, dev, L, B = self.model, self.store, self.dev, self.L, self.B
         # ---- per-level shapes, operand copies and work buffers ------------------------------
         self.h = [l.output_dim_ for l in self.layers]
         self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
@@ -298,8 +322,6 @@ class FusedMeanTrainStep(object):
         #   ids   the concatenated frontier [hop 0 | hop 1 | ... | hop L]
         #   xa0   level-0 operands [x rows | neighbour means], gathered ONCE per step so the forward
         #         GEMM and the weight-gradient kernel both read plain row-major operands
-        self.ids_set = [torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev) for _ in range(self.nset)]
-        self.tg_set = [example_targets.clone() for _ in range(self.nset)]
         self.xa0_set = [torch.zeros(2, self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
         for l in range(L):
@@ -314,16 +336,11 @@ class FusedMeanTrainStep(object):
         self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
         self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
 
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.preds = None
-        self.ids_set[0][:B].copy_(example_ids)
-        self.n_calls = 0
-        # optional device-resident batch queue (load_epoch): the graph then needs no per-step copies
-        self.queue = None
-        self.batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
 
-        # classification head as one fused kernel pair when it applies (else stock torch autograd)
+    def _init_head(self, loss_fn, example_targets):
+        """Classification head as one fused kernel pair when it applies (else stock torch autograd)."""
         from .problem import ProblemLosses
+        model, dev, L, B = self.model, self.dev, self.L, self.B
         C, D2 = model.fc.weight.shape
         probe = torch.randn(3, 4, device=dev)
         ident = self.post is None or torch.equal(self.post(probe), probe)
@@ -341,7 +358,11 @@ class FusedMeanTrainStep(object):
             self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
             self.preds = torch.zeros(B, C, dtype=torch.float32, device=dev)
 
-        # ---- gradient partial buffers + the descriptor table gsage_finalize_grads sums them with
+
+    def _init_reduce(self):
+        """Gradient partial buffers + the descriptor table gsage_finalize_grads sums them with."""
+        model, dev, L = self.model, self.dev, self.L
+        f32 = torch.float32
         rdesc, self.slabs = [], []
         for l in range(L):
             h, din, R = self.h[l], self.din[l], self.rows[l]
@@ -354,6 +375,12 @@ class FusedMeanTrainStep(object):
                 bufs.append(buf)
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[ix + g], S, ntot, din, ldk))
             self.slabs.append(bufs)
+        self._install_reduce(rdesc)
+
+    def _install_reduce(self, rdesc):
+        """Append the head's gradient source, check that every parameter is covered, upload."""
+        model, dev = self.model, self.dev
+        f32 = torch.float32
         Cc, D2c = model.fc.weight.shape
         ifc = self.pidx[id(model.fc.weight)]
         assert self.pidx[id(model.fc.bias)] == ifc + 1
@@ -375,6 +402,8 @@ class FusedMeanTrainStep(object):
         self.partial = torch.zeros(max(self.n_partial, self.partial.numel()), dtype=f32, device=dev)
         self.refresh_weights()
 
+    def _finish_init(self, capture, warmup):
+        ddp = self.ddp
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
         side = torch.cuda.Stream()
