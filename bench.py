@@ -255,10 +255,11 @@ def main():
     use_graph = args.launch != "eager"
     step_fn = None
     engine = args.engine
-    if engine == "fused" and not gs.engine.FusedMeanTrainStep.supports(model, store):
+    fused_cls = gs.engine.fused_engine_for(model, store)
+    if engine == "fused" and fused_cls is None:
         engine = "autograd"
     if engine == "fused":
-        step_fn = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
+        step_fn = fused_cls(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
                                                capture=args.launch if use_graph else False,
                                                pipelined=args.pipeline)
     elif use_graph:

@@ -142,7 +142,7 @@ import ctypes
 import os
 
 from . import ops
-from .nn_modules import IdentityPrep, MeanAggregator, SparseUniformNeighborSampler, \
+from .nn_modules import IdentityPrep, MaxPoolAggregator, MeanAggregator, SparseUniformNeighborSampler, \
     _split_activation, concat_combine
 from .store import FeatureStore
 
@@ -642,7 +642,11 @@ class FusedMeanTrainStep(object):
                                   self.slabs[l][g]))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
-        # every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick
+        self._stage_finalize(s)
+
+    def _stage_finalize(self, s):
+        """Every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick."""
+        L, lib, stream = self.L, nat.lib(), ops._stream()
         if self.prefetch:
             # ... side by side with the sampling of the NEXT batch of the queue (counters are
             # ticked by the Adam launch that follows)
@@ -824,3 +828,219 @@ class FusedMeanTrainStep(object):
         torch.cuda.current_stream().wait_stream(self.s_front)
         self.n_calls = 0                              # the next call primes a fresh pipeline
         return self.preds
+
+
+def _r64(v):
+    return (int(v) + 63) // 64 * 64
+
+
+class FusedPoolTrainStep(FusedMeanTrainStep):
+    """train_step for max-pool aggregators (reference nn_modules.py:207-244; BASELINE config 3) with no
+    autograd and no framework glue, on the same machinery as FusedMeanTrainStep (flat buckets, fused
+    multi-hop sampler, head kernel, finalisation + Adam, command lists, batch queue, data-parallel
+    order).  Per level l, rows = hops 0 .. L-l-1 ("x"), neighbour rows = hops 1 .. L-l:
+
+      forward    K3   pooled = max_j relu(Wm nb_j + bm) per hop (hidden [M*n, Hm] never leaves the chip),
+                      fp32 + bf16 operand copy + argmax
+                 K5   out[:, :h] = act(x Wx^T);  K5  out[:, h:] = act(pooled Wn^T)
+      backward   K5   d pooled = dC[:, h:] Wn            (NT GEMM against the transposed operand copy)
+                 route d pooled through the max / ReLU -> bf16 d hidden [M*n, Hm]   (gsage_pool_route_bwd)
+                 bias partials of the MLP                                           (gsage_pool_bias_partials)
+                 l > 0: K5 dX = dC[:, :h] Wx, K5 dN = d hidden Wm, merge + ReLU mask -> dC of level l-1
+                 K5b  all weight gradients of all levels in one grouped launch (fc_x, fc_neib, mlp)
+    Level 0 reads its operands from two row buffers gathered once per step (x rows, neighbour rows):
+    K3, K5 and K5b all want plain row-major operands, and the gathers run one batch ahead beside Adam.
+    """
+
+    @staticmethod
+    def supports(model, feats):
+        layers = list(model.agg_layers.children())
+        if not layers or not all(type(l) is MaxPoolAggregator and l.combine_fn is concat_combine for l in layers):
+            return False
+        codes = [_split_activation(l.activation)[0] for l in layers]
+        if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
+            return False
+        if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
+            return False
+        if feats.dtype != torch.bfloat16 or not feats.is_cuda or feats.ld % 64 != 0:
+            return False
+        if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
+            return False
+        if any(fn.keywords["n_samples"] > 64 for fn in model.train_sample_fns) or len(layers) > 2:
+            return False                                     # K3 tiles hold whole segments up to 64 rows
+        return all(l.output_dim_ % 64 == 0 and l.mlp[0].weight.shape[0] % 64 == 0 for l in layers)
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _init_levels(self, example_ids, example_targets):
+        feats, dev, L = self.store, self.dev, self.L
+        bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+        self.h = [l.output_dim_ for l in self.layers]
+        self.Hm = [int(l.mlp[0].weight.shape[0]) for l in self.layers]
+        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
+        self.rows = [self.off[L - l] for l in range(L)]                     # x rows of level l
+        self.nrows = [self.off[L - l + 1] - self.off[1] for l in range(L)]  # neighbour rows of level l
+        assert all(d % 64 == 0 for d in self.din[1:]), "hidden widths must be multiples of 32"
+        descs = []
+
+        def copies(prm, need_t):
+            r, c = prm.shape
+            w = torch.zeros(r, _r64(c), dtype=bf, device=dev)
+            wt = torch.zeros(c, _r64(r), dtype=bf, device=dev) if need_t else None
+            descs.append(_PrepDesc(prm.data_ptr(), w.data_ptr(), wt.data_ptr() if need_t else None, r, c,
+                                   w.shape[1], wt.shape[1] if need_t else 0))
+            return w, wt
+        self.wm, self.wx, self.wn, self.wmT, self.wxT, self.wnT = [], [], [], [], [], []
+        for l, layer in enumerate(self.layers):
+            order = [self.pidx[id(p)] for p in (layer.mlp[0].weight, layer.mlp[0].bias, layer.fc_x.weight,
+                                                layer.fc_neib.weight)]
+            assert order == list(range(order[0], order[0] + 4)), "unexpected parameter order"
+            wm, wmT = copies(layer.mlp[0].weight, l > 0)
+            wx, wxT = copies(layer.fc_x.weight, l > 0)
+            wn, wnT = copies(layer.fc_neib.weight, True)
+            self.wm.append(wm); self.wmT.append(wmT); self.wx.append(wx); self.wxT.append(wxT)
+            self.wn.append(wn); self.wnT.append(wnT)
+        self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
+        self.n_desc = len(descs)
+        self.max_elems = max(d.rows * d.cols for d in descs)
+
+        # level-0 operands, gathered once per step: x rows (hops 0..L-1) and neighbour rows (hops 1..L)
+        self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+        self.xn0_set = [torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+        self.pooled, self.pooled_b, self.argmax, self.hout, self.dc = [], [], [], [], []
+        self.dpool, self.ghc, self.dxb, self.dnb, self.bpart = [], [], [], [], []
+        for l in range(L):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            last = l == L - 1
+            self.pooled.append(torch.zeros(R, Hm, dtype=f32, device=dev))
+            self.pooled_b.append(torch.zeros(R, _r64(Hm), dtype=bf, device=dev))
+            self.argmax.append(torch.zeros(R, Hm, dtype=i32, device=dev))
+            self.hout.append(torch.zeros(R, 2 * h, dtype=f32 if last else bf, device=dev))
+            self.dc.append(torch.zeros(R, 2 * h, dtype=bf, device=dev))
+            self.dpool.append(torch.zeros(R, Hm, dtype=f32, device=dev))
+            self.ghc.append(torch.zeros(NR, Hm, dtype=bf, device=dev))
+            self.dxb.append(torch.zeros(R, din, dtype=f32, device=dev) if l > 0 else None)
+            self.dnb.append(torch.zeros(NR, din, dtype=f32, device=dev) if l > 0 else None)
+            self.bpart.append(torch.zeros((L - l) * 64, Hm, dtype=f32, device=dev))
+
+    def _init_head(self, loss_fn, example_targets):
+        super(FusedPoolTrainStep, self)._init_head(loss_fn, example_targets)
+        self.fused_tail = False
+        assert self.fused_head, "FusedPoolTrainStep needs the fused classification head"
+
+    def _x_operand(self, l, s):
+        return (self.x0_set[s], self.store.ld) if l == 0 else (self.hout[l - 1], self.din[l])
+
+    def _nb_operand(self, l, s):
+        """neighbour rows of level l as one contiguous row block + its leading dimension"""
+        if l == 0:
+            return self.xn0_set[s], self.store.ld
+        return self.hout[l - 1][self.off[1]:], self.din[l]
+
+    def _init_reduce(self):
+        dev, L, f32 = self.dev, self.L, torch.float32
+        rdesc, self.slabs = [], []
+        for l, layer in enumerate(self.layers):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            bufs = {}
+            for key, prm, M, ntot, K in (("m", layer.mlp[0].weight, NR, Hm, din), ("x", layer.fc_x.weight, R, h, din),
+                                         ("n", layer.fc_neib.weight, R, h, Hm)):
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K)
+                buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
+                bufs[key] = buf
+                rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
+            ib = self.pidx[id(layer.mlp[0].bias)]
+            rdesc.append(_ReduceDesc(self.bpart[l].data_ptr(), Hm, self.poff[ib], self.bpart[l].shape[0], 1, Hm, Hm))
+            self.slabs.append(bufs)
+        self._install_reduce(rdesc)
+
+    # ---- stages ----------------------------------------------------------------------------------------
+    def _stage_gather(self, s, with_adam=False):
+        L, st, ids = self.L, self.store, self.ids_set[s]
+        segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1),
+                (st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1)]
+        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None)
+
+    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
+        ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
+                           nat.BF16, c_code)
+
+    def _stage_compute(self, s):
+        L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
+        for l, layer in enumerate(self.layers):
+            R, Hm, h, din = self.rows[l], self.Hm[l], self.h[l], self.din[l]
+            nb, ldnb = self._nb_operand(l, s)
+            for k in range(L - l):                       # one K3 launch per hop: its fan-out is the segment
+                r0, r1 = self.off[k], self.off[k + 1]
+                a0 = self.off[k + 1] - self.off[1]
+                nat.check(lib.gsage_pool_mlp(
+                    nb[a0:].data_ptr(), nat.BF16, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
+                    layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, nat.POOL_MAX,
+                    self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr(),
+                    self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1], stream), "pool_mlp")
+            x, ldx = self._x_operand(l, s)
+            last = l == L - 1
+            out, code = self.hout[l], (nat.F32 if last else nat.BF16)
+            act = nat.ACT_NONE if last else nat.ACT_RELU
+            self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act)
+            self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
+                       out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act)
+        C, D2 = m.fc.weight.shape
+        tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+        nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), 2 * self.h[L - 1], m.fc.weight.data_ptr(),
+                                    m.fc.bias.data_ptr(), tg.data_ptr(), B, C, D2, self.preds.data_ptr(),
+                                    self.dc[L - 1].data_ptr(), nat.BF16, 2 * self.h[L - 1], None, None, None,
+                                    self.head_scratch.data_ptr(),
+                                    self.batch_idx.data_ptr() if self.queue else None,
+                                    self.queue[2] if self.queue else 0, stream), "head_ce")
+        self._backward_levels(s)
+
+    def _backward_levels(self, s):
+        L, lib, stream = self.L, nat.lib(), ops._stream()
+        for l in range(L - 1, -1, -1):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            dc = self.dc[l]
+            # d pooled = dC[:, h:] Wn
+            self._gemm(dc.data_ptr() + h * 2, 2 * h, self.wnT[l], self.dpool[l].data_ptr(), nat.F32, Hm, R, Hm, h,
+                       nat.ACT_NONE)
+            for k in range(L - l):
+                r0, r1 = self.off[k], self.off[k + 1]
+                a0 = self.off[k + 1] - self.off[1]
+                nat.check(lib.gsage_pool_route_bwd(self.dpool[l][r0:r1].data_ptr(), Hm, self.pooled[l][r0:r1].data_ptr(),
+                                                   Hm, self.argmax[l][r0:r1].data_ptr(), Hm, self.size[k],
+                                                   self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), Hm, stream),
+                          "pool_route_bwd")
+                nat.check(lib.gsage_pool_bias_partials(self.dpool[l][r0:r1].data_ptr(), Hm,
+                                                       self.pooled[l][r0:r1].data_ptr(), Hm, self.size[k], Hm,
+                                                       self.bpart[l][k * 64:].data_ptr(), 64, stream),
+                          "pool_bias_partials")
+            if l > 0:
+                self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dxb[l].data_ptr(), nat.F32, din, R, din, h,
+                           nat.ACT_NONE)
+                self._gemm(self.ghc[l].data_ptr(), Hm, self.wmT[l], self.dnb[l].data_ptr(), nat.F32, din, NR, din,
+                           Hm, nat.ACT_NONE)
+                below = self.hout[l - 1]
+                nat.check(lib.gsage_pool_merge_bwd(below.data_ptr(), below.stride(0), self.dxb[l].data_ptr(), din, R,
+                                                   self.dnb[l].data_ptr(), din, self.off[1],
+                                                   self.dc[l - 1].data_ptr(), self.dc[l - 1].stride(0),
+                                                   self.rows[l - 1], din, stream), "pool_merge_bwd")
+        probs = []
+        for l in range(L - 1, -1, -1):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            x, ldx = self._x_operand(l, s)
+            nb, ldnb = self._nb_operand(l, s)
+            dc = self.dc[l]
+            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"]))
+            probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"]))
+            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"]))
+        for i in range(0, len(probs), 8):
+            ops.wgrad_multi(probs[i:i + 8])
+        self._stage_finalize(s)
+
+
+def fused_engine_for(model, feats):
+    """The fused train-step engine that covers (model, feats), or None (callers then fall back to
+    GSSupervised.train_step, optionally captured by CapturedTrainStep)."""
+    for cls in (FusedMeanTrainStep, FusedPoolTrainStep):
+        if cls.supports(model, feats):
+            return cls
+    return None

@@ -30,7 +30,7 @@ def _problem(n=600, D=40, C=5, seed=0, max_deg=30):
     return adj, feats, rng
 
 
-def _model(adj, D, C, dims, fans, seed=3):
+def _model(adj, D, C, dims, fans, seed=3, agg="mean"):
     torch.manual_seed(seed)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
     specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
@@ -38,7 +38,7 @@ def _model(adj, D, C, dims, fans, seed=3):
              for i, (h, f) in enumerate(zip(dims, fans))]
     m = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj,
                         train_adj=adj, prep_class=gs.prep_lookup["identity"],
-                        aggregator_class=gs.aggregator_lookup["mean"], input_dim=D,
+                        aggregator_class=gs.aggregator_lookup[agg], input_dim=D,
                         n_nodes=adj.shape[0], n_classes=C, layer_specs=specs, lr_init=0.01,
                         weight_decay=1e-4)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
@@ -86,6 +86,52 @@ def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
     ev = eng_model(batches[0][0], store, train=False)
     assert ev.shape == (B, C) and torch.isfinite(ev).all()
     eng_model.train_sampler.csr(DEV).check()
+
+
+@pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((64, 64), (5, 3), 33), ((64,), (7,), 20)])
+@pytest.mark.parametrize("capture", [False, "cmdlist"])
+def test_fused_pool_engine_matches_eager_autograd_path(dims, fans, B, capture):
+    """FusedPoolTrainStep (max-pool aggregators, BASELINE config 3) against GSSupervised.train_step on
+    the eager product path: same Philox samples, same K3 forward kernel; the engine's own backward
+    (argmax routing, K5 input gradients, grouped K5b) against autograd."""
+    adj, feats, rng = _problem()
+    D, C = feats.shape[1], 5
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ref_model = _model(adj, D, C, dims, fans, agg="max_pool")
+    eng_model = _model(adj, D, C, dims, fans, agg="max_pool")
+    eng_model.load_state_dict(ref_model.state_dict())
+    ref_model.optimizer = torch.optim.Adam(ref_model.parameters(), lr=0.01, weight_decay=1e-4)
+    loss_fn = gs.ProblemLosses.classification
+    assert gs.engine.fused_engine_for(eng_model, store) is gs.engine.FusedPoolTrainStep
+    batches = [(torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV),
+                torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)) for _ in range(3)]
+    eng = gs.engine.FusedPoolTrainStep(eng_model, store, loss_fn, batches[0][0], batches[0][1], capture=capture)
+    for step, (ids, tg) in enumerate(batches):
+        ref_model.load_state_dict(eng_model.state_dict())
+        p_ref = ref_model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn).detach().float().cpu().numpy()
+        p_eng = eng(ids, tg).detach().float().cpu().numpy()
+        close(p_eng, p_ref, ("preds", step), 3e-2, 3e-2)
+        for (k, a), (_, b) in zip(eng_model.named_parameters(), ref_model.named_parameters()):
+            close_fro(a.grad.cpu().numpy(), b.grad.cpu().numpy(), ("grad", step, k), 0.1)
+            if step == 0:
+                close_fro(a.detach().cpu().numpy(), b.detach().cpu().numpy(), ("weight", k), 0.05)
+    ev = eng_model(batches[0][0], store, train=False)
+    assert ev.shape == (B, C) and torch.isfinite(ev).all()
+    eng_model.train_sampler.csr(DEV).check()
+    # queue mode (next batch sampled / gathered one step ahead) == per-step copies, bit for bit
+    ids_all = torch.stack([b[0] for b in batches])
+    tg_all = torch.stack([b[1] for b in batches])
+    outs = []
+    for queued in (False, True):
+        mdl = _model(adj, D, C, dims, fans, agg="max_pool")
+        e2 = gs.engine.FusedPoolTrainStep(mdl, store, loss_fn, batches[0][0], batches[0][1], capture=capture)
+        if queued:
+            e2.load_epoch(ids_all, tg_all)
+            preds = [e2.step_queue().clone() for _ in range(4)]
+        else:
+            preds = [e2(ids_all[k % 3], tg_all[k % 3]).clone() for k in range(4)]
+        outs.append((torch.stack(preds), e2.flat_p.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
