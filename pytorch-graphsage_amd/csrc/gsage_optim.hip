@@ -213,16 +213,35 @@ k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restri
 }
 
 // part[b, c] = sum over rows i = b, b + n_part, ... of g[i, c] * (pooled[i, c] > 0)
+// thread = 4 consecutive channels (16-byte loads), 4 rows in flight; blockIdx.y walks the channels
 __global__ void __launch_bounds__(256)
 k_pool_bias_partials(const float *__restrict__ g, int64_t ldg, const float *__restrict__ pooled, int64_t ldp,
                      int64_t M, int32_t H, float *__restrict__ part)
 {
-    for (int c = threadIdx.x; c < H; c += 256) {
-        float s = 0.f;
-        for (int64_t i = blockIdx.x; i < M; i += gridDim.x)
-            s += pooled[i * ldp + c] > 0.f ? g[i * ldg + c] : 0.f;
-        part[(int64_t)blockIdx.x * H + c] = s;
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c >= H) return;
+    const int64_t step = gridDim.x;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = blockIdx.x;
+    for (; i + 3 * step < M; i += 4 * step) {
+        f32x4 gv[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gv[u] = *reinterpret_cast<const f32x4 *>(g + (i + u * step) * ldg + c);
+            pv[u] = *reinterpret_cast<const f32x4 *>(pooled + (i + u * step) * ldp + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += pv[u][e] > 0.f ? gv[u][e] : 0.f;
     }
+    for (; i < M; i += step) {
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + i * ldg + c);
+        const f32x4 pv = *reinterpret_cast<const f32x4 *>(pooled + i * ldp + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += pv[e] > 0.f ? gv[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(part + (int64_t)blockIdx.x * H + c) = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -363,10 +382,12 @@ int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, i
                              int32_t H, float *part, int32_t n_part, void *stream)
 {
     GSAGE_REQUIRE(g && pooled && part, "pool_bias_partials: null pointer");
-    GSAGE_REQUIRE(M >= 0 && H > 0 && ldg >= H && ldp >= H && n_part >= 1 && n_part <= 1024,
-                  "pool_bias_partials: bad sizes");
-    launch(k_pool_bias_partials, dim3((unsigned)n_part), dim3(256), 0, (hipStream_t)stream, g, ldg, pooled,
-           ldp, M, H, part);
+    GSAGE_REQUIRE(M >= 0 && H > 0 && H % 4 == 0 && ldg >= H && ldp >= H && ldg % 4 == 0 && ldp % 4 == 0 &&
+                  n_part >= 1 && n_part <= 1024, "pool_bias_partials: bad sizes (H, ldg, ldp multiples of 4)");
+    GSAGE_REQUIRE((((uintptr_t)g | (uintptr_t)pooled | (uintptr_t)part) & 15) == 0,
+                  "pool_bias_partials: buffers must be 16-byte aligned");
+    launch(k_pool_bias_partials, dim3((unsigned)n_part, (unsigned)ceil_div(H, 1024)), dim3(256), 0,
+           (hipStream_t)stream, g, ldg, pooled, ldp, M, H, part);
     return check_launch("pool_bias_partials");
 }
 

@@ -852,6 +852,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
     K3, K5 and K5b all want plain row-major operands, and the gathers run one batch ahead beside Adam.
     """
 
+    NPART = 256          # partial rows per hop for the MLP bias gradient (summed by the finalisation)
+
     @staticmethod
     def supports(model, feats):
         layers = list(model.agg_layers.children())
@@ -920,7 +922,7 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             self.ghc.append(torch.zeros(NR, Hm, dtype=bf, device=dev))
             self.dxb.append(torch.zeros(R, din, dtype=f32, device=dev) if l > 0 else None)
             self.dnb.append(torch.zeros(NR, din, dtype=f32, device=dev) if l > 0 else None)
-            self.bpart.append(torch.zeros((L - l) * 64, Hm, dtype=f32, device=dev))
+            self.bpart.append(torch.zeros((L - l) * self.NPART, Hm, dtype=f32, device=dev))
 
     def _init_head(self, loss_fn, example_targets):
         super(FusedPoolTrainStep, self)._init_head(loss_fn, example_targets)
@@ -1011,7 +1013,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                           "pool_route_bwd")
                 nat.check(lib.gsage_pool_bias_partials(self.dpool[l][r0:r1].data_ptr(), Hm,
                                                        self.pooled[l][r0:r1].data_ptr(), Hm, self.size[k], Hm,
-                                                       self.bpart[l][k * 64:].data_ptr(), 64, stream),
+                                                       self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
+                                                       stream),
                           "pool_bias_partials")
             if l > 0:
                 self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dxb[l].data_ptr(), nat.F32, din, R, din, h,
