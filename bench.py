@@ -188,6 +188,42 @@ def dominant_kernel_roofline(gs, model, store, data, dev, reps=40, n_frontiers=8
             "alg_bytes_per_launch": alg_bytes, "avg_launch_us": dur_s * 1e6}
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
+
+
+def pool_kernel_roofline(gs, model, store, data, dev, reps=20, n_frontiers=4):
+    """BASELINE configs[2] (max-pool): the dominant kernel is K3 (pooling MLP + bias + ReLU + segment
+    max fused, gather fused) on the hop-2 frontier -- MFMA-bound.  FLOPs = 2 * rows * D * hidden of the
+    contraction the reference runs as mlp(neibs) (nn_modules.py:224)."""
+    ops, nat = gs.ops, gs._native
+    layer = list(model.agg_layers.children())[0]
+    lin = layer.mlp[0]
+    rng = np.random.RandomState(7)
+    M, n = BATCH * FANOUT[0], FANOUT[1]
+    fronts = []
+    for _ in range(n_frontiers):
+        ids0 = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=BATCH)]).to(dev)
+        fronts.append(model.train_sampler(model.train_sampler(ids0, n_samples=FANOUT[0]), n_samples=n))
+    run = lambda f: ops.pool_mlp(gs.RowRef(store, f), lin.weight, lin.bias, M, nat.POOL_MAX)
+    with torch.no_grad():
+        for f in fronts:
+            run(f)
+        torch.cuda.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for r in range(reps):
+            run(fronts[r % n_frontiers])
+        stop.record()
+        torch.cuda.synchronize()
+    # each call also converts the weight to bf16 (a 0.6 MB elementwise kernel): < 1 % of the launch
+    dur_s = start.elapsed_time(stop) / 1e3 / reps
+    flops = 2.0 * M * n * FEAT_DIM * lin.weight.shape[0]
+    achieved = flops / dur_s / 1e12
+    return {"bound": "mfma", "kernel": "k_linear_nt<bf16, POOL> (K3, hop 2: 128 000 rows x 602 -> 512)",
+            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+            "traffic": None, "alg_flops_per_launch": flops, "avg_launch_us": dur_s * 1e6}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,7 +342,10 @@ def main():
 
     if rank == 0:
         value = args.steps * B * world / elapsed
-        roof = dominant_kernel_roofline(gs, model, store, data, dev)
+        if args.aggregator == "max_pool" and fanout == FANOUT and B == BATCH:
+            roof = pool_kernel_roofline(gs, model, store, data, dev)
+        else:
+            roof = dominant_kernel_roofline(gs, model, store, data, dev)
         line = {
             "metric": "seed-nodes/sec", "value": value, "unit": "seed-nodes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
