@@ -176,22 +176,25 @@ class _ListRunner(object):
 class FusedMeanTrainStep(object):
     """train_step (reference models.py:97-104) for the north-star configuration -- sparse sampler,
     identity prep over a bf16 FeatureStore, mean aggregators (ReLU on all but the last layer) --
-    as ~20 kernel launches replayed from a hipGraph:
+    without autograd below the loss and without framework glue kernels.  For the 2-layer Reddit
+    shape a step is FIVE launches, recorded once into a native command list (or a hipGraph) and
+    replayed per batch:
 
-        K-prep   fp32 weights -> bf16 operand copies (one launch)
-        K1       one launch per hop, ids written straight into the concatenated frontier
-        K2       gather+mean per hop (level 0 from the feature table, upper levels in order)
-        K5       ONE grouped MFMA GEMM per level (x | agg against Wx | Wn, gather fused for level 0)
-        head     normalize + fc + loss and their gradients (stock torch: 0.01 % of the work)
-        K5b      ONE MFMA weight-gradient launch per level (+ deterministic slab reduce)
-        K5/merge input gradients of upper levels: grouped GEMM against W^T, ReLU mask + hop routing
-        [RCCL]   one all-reduce of the flat gradient bucket (between the two graphs, DP only)
-        Adam     grad-norm partials + clip + Adam over the flat bucket (3 launches)
+        K5            level 0: ONE grouped MFMA GEMM (x | agg against Wx | Wn), bf16 out
+        seed level    segment mean + both projections + normalize/fc/CE + all gradients down to the
+                      level-0 activations in one kernel (gsage_mean_tail_ce; generic models use K2 + K5
+                      + gsage_head_ce + K5/merge per level instead)
+        K5b           every level's weight gradient in one grouped launch (partial tiles -> slabs)
+        finalise      partial tiles + head partials -> flat gradient bucket + norm partials, side by
+                      side with K1 (all hops) for the NEXT batch of the queue
+        [RCCL]        one all-reduce of the flat gradient bucket (data-parallel runs only)
+        Adam          clip + Adam + refresh of the bf16 operand copies, side by side with the level-0
+                      gathers (x rows | neighbour means of every hop) of the NEXT batch
 
-    The arithmetic is that of GSSupervised.train_step; autograd is not involved below the head, so
-    nothing is saved per op and no framework glue kernels (casts, fills, masks) remain.
-    Parameters and gradients live in flat fp32 buckets; the model's Parameters become views of
-    them, so `model.state_dict()`, evaluation and checkpointing keep working.
+    The arithmetic is that of GSSupervised.train_step.  Parameters and gradients live in flat fp32
+    buckets; the model's Parameters become views of them, so `model.state_dict()`, evaluation and
+    checkpointing keep working.  `__call__(ids, targets)` has the contract of train_step;
+    `load_epoch()` + `step_queue()` walk a device-resident queue of seed batches with no host copies.
     """
 
     @staticmethod
