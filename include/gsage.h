@@ -249,9 +249,11 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
 int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
                    int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
-                   int64_t pooled_bf16_ld, void *stream);
+                   int64_t pooled_bf16_ld, uint32_t *relu_mask, void *stream);
 /* pooled_bf16 (may be NULL): the same result rounded to bf16, [M, pooled_bf16_ld] -- the operand
- * copy the following projection (gsage_linear_nt) and its weight gradient (gsage_wgrad) read. */
+ * copy the following projection (gsage_linear_nt) and its weight gradient (gsage_wgrad) read.
+ * relu_mask (may be NULL; H % 32 == 0): [M*n, H/32] words, bit c%32 of word c/32 of row r = hidden
+ * activation (r, c) > 0 -- all the mean pool's backward needs of the hidden layer. */
 
 /* Backward routing of the max pool: the bf16 [M*n, ldo] gradient of the hidden activations,
  *     out[i*n + j, c] = (argmax[i, c] == j && pooled[i, c] > 0) ? g[i, c] : 0
@@ -261,6 +263,13 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
 int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
                          const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
                          int64_t ldo, void *stream);
+
+/* Same for the mean pool: out[i*n + j, c] = relu_mask(i*n + j, c) ? g[i, c] / n : 0   (autograd of
+ * nn_modules.py:224-226,252), plus -- when bias_part != NULL -- the MLP bias gradient as n_part
+ * deterministic partial rows (summed by gsage_finalize_grads).  H % 32 == 0. */
+int gsage_pool_route_mean_bwd(const float *g, int64_t ldg, const uint32_t *relu_mask, int64_t M, int32_t n,
+                              int32_t H, void *out, int64_t ldo, float *bias_part, int32_t n_part,
+                              void *stream);
 
 /* Bias gradient of the pooling MLP under the max pool: column sums of g * (pooled > 0) over the M
  * segments, as `n_part` deterministic partial rows part[b, c] (b < n_part; summed by

@@ -55,6 +55,7 @@ struct LinearParams {
     float *pooled;
     int64_t pooled_ld;
     int32_t *argmax;
+    uint32_t *relu_mask;   // optional [M, N/32] sign bits of the bias+ReLU'd tile (mean-pool backward)
     int32_t dbg;           // GSAGE_DBG ablation switches (tools/kbench.py only): 1 no MFMA, 2 no DMA, 4 no stores
 };
 
@@ -303,6 +304,20 @@ k_linear_nt(const LinearParams p)
             }
         }
         __syncthreads();
+        if (p.relu_mask) {
+            // sign bits of the hidden activations: thread t packs 32 channels of tile row t >> 2
+            const int i = tid >> 2, q = tid & 3;
+            const int64_t row = (int64_t)blockIdx.x * rows_per_wg + i;
+            if (i < rows_per_wg && row < p.M && n0 + q * 32 < p.N) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int e0 = 0; e0 < 32; ++e0) {
+                    const int e = (e0 + i) & 31;               // rotate per row: spreads the LDS banks
+                    bits |= (tile[i * BN + q * 32 + e] > 0.f ? 1u : 0u) << e;
+                }
+                p.relu_mask[row * (p.N / 32) + (n0 >> 5) + q] = bits;
+            }
+        }
         const int jl = tid & (BN - 1);
         const int64_t j = n0 + jl;
         for (int sg = tid >> 7; sg < p.pool_groups; sg += 2) {
@@ -494,7 +509,7 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     p.a_gstride = a_gstride; p.w_gstride = w_gstride; p.c_gstride = c_gstride;
     p.a_rows_group0_only = a_rows_group0_only; p.act = act; p.c_dtype = c_dtype;
     p.pool_n = 0; p.pool_groups = 0; p.pool_mode = 0; p.pooled = nullptr; p.pooled_ld = 0;
-    p.argmax = nullptr;
+    p.argmax = nullptr; p.relu_mask = nullptr;
     { static const char *e = getenv("GSAGE_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
@@ -539,8 +554,9 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
 int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
                    int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
-                   int64_t pooled_bf16_ld, void *stream)
+                   int64_t pooled_bf16_ld, uint32_t *relu_mask, void *stream)
 {
+    GSAGE_REQUIRE(!relu_mask || H % 32 == 0, "pool_mlp: relu_mask needs H % 32 == 0");
     GSAGE_REQUIRE(n >= 1 && n <= BM, "pool_mlp: fanout must be in [1, %d]", BM);
     GSAGE_REQUIRE(!pooled_bf16 || pooled_bf16_ld >= H, "pool_mlp: bad bf16 output");
     int rc = check_operands("pool_mlp", A, dtype, lda, W, ldw, M * (int64_t)n, H, K);
@@ -554,7 +570,7 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     p.a_gstride = 0; p.w_gstride = 0; p.c_gstride = 0;
     p.a_rows_group0_only = 0; p.act = ACT_RELU; p.c_dtype = GSAGE_F32;
     p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled;
-    p.pooled_ld = pooled_ld; p.argmax = argmax; p.dbg = 0;
+    p.pooled_ld = pooled_ld; p.argmax = argmax; p.relu_mask = relu_mask; p.dbg = 0;
     dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, BN), 1);
     if (dtype == GSAGE_BF16)
         launch(k_linear_nt<uint16_t, true, ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -212,6 +212,50 @@ k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restri
     }
 }
 
+// mean pool: hidden[i*n + j, c] receives g[i, c] / n iff its ReLU was active (sign bit from K3)
+__global__ void __launch_bounds__(256)
+k_pool_route_mean_bwd(const float *__restrict__ g, int64_t ldg, const uint32_t *__restrict__ mask, int64_t M,
+                      int32_t n, int32_t H, uint16_t *__restrict__ out, int64_t ldo)
+{
+    const int chunks = H / 8;
+    const int words = H / 32;
+    const int64_t total = M * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float inv = 1.f / (float)n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / chunks;
+        const int c0 = (int)(t - i * chunks) * 8;
+        uint16_t gb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb[e] = f32_to_bf16(g[i * ldg + c0 + e] * inv);
+        for (int j = 0; j < n; ++j) {
+            const uint32_t m = mask[(i * n + j) * words + (c0 >> 5)] >> (c0 & 31);
+            vec16 o;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+                o[e >> 1] = (((m >> e) & 1u) ? (uint32_t)gb[e] : 0u) | ((((m >> (e + 1)) & 1u) ? (uint32_t)gb[e + 1] : 0u) << 16);
+            *reinterpret_cast<vec16 *>(out + (i * n + j) * ldo + c0) = o;
+        }
+    }
+}
+
+// part[b, c] = sum over segments i = b, b + n_part, ... of g[i, c] / n * #(active rows of segment i at c)
+__global__ void __launch_bounds__(256)
+k_pool_bias_partials_mean(const float *__restrict__ g, int64_t ldg, const uint32_t *__restrict__ mask,
+                          int64_t M, int32_t n, int32_t H, float *__restrict__ part)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= H) return;
+    const int words = H / 32;
+    float s = 0.f;
+    for (int64_t i = blockIdx.x; i < M; i += gridDim.x) {
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) cnt += (mask[(i * n + j) * words + (c >> 5)] >> (c & 31)) & 1u;
+        s += g[i * ldg + c] * (float)cnt;
+    }
+    part[(int64_t)blockIdx.x * H + c] = s / (float)n;
+}
+
 // part[b, c] = sum over rows i = b, b + n_part, ... of g[i, c] * (pooled[i, c] > 0)
 // thread = 4 consecutive channels (16-byte loads), 4 rows in flight; blockIdx.y walks the channels
 __global__ void __launch_bounds__(256)
@@ -376,6 +420,24 @@ int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64
     launch(k_pool_route_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
            pooled, ldp, argmax, lda, M, n, H, (uint16_t *)out, ldo);
     return check_launch("pool_route_bwd");
+}
+
+int gsage_pool_route_mean_bwd(const float *g, int64_t ldg, const uint32_t *relu_mask, int64_t M, int32_t n,
+                              int32_t H, void *out, int64_t ldo, float *bias_part, int32_t n_part,
+                              void *stream)
+{
+    GSAGE_REQUIRE(g && relu_mask && out, "pool_route_mean_bwd: null pointer");
+    GSAGE_REQUIRE(M >= 0 && n > 0 && H > 0 && H % 32 == 0 && ldo % 8 == 0 && ldo >= H && ldg >= H &&
+                  ((uintptr_t)out % 16) == 0, "pool_route_mean_bwd: H % 32, ldo % 8, out 16-byte aligned");
+    GSAGE_REQUIRE(!bias_part || (n_part >= 1 && n_part <= 1024), "pool_route_mean_bwd: bad n_part");
+    if (M == 0) return GSAGE_OK;
+    launch(k_pool_route_mean_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+           relu_mask, M, n, H, (uint16_t *)out, ldo);
+    int rc = check_launch("pool_route_mean_bwd");
+    if (rc != GSAGE_OK || !bias_part) return rc;
+    launch(k_pool_bias_partials_mean, dim3((unsigned)n_part, (unsigned)ceil_div(H, 256)), dim3(256), 0,
+           (hipStream_t)stream, g, ldg, relu_mask, M, n, H, bias_part);
+    return check_launch("pool_bias_partials_mean");
 }
 
 int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, int64_t ldp, int64_t M,

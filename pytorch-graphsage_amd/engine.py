@@ -142,7 +142,8 @@ import ctypes
 import os
 
 from . import ops
-from .nn_modules import IdentityPrep, MaxPoolAggregator, MeanAggregator, SparseUniformNeighborSampler, \
+from .nn_modules import IdentityPrep, MaxPoolAggregator, MeanAggregator, MeanPoolAggregator, \
+    SparseUniformNeighborSampler, \
     _split_activation, concat_combine
 from .store import FeatureStore
 
@@ -838,7 +839,7 @@ def _r64(v):
 
 
 class FusedPoolTrainStep(FusedMeanTrainStep):
-    """train_step for max-pool aggregators (reference nn_modules.py:207-244; BASELINE config 3) with no
+    """train_step for max-pool / mean-pool aggregators (reference nn_modules.py:207-256; BASELINE config 3) with no
     autograd and no framework glue, on the same machinery as FusedMeanTrainStep (flat buckets, fused
     multi-hop sampler, head kernel, finalisation + Adam, command lists, batch queue, data-parallel
     order).  Per level l, rows = hops 0 .. L-l-1 ("x"), neighbour rows = hops 1 .. L-l:
@@ -847,7 +848,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                       fp32 + bf16 operand copy + argmax
                  K5   out[:, :h] = act(x Wx^T);  K5  out[:, h:] = act(pooled Wn^T)
       backward   K5   d pooled = dC[:, h:] Wn            (NT GEMM against the transposed operand copy)
-                 route d pooled through the max / ReLU -> bf16 d hidden [M*n, Hm]   (gsage_pool_route_bwd)
+                 route d pooled through the max / ReLU -> bf16 d hidden [M*n, Hm]   (gsage_pool_route_bwd;
+                       mean pool: g / n where K3's sign mask is set, gsage_pool_route_mean_bwd)
                  bias partials of the MLP                                           (gsage_pool_bias_partials)
                  l > 0: K5 dX = dC[:, :h] Wx, K5 dN = d hidden Wm, merge + ReLU mask -> dC of level l-1
                  K5b  all weight gradients of all levels in one grouped launch (fc_x, fc_neib, mlp)
@@ -860,7 +862,10 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
     @staticmethod
     def supports(model, feats):
         layers = list(model.agg_layers.children())
-        if not layers or not all(type(l) is MaxPoolAggregator and l.combine_fn is concat_combine for l in layers):
+        kinds = {type(l) for l in layers}
+        if not layers or kinds not in ({MaxPoolAggregator}, {MeanPoolAggregator}):
+            return False
+        if not all(l.combine_fn is concat_combine for l in layers):
             return False
         codes = [_split_activation(l.activation)[0] for l in layers]
         if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
@@ -873,12 +878,13 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             return False
         if any(fn.keywords["n_samples"] > 64 for fn in model.train_sample_fns) or len(layers) > 2:
             return False                                     # K3 tiles hold whole segments up to 64 rows
-        return all(l.output_dim_ % 64 == 0 and l.mlp[0].weight.shape[0] % 64 == 0 for l in layers)
+        return all(l.output_dim_ % 64 == 0 and l.mlp[0].weight.shape[0] % 128 == 0 for l in layers)
 
     # ---- construction ------------------------------------------------------------------------------
     def _init_levels(self, example_ids, example_targets):
         feats, dev, L = self.store, self.dev, self.L
         bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+        self.pool_mode = nat.POOL_MAX if type(self.layers[0]) is MaxPoolAggregator else nat.POOL_MEAN
         self.h = [l.output_dim_ for l in self.layers]
         self.Hm = [int(l.mlp[0].weight.shape[0]) for l in self.layers]
         self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
@@ -918,7 +924,9 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             last = l == L - 1
             self.pooled.append(torch.zeros(R, Hm, dtype=f32, device=dev))
             self.pooled_b.append(torch.zeros(R, _r64(Hm), dtype=bf, device=dev))
-            self.argmax.append(torch.zeros(R, Hm, dtype=i32, device=dev))
+            # what the backward needs of the hidden layer: the winning row (max) / the ReLU sign bits (mean)
+            self.argmax.append(torch.zeros(R, Hm, dtype=i32, device=dev) if self.pool_mode == nat.POOL_MAX
+                               else torch.zeros(NR, Hm // 32, dtype=i32, device=dev))
             self.hout.append(torch.zeros(R, 2 * h, dtype=f32 if last else bf, device=dev))
             self.dc.append(torch.zeros(R, 2 * h, dtype=bf, device=dev))
             self.dpool.append(torch.zeros(R, Hm, dtype=f32, device=dev))
@@ -977,11 +985,13 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             for k in range(L - l):                       # one K3 launch per hop: its fan-out is the segment
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
+                is_max = self.pool_mode == nat.POOL_MAX
                 nat.check(lib.gsage_pool_mlp(
                     nb[a0:].data_ptr(), nat.BF16, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
-                    layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, nat.POOL_MAX,
-                    self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr(),
-                    self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1], stream), "pool_mlp")
+                    layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
+                    self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
+                    self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1],
+                    None if is_max else self.argmax[l][a0:].data_ptr(), stream), "pool_mlp")
             x, ldx = self._x_operand(l, s)
             last = l == L - 1
             out, code = self.hout[l], (nat.F32 if last else nat.BF16)
@@ -1010,6 +1020,13 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             for k in range(L - l):
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
+                if self.pool_mode == nat.POOL_MEAN:
+                    nat.check(lib.gsage_pool_route_mean_bwd(self.dpool[l][r0:r1].data_ptr(), Hm,
+                                                            self.argmax[l][a0:].data_ptr(), self.size[k],
+                                                            self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), Hm,
+                                                            self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
+                                                            stream), "pool_route_mean_bwd")
+                    continue
                 nat.check(lib.gsage_pool_route_bwd(self.dpool[l][r0:r1].data_ptr(), Hm, self.pooled[l][r0:r1].data_ptr(),
                                                    Hm, self.argmax[l][r0:r1].data_ptr(), Hm, self.size[k],
                                                    self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), Hm, stream),

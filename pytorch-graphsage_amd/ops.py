@@ -536,7 +536,7 @@ class _PoolMLP(torch.autograd.Function):
         argmax = torch.empty(M, H, dtype=torch.int32, device=A.device) if mode == nat.POOL_MAX else None
         nat.check(nat.lib().gsage_pool_mlp(_ptr(A), _code(cdt), A.stride(0), _ptr(a_rows), _ptr(wa),
                                            wa.stride(0), _ptr(bf), M, n, H, K, mode, _ptr(pooled),
-                                           H, _ptr(argmax), None, 0, _stream()), "pool_mlp")
+                                           H, _ptr(argmax), None, 0, None, _stream()), "pool_mlp")
         ctx.save_for_backward(A, a_rows, wa, bf, pooled, argmax)
         ctx.meta = (M, n, H, K, mode, cdt, neibs.dtype if neibs is not None else None, Wm.dtype, epc)
         return pooled

@@ -90,15 +90,16 @@ def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
 
 @pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((64, 64), (5, 3), 33), ((64,), (7,), 20)])
 @pytest.mark.parametrize("capture", [False, "cmdlist"])
-def test_fused_pool_engine_matches_eager_autograd_path(dims, fans, B, capture):
+@pytest.mark.parametrize("agg", ["max_pool", "mean_pool"])
+def test_fused_pool_engine_matches_eager_autograd_path(dims, fans, B, capture, agg):
     """FusedPoolTrainStep (max-pool aggregators, BASELINE config 3) against GSSupervised.train_step on
     the eager product path: same Philox samples, same K3 forward kernel; the engine's own backward
     (argmax routing, K5 input gradients, grouped K5b) against autograd."""
     adj, feats, rng = _problem()
     D, C = feats.shape[1], 5
     store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
-    ref_model = _model(adj, D, C, dims, fans, agg="max_pool")
-    eng_model = _model(adj, D, C, dims, fans, agg="max_pool")
+    ref_model = _model(adj, D, C, dims, fans, agg=agg)
+    eng_model = _model(adj, D, C, dims, fans, agg=agg)
     eng_model.load_state_dict(ref_model.state_dict())
     ref_model.optimizer = torch.optim.Adam(ref_model.parameters(), lr=0.01, weight_decay=1e-4)
     loss_fn = gs.ProblemLosses.classification
@@ -123,7 +124,7 @@ def test_fused_pool_engine_matches_eager_autograd_path(dims, fans, B, capture):
     tg_all = torch.stack([b[1] for b in batches])
     outs = []
     for queued in (False, True):
-        mdl = _model(adj, D, C, dims, fans, agg="max_pool")
+        mdl = _model(adj, D, C, dims, fans, agg=agg)
         e2 = gs.engine.FusedPoolTrainStep(mdl, store, loss_fn, batches[0][0], batches[0][1], capture=capture)
         if queued:
             e2.load_epoch(ids_all, tg_all)

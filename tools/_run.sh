@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python bench.py --no-cpu-baseline --aggregator max_pool --steps 50 --warmup 5 > gpurun_out/bench_maxpool.log 2>&1; tail -1 gpurun_out/bench_maxpool.log | cut -c1-200; tail -1 gpurun_out/bench_maxpool.log | python -c "import sys,json; print(json.loads(sys.stdin.read())['roofline'])"
-rm -rf gpurun_out/prof_mp
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_mp -o r --output-format csv -- python bench.py --aggregator max_pool --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_mp.log 2>&1
-python tools/timeline.py gpurun_out/prof_mp/r_kernel_trace.csv 60 k_gather_multi_adam > gpurun_out/prof_mp_timeline.txt
-find gpurun_out/prof_mp -name "*kernel_trace*.csv" -size +20M -delete
+python -m pytest tests/test_gpu_engine.py tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider -k "pool" 2>&1 | tail -12
+for a in max_pool mean_pool; do python bench.py --no-cpu-baseline --aggregator $a --steps 30 --warmup 5 2>&1 | grep -E "metric|rror" | cut -c1-200; done
