@@ -30,7 +30,7 @@ def _free_port():
     return port
 
 
-def _build(gs):
+def _build(gs, agg="mean"):
     rng = np.random.RandomState(0)
     n, D, C = 500, 40, 5
     deg = rng.randint(0, 30, size=n + 1)
@@ -46,7 +46,7 @@ def _build(gs):
              {"n_train_samples": 3, "n_val_samples": 3, "output_dim": 128, "activation": lambda x: x}]
     model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj,
                             train_adj=adj, prep_class=gs.prep_lookup["identity"],
-                            aggregator_class=gs.aggregator_lookup["mean"], input_dim=D, n_nodes=n + 1,
+                            aggregator_class=gs.aggregator_lookup[agg], input_dim=D, n_nodes=n + 1,
                             n_classes=C, layer_specs=specs, lr_init=0.01, weight_decay=1e-4)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
     model.train_sampler.seed = model.val_sampler.seed = 77
@@ -59,14 +59,15 @@ def _run(gs, model, feats, ids, tg, ddp):
     gs.ops.set_compute_dtype("bf16")
     gs.ops.warmup(torch.device("cuda"))
     store = gs.FeatureStore.from_array(feats, torch.device("cuda"), dtype="bf16")
-    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids[0], tg[0], ddp=ddp)
+    eng = gs.engine.fused_engine_for(model, store)(model, store, gs.ProblemLosses.classification, ids[0], tg[0],
+                                                    ddp=ddp)
     eng.load_epoch(ids, tg)
     preds = [eng.step_queue().clone() for _ in range(STEPS)]
     torch.cuda.synchronize()
     return torch.stack(preds).cpu(), eng.flat_p.clone().cpu()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, agg):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world),
@@ -74,7 +75,7 @@ def _worker(rank, world, port, out_dir):
     gs = pkg()
     ddp = gs.dist.init_from_env(cuda=True)
     assert ddp is not None and ddp.world == world
-    model, feats, ids, tg = _build(gs)
+    model, feats, ids, tg = _build(gs, agg)
     gs.dist.attach(model, ddp, seed=77)
     lo, hi = rank * B_RANK, (rank + 1) * B_RANK
     preds, w = _run(gs, model, feats, ids[:, lo:hi].contiguous(), tg[:, lo:hi].contiguous(), ddp)
@@ -83,11 +84,12 @@ def _worker(rank, world, port, out_dir):
     ddp.close()
 
 
-def test_two_rank_engine_equals_single_process_global_batch(tmp_path):
+@pytest.mark.parametrize("agg", ["mean", "max_pool"])
+def test_two_rank_engine_equals_single_process_global_batch(tmp_path, agg):
     gs = pkg()
-    model, feats, ids, tg = _build(gs)
+    model, feats, ids, tg = _build(gs, agg)
     ref_preds, ref_w = _run(gs, model, feats, ids, tg, None)
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), agg), nprocs=2, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "r0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "r1.pt"))
     assert torch.equal(r0["w"], r1["w"]), "replicas diverged"
