@@ -53,24 +53,57 @@ __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict_
                                                    float *red)
 {
     const ReduceDesc d = descs[by];
-    const int64_t total = (int64_t)d.rows * d.cols;
     const int64_t gstride = (int64_t)gx * 256;
     float sq = 0.f;
-    for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
-        const int64_t r = t / d.cols;
-        const float *src = d.src + r * d.ld + (t - r * d.cols);
-        float s = 0.f;
-        int i = 0;
-        for (; i + 8 <= d.S; i += 8) {                 // 8 independent loads in flight
-            float v[8];
+    // 16-byte loads whenever the partial buffers allow it (the K5b slabs do: ld, stride % 4 == 0);
+    // a wave-wide load costs the same issue slot whatever its width
+    // -- and the descriptor has enough 4-column chunks to keep every thread of its grid row busy
+    // (small descriptors with many partials want all the threads they can get instead)
+    const bool vec = d.ld % 4 == 0 && d.stride % 4 == 0 && ((uintptr_t)d.src & 15) == 0 &&
+                     (int64_t)d.rows * ((d.cols + 3) / 4) >= gstride / 2;
+    if (vec) {
+        const int cpr = (d.cols + 3) / 4;                  // 4-column chunks per row (last may be ragged)
+        const int64_t total = (int64_t)d.rows * cpr;
+        for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
+            const int64_t r = t / cpr;
+            const int c = (int)(t - r * cpr) * 4;           // c + 3 < ld because ld % 4 == 0 and c < cols <= ld
+            const float *src = d.src + r * d.ld + c;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int i = 0;
+            for (; i + 8 <= d.S; i += 8) {                  // 8 independent 16-byte loads in flight
+                f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(i + u) * d.stride);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; i < d.S; ++i) s += *reinterpret_cast<const f32x4 *>(src + (int64_t)i * d.stride);
+            float *dst = flat_g + d.out_off + r * d.cols + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < d.cols) {
+                    dst[e] = s[e];
+                    sq += s[e] * s[e];
+                }
         }
-        for (; i < d.S; ++i) s += src[(int64_t)i * d.stride];
-        flat_g[d.out_off + t] = s;
-        sq += s * s;
+    } else {
+        const int64_t total = (int64_t)d.rows * d.cols;
+        for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
+            const int64_t r = t / d.cols;
+            const float *src = d.src + r * d.ld + (t - r * d.cols);
+            float s = 0.f;
+            int i = 0;
+            for (; i + 8 <= d.S; i += 8) {                 // 8 independent loads in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; i < d.S; ++i) s += src[(int64_t)i * d.stride];
+            flat_g[d.out_off + t] = s;
+            sq += s * s;
+        }
     }
     const float tot = block_sum_256(sq, red);
     if (threadIdx.x == 0) partial_sq[by * gx + bx] = tot;

@@ -11,9 +11,9 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
+    lds_barrier();              // LDS-only: callers may have global stores in flight that nobody here reads
     if (lane == 0) red[wave] = v;
-    __syncthreads();
+    lds_barrier();
     return red[0] + red[1] + red[2] + red[3];
 }
 

@@ -858,6 +858,9 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
     """
 
     NPART = 256          # partial rows per hop for the MLP bias gradient (summed by the finalisation)
+    # K5b workgroups per problem: the MLP's weight gradient is 20x the work of the two projections that
+    # share its launch, so those take few, long M-slices (fewer partial tiles to write and to sum)
+    WG_TARGET = {"m": 240, "x": 40, "n": 40}
 
     @staticmethod
     def supports(model, feats):
@@ -957,7 +960,7 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             bufs = {}
             for key, prm, M, ntot, K in (("m", layer.mlp[0].weight, NR, Hm, din), ("x", layer.fc_x.weight, R, h, din),
                                          ("n", layer.fc_neib.weight, R, h, Hm)):
-                rps, S, ldk = ops.wgrad_plan(M, ntot, K)
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET[key])
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs[key] = buf
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
@@ -1052,9 +1055,11 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             x, ldx = self._x_operand(l, s)
             nb, ldnb = self._nb_operand(l, s)
             dc = self.dc[l]
-            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"]))
-            probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"]))
-            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"]))
+            T = self.WG_TARGET
+            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"], T["x"]))
+            probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"],
+                          T["n"]))
+            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"]))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)

@@ -297,14 +297,16 @@ def gather_mean_multi(segments, ld, D, out_ld, adam=None):
                                                 _stream()), "gather_mean_multi")
 
 
-def wgrad_plan(M, Ntot, K):
+def wgrad_plan(M, Ntot, K, target=240):
     """(rows_per_split, n_slabs, ldk) used by wgrad.  A workgroup owns one 128 x 128 output tile and
     one M-slice (its four waves quarter the slice and meet in LDS), one workgroup fits per CU, and
     every slice costs a partial tile in HBM: so aim at ~240 workgroups (MI355X: 256 CUs, the rest is
-    left to the small problems sharing a gsage_wgrad_multi launch) and never below 64 rows per wave."""
+    left to the small problems sharing a gsage_wgrad_multi launch) and never below 64 rows per wave.
+    target: workgroups to aim at (small problems that share a launch with a big one take fewer, longer
+    slices: fewer partial tiles to write and to sum)."""
     ldk = _round_up(K, 4)
     tiles = ((Ntot + 127) // 128) * ((ldk + 127) // 128)
-    s_target = max(1, 240 // tiles)
+    s_target = max(1, target // tiles)
     rps = max(256, _round_up((M + s_target - 1) // s_target, 16))
     return rps, (M + rps - 1) // rps, ldk
 
@@ -331,8 +333,9 @@ def wgrad_multi(problems):
     (gsage_finalize_grads sums them).  problems: list of (dC, A, lda, a_gstride, M, Ntot, K,
     n_per_group, slabs) with the meaning of wgrad()."""
     descs = (nat.WgradDesc * len(problems))()
-    for d, (dC, A, lda, a_gs, M, Ntot, K, npg, slabs) in zip(descs, problems):
-        rps, S, ldk = wgrad_plan(M, Ntot, K)
+    for d, prob in zip(descs, problems):
+        dC, A, lda, a_gs, M, Ntot, K, npg, slabs = prob[:9]
+        rps, S, ldk = wgrad_plan(M, Ntot, K, *prob[9:])       # optional 10th entry: workgroup target
         assert tuple(slabs.shape) == (S, Ntot, ldk) and slabs.is_contiguous()
         d.dC, d.A, d.slabs = _ptr(dC), _ptr(A), _ptr(slabs)
         d.ldc, d.lda, d.a_gstride = dC.stride(0), lda, a_gs
