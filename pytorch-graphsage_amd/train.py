@@ -5,8 +5,15 @@ train.py:44-66 with the same defaults, the same seeding order (train.py:81,133),
 per-batch / final / test JSON lines on stdout (train.py:151-157,165-170,174-176) and the
 model repr on stderr, so run.sh / utils/pokec.sh work unchanged.
 
-Additions (all optional): --rng {compat,philox}, --precision {bf16,fp32}, and data-parallel
-execution when launched under torch.distributed.run (one process per GPU, RCCL grad all-reduce).
+Additions (all optional): --rng {compat,philox}, --precision {bf16,fp32}, data-parallel execution
+when launched under torch.distributed.run (one process per GPU, RCCL grad all-reduce), and
+--engine fused: the epoch runs through engine.Fused{Mean,Pool}TrainStep (five kernel launches per
+step for the Reddit mean configuration instead of one framework op per tensor expression).  The
+fused engines need batches of one fixed size, so that mode shuffles with the same numpy stream but
+cuts the permutation into whole batches of --batch-size (the < batch-size tail of an epoch is
+dropped, where the reference's iterate yields n_chunks near-equal chunks, problem.py:141-153) and
+logs every --log-interval batches (the reference parses that flag and logs every batch,
+train.py:64,150-158 -- a host-side sklearn F1 per step).
 """
 from __future__ import division, print_function
 
@@ -78,6 +85,7 @@ def parse_args(argv=None):
     # build-specific (not in the reference)
     parser.add_argument('--rng', type=str, default='compat', choices=['compat', 'philox'])
     parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32'])
+    parser.add_argument('--engine', type=str, default='eager', choices=['eager', 'fused'])
 
     args = parser.parse_args(argv)
     args.cuda = not args.no_cuda
@@ -130,6 +138,8 @@ def main(argv=None):
     start_time = time()
     val_metric = train_metric = None
     epoch = 0
+    if args.engine == 'fused':
+        return train_fused(args, problem, model, ddp, start_time)
     for epoch in range(args.epochs):
         model.train()
         for ids, targets, epoch_progress in problem.iterate(mode='train', shuffle=True,
@@ -150,6 +160,55 @@ def main(argv=None):
 
     print('-- done --', file=sys.stderr)
     if ddp is None or ddp.rank == 0:
+        print(dumps({"epoch": epoch, "train_metric": train_metric, "val_metric": val_metric,
+                     "time": time() - start_time}))
+        sys.stdout.flush()
+        if args.show_test:
+            print(dumps({"test_f1": evaluate(model, problem, mode='test')}))
+    if ddp is not None:
+        ddp.close()
+
+
+def train_fused(args, problem, model, ddp, start_time):
+    """--engine fused: the same training run on the fused engines (see the module docstring)."""
+    assert args.cuda and args.rng == 'philox', '--engine fused needs CUDA and --rng philox'
+    cls = gs.engine.fused_engine_for(model, problem.feats)
+    assert cls is not None, '--engine fused: no fused engine covers this model (use --engine eager)'
+    assert problem.task == 'classification', '--engine fused: classification problems only'
+    world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
+    B = args.batch_size // world                       # per-rank share of the global batch
+    nodes = problem.nodes['train']
+    n_batches = nodes.shape[0] // (B * world)
+    assert n_batches >= 1, '--engine fused: fewer training nodes than one batch'
+    dev = torch.device('cuda')
+
+    def epoch_batches():
+        order = np.random.permutation(np.arange(nodes.shape[0]))[:n_batches * B * world]     # problem.py:146
+        mids = nodes[order].reshape(n_batches, world, B)[:, rank]
+        ids = torch.from_numpy(np.ascontiguousarray(mids)).to(dev)
+        tgs = torch.from_numpy(np.asarray(problem.targets[mids.reshape(-1)]).reshape(n_batches, B)).long().to(dev)
+        return ids, tgs
+    ids, tgs = epoch_batches()
+    step = cls(model, problem.feats, problem.loss_fn, ids[0], tgs[0].view(B, 1), ddp=ddp)
+    val_metric = train_metric = None
+    epoch = 0
+    for epoch in range(args.epochs):
+        model.train()
+        if epoch > 0:
+            ids, tgs = epoch_batches()
+        step.load_epoch(ids, tgs)
+        for b in range(n_batches):
+            step.set_progress((epoch + b / n_batches) / args.epochs)
+            preds = step.step_queue()
+            if (b % max(args.log_interval, 1) == 0 or b == n_batches - 1) and rank == 0:
+                train_metric = problem.metric_fn(to_numpy(tgs[b].view(B, 1)), to_numpy(preds))
+                print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
+                             "val_metric": val_metric, "time": time() - start_time}))
+                sys.stdout.flush()
+        model.eval()
+        val_metric = evaluate(model, problem, mode='val')
+    print('-- done --', file=sys.stderr)
+    if rank == 0:
         print(dumps({"epoch": epoch, "train_metric": train_metric, "val_metric": val_metric,
                      "time": time() - start_time}))
         sys.stdout.flush()

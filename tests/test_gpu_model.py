@@ -159,3 +159,42 @@ def test_full_size_reddit_properties():
     uniq, inv = np.unique(sub, return_inverse=True)
     small = store.data[torch.from_numpy(uniq).to(DEV), :store.dim].float().cpu().numpy()
     close(a[:64].cpu().numpy(), ocpu.gather_mean_f32(small, inv, 64, 10), "oracle spot", 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("agg,dims", [("mean", "128,128"), ("max_pool", "64,64")])
+def test_train_cli_with_fused_engine(tmp_path, capsys, agg, dims):
+    """train.py --engine fused: the reference's command line driving the fused engines through the
+    device batch queue -- a learnable toy problem (class = arg-max feature of the node) must be learnt,
+    and the stdout protocol (one JSON object per logged batch, a final one, train.py:151-170) holds."""
+    import importlib
+    import json
+    import os
+    from scipy import sparse
+    rng = np.random.RandomState(0)
+    n, D, C = 900, 12, 4
+    degs = rng.randint(1, 12, size=n + 1)
+    degs[0] = 0
+    rows = np.repeat(np.arange(n + 1), degs)
+    cols = np.concatenate([np.arange(d) for d in degs])
+    vals = rng.randint(1, n + 1, size=rows.shape[0])
+    adj = sparse.csr_matrix((vals, (rows, cols)))
+    feats = rng.normal(size=(n + 1, D)).astype(np.float32)
+    feats[0] = 0
+    targets = feats[:, :C].argmax(1).reshape(-1, 1)
+    folds = np.array(["train"] * 700 + ["val"] * 150 + ["test"] * 51)
+    folds[0] = "dummy"
+    path = os.path.join(str(tmp_path), "problem.npz")
+    gs.problem.save_problem_npz(path, {"task": "classification", "n_classes": C, "feats": feats, "folds": folds,
+                                       "targets": targets, "sparse": True, "adj": adj, "train_adj": adj})
+    train = importlib.import_module("pytorch-graphsage_amd.train")
+    train.main(["--problem-path", path, "--engine", "fused", "--rng", "philox", "--batch-size", "64",
+                "--epochs", "6", "--lr-init", "0.01", "--sampler-class", "sparse_uniform_neighbor_sampler",
+                "--aggregator-class", agg, "--n-train-samples", "5,3", "--n-val-samples", "5,3",
+                "--output-dims", dims, "--log-interval", "4", "--show-test"])
+    out = [json.loads(l) for l in capsys.readouterr().out.strip().split("\n") if l.startswith("{")]
+    assert "test_f1" in out[-1] and set(out[-2]) == {"epoch", "train_metric", "val_metric", "time"}
+    logged = [o for o in out if "epoch_progress" in o]
+    assert len(logged) >= 6 * 3 and logged[0]["val_metric"] is None
+    first, last = logged[0]["train_metric"]["micro"], out[-2]["train_metric"]["micro"]
+    assert last > max(0.6, first + 0.2), (first, last)           # chance = 0.25
+    assert out[-2]["val_metric"]["micro"] > 0.6
