@@ -122,12 +122,18 @@ def _reddit_like(n_nodes=232965, seed=0):
     return bench.synthetic_reddit(n_nodes=n_nodes, seed=seed)
 
 
-def test_full_size_reddit_properties():
+@pytest.fixture(scope="module")
+def reddit():
+    """the bench's Reddit-shaped synthetic graph + features (built once: ~25 s of host time)"""
+    import bench
+    return bench.synthetic_reddit(seed=0)
+
+
+def test_full_size_reddit_properties(reddit):
     """BASELINE config 2 shapes (N=232 965, D=602, B=512, fanout 25/10): sampled ids are real
     neighbours; gather+mean is linear in the table; means of a constant table are that constant."""
-    import bench
     ops.set_compute_dtype("bf16")
-    data = bench.synthetic_reddit(seed=0)
+    data = reddit
     adj = data["adj"]
     s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="philox", seed=1)
     ids0 = torch.from_numpy(np.random.RandomState(0).randint(1, adj.shape[0], size=512)).to(DEV)
@@ -159,6 +165,58 @@ def test_full_size_reddit_properties():
     uniq, inv = np.unique(sub, return_inverse=True)
     small = store.data[torch.from_numpy(uniq).to(DEV), :store.dim].float().cpu().numpy()
     close(a[:64].cpu().numpy(), ocpu.gather_mean_f32(small, inv, 64, 10), "oracle spot", 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("agg", ["mean", "max_pool"])
+def test_full_size_fused_step_vs_eager_step(reddit, agg):
+    """The exact bench workload (BASELINE configs[1] / [2] shapes: Reddit-sized graph, B = 512, fan-out
+    25/10, hidden 128): one fused-engine step against one step of GSSupervised.train_step on the eager
+    product path from the same weights and the same Philox samples; and size-independent invariants
+    of the step -- the loss gradient w.r.t. the logits sums to zero per row, so d fc.bias sums to 0;
+    gradient clipping bounds the applied update; a second run reproduces the first bit for bit."""
+    import bench
+    ops.set_compute_dtype("bf16")
+    data = reddit
+    dev = torch.device(DEV)
+    store = data["feats"](dev, "bf16")
+    rng = np.random.RandomState(3)
+    pick = rng.randint(0, len(data["train_ids"]), size=(2, 512))
+    ids = torch.from_numpy(data["train_ids"][pick]).to(dev)
+    tg = torch.from_numpy(data["targets"][data["train_ids"][pick]]).to(dev).view(2, 512, 1)
+    loss_fn = gs.ProblemLosses.classification
+
+    def fresh():
+        torch.manual_seed(11)                                  # identical initial weights every time
+        m = bench.build_model(gs, data["adj"], aggregator=agg, rng="philox").to(dev)
+        m.train_sampler.csr(dev)
+        return m
+    ref, mdl = fresh(), fresh()
+    mdl.load_state_dict(ref.state_dict())
+    eng = gs.engine.fused_engine_for(mdl, store)(mdl, store, loss_fn, ids[0], tg[0])
+    w0 = eng.flat_p.clone()
+    p_eng = eng(ids[0], tg[0]).float().cpu().numpy()
+    p_ref = ref.train_step(ids=ids[0], feats=store, targets=tg[0], loss_fn=loss_fn).detach().float().cpu().numpy()
+    close(p_eng, p_ref, "preds at full size", 3e-2, 3e-2)
+    for (k, a), (_, b) in zip(mdl.named_parameters(), ref.named_parameters()):
+        close_fro(a.grad.cpu().numpy(), b.grad.cpu().numpy(), ("grad", k), 0.1)
+    # invariants
+    gb = mdl.fc.bias.grad
+    assert abs(float(gb.sum())) <= 1e-5 * float(gb.abs().sum() + 1e-12)
+    assert float(eng.gnorm) > 0 and np.isfinite(float(eng.gnorm))
+    clipped = float(torch.linalg.vector_norm(eng.flat_g))             # the bucket holds the CLIPPED gradient
+    assert clipped <= 5.0 * (1 + 1e-4) and abs(clipped - min(float(eng.gnorm), 5.0)) <= 1e-3 * clipped + 1e-6
+    assert float((eng.flat_p - w0).abs().max()) <= 0.01 * 1.001      # Adam's first step moves each weight by <= lr
+    mdl.train_sampler.csr(dev).check()
+    # determinism of the whole step (sampling, split reductions, Adam): an identical second engine
+    # reproduces predictions and weights bit for bit
+    outs = []
+    for _ in range(2):
+        m = fresh()
+        e = gs.engine.fused_engine_for(m, store)(m, store, loss_fn, ids[0], tg[0])
+        e.load_epoch(ids, tg)
+        pr = torch.stack([e.step_queue().clone() for _ in range(3)])
+        outs.append((pr, e.flat_p.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("agg,dims", [("mean", "128,128"), ("max_pool", "64,64")])
