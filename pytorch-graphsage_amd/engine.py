@@ -757,6 +757,10 @@ class FusedMeanTrainStep(object):
             self.g_main[0].replay()
         else:
             self._stage_compute(0)
+        # Order matters: the collective is submitted BEFORE the gathers.  Submitted after them (from a
+        # side stream that only waits for the gradients, which would hide the ~25 us the collective
+        # call costs the host) it did not start until the 8 320-workgroup gather launch had been
+        # dispatched completely -- no overlap at all (tools/overlap_check.py).
         work = self._all_reduce(async_op=True)
         if rec:                                      # batch i+1's gathers overlap the exchange
             self.g_qfront.replay()
