@@ -56,7 +56,6 @@ struct LinearParams {
     int64_t pooled_ld;
     int32_t *argmax;
     uint32_t *relu_mask;   // optional [M, N/32] sign bits of the bias+ReLU'd tile (mean-pool backward)
-    int32_t dbg;           // GSAGE_DBG ablation switches (tools/kbench.py only): 1 no MFMA, 2 no DMA, 4 no stores
 };
 
 constexpr int BM = 64;
@@ -107,7 +106,7 @@ __device__ __forceinline__ float apply_act(float v, int act)
 // Epilogue shared by both K5 kernels: bias + activation, then the 64x128 tile goes through LDS
 // so that global memory sees full 16-byte row chunks (256 B contiguous per 16 lanes) instead of the
 // MFMA layout's 2-byte column-per-lane scatter -- the scatter alone cost ~5.5 us per launch at the
-// layer-0 shape (ablation: tools/kbench.py linK with GSAGE_DBG=4).  Falls back to per-element
+// layer-0 shape (measured by ablating the stores).  Falls back to per-element
 // stores when the output rows are not 16-byte chunk aligned or the tile is ragged in N.
 // C/D layout of the 32x32 MFMA: lane l, register r -> column (l & 31),
 // row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
@@ -121,7 +120,7 @@ __device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t
     const int epc = 16 / esz;                                    // output elements per 16-byte chunk
     const int64_t cbase = (int64_t)g * p.c_gstride + n0;         // first output column of the tile
     const bool wide = n0 + BN <= p.N && p.ldc % epc == 0 && cbase % epc == 0 &&
-                      ((uintptr_t)p.C % 16) == 0 && !(p.dbg & 8);
+                      ((uintptr_t)p.C % 16) == 0;
     if (wide) {
         __syncthreads();                                         // operand buffers are free now
         const int ldt = BN + epc;                                // padded row, still 16-byte aligned
@@ -162,7 +161,7 @@ __device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int64_t m = m0 + wm * 32 + i;
-            if (m < p.M && j < p.N && !((p.dbg & 4) && acc[r] != 12345.f)) {
+            if (m < p.M && j < p.N) {
                 const float v = apply_act(acc[r] + bj, ACT);
                 const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
                 if (p.c_dtype == GSAGE_BF16)
@@ -438,7 +437,7 @@ k_linear_nt_dma(const LinearParams p)
         // ... and after the barrier so have everybody's; it also proves every wave is done
         // reading the buffer tile kt+2 is about to overwrite (it was tile kt-1's)
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk && !(p.dbg & 2)) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
+        if (kt + 2 < nk) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
         const vec16 *sA = smem + buf * TILE;
         const vec16 *sW = sA + BM * CH;
         // all 12 fragment reads of the tile first (one LDS latency per tile instead of one per
@@ -453,15 +452,10 @@ k_linear_nt_dma(const LinearParams p)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done: this buffer may be
         __builtin_amdgcn_sched_barrier(0);                       // overwritten after the next barrier
-        if (!(p.dbg & 1)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
-                mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { acc0[kk] += __uint_as_float(fa[kk][0] ^ fb0[kk][1]); acc1[kk] += __uint_as_float(fb1[kk][2]); }
+        for (int kk = 0; kk < 4; ++kk) {
+            mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
+            mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
@@ -510,7 +504,6 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     p.a_rows_group0_only = a_rows_group0_only; p.act = act; p.c_dtype = c_dtype;
     p.pool_n = 0; p.pool_groups = 0; p.pool_mode = 0; p.pooled = nullptr; p.pooled_ld = 0;
     p.argmax = nullptr; p.relu_mask = nullptr;
-    { static const char *e = getenv("GSAGE_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
     // whole-line operand rows -> LDS-DMA pipelined kernel
@@ -570,7 +563,7 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     p.a_gstride = 0; p.w_gstride = 0; p.c_gstride = 0;
     p.a_rows_group0_only = 0; p.act = ACT_RELU; p.c_dtype = GSAGE_F32;
     p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled;
-    p.pooled_ld = pooled_ld; p.argmax = argmax; p.relu_mask = relu_mask; p.dbg = 0;
+    p.pooled_ld = pooled_ld; p.argmax = argmax; p.relu_mask = relu_mask;
     dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, BN), 1);
     if (dtype == GSAGE_BF16)
         launch(k_linear_nt<uint16_t, true, ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p);
