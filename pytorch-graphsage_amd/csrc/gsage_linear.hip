@@ -348,7 +348,7 @@ k_linear_nt(const LinearParams p)
 //
 // Same tile, same LDS image and same MFMA loop as k_linear_nt, but the tiles travel global -> LDS
 // with `global_load_lds_dwordx4` (no staging VGPRs, no ds_write pass) through a 3-buffer ring:
-//     wait vmcnt(6) -> s_barrier -> issue tile kt+2 -> MFMAs on tile kt
+//     wait vmcnt(6) -> s_barrier -> issue tile kt+3 -> read fragments of tile kt+1 -> MFMAs on tile kt
 // i.e. ONE barrier per K-tile and two tiles (48 KiB per workgroup) in flight across it.  hipcc
 // cannot express "wait for the older of two in-flight tiles" across a barrier by itself (it drains
 // to vmcnt(0)), hence the raw s_barrier + explicit counted waits (CDNA guide, "Pipelining across
@@ -427,22 +427,17 @@ k_linear_nt_dma(const LinearParams p)
     const int arow = wm * 32 + (lane & 31);
     const int wrow0 = wn * 64 + (lane & 31), wrow1 = wrow0 + 32;
 
-    issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // my own DMAs of tile kt have landed (tile kt+1 may still be in flight) ...
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and after the barrier so have everybody's; it also proves every wave is done
-        // reading the buffer tile kt+2 is about to overwrite (it was tile kt-1's)
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);
-        const vec16 *sA = smem + buf * TILE;
+    // Fragment reads run ONE tile ahead of the MFMAs (two static register sets, loop unrolled x 2):
+    // with the reads and the MFMAs of the same tile back to back, LDS bandwidth (96 KiB per k-tile
+    // and CU) and the MFMA pipe took turns instead of overlapping.  Step kt:
+    //     wait: my DMAs of tile kt+1 landed, my fragment reads of tile kt completed
+    //     s_barrier                      -> everybody's did; tile kt's buffer is free
+    //     issue tile kt+3 into it        -> still two tiles in flight across the barrier
+    //     read fragments of tile kt+1    (no wait)
+    //     MFMAs of tile kt               (fragments read during step kt-1)
+    auto read_frags = [&](int b, vec16 (&fa)[4], vec16 (&fb0)[4], vec16 (&fb1)[4]) {
+        const vec16 *sA = smem + b * TILE;
         const vec16 *sW = sA + BM * CH;
-        // all 12 fragment reads of the tile first (one LDS latency per tile instead of one per
-        // MFMA pair), then the 8 MFMAs back to back
-        vec16 fa[4], fb0[4], fb1[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ch = kk * 2 + (lane >> 5);
@@ -450,14 +445,47 @@ k_linear_nt_dma(const LinearParams p)
             fb0[kk] = sW[lds_slot(wrow0, ch)];
             fb1[kk] = sW[lds_slot(wrow1, ch)];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done: this buffer may be
-        __builtin_amdgcn_sched_barrier(0);                       // overwritten after the next barrier
+    };
+    auto mma_tile = [&](const vec16 (&fa)[4], const vec16 (&fb0)[4], const vec16 (&fb1)[4]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
             mma_chunk<T>::run(fa[kk], fb1[kk], acc1);
         }
+    };
+    vec16 xa[4], xb0[4], xb1[4], ya[4], yb0[4], yb1[4];
+    auto step = [&](int kt, int b, vec16 (&ca)[4], vec16 (&cb0)[4], vec16 (&cb1)[4], vec16 (&na)[4],
+                    vec16 (&nb0)[4], vec16 (&nb1)[4]) {
+        // my fragment reads of tile kt are complete (the builtin, not inline asm, and on every path:
+        // the compiler's own wait insertion then knows the current set is ready and does not drain
+        // the reads issued below before the MFMAs)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) issue_tile(kt + 3, b);               // tile kt's own buffer
+            read_frags(b == 2 ? 0 : b + 1, na, nb0, nb1);
+        }
+        mma_tile(ca, cb0, cb1);
+    };
+
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    if (nk > 2) issue_tile(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, xa, xb0, xb1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, buf, xa, xb0, xb1, ya, yb0, yb1);
         buf = buf == 2 ? 0 : buf + 1;
+        if (kt + 1 < nk) {
+            step(kt + 1, buf, ya, yb0, yb1, xa, xb0, xb1);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
     }
 
     store_tile<ACT>(p, acc0, acc1, g, m0, n0, wm, wn, lane, tid, smem);
