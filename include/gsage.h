@@ -300,6 +300,15 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
                          const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
                          int32_t n, int64_t Ha, int64_t D, float *agg, int64_t agg_ld, float *ws,
                          void *stream);
+/* Backward of the weighting w.r.t. att(neibs) and att(x), one launch (autograd of the three lines
+ * above):  dws[i,r] = <neibs[i*n+r,:], g[i,:]>;  ds = ws * (dws - sum_r dws*ws);
+ *          dxa[i,:] = sum_r ds[i,r] * na[i*n+r,:];   dna[i*n+r,:] = ds[i,r] * xa[i,:].
+ * g: fp32 [M, g_ld] gradient of agg.  Rows must be whole 16-byte chunks (ld % 8 == 0 bf16 / % 4 == 0
+ * fp32, 16-byte aligned table); n <= 32. */
+int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *na, int64_t na_ld,
+                   const float *xa, int64_t xa_ld, const void *table, int dtype, int64_t ld,
+                   const int64_t *ids, int64_t M, int32_t n, int64_t Ha, int64_t D, float *dna,
+                   int64_t dna_ld, float *dxa, int64_t dxa_ld, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Classification head, forward + backward   replaces F.normalize(dim=1) -> fc -> F.cross_entropy

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gsage_pool_merge_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_aggregate": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
                                     _i64, _vp, _i64, _vp, _vp]),
+    "gsage_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64, _i64,
+                              _vp, _i64, _vp, _i64, _vp]),
 }
 
 

@@ -74,9 +74,207 @@ k_attn_aggregate(const float *__restrict__ na, int64_t na_ld, const float *__res
     }
 }
 
+// ---- wide variants: 16-byte lanes, all of a batch of neighbour rows in flight ------------------------
+// The kernel above is the general fallback (any D / ld / alignment): one 2-byte or 4-byte column per
+// lane and one dependent (id -> row) round trip per neighbour, ~10 % of the HBM roofline at Reddit
+// shapes.  Whenever rows are whole 16-byte chunks (FeatureStore tables, hidden activations) the
+// kernels below run instead: still one wavefront per parent row (its softmax lives in the lanes), but
+// lanes own 16-byte column chunks and up to 8 neighbour rows are requested before any is consumed.
+template <typename T, int VEC>
+__device__ __forceinline__ void chunk_to_f32(const vec16 &raw, float (&f)[VEC]);
+template <>
+__device__ __forceinline__ void chunk_to_f32<uint16_t, 8>(const vec16 &raw, float (&f)[8])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w = raw[e >> 1];
+        f[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+}
+template <>
+__device__ __forceinline__ void chunk_to_f32<float, 4>(const vec16 &raw, float (&f)[4])
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(raw[e]);
+}
+
+// lane r < n: s[r] = <na[i*n + r, :], xa[i, :]>, then w = softmax over the n lanes
+__device__ __forceinline__ float attn_weights(const float *__restrict__ na, int64_t na_ld,
+                                              const float *__restrict__ xa, int64_t xa_ld, int64_t i, int32_t n,
+                                              int32_t Ha, int lane)
+{
+    float mine = -INFINITY;
+    if (lane < n) {
+        const float *a = na + (i * n + lane) * na_ld;
+        const float *x = xa + i * xa_ld;
+        float s = 0.f;
+        if ((Ha & 3) == 0 && (na_ld & 3) == 0 && (xa_ld & 3) == 0 && (((uintptr_t)na | (uintptr_t)xa) & 15) == 0) {
+            for (int h = 0; h < Ha; h += 4) {
+                const float4 av = *reinterpret_cast<const float4 *>(a + h);
+                const float4 xv = *reinterpret_cast<const float4 *>(x + h);
+                s += av.x * xv.x + av.y * xv.y + av.z * xv.z + av.w * xv.w;
+            }
+        } else {
+            for (int h = 0; h < Ha; ++h) s += a[h] * x[h];
+        }
+        mine = s;
+    }
+    const float mx = wave_max(mine);
+    const float e = (lane < n) ? expf(mine - mx) : 0.f;
+    return e / wave_sum(e);
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_attn_aggregate_wide(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa,
+                      int64_t xa_ld, const T *__restrict__ table, int64_t ld,
+                      const int64_t *__restrict__ ids, int64_t M, int32_t n, int32_t Ha, int32_t D,
+                      float *__restrict__ agg, int64_t agg_ld, float *__restrict__ ws)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;                                                 // wave-uniform exit
+    const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
+    if (lane < n) ws[i * n + lane] = w;
+    const int chunks = (D + VEC - 1) / VEC;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {                            // wave-uniform trip count
+        const int c = c0 + lane < chunks ? c0 + lane : chunks - 1;       // clamped: loads stay unconditional
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            int64_t row[8];
+            vec16 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < n ? j0 + u : n - 1;
+                row[u] = ids ? ids[i * n + j] : i * n + j;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const vec16 *>(table + row[u] * ld + c * VEC);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float wj = j0 + u < n ? __shfl(w, j0 + u < n ? j0 + u : 0, 64) : 0.f;
+                float f[VEC];
+                chunk_to_f32<T, VEC>(raw[u], f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += wj * f[e];
+            }
+        }
+        if (c0 + lane < chunks) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (c * VEC + e < D) agg[i * agg_ld + c * VEC + e] = acc[e];
+        }
+    }
+}
+
+// Backward of the weighting in one launch (autograd of nn_modules.py:309-315 w.r.t. att(neibs) and
+// att(x)): dws[j] = <row_j, g_i>, ds = softmax backward, dxa[i,:] = sum_j ds[j] na[i,j,:],
+// dna[i,j,:] = ds[j] xa[i,:].  n <= NMAX (per-neighbour partial dots live in registers).
+template <typename T, int VEC, int NMAX>
+__global__ void __launch_bounds__(256)
+k_attn_bwd_wide(const float *__restrict__ g, int64_t g_ld, const float *__restrict__ ws,
+                const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
+                const T *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M,
+                int32_t n, int32_t Ha, int32_t D, float *__restrict__ dna, int64_t dna_ld,
+                float *__restrict__ dxa, int64_t dxa_ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    float p[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) p[j] = 0.f;
+    const int chunks = (D + VEC - 1) / VEC;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const bool live = c0 + lane < chunks;
+        const int c = live ? c0 + lane : chunks - 1;
+        float gv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gv[e] = (live && c * VEC + e < D) ? g[i * g_ld + c * VEC + e] : 0.f;
+#pragma unroll
+        for (int j0 = 0; j0 < NMAX; j0 += 8) {
+            if (j0 < n) {                                               // wave-uniform
+                int64_t row[8];
+                vec16 raw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u < n ? j0 + u : n - 1;
+                    row[u] = ids ? ids[i * n + j] : i * n + j;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const vec16 *>(table + row[u] * ld + c * VEC);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float f[VEC], d = 0.f;
+                    chunk_to_f32<T, VEC>(raw[u], f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) d += f[e] * gv[e];
+                    p[j0 + u] += d;                                     // (rows >= n repeat row n-1: never read)
+                }
+            }
+        }
+    }
+    // lane j keeps dws[j]; softmax backward
+    float dws = 0.f;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < n) {
+            const float t = wave_sum(p[j]);
+            if (lane == j) dws = t;
+        }
+    const float w = lane < n ? ws[i * n + lane] : 0.f;
+    const float dot = wave_sum(dws * w);
+    const float ds = w * (dws - dot);
+    for (int h = lane; h < Ha; h += 64) {
+        const float xh = xa[i * xa_ld + h];
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float dsj = __shfl(ds, j, 64);
+            acc += dsj * na[(i * n + j) * na_ld + h];
+            dna[(i * n + j) * dna_ld + h] = dsj * xh;
+        }
+        dxa[i * dxa_ld + h] = acc;
+    }
+}
+
 }  // namespace gsage
 
 using namespace gsage;
+
+template <typename T, int VEC>
+static bool attn_wide_ok(const void *table, int64_t ld, int64_t D)
+{
+    return ld % VEC == 0 && ((uintptr_t)table % 16) == 0 && ceil_div(D, VEC) * VEC <= ld;
+}
+
+extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *na, int64_t na_ld,
+                              const float *xa, int64_t xa_ld, const void *table, int dtype, int64_t ld,
+                              const int64_t *ids, int64_t M, int32_t n, int64_t Ha, int64_t D, float *dna,
+                              int64_t dna_ld, float *dxa, int64_t dxa_ld, void *stream)
+{
+    GSAGE_REQUIRE(n >= 1 && n <= 32, "attn_bwd: fanout must be in [1, 32]");
+    GSAGE_REQUIRE(M >= 0 && Ha > 0 && D > 0, "attn_bwd: bad sizes");
+    GSAGE_REQUIRE(g_ld >= D && na_ld >= Ha && xa_ld >= Ha && dna_ld >= Ha && dxa_ld >= Ha && ld >= D,
+                  "attn_bwd: leading dimension too small");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(g && ws && na && xa && table && dna && dxa, "attn_bwd: null pointer");
+    dim3 grid((unsigned)ceil_div(M, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
+        launch(k_attn_bwd_wide<uint16_t, 8, 32>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld);
+    else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D))
+        launch(k_attn_bwd_wide<float, 4, 32>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld);
+    else {
+        set_error("attn_bwd: rows must be whole 16-byte chunks of bf16 / fp32 (ld %% %d == 0, aligned)",
+                  dtype == GSAGE_BF16 ? 8 : 4);
+        return GSAGE_EINVAL;
+    }
+    return check_launch("attn_bwd");
+}
 
 extern "C" int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld,
                                     const void *table, int dtype, int64_t ld, const int64_t *ids,
@@ -90,6 +288,16 @@ extern "C" int gsage_attn_aggregate(const float *na, int64_t na_ld, const float 
     if (M == 0) return GSAGE_OK;
     GSAGE_REQUIRE(na && xa && table && agg && ws, "attn_aggregate: null pointer");
     dim3 grid((unsigned)ceil_div(M, 4));
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D)) {
+        launch(k_attn_aggregate_wide<uint16_t, 8>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
+               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws);
+        return check_launch("attn_aggregate");
+    }
+    if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D)) {
+        launch(k_attn_aggregate_wide<float, 4>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
+               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws);
+        return check_launch("attn_aggregate");
+    }
     if (dtype == GSAGE_F32)
         launch(k_attn_aggregate<float>, grid, dim3(256), 0, (hipStream_t)stream, na,
                            na_ld, xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha,

@@ -631,7 +631,23 @@ class _AttnAggregate(torch.autograd.Function):
     def backward(ctx, g):
         na, xa, T, rows_ids, ws = ctx.saved_tensors
         M, n, D, ndt = ctx.meta
-        g = g.float()
+        g = g.float().contiguous()
+        vec = 8 if T.dtype == torch.bfloat16 else 4
+        wide = (T.dtype in (torch.bfloat16, torch.float32) and n <= 32 and T.stride(0) % vec == 0 and
+                T.data_ptr() % 16 == 0 and _round_up(D, vec) <= T.stride(0))
+        if wide:
+            # dws, the softmax backward and both products in one launch; the rows are read once, in
+            # storage precision, straight from the table
+            Ha = na.shape[1]
+            dna = torch.empty(M * n, Ha, dtype=torch.float32, device=g.device)
+            dxa = torch.empty(M, Ha, dtype=torch.float32, device=g.device)
+            nat.check(nat.lib().gsage_attn_bwd(_ptr(g), g.stride(0), _ptr(ws), _ptr(na), na.stride(0), _ptr(xa),
+                                               xa.stride(0), _ptr(T), _code(T.dtype), T.stride(0), _ptr(rows_ids),
+                                               M, n, Ha, D, _ptr(dna), Ha, _ptr(dxa), Ha, _stream()), "attn_bwd")
+            dneibs = None
+            if ctx.needs_input_grad[2]:
+                dneibs = (ws.unsqueeze(2) * g.unsqueeze(1)).reshape(M * n, D).to(ndt)
+            return dna, dxa, dneibs, None, None, None, None, None
         rows = T if rows_ids is None else _gather_mean_raw(T, D, rows_ids, M * n, 1, torch.float32)
         rows = rows[:, :D].float().view(M, n, D)
         dws = torch.bmm(rows, g.unsqueeze(2)).squeeze(2)                    # [M, n]
