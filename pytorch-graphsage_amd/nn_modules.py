@@ -329,6 +329,19 @@ class AttentionAggregator(nn.Module, AggregatorMixin):
         self.activation = activation
         self.combine_fn = combine_fn
 
+    @staticmethod
+    def _rows(t):
+        """Operand of the att MLP.  Lazy feature rows of a bf16 table are gathered ONCE, in storage
+        precision and with the table's zero padding, i.e. already in the layout K5 wants (the generic
+        route materialises fp32 rows and re-casts them: 3x the bytes and two extra passes)."""
+        if isinstance(t, RowRef) and t.store.data.is_cuda and t.store.data.dtype == torch.bfloat16 \
+                and ops.config.compute_dtype == "bf16":
+            st = t.store
+            ids = t.ids.contiguous().view(-1)
+            buf = ops._gather_mean_raw(st.data, st.ld, ids, int(ids.shape[0]), 1, torch.bfloat16, st.ld)
+            return buf[:, :st.dim]
+        return _as_tensor(t)
+
     def _att(self, t):
         hid = ops.linear(t, self.att[0].weight, None, nat.ACT_TANH)
         return ops.linear(hid, self.att[2].weight)
@@ -339,7 +352,7 @@ class AttentionAggregator(nn.Module, AggregatorMixin):
         # the reference's bare .squeeze() (nn_modules.py:311) changes meaning for M == 1 or
         # fanout == 1 (train.py:75 forbids batch 1); refuse instead of silently diverging
         assert M > 1 and n > 1, "AttentionAggregator: needs batch > 1 and fanout > 1"
-        xt, nt = _as_tensor(x), _as_tensor(neibs)
+        xt, nt = self._rows(x), self._rows(neibs)
         agg = ops.attn_aggregate(self._att(nt), self._att(xt), neibs if isinstance(neibs, RowRef)
                                  else nt, M)
         return self._project(x, agg)

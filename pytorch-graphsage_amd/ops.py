@@ -83,6 +83,8 @@ def _pad_cast(t, dtype, mult):
     ld = _round_up(D, mult)
     if t.dtype == dtype and ld == D and t.is_contiguous():
         return t
+    if t.dtype == dtype and t.stride(1) == 1 and t.stride(0) == ld and t.data_ptr() % 16 == 0:
+        return t              # [:, :D] view of rows that are already padded (pad columns zero: gathered rows)
     out = torch.zeros(M, ld, dtype=dtype, device=t.device) if ld != D else \
         torch.empty(M, ld, dtype=dtype, device=t.device)
     out[:, :D] = t
