@@ -268,7 +268,16 @@ k_reduce_slabs(const float *__restrict__ slabs, int32_t S, int64_t Ntot, int64_t
         const int64_t k = t - n * K;
         const float *src = slabs + n * ldk + k;
         float s = 0.f;
-        for (int i = 0; i < S; ++i) s += src[(int64_t)i * Ntot * ldk];
+        const int64_t sstride = Ntot * ldk;
+        int i = 0;
+        for (; i + 8 <= S; i += 8) {                       // 8 independent loads in flight (same order of sums)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * sstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < S; ++i) s += src[(int64_t)i * sstride];
         const int64_t g = n / n_per_group;
         out[g * out_gstride + (n - g * n_per_group) * K + k] = s;
     }
