@@ -10,7 +10,7 @@ surface of bkj/pytorch-graphsage.  Directory name has a hyphen: import it with
                               same names and interfaces as the reference's files
     dist.py, engine.py        RCCL data-parallel gradient sync, hipGraph-captured train step
 """
-from . import _native, dist, engine, nn_modules, ops, store                                   # noqa: F401
+from . import _native, dist, engine, nn_modules, ops, optim, store                                   # noqa: F401
 from .helpers import set_seeds, to_numpy                            # noqa: F401
 from .lr import LRSchedule                                          # noqa: F401
 from .models import GSSupervised                                    # noqa: F401

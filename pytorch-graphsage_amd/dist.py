@@ -40,6 +40,12 @@ class DataParallel(object):
     # ---- gradient exchange -------------------------------------------------------------------
     def sync(self, model):
         """Average gradients across ranks with one all-reduce of one flat fp32 bucket."""
+        opt = getattr(model, "optimizer", None)
+        if hasattr(opt, "flat_g") and opt.owns():
+            # optim.FlatAdam: the gradients already ARE one flat bucket -- no copy in, no copy out
+            opt.flat_g.div_(self.world)
+            dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM)
+            return
         params = [p for p in model.parameters() if p.requires_grad]
         total = sum(p.numel() for p in params)
         if self._flat is None or self._flat.numel() != total or self._flat.device != params[0].device:

@@ -28,13 +28,17 @@ class CapturedTrainStep(object):
         self.targets = example_targets.clone()
         dev = self.ids.device
 
-        # Adam with device-side step count and a tensor learning rate (set_progress fills it)
+        # clip + Adam over flat buckets (optim.FlatAdam: step count and learning rate live on the
+        # device, two launches, capturable; the gradient bucket is also what data-parallel runs exchange)
+        from .optim import FlatAdam
         old = model.optimizer
-        wd = old.param_groups[0].get("weight_decay", 0.0)
-        self.lr = torch.tensor(float(model.lr), device=dev)
-        model.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr, weight_decay=wd,
-                                           capturable=True)
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not isinstance(old, FlatAdam):
+            wd = old.param_groups[0].get("weight_decay", 0.0)
+            model.optimizer = FlatAdam([p for p in model.parameters() if p.requires_grad],
+                                       lr=float(model.lr), weight_decay=wd)
+        self.opt = model.optimizer
+        self.lr = self.opt.lr_t
+        self.params = self.opt.params
 
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.samplers = [s for s in (model.train_sampler,) if hasattr(s, "begin_capture")]
@@ -42,10 +46,7 @@ class CapturedTrainStep(object):
             assert s.rng == "philox", "captured steps need the counter-based sampler (rng='philox')"
             s.begin_capture(self.counter)
 
-        self.flat = None
-        if ddp is not None:
-            self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32,
-                                    device=dev)
+        self.flat = self.opt.flat_g if ddp is not None else None
 
         # warm-up on a side stream (allocator, lazy Adam state, library handles), then put weights,
         # optimizer state and the sample counter back so the captured run starts from step 0
@@ -63,10 +64,8 @@ class CapturedTrainStep(object):
         with torch.no_grad():
             for p, q in zip(self.params, saved):
                 p.copy_(q)
-            for st in model.optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            for t in (self.opt.flat_m, self.opt.flat_v, self.opt.step_count):
+                t.zero_()
             self.counter.zero_()
         torch.cuda.synchronize()
 
@@ -86,32 +85,21 @@ class CapturedTrainStep(object):
         m = self.model
         for s in self.samplers:
             s._static_calls = 0
-        m.optimizer.zero_grad(set_to_none=True)
+        self.opt.zero_grad()
         preds = m(self.ids, self.feats, train=True)
         loss = self.loss_fn(preds, self.targets.squeeze())
         loss.backward()
         if self.ddp is None:
             self._finish()
         else:
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
-            self.flat.div_(self.ddp.world)
+            self.flat.div_(self.ddp.world)         # the gradients already are one flat bucket
         return preds
 
     def _back(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
         self._finish()
 
     def _finish(self):
-        torch.nn.utils.clip_grad_norm_(self.params, 5)
-        self.model.optimizer.step()
+        self.opt.clip_and_step(5.0)
         calls = sum(s.calls_in_capture() for s in self.samplers)
         if calls:
             nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), calls,
@@ -121,6 +109,8 @@ class CapturedTrainStep(object):
     # ---- per-batch entry ----------------------------------------------------------------------
     def set_progress(self, progress):
         self.model.lr = self.model.lr_scheduler(progress)
+        self.opt.param_groups[0]["lr"] = float(self.model.lr)
+        self.opt._lr_seen = float(self.model.lr)
         self.lr.fill_(float(self.model.lr))
 
     def __call__(self, ids, targets):

@@ -14,8 +14,11 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+import os
+
 from . import ops
 from .lr import LRSchedule
+from .optim import FlatAdam
 from .store import FeatureStore
 
 
@@ -49,6 +52,7 @@ class GSSupervised(nn.Module):
         self.lr_scheduler = partial(getattr(LRSchedule, lr_schedule), lr_init=lr_init)
         self.lr = self.lr_scheduler(0.0)
         self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=weight_decay)
+        self._init_optimizer = self.optimizer
 
         self.grad_sync = None                 # set by dist.attach(): called after backward
         self._wrapped = {}
@@ -87,13 +91,37 @@ class GSSupervised(nn.Module):
         self.lr = self.lr_scheduler(progress)
         LRSchedule.set_lr(self.optimizer, self.lr)
 
+    def _flat_optimizer(self):
+        """On the GPU the optimizer built in __init__ (torch.optim.Adam, never stepped yet) is replaced,
+        on the first train_step, by optim.FlatAdam: same arithmetic, Parameters and gradients become
+        views of flat buckets, clip + Adam become two launches.  An optimizer assigned from outside,
+        one that has state already, CPU parameters or GSAGE_TORCH_ADAM=1 keep the stock route."""
+        opt = self.optimizer
+        if isinstance(opt, FlatAdam):
+            if not opt.owns():                    # somebody re-pointed the Parameters (e.g. a fused engine)
+                opt._attach()
+            return opt
+        if opt is not self._init_optimizer or opt.state or os.environ.get("GSAGE_TORCH_ADAM", "0") == "1":
+            return None
+        params = [p for p in self.parameters() if p.requires_grad]
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return None
+        g = opt.param_groups[0]
+        self.optimizer = FlatAdam(params, lr=g["lr"], weight_decay=g.get("weight_decay", 0.0),
+                                  betas=g.get("betas", (0.9, 0.999)), eps=g.get("eps", 1e-8))
+        return self.optimizer
+
     def train_step(self, ids, feats, targets, loss_fn):
+        flat = self._flat_optimizer()
         self.optimizer.zero_grad()
         preds = self(ids, feats, train=True)
         loss = loss_fn(preds, targets.squeeze())
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(self)
-        torch.nn.utils.clip_grad_norm_(self.parameters(), 5)
-        self.optimizer.step()
+        if flat is not None:
+            flat.clip_and_step(5.0)               # models.py:101-102 in two launches
+        else:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), 5)
+            self.optimizer.step()
         return preds

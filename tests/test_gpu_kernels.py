@@ -485,3 +485,36 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
     sc = max(float(ref.abs().max()), 1e-30)
     assert float((got - ref).abs().max()) <= 2 ** -8 * sc + 1e-12, "dH beyond one bf16 rounding"
     assert bool(((got == 0) == (ref == 0)).all()) or float((got - ref).abs().max()) <= 2 ** -8 * sc
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-3])
+def test_flat_adam_equals_torch_clip_plus_adam(wd):
+    """optim.FlatAdam (Parameters as views of flat buckets, clip + Adam in two launches) against
+    torch.nn.utils.clip_grad_norm_(params, 5) + torch.optim.Adam over 6 steps: gradients large enough
+    to be clipped on some steps and not on others, a learning-rate change in between."""
+    torch.manual_seed(0)
+    shapes = [(37, 19), (128,), (5, 64, 3), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt_r = torch.optim.Adam(ref, lr=0.01, weight_decay=wd)
+    opt_m = gs.optim.FlatAdam(mine, lr=0.01, weight_decay=wd)
+    assert opt_m.owns() and all(torch.equal(a, b) for a, b in zip(ref, mine))
+    for step in range(6):
+        scale = [0.01, 3.0, 0.2, 10.0, 0.001, 1.0][step]
+        grads = [torch.randn(*s, device=DEV) * scale for s in shapes]
+        opt_r.zero_grad()
+        opt_m.zero_grad()
+        for p, q, g in zip(ref, mine, grads):
+            p.grad = g.clone()
+            q.grad.add_(g)                                   # in place, as autograd accumulates
+        if step == 3:
+            gs.LRSchedule.set_lr(opt_r, 0.003)
+            gs.LRSchedule.set_lr(opt_m, 0.003)
+        total = torch.nn.utils.clip_grad_norm_(ref, 5)
+        opt_r.step()
+        opt_m.clip_and_step(5.0)
+        assert abs(float(opt_m.grad_norm) - float(total)) <= 1e-5 * float(total)
+        for p, q in zip(ref, mine):
+            close(q.detach().cpu().numpy(), p.detach().cpu().numpy(), ("weights", step), 2e-6, 2e-7)
+            close(q.grad.cpu().numpy(), p.grad.cpu().numpy(), ("clipped grad", step), 2e-6, 1e-7)
+    assert int(opt_m.step_count) == 6
