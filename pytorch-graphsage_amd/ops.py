@@ -196,6 +196,7 @@ class _GatherTrainable(torch.autograd.Function):
     def forward(ctx, table, ids):
         ctx.save_for_backward(ids)
         ctx.tshape = table.shape
+        ctx.table = table if (table.is_leaf and table.requires_grad) else None
         return _gather_mean_raw(table.detach(), table.shape[1], ids, int(ids.shape[0]), 1,
                                 torch.float32)
 
@@ -203,6 +204,17 @@ class _GatherTrainable(torch.autograd.Function):
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         g = g.contiguous().float()
+        t = ctx.table
+        if (g.is_cuda and t is not None and t.grad is not None and t.grad.dtype == torch.float32 and
+                t.grad.shape == t.shape and t.grad.is_contiguous() and not torch.is_grad_enabled()):
+            # The parameter already has a (zeroed, persistent) gradient buffer -- optim.FlatAdam's view:
+            # scatter-add straight into it.  The stock route materialises a dense zero table per use of
+            # the embedding and lets autograd add it to .grad: 4 extra passes over the table per use
+            # (Pokec: 3 uses x 418 MB).  Same result: the adds commute.
+            nat.check(nat.lib().gsage_scatter_add_rows(_ptr(g), g.stride(0), _ptr(ids), int(ids.shape[0]), 1,
+                                                       g.shape[1], 1.0, _ptr(t.grad), t.grad.stride(0),
+                                                       _stream()), "scatter_add_rows")
+            return None, None
         grad = torch.zeros(ctx.tshape, dtype=torch.float32, device=g.device)
         if g.is_cuda:
             nat.check(nat.lib().gsage_scatter_add_rows(_ptr(g), g.stride(0), _ptr(ids),
