@@ -23,9 +23,18 @@ k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partia
     __shared__ float red[4];
     float s = 0.f;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float v = g[i];
-        s += v * v;
+    if ((n & 3) == 0 && ((uintptr_t)g & 15) == 0) {                     // 16-byte lanes
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const v4 v = reinterpret_cast<const v4 *>(g)[i];
+            s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float v = g[i];
+            s += v * v;
+        }
     }
     const float tot = block_sum_256(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;

@@ -61,9 +61,33 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
     }
 
     const int64_t stride = (int64_t)gx * 256;
+    const bool clipped = coef < 1.f;                    // (block-uniform) unclipped gradients are not rewritten
+    if (a.n_prep == 0 && (a.n & 3) == 0 &&
+        ((((uintptr_t)a.p | (uintptr_t)a.g | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0)) {
+        // big plain buckets (a trainable embedding table): 16-byte lanes, no operand copies to refresh
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = a.n >> 2;
+        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4; i += stride) {
+            v4 g = reinterpret_cast<const v4 *>(a.g)[i] * coef;
+            const v4 p = reinterpret_cast<const v4 *>(a.p)[i];
+            v4 m = reinterpret_cast<const v4 *>(a.m)[i];
+            v4 v = reinterpret_cast<const v4 *>(a.v)[i];
+            if (clipped) reinterpret_cast<v4 *>(a.g)[i] = g;
+            if (a.weight_decay != 0.f) g += a.weight_decay * p;
+            m = a.beta1 * m + (1.f - a.beta1) * g;
+            v = a.beta2 * v + (1.f - a.beta2) * g * g;
+            v4 pn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pn[e] = p[e] - step_size * (m[e] / (sqrtf(v[e]) * rsqrt_bc2 + a.eps));
+            reinterpret_cast<v4 *>(a.m)[i] = m;
+            reinterpret_cast<v4 *>(a.v)[i] = v;
+            reinterpret_cast<v4 *>(a.p)[i] = pn;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride) {
         float g = a.g[i] * coef;
-        a.g[i] = g;                                     // clipped gradient stays visible (p.grad)
+        if (clipped) a.g[i] = g;                        // clipped gradient stays visible (p.grad)
         float p = a.p[i];
         if (a.weight_decay != 0.f) g += a.weight_decay * p;
         const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
