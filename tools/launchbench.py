@@ -1,3 +1,5 @@
+"""Launch-path micro-benchmarks on the GPU box: host cost of a ctypes launch, dependent-kernel boundary,
+hipGraph replay floor, two-stream concurrency of trivial kernels (numbers quoted in DESIGN.md)."""
 import importlib, sys, time
 sys.path.insert(0, '.')
 import torch
