@@ -95,6 +95,8 @@ def init_from_env(cuda=True):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if cuda:
+        if os.environ.get("GSAGE_DIST_BACKEND") == "gloo" and torch.cuda.device_count() == 1:
+            local = 0                 # several ranks sharing the only GPU (single-GPU test boxes)
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         # "nccl" is RCCL on ROCm.  GSAGE_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL
