@@ -213,11 +213,13 @@ k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
                     int n_adam, const AdamParams a)
 {
     __shared__ float red[4];
-    if ((int)blockIdx.x < n_adam)
-        adam_workgroup(a, blockIdx.x, n_adam, red);
+    const int n_gather = (int)gridDim.x - n_adam;
+    const int first = n_gather / 2;                  // the update's workgroups sit in the MIDDLE of the grid
+    const int bx = (int)blockIdx.x;
+    if (bx >= first && bx < first + n_adam)
+        adam_workgroup(a, bx - first, n_adam, red);
     else
-        gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, (int)blockIdx.x - n_adam,
-                                            (int)gridDim.x - n_adam);
+        gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_adam, n_gather);
 }
 
 // dneibs[i*n+j, :] = dagg[i, :] / n     (fp32, 16-byte chunks when aligned)
