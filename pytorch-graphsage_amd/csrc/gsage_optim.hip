@@ -132,8 +132,8 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
     finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red);
 }
 
-// Gradient finalisation of batch i and the frontier sampling of batch i+1 side by side: workgroups
-// [0, gx*n_desc) finalise, the rest sample.  Neither job fills the chip and both are bound by
+// Gradient finalisation of batch i and the frontier sampling of batch i+1 side by side: the first
+// ceil(B / HOPS_SPW) workgroups sample, the remaining gx*n_desc finalise.  Neither job fills the chip and both are bound by
 // dependent-load latency, so together they take the longer of the two (11 vs 8 us at Reddit
 // shapes) instead of the sum.  Nothing here may advance the sampler's counters (its workgroups
 // read them while this launch runs): HopsParams carries call_base / batch_base offsets instead and
@@ -144,12 +144,16 @@ k_finalize_sample(const ReduceDesc *__restrict__ descs, float *__restrict__ flat
 {
     extern __shared__ int64_t frontier[];
     __shared__ float red[4];
+    // the sampler's workgroups come FIRST: theirs is the longer dependent chain (two hops of
+    // rowptr -> col round trips), so they should not queue behind the reduction's
     const int n_fin = gx * n_desc;
-    if ((int)blockIdx.x < n_fin) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && tick) *tick += 1;
-        finalize_workgroup(descs, flat_g, partial_sq, (int)blockIdx.x % gx, (int)blockIdx.x / gx, gx, red);
+    const int n_smp = (int)gridDim.x - n_fin;
+    if ((int)blockIdx.x >= n_smp) {
+        const int b = (int)blockIdx.x - n_smp;
+        if (b == 0 && threadIdx.x == 0 && tick) *tick += 1;
+        finalize_workgroup(descs, flat_g, partial_sq, b % gx, b / gx, gx, red);
     } else {
-        sample_hops_workgroup(h, (int)blockIdx.x - n_fin, frontier);
+        sample_hops_workgroup(h, (int)blockIdx.x, frontier);
     }
 }
 
