@@ -54,6 +54,29 @@ def test_aggregator_golden_vectors_on_gpu(dtype):
     assert nat.launch_count() - before >= 2 * int(g["n_cases"])
 
 
+def test_lstm_aggregator_golden_vectors_on_gpu():
+    """LSTMAggregator on the GPU (MIOpen recurrence + K5 projection, fp32 compute mode) against the
+    vectors recorded from the reference."""
+    ops.set_compute_dtype("fp32")
+    g = load_golden("lstm_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        M, n, D, h, hid, bidir = [int(v) for v in g[p + "dims"]]
+        agg = gs.aggregator_lookup["lstm"](input_dim=D, output_dim=h, activation=ACTS[str(g[p + "act"])],
+                                           hidden_dim=hid, bidirectional=bool(bidir))
+        agg.load_state_dict(weights(g, p + "w_"))
+        agg = agg.to(DEV)
+        x = torch.from_numpy(g[p + "x"].copy()).to(DEV).requires_grad_(True)
+        nb = torch.from_numpy(g[p + "neibs"].copy()).to(DEV).requires_grad_(True)
+        out = agg(x, nb)
+        close(out.detach().float().cpu().numpy(), g[p + "out"], (c, "lstm out"), 2e-4, 2e-5)
+        (out.float() * torch.from_numpy(g[p + "G"]).to(DEV)).sum().backward()
+        close(x.grad.cpu().numpy(), g[p + "dx"], (c, "dx"), 2e-4, 2e-5)
+        close(nb.grad.cpu().numpy(), g[p + "dneibs"], (c, "dneibs"), 2e-4, 2e-5)
+        for k, v in agg.named_parameters():
+            close(v.grad.cpu().numpy(), g[p + "g_" + k], (c, k), 2e-4, 2e-5)
+
+
 def test_aggregator_rowref_equals_tensor_path():
     """feats[ids] as a lazy RowRef (fused gather) must equal the materialised-tensor route."""
     ops.set_compute_dtype("fp32")

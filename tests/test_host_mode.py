@@ -95,6 +95,29 @@ def test_aggregators_host_mode_forward_backward():
             close(v.grad.numpy(), g[p + "g_" + k], (c, name, k))
 
 
+def test_lstm_aggregator_host_mode_forward_backward():
+    """LSTMAggregator (nn_modules.py:259-286; kept so that aggregator_lookup is complete -- the
+    recurrence is stock torch / MIOpen) against vectors recorded from the reference, uni- and
+    bidirectional."""
+    g = load_golden("lstm_kat.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        M, n, D, h, hid, bidir = [int(v) for v in g[p + "dims"]]
+        agg = gs.aggregator_lookup["lstm"](input_dim=D, output_dim=h, activation=ACTS[str(g[p + "act"])],
+                                           hidden_dim=hid, bidirectional=bool(bidir))
+        agg.load_state_dict(weights(g, p + "w_"))
+        assert agg.output_dim == int(g[p + "output_dim"])
+        x = torch.from_numpy(g[p + "x"].copy()).requires_grad_(True)
+        nb = torch.from_numpy(g[p + "neibs"].copy()).requires_grad_(True)
+        out = agg(x, nb)
+        close(out.detach().numpy(), g[p + "out"], (c, "lstm"), 1e-5, 1e-6)
+        (out * torch.from_numpy(g[p + "G"])).sum().backward()
+        close(x.grad.numpy(), g[p + "dx"], (c, "dx"), 1e-5, 1e-6)
+        close(nb.grad.numpy(), g[p + "dneibs"], (c, "dneibs"), 1e-5, 1e-6)
+        for k, v in agg.named_parameters():
+            close(v.grad.numpy(), g[p + "g_" + k], (c, k), 1e-5, 1e-6)
+
+
 def test_attention_refuses_squeeze_quirk_shapes():
     agg = gs.aggregator_lookup["attention"](input_dim=4, output_dim=3, activation=None)
     with pytest.raises(AssertionError):
