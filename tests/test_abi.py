@@ -88,3 +88,29 @@ def test_host_legacy_stream_equals_numpy(seed):
         assert np.array_equal(out, np.random.choice(100, 7))
     finally:
         L.gsage_mt_destroy(mt)
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: nothing under the product package, bench.py's timed path or
+    the C sources may import, load or mention it (bench.py's cpu_baseline leg and
+    __graft_entry__.smoke() are the two documented exceptions); nothing that runs on the GPU box may
+    read /root/reference."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = glob.glob(os.path.join(root, "pytorch-graphsage_amd", "*.py")) + \
+        glob.glob(os.path.join(root, "pytorch-graphsage_amd", "csrc", "*")) + \
+        glob.glob(os.path.join(root, "include", "*.h"))
+    prod = [f for f in prod if os.path.isfile(f) and not f.endswith((".o", ".so"))]
+    assert len(prod) > 20
+    for f in prod:
+        text = open(f, errors="replace").read()
+        assert not re.search(r"(^|\W)(import\s+oracle|from\s+oracle|libgsage_oracle|gso_)", text), f
+        assert "/root/reference" not in text, f
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    body = bench[bench.index("def cpu_baseline("):bench.index("def dominant_kernel_roofline(")]
+    assert uses and all(bench.index("def cpu_baseline(") < u < bench.index("def dominant_kernel_roofline(") for u in uses)
+    assert "from oracle import" in body
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(root, f)).read() or f == "__graft_entry__.py"
