@@ -118,9 +118,9 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
                              uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
                              uint64_t rank, const int64_t *seed_queue, const int64_t *batch_idx,
                              int64_t n_batches, int32_t *err_flag, void *stream);
-/* The same arguments as a struct (HOST memory), for entry points that launch the sampler together
- * with something else.  batch_base is added to *batch_idx before the modulo: with call_base it lets
- * the sampler run AHEAD of the counters' tick (gsage_finalize_grads_sample). */
+/* The same arguments as a struct (HOST memory).  batch_base is added to *batch_idx before the modulo:
+ * with call_base it addresses a batch AHEAD of the device counters without touching them -- how a
+ * later batch's frontier is sampled from inside another launch (gsage_gather_mean_multi_adam). */
 typedef struct gsage_hops_desc {
     const int64_t *rowptr;
     const int32_t *col;
@@ -140,6 +140,8 @@ typedef struct gsage_hops_desc {
     int64_t n_batches;
     int32_t *err_flag;
 } gsage_hops_desc;
+/* gsage_sample_hops_philox from a descriptor (the only way to pass batch_base). */
+int gsage_sample_hops(const gsage_hops_desc *hops, void *stream);
 
 /* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
@@ -380,17 +382,22 @@ typedef struct gsage_adam_desc {
     int64_t *tick2;
     int64_t inc2;
 } gsage_adam_desc;
-/* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts -- the Philox
- * call index and batch-queue index when the NEXT batch was sampled ahead of the tick by
- * gsage_finalize_grads_sample (nothing in this kernel reads them). */
-/* gsage_gather_mean_multi (the NEXT batch's level-0 gathers: they read features and ids only) and
- * the clip + Adam update of the CURRENT batch in one launch.  The update is ~8 us of latency-bound
- * work on a few hundred workgroups; next to the HBM-bound gather it is free.  adam->n_partial_ready
- * must be > 0 (norm partials from gsage_finalize_grads[_sample]) and adam->step_is_current != 0. */
+/* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
+ * Philox call index and batch-queue index, when nothing in the same launch reads them). */
+/* gsage_gather_mean_multi (the NEXT batch's level-0 gathers: they read features and ids only) with up
+ * to two short latency-bound jobs riding in the same launch, each a few hundred workgroups that are
+ * free next to the HBM-bound gather:
+ *   adam (may be NULL)  the clip + Adam update of the CURRENT batch (~8 us alone).  n_partial_ready
+ *                       must be > 0 (norm partials from gsage_finalize_grads) and step_is_current != 0.
+ *   hops (may be NULL)  gsage_sample_hops_philox of the batch AFTER the next one (~9 us alone) into
+ *                       its own frontier buffer (hops->ids must not alias the ids being gathered).
+ *                       adam's ticks must then not touch hops->call_ctr / hops->batch_idx: address the
+ *                       future batch through call_base / batch_base instead.
+ * At least one of the two must be given. */
 int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
                                  void *const *outs, const int64_t *M, const int32_t *n, int dtype,
                                  int64_t ld, int64_t D, int out_dtype, int64_t out_ld,
-                                 const gsage_adam_desc *adam, void *stream);
+                                 const gsage_adam_desc *adam, const gsage_hops_desc *hops, void *stream);
 
 /* Sums partial gradient buffers into the flat bucket and emits the squared-norm partials the
  * clip needs, in one launch: for descriptor d, flat_g[out_off + r*cols + c] =
@@ -409,15 +416,6 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                          float *partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
                          int64_t *tick2, int64_t inc2, void *stream);
 int gsage_finalize_partials(int32_t n_desc, int64_t max_elems);
-/* gsage_finalize_grads and gsage_sample_hops_philox for the NEXT batch in one launch: the two are
- * independent (sampling does not read weights or gradients), both are latency-bound and neither
- * fills the chip, so side by side they cost the longer one.  The sampler's workgroups must see
- * the counters of the next batch while this launch is in flight, so nothing here ticks them:
- * pass call_base = (calls per batch) and batch_base = 1 in `hops`, and tick the counters in the
- * following gsage_clip_adam_step (tick1 / tick2).  `tick` (Adam step counter) as above. */
-int gsage_finalize_grads_sample(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
-                                float *partial_sq, int64_t *tick, const gsage_hops_desc *hops,
-                                void *stream);
 int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:

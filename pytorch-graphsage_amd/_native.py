@@ -40,6 +40,7 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp]),
     "gsage_sample_hops_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _u32, _u64, _vp, _u64, _u64,
                                         _vp, _vp, _i64, _vp, _vp]),
+    "gsage_sample_hops": (_int, [_vp, _vp]),
     "gsage_counter_add": (_int, [_vp, _u64, _vp]),
     "gsage_mt_create": (_vp, [_u32]),
     "gsage_mt_destroy": (None, [_vp]),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
     "gsage_gather_mean_multi": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64, _vp]),
     "gsage_gather_mean_multi_adam": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64,
-                                            _vp, _vp]),
+                                            _vp, _vp, _vp]),
     "gsage_segment_mean_bwd": (_int, [_vp, _i64, _i64, _i32, _i64, _vp, _i64, _vp]),
     "gsage_scatter_add_rows": (_int, [_vp, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _i64, _vp]),
     "gsage_linear_nt": (_int, [_vp, _int, _i64, _vp, _int, _vp, _i64, _vp, _vp, _int, _i64, _i64,
@@ -68,7 +69,6 @@ SIGNATURES = {
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
-    "gsage_finalize_grads_sample": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsage_finalize_partials": (_int, [_i32, _i64]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -14,6 +14,7 @@
 // with replacement produces.
 #include "gsage_common.h"
 #include "gsage_optim_dev.h"
+#include "gsage_sample_dev.h"
 
 namespace gsage {
 
@@ -201,25 +202,33 @@ k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
     gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, blockIdx.x, gridDim.x);
 }
 
-// The level-0 gathers of batch i+1 and the clip + Adam update of batch i side by side: workgroups
-// [0, n_adam) update (they come first so the short job is done long before the gather drains),
-// the rest gather.  The two touch disjoint data: the gather reads features and ids, Adam reads and
-// writes the parameter / gradient / moment buckets and the bf16 operand copies.
+// The level-0 gathers of batch i+1, the clip + Adam update of batch i and the frontier sampling of
+// batch i+2 side by side.  The three touch disjoint data: the gather reads features and the ids of
+// batch i+1, Adam reads and writes the parameter / gradient / moment buckets and the bf16 operand
+// copies, the sampler reads the graph and writes the OTHER frontier buffer.  The two short jobs
+// (~10 us and ~6 us of dependent-load latency, a few hundred workgroups) sit in the MIDDLE of the
+// grid: the gather's pipeline is in steady state by then and both are done long before it drains.
+// Neither side job may advance a counter the sampler reads (batch index, Philox call counter):
+// those are ticked by the gradient finalisation that precedes this launch.
 // (waves_per_eu: the Adam role's powf/sqrtf would otherwise raise the register count and cost the
 // HBM-bound gather role two of its seven waves per SIMD)
 template <typename TI, typename TO, int VEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
-                    int n_adam, const AdamParams a)
+                    int n_adam, const AdamParams a, int n_smp, const HopsParams h)
 {
+    extern __shared__ int64_t frontier[];
     __shared__ float red[4];
-    const int n_gather = (int)gridDim.x - n_adam;
-    const int first = n_gather / 2;                  // the update's workgroups sit in the MIDDLE of the grid
+    const int n_side = n_adam + n_smp;
+    const int n_gather = (int)gridDim.x - n_side;
+    const int first = n_gather / 2;
     const int bx = (int)blockIdx.x;
     if (bx >= first && bx < first + n_adam)
         adam_workgroup(a, bx - first, n_adam, red);
+    else if (bx >= first + n_adam && bx < first + n_side)
+        sample_hops_workgroup(h, bx - first - n_adam, frontier);
     else
-        gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_adam, n_gather);
+        gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_side, n_gather);
 }
 
 // dneibs[i*n+j, :] = dagg[i, :] / n     (fp32, 16-byte chunks when aligned)
@@ -381,20 +390,34 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
 int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
                                  void *const *outs, const int64_t *M, const int32_t *n, int dtype,
                                  int64_t ld, int64_t D, int out_dtype, int64_t out_ld,
-                                 const gsage_adam_desc *adam, void *stream)
+                                 const gsage_adam_desc *adam, const gsage_hops_desc *hops, void *stream)
 {
     MultiSeg q;
     int32_t chunks = 0;
     int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
     if (rc != GSAGE_OK) return rc;
-    GSAGE_REQUIRE(adam && adam->step_is_current && q.first[n_seg] > 0,
-                  "gather_mean_multi_adam: needs an Adam descriptor with step_is_current and a non-empty gather");
-    AdamParams a;
-    rc = fill_adam(a, *adam);
-    if (rc != GSAGE_OK) return rc;
-    const int n_adam = adam_grid(adam->n, 2048);
-    launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam),
-           dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a);
+    GSAGE_REQUIRE((adam || hops) && q.first[n_seg] > 0,
+                  "gather_mean_multi_adam: needs an Adam or a sampler descriptor and a non-empty gather");
+    GSAGE_REQUIRE(!adam || adam->step_is_current, "gather_mean_multi_adam: Adam descriptor needs step_is_current");
+    AdamParams a = {};
+    int n_adam = 0, n_smp = 0;
+    if (adam) {
+        rc = fill_adam(a, *adam);
+        if (rc != GSAGE_OK) return rc;
+        n_adam = adam_grid(adam->n, 2048);
+        GSAGE_REQUIRE(!hops || (adam->tick1 != (int64_t *)hops->call_ctr && adam->tick2 != (int64_t *)hops->batch_idx) ||
+                      (!adam->tick1 && !adam->tick2),
+                      "gather_mean_multi_adam: the update may not tick a counter the sampler reads");
+    }
+    HopsParams h = {};
+    size_t lds = 0;
+    if (hops) {
+        rc = fill_hops(h, lds, *hops);
+        if (rc != GSAGE_OK) return rc;
+        n_smp = (int)ceil_div(hops->B, HOPS_SPW);
+    }
+    launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
+           dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
     return check_launch("gather_mean_multi_adam");
 }
 

@@ -59,7 +59,7 @@ struct ReduceDesc {
 __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
                                                    float *__restrict__ flat_g,
                                                    float *__restrict__ partial_sq, int bx, int by, int gx,
-                                                   float *red)
+                                                   float *red, float *red4)
 {
     const ReduceDesc d = descs[by];
     const int64_t gstride = (int64_t)gx * 256;
@@ -95,6 +95,39 @@ __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict_
                     sq += s[e] * s[e];
                 }
         }
+    } else if (d.S >= 32 && (int64_t)d.rows * d.cols * 4 <= gstride) {
+        // few elements, many partials (the seed-level kernel's per-workgroup head gradients: 10.5 k
+        // elements x 128 partials): one thread per element would walk all S partials alone -- 16
+        // rounds of 8 loads, the longest dependent chain of the launch.  The four waves of a
+        // workgroup take a quarter of the partials each for the same 64 elements and meet in LDS.
+        const int64_t total = (int64_t)d.rows * d.cols;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int s0 = (d.S * wave) / 4, s1 = (d.S * (wave + 1)) / 4;
+        for (int64_t t0 = (int64_t)bx * 64; t0 < total; t0 += (int64_t)gx * 64) {
+            const int64_t t = t0 + lane;
+            float s = 0.f;
+            if (t < total) {
+                const int64_t r = t / d.cols;
+                const float *src = d.src + r * d.ld + (t - r * d.cols);
+                int i = s0;
+                for (; i + 8 <= s1; i += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; i < s1; ++i) s += src[(int64_t)i * d.stride];
+            }
+            lds_barrier();
+            red4[threadIdx.x] = s;
+            lds_barrier();
+            if (wave == 0 && t < total) {
+                const float tot = (red4[lane] + red4[64 + lane]) + (red4[128 + lane] + red4[192 + lane]);
+                flat_g[d.out_off + t] = tot;
+                sq += tot * tot;
+            }
+        }
     } else {
         const int64_t total = (int64_t)d.rows * d.cols;
         for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
@@ -124,37 +157,13 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
                  int64_t *tick2, int64_t inc2)
 {
     __shared__ float red[4];
+    __shared__ float red4[256];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (tick) *tick += 1;
         if (tick1) *tick1 += inc1;
         if (tick2) *tick2 += inc2;
     }
-    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red);
-}
-
-// Gradient finalisation of batch i and the frontier sampling of batch i+1 side by side: the first
-// ceil(B / HOPS_SPW) workgroups sample, the remaining gx*n_desc finalise.  Neither job fills the chip and both are bound by
-// dependent-load latency, so together they take the longer of the two (11 vs 8 us at Reddit
-// shapes) instead of the sum.  Nothing here may advance the sampler's counters (its workgroups
-// read them while this launch runs): HopsParams carries call_base / batch_base offsets instead and
-// the following k_adam_clip ticks.
-__global__ void __launch_bounds__(256)
-k_finalize_sample(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
-                  float *__restrict__ partial_sq, int64_t *tick, int gx, int n_desc, const HopsParams h)
-{
-    extern __shared__ int64_t frontier[];
-    __shared__ float red[4];
-    // the sampler's workgroups come FIRST: theirs is the longer dependent chain (two hops of
-    // rowptr -> col round trips), so they should not queue behind the reduction's
-    const int n_fin = gx * n_desc;
-    const int n_smp = (int)gridDim.x - n_fin;
-    if ((int)blockIdx.x >= n_smp) {
-        const int b = (int)blockIdx.x - n_smp;
-        if (b == 0 && threadIdx.x == 0 && tick) *tick += 1;
-        finalize_workgroup(descs, flat_g, partial_sq, b % gx, b / gx, gx, red);
-    } else {
-        sample_hops_workgroup(h, (int)blockIdx.x, frontier);
-    }
+    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red, red4);
 }
 
 __global__ void k_step_inc(int64_t *step) { *step += 1; }
@@ -435,23 +444,6 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                        (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, tick1, inc1,
                        tick2, inc2);
     return check_launch("finalize_grads");
-}
-
-int gsage_finalize_grads_sample(const void *descs, int32_t n_desc, int64_t max_elems, float *flat_g,
-                                float *partial_sq, int64_t *tick, const gsage_hops_desc *hops,
-                                void *stream)
-{
-    GSAGE_REQUIRE(descs && flat_g && partial_sq && n_desc > 0 && max_elems > 0 && hops,
-                  "finalize_grads_sample: bad arguments");
-    HopsParams h;
-    size_t lds = 0;
-    int rc = fill_hops(h, lds, *hops);
-    if (rc != GSAGE_OK) return rc;
-    const int gx = grid_for(max_elems, 256);
-    const int n_sample = (int)ceil_div(hops->B, HOPS_SPW);
-    launch(k_finalize_sample, dim3((unsigned)(gx * n_desc + n_sample)), dim3(256), lds,
-           (hipStream_t)stream, (const ReduceDesc *)descs, flat_g, partial_sq, tick, gx, (int)n_desc, h);
-    return check_launch("finalize_grads_sample");
 }
 
 int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,

@@ -188,12 +188,18 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
     d.max_deg = max_deg; d.seed = seed; d.call_ctr = call_ctr; d.call_base = call_base; d.rank = rank;
     d.seed_queue = seed_queue; d.batch_idx = batch_idx; d.batch_base = 0; d.n_batches = n_batches;
     d.err_flag = err_flag;
+    return gsage_sample_hops(&d, stream);
+}
+
+int gsage_sample_hops(const gsage_hops_desc *hops, void *stream)
+{
+    GSAGE_REQUIRE(hops, "sample_hops: null descriptor");
     HopsParams p;
     size_t lds = 0;
-    int rc = fill_hops(p, lds, d);
-    if (rc != GSAGE_OK || d.B == 0) return rc;
-    launch(k_sample_hops, dim3((unsigned)ceil_div(B, HOPS_SPW)), dim3(256), lds, (hipStream_t)stream, p);
-    return check_launch("sample_hops_philox");
+    int rc = fill_hops(p, lds, *hops);
+    if (rc != GSAGE_OK || hops->B == 0) return rc;
+    launch(k_sample_hops, dim3((unsigned)ceil_div(hops->B, HOPS_SPW)), dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("sample_hops");
 }
 
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream)

@@ -1,6 +1,6 @@
 // gsage_sample_dev.h -- device body of the fused multi-hop sampler (K1), shared by the stand-alone
-// kernel (gsage_sample.hip) and by k_finalize_sample (gsage_optim.hip), which samples the NEXT
-// batch's frontier side by side with the gradient finalisation of the current one.
+// kernel (gsage_sample.hip) and by k_gather_multi_adam (gsage_gather.hip), which samples a LATER
+// batch's frontier inside the launch that gathers the next batch's rows.
 #pragma once
 #include "gsage_common.h"
 
@@ -36,7 +36,7 @@ struct HopsParams {
     const int64_t *seed_queue;    // optional [n_batches, B] device-resident seed batches ...
     const int64_t *batch_idx;     // ... and the device word selecting the current one
     int64_t n_batches;
-    int64_t batch_base;           // added to *batch_idx (sampling AHEAD of the tick, see k_finalize_sample)
+    int64_t batch_base;           // added to *batch_idx (sampling AHEAD of the counters, see k_gather_multi_adam)
     int64_t n_rows;
     int64_t off[6];               // first element of hop k in ids
     uint64_t g0[6];               // global sample index of this rank's first sample of hop k

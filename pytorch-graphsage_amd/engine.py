@@ -223,8 +223,8 @@ class FusedMeanTrainStep(object):
         # to the sequential order, `__call__` then returns the predictions of the previous batch.
         self.pipelined = bool(pipelined)
         self.nset = 2 if self.pipelined else 1
-        self._front_ready, self.g_qfront = False, None
-        self.prefetch = False                        # queue mode: batch i+1 is sampled during step i
+        self._front_ready, self._qstep = False, 0
+        self.g_prime, self.g_qfront, self.g_queue = None, None, None
         self._reduce_op = None
         if ddp is not None:
             # averaging inside the collective saves a launch; fall back to divide-then-sum where
@@ -475,13 +475,14 @@ class FusedMeanTrainStep(object):
                            c_gs, nat.BF16, c_dtype)
 
     # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
-    def _hops_desc(self, s, ahead):
-        """gsage_hops_desc of batch set s; ahead=True: sample the NEXT batch of the queue before the
-        counters are ticked (call_base / batch_base offsets)."""
+    def _hops_desc(self, ids, ahead):
+        """gsage_hops_desc that samples a whole frontier into `ids`; ahead=True: the batch AFTER the
+        one the device counters point at (call_base / batch_base offsets, the counters themselves
+        are not touched)."""
         L = self.L
         d = nat.HopsDesc()
         d.rowptr, d.col, d.n_rows = self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows
-        d.ids, d.B, d.n_hops = self.ids_set[s].data_ptr(), self.B, L
+        d.ids, d.B, d.n_hops = ids.data_ptr(), self.B, L
         for k in range(5):
             d.fan[k] = int(self.fan[k + 1]) if k < L else 1
         d.max_deg, d.seed = self.csr.max_deg, self.sampler.seed
@@ -492,13 +493,10 @@ class FusedMeanTrainStep(object):
         d.err_flag = self.csr.err_flag.data_ptr()
         return d
 
-    def _stage_sample(self, s):
+    def _stage_sample(self, s, ids=None, ahead=False):
         """K1: every hop in one launch, frontier written in place into the concatenated ids."""
-        d = self._hops_desc(s, False)
-        nat.check(nat.lib().gsage_sample_hops_philox(
-            d.rowptr, d.col, d.n_rows, d.ids, d.B, d.n_hops, d.fan, d.max_deg, d.seed, d.call_ctr,
-            d.call_base, d.rank, d.seed_queue, d.batch_idx, d.n_batches, d.err_flag, ops._stream()),
-            "sample_hops_philox")
+        d = self._hops_desc(self.ids_set[s] if ids is None else ids, ahead)
+        nat.check(nat.lib().gsage_sample_hops(ctypes.addressof(d), ops._stream()), "sample_hops")
 
     def _stage_sample_gather(self, s):
         """K1 for every hop + the level-0 gathers of batch set `s`; independent of the weights."""
@@ -519,15 +517,17 @@ class FusedMeanTrainStep(object):
         d.norm_out, d.step_is_current = self.gnorm.data_ptr(), 1
         d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
         d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
-        d.tick1, d.inc1 = (self.counter.data_ptr() if self.prefetch else None), self.L
-        d.tick2, d.inc2 = (self.batch_idx.data_ptr() if self.prefetch else None), 1
+        d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
         return d
 
-    def _stage_gather(self, s, with_adam=False):
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
-        launch; with_adam: the clip + Adam update of the batch just finished rides along."""
+        launch; with_adam: the clip + Adam update of the batch just finished rides along; hops: so
+        does the sampling of a later batch's frontier (a gsage_hops_desc writing ANOTHER buffer).
+        ids: frontier to gather from (default: the set's own)."""
         L, st = self.L, self.store
-        ids = self.ids_set[s]
+        if ids is None:
+            ids = self.ids_set[s]
         # one launch: x rows of every hop + the mean of each hop's sampled neighbours
         R = self.rows[0]
         xa = self.xa0_set[s]
@@ -535,7 +535,8 @@ class FusedMeanTrainStep(object):
         for k in range(L):
             segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
                          self.size[k], self.fan[k + 1]))
-        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None)
+        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None,
+                              hops=hops)
 
     def _stage_compute(self, s):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
@@ -639,23 +640,15 @@ class FusedMeanTrainStep(object):
         self._stage_finalize(s)
 
     def _stage_finalize(self, s):
-        """Every partial buffer -> flat gradient bucket, + squared-norm partials, + Adam step tick."""
+        """Every partial buffer -> flat gradient bucket, + squared-norm partials, + the step's ticks:
+        Adam step, Philox call counter, batch-queue index (nothing else in this launch reads them)."""
         L, lib, stream = self.L, nat.lib(), ops._stream()
-        if self.prefetch:
-            # ... side by side with the sampling of the NEXT batch of the queue (counters are
-            # ticked by the Adam launch that follows)
-            d = self._hops_desc(s, True)
-            nat.check(lib.gsage_finalize_grads_sample(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
-                                                      self.flat_g.data_ptr(), self.partial.data_ptr(),
-                                                      self.step.data_ptr(), ctypes.addressof(d), stream),
-                      "finalize_grads_sample")
-        else:
-            nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
-                                               self.flat_g.data_ptr(), self.partial.data_ptr(),
-                                               self.step.data_ptr(),
-                                               None if self.pipelined else self.counter.data_ptr(), L,
-                                               self.batch_idx.data_ptr() if self.queue else None, 1,
-                                               stream), "finalize_grads")
+        nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
+                                           self.flat_g.data_ptr(), self.partial.data_ptr(),
+                                           self.step.data_ptr(),
+                                           None if self.pipelined else self.counter.data_ptr(), L,
+                                           self.batch_idx.data_ptr() if self.queue else None, 1,
+                                           stream), "finalize_grads")
 
     def _all_reduce(self, async_op=False):
         """The step's ONE exchange: average the flat fp32 gradient bucket over the ranks (RCCL)."""
@@ -697,54 +690,68 @@ class FusedMeanTrainStep(object):
         assert tq.dtype == torch.int64
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
         self.batch_idx.zero_()
-        # From here on batch i+1's frontier is sampled DURING step i (side by side with the gradient
-        # finalisation, gsage_finalize_grads_sample) and the counters are ticked by Adam.
-        self.prefetch = True
-        self._front_ready = False
+        # From here on the step is software-pipelined (see step_queue): two frontier buffers, batch
+        # i+2 is sampled while batch i+1 is gathered and batch i is updated.
+        self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
+        self._front_ready, self._qstep = False, 0
+        self.g_prime, self.g_qfront, self.g_queue = None, None, None
         if self.g_main is not None:
             torch.cuda.synchronize()
-            self.g_prime = self._record(lambda: self._stage_sample(0))
+            self.g_prime = self._record(self._queue_prime)
             if self.ddp is None:
-                def whole():
-                    self._stage_compute(0)
-                    self._stage_gather(0, with_adam=True)     # Adam(i) || gathers of batch i+1
-                self.g_main = [self._record(whole)]
+                self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(2)]
             else:
                 # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
                 # gathers (see step_queue)
-                self.g_qfront = self._record(lambda: self._stage_gather(0))
-                self.g_main = [self._record(lambda: self._stage_compute(0))]
+                self.g_queue = [self._record(lambda: self._stage_compute(0))] * 2
+                self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
                 self.g_opt = self._record(self._stage_opt)
         return self
+
+    # the queue pipeline's pieces; par = parity of the step: batch i+1 is gathered from ids_q[1 - par]
+    # while batch i+2 is sampled into ids_q[par]
+    def _queue_prime(self):
+        self._stage_sample(0, ids=self.ids_q[0])
+        self._stage_sample(0, ids=self.ids_q[1], ahead=True)
+        self._stage_gather(0, ids=self.ids_q[0])
+
+    def _queue_front(self, par, with_adam):
+        self._stage_gather(0, with_adam=with_adam, ids=self.ids_q[1 - par],
+                           hops=self._hops_desc(self.ids_q[par], True))
+
+    def _queue_step(self, par):
+        self._stage_compute(0)
+        self._queue_front(par, True)              # Adam(i) || gathers(i+1) || sampling(i+2)
 
     def step_queue(self):
         """One train_step on the next batch of the loaded epoch queue -> preds (static buffer).
 
-        Software-pipelined by one stage, because sampling and the level-0 gathers do not depend on
-        the weights: batch i+1's frontier is sampled side by side with batch i's gradient
-        finalisation, and its gathers run side by side with Adam(i) (one launch) -- or, in
-        data-parallel runs, while batch i's gradient all-reduce is in flight on RCCL's stream, Adam(i)
-        following both.  Every call performs exactly one sampling, one gather, one forward/backward,
-        (one exchange) and one optimizer step, and the weights are up to date when it returns; the
-        first call after load_epoch() additionally samples and gathers batch 0."""
+        Software-pipelined, because sampling and the level-0 gathers do not depend on the weights:
+        the launch that gathers batch i+1 also carries Adam(i) and the frontier sampling of batch i+2
+        (two short latency-bound jobs that are free beside the HBM-bound gather); in data-parallel
+        runs the gathers + sampling run while batch i's gradient all-reduce is in flight on RCCL's
+        stream, Adam(i) following both.  Every call performs exactly one sampling, one gather, one
+        forward/backward, (one exchange) and one optimizer step, and the weights are up to date when
+        it returns; the first call after load_epoch() additionally samples batches 0 and 1 and
+        gathers batch 0."""
         assert self.queue is not None, "call load_epoch() first"
-        rec = self.g_main is not None
+        rec = self.g_queue is not None
         if not self._front_ready:
             if rec:
                 self.g_prime.replay()
             else:
-                self._stage_sample(0)
-            self._stage_gather(0)
+                self._queue_prime()
             self._front_ready = True
+        par = self._qstep % 2
+        self._qstep += 1
         if self.ddp is None:
             if rec:
-                self.g_main[0].replay()
+                self.g_queue[par].replay()
             else:
-                self._stage_compute(0)
-                self._stage_gather(0, with_adam=True)
+                self._queue_step(par)
             return self.preds
         if rec:
-            self.g_main[0].replay()
+            self.g_queue[par].replay()
         else:
             self._stage_compute(0)
         # Order matters: the collective is submitted BEFORE the gathers.  Submitted after them (from a
@@ -753,9 +760,9 @@ class FusedMeanTrainStep(object):
         # dispatched completely -- no overlap at all (tools/overlap_check.py).
         work = self._all_reduce(async_op=True)
         if rec:                                      # batch i+1's gathers overlap the exchange
-            self.g_qfront.replay()
+            self.g_qfront[par].replay()
         else:
-            self._stage_gather(0)
+            self._queue_front(par, False)
         work.wait()                                  # stream-level wait, the host does not block
         if rec:
             self.g_opt.replay()
@@ -964,11 +971,14 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         self._install_reduce(rdesc)
 
     # ---- stages ----------------------------------------------------------------------------------------
-    def _stage_gather(self, s, with_adam=False):
-        L, st, ids = self.L, self.store, self.ids_set[s]
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None):
+        L, st = self.L, self.store
+        if ids is None:
+            ids = self.ids_set[s]
         segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1),
                 (st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1)]
-        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None)
+        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None,
+                              hops=hops)
 
     def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
         ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,

@@ -292,20 +292,22 @@ def _prep_weight(W, cdt, epc):
     return _pad_cast(W.detach(), cdt, epc)
 
 
-def gather_mean_multi(segments, ld, D, out_ld, adam=None):
+def gather_mean_multi(segments, ld, D, out_ld, adam=None, hops=None):
     """All hops of a level in one K2 launch.  segments: list of (table, ids|None, out, M, n) with
     bf16 row-major tensors sharing ld / out_ld.  adam: optional _native.AdamDesc -- the clip + Adam
-    update of the previous batch rides in the same launch (gsage_gather_mean_multi_adam)."""
+    update of the previous batch rides in the same launch; hops: optional _native.HopsDesc -- so does
+    the frontier sampling of a later batch (gsage_gather_mean_multi_adam)."""
     k = len(segments)
     T = (ctypes.c_void_p * k)(*[s[0].data_ptr() for s in segments])
     I = (ctypes.c_void_p * k)(*[(s[1].data_ptr() if s[1] is not None else None) for s in segments])
     O = (ctypes.c_void_p * k)(*[s[2].data_ptr() for s in segments])
     Ms = (ctypes.c_int64 * k)(*[int(s[3]) for s in segments])
     ns = (ctypes.c_int32 * k)(*[int(s[4]) for s in segments])
-    if adam is not None:
-        nat.check(nat.lib().gsage_gather_mean_multi_adam(k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16,
-                                                         out_ld, ctypes.addressof(adam), _stream()),
-                  "gather_mean_multi_adam")
+    if adam is not None or hops is not None:
+        nat.check(nat.lib().gsage_gather_mean_multi_adam(
+            k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16, out_ld,
+            ctypes.addressof(adam) if adam is not None else None,
+            ctypes.addressof(hops) if hops is not None else None, _stream()), "gather_mean_multi_adam")
         return
     nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16, out_ld,
                                                 _stream()), "gather_mean_multi")

@@ -163,7 +163,10 @@ def test_pipelined_engine_is_bit_identical_to_sequential(capture):
     assert torch.equal(outs[False][1], outs[True][1])
 
 
-def test_batch_queue_equals_per_step_copies():
+@pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
+def test_batch_queue_equals_per_step_copies(capture):
+    """step_queue (batch i+2 sampled and batch i+1 gathered in the launch that applies Adam(i)) is
+    the plain one-batch-at-a-time engine, bit for bit, across the queue's wrap-around."""
     adj, feats, rng = _problem(seed=4)
     D, C, B, dims, fans = feats.shape[1], 5, 24, (128, 128), (5, 3)
     store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
@@ -172,14 +175,15 @@ def test_batch_queue_equals_per_step_copies():
     res = []
     for queued in (False, True):
         model = _model(adj, D, C, dims, fans)
-        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0], tg_all[0])
+        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0], tg_all[0],
+                                           capture=capture)
         preds = []
         if queued:
             eng.load_epoch(ids_all, tg_all)
-            for k in range(5):                       # wraps around the 3-batch queue
+            for k in range(7):                       # wraps around the 3-batch queue
                 preds.append(eng.step_queue().clone())
         else:
-            for k in range(5):
+            for k in range(7):
                 preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
         res.append((torch.stack(preds), eng.flat_p.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

@@ -370,6 +370,72 @@ def test_fused_multi_hop_sampler_equals_per_hop_launches(B, fans):
     csr.check()
 
 
+def test_gather_launch_carrying_a_sampler_equals_separate_launches():
+    """gsage_gather_mean_multi_adam with hops: the frontier of a LATER batch sampled inside the gather
+    launch (engine.step_queue) is the frontier the stand-alone K1 launch produces, and the gather's
+    own output is unchanged."""
+    import ctypes
+    g = load_golden("sampler_kat.npz")
+    adj = csr_of(g, "g2_")
+    csr = dcsr(adj)
+    rng = np.random.RandomState(11)
+    B, fans, D, ld = 37, (6, 4), 40, 64
+    sizes = [B, B * 6, B * 24]
+    table = torch.zeros(adj.shape[0], ld, dtype=torch.bfloat16, device=DEV)
+    table[:, :D] = torch.from_numpy(rng.normal(size=(adj.shape[0], D)).astype(np.float32)).to(DEV).bfloat16()
+    queue = torch.from_numpy(rng.randint(0, adj.shape[0], size=(4, B))).to(DEV)
+    bidx = torch.full((1,), 2, dtype=torch.int64, device=DEV)
+    ctr = torch.full((1,), 8, dtype=torch.int64, device=DEV)
+
+    def desc(ids, call_base, batch_base):
+        d = nat.HopsDesc()
+        d.rowptr, d.col, d.n_rows = csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.n_rows
+        d.ids, d.B, d.n_hops = ids.data_ptr(), B, 2
+        for k in range(5):
+            d.fan[k] = fans[k] if k < 2 else 1
+        d.max_deg, d.seed, d.call_ctr, d.call_base, d.rank = csr.max_deg, 5, ctr.data_ptr(), call_base, 1
+        d.seed_queue, d.batch_idx, d.batch_base, d.n_batches = queue.data_ptr(), bidx.data_ptr(), batch_base, 4
+        d.err_flag = csr.err_flag.data_ptr()
+        return d
+
+    def sample(ids, call_base, batch_base):
+        d = desc(ids, call_base, batch_base)
+        nat.check(nat.lib().gsage_sample_hops(ctypes.addressof(d), None), "sample_hops")
+
+    cur = torch.zeros(sum(sizes), dtype=torch.int64, device=DEV)
+    sample(cur, 0, 0)                                   # the frontier being gathered (batch 2)
+    ref_next = torch.zeros_like(cur)
+    sample(ref_next, 2, 1)                              # batch 3, the next two Philox call indices
+    assert torch.equal(cur[:B], queue[2]) and torch.equal(ref_next[:B], queue[3])
+    # ... which is what ticking both counters and sampling without offsets gives
+    bidx += 1
+    ctr += 2
+    chk = torch.zeros_like(cur)
+    sample(chk, 0, 0)
+    bidx -= 1
+    ctr -= 2
+    assert torch.equal(chk, ref_next)
+
+    def gather(hops):
+        o1 = torch.zeros(B + sizes[1], ld, dtype=torch.bfloat16, device=DEV)
+        o2 = torch.zeros(B, ld, dtype=torch.bfloat16, device=DEV)
+        o3 = torch.zeros(sizes[1], ld, dtype=torch.bfloat16, device=DEV)
+        ops.gather_mean_multi([(table, cur[:B + sizes[1]], o1, B + sizes[1], 1),
+                               (table, cur[B:B + sizes[1]], o2, B, fans[0]),
+                               (table, cur[B + sizes[1]:], o3, sizes[1], fans[1])], ld, D, ld, hops=hops)
+        return o1, o2, o3
+
+    ref = gather(None)
+    got_next = torch.zeros_like(cur)
+    got = gather(desc(got_next, 2, 1))
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert torch.equal(got_next, ref_next)
+    assert int(bidx.item()) == 2 and int(ctr.item()) == 8      # nothing ticked
+    csr.check()
+
+
 def test_command_list_replay_equals_direct_launches():
     """include/gsage.h "Command lists": recorded launches do not run until replayed, replay
     re-issues them (on any stream) with the recorded arguments, and the launch counter counts them."""
