@@ -131,6 +131,8 @@ struct MultiSeg {
     int64_t M[8];
     int64_t first[9];
     int32_t n[8];
+    int32_t rpi[8];         // rows per work item: 4 for n == 1 segments of a mixed launch (a row copy has
+                            // ONE load per row, so a lane takes the same chunk of four rows), else 1
     int32_t n_seg;
     int32_t all_single;     // every segment has n == 1 (plain row copies): 4 rows in flight per lane
 };
@@ -190,6 +192,32 @@ __device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_
         const int64_t u = t - q.first[s];
         const int64_t row = u / chunks;
         const int32_t c0 = (int32_t)(u - row * chunks) * VEC;
+        if (q.rpi[s] == 4 && sizeof(TI) == 2 && sizeof(TO) == 2 && VEC == 8) {
+            // row copies: rows 4*row .. 4*row+3, same chunk; ids, then rows, then stores
+            const int64_t M = q.M[s];
+            int64_t src[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t r = min(row * 4 + k, M - 1);
+                src[k] = q.ids[s] ? q.ids[s][r] : r;
+            }
+            vec16 raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                raw[k] = *reinterpret_cast<const vec16 *>((const uint16_t *)q.table[s] + src[k] * ld + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (row * 4 + k >= M) continue;
+                vec16 v = raw[k];
+                if (c0 + VEC > D) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (c0 + e >= D) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                }
+                *reinterpret_cast<vec16 *>((uint16_t *)q.out[s] + (row * 4 + k) * out_ld + c0) = v;
+            }
+            continue;
+        }
         gather_mean_chunk<TI, TO, VEC>((const TI *)q.table[s], ld, q.ids[s], row, q.n[s], D, c0,
                                        (TO *)q.out[s], out_ld);
     }
@@ -365,11 +393,14 @@ static int fill_multi(MultiSeg &q, int32_t &chunks, int32_t n_seg, const void *c
                           aligned_to(q.table[s], 16) && aligned_to(q.out[s], 16),
                           "gather_mean_multi: bad segment %d", s);
         }
-        q.first[s + 1] = q.first[s] + q.M[s] * chunks;
     }
     q.all_single = 1;
     for (int s = 0; s < n_seg; ++s)
         if (q.n[s] != 1) q.all_single = 0;
+    for (int s = 0; s < 8; ++s) {
+        q.rpi[s] = (!q.all_single && s < n_seg && q.n[s] == 1) ? 4 : 1;
+        q.first[s + 1] = q.first[s] + ceil_div(q.M[s], (int64_t)q.rpi[s]) * chunks;
+    }
     return GSAGE_OK;
 }
 

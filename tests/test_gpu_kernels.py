@@ -298,7 +298,7 @@ def test_wgrad_mfma_vs_fp64(M, N, K, groups):
 def test_gather_mean_multi_equals_single_launches():
     rng = np.random.RandomState(4)
     store = gs.FeatureStore.from_array(rng.normal(size=(900, 602)).astype(np.float32), torch.device(DEV), "bf16")
-    specs = [(300, 1), (12, 25), (300, 10)]
+    specs = [(301, 1), (12, 25), (300, 10), (7, 1)]      # row copies of a mixed launch go four rows per lane
     segs, refs = [], []
     for M, n in specs:
         ids = torch.from_numpy(rng.randint(0, 900, size=M * n)).to(DEV)

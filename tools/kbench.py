@@ -112,3 +112,24 @@ if 'tail' in which:
                                        preds.data_ptr(), dH.data_ptr(), part.data_ptr(), ops._stream()))
     print('tail (B=%d n=%d): %.1f us' % (B, n, timeit(f)))
 
+
+if 'gmulti' in which:
+    # the level-0 gathers of one step (x rows of 13 312 nodes | 512 means of 25 | 12 800 means of 10)
+    # in one launch, for several segment orders
+    store = gs.FeatureStore(table, D)
+    tot = B * (1 + f1 + f1 * f2)
+    idsets = [torch.randint(1, N, (tot,), device=dev) for _ in range(8)]
+    xa = torch.zeros(2, R0, ld, dtype=torch.bfloat16, device=dev)
+    i = [0]
+    def segs(ids):
+        return {"x": (table, ids[:R0], xa[0], R0, 1),
+                "h1": (table, ids[B:R0], xa[1][:B], B, f1),
+                "h2": (table, ids[R0:], xa[1][B:], B * f1, f2)}
+    for order in (("x", "h1", "h2"), ("h2", "h1", "x"), ("h2", "x", "h1"), ("h1", "h2", "x"), ("h2",), ("x",), ("h1",)):
+        def f():
+            i[0] += 1
+            sg = segs(idsets[i[0] % 8])
+            ops.gather_mean_multi([sg[k] for k in order], ld, D, ld)
+        t = timeit(f)
+        rows = sum({"x": R0, "h1": B * f1, "h2": B * f1 * f2}[k] for k in order)
+        print('gmulti %-12s: %.1f us (%.2f TB/s read)' % ('+'.join(order), t, rows * D * 2 / t / 1e6))
