@@ -210,6 +210,22 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
                     int groups, int64_t a_gstride, int64_t w_gstride, int64_t c_gstride,
                     void *stream);
 
+/* K5 with the weight operand in MFMA fragment order (bf16 only): a wave's B fragment is one coalesced
+ * 1 KiB load from L2 straight into registers, so only A goes through LDS and both operand rings run
+ * deeper than LDS capacity allows the plain kernel.  Same arithmetic and
+ * arguments as gsage_linear_nt with dtype = bf16; Wp from gsage_pack_weight (or kept current by the
+ * optimizer through gsage_prep_desc.dst_p), groups laid out back to back.  A rows must be whole
+ * 128-byte lines, zero padded up to round_up(K, 64).
+ *     Wp[g][jb][kc][lane][e] = W_g[jb*32 + (lane & 31)][kc*16 + (lane >> 5)*8 + e]   (0 outside N x K)
+ *     jb < ceil(N/32), kc < 4*ceil(K/64), lane < 64, e < 8;  gsage_packed_weight_elems() bf16 elements. */
+int64_t gsage_packed_weight_elems(int64_t N, int64_t K, int32_t groups);
+int gsage_pack_weight(const void *W, int dtype, int64_t ldw, int64_t w_gstride, int64_t N, int64_t K,
+                      int32_t groups, void *Wp, void *stream);
+int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, int a_rows_group0_only,
+                           const void *Wp, const float *bias, void *C, int c_dtype, int64_t ldc,
+                           int64_t M, int64_t N, int64_t K, int act, int groups, int64_t a_gstride,
+                           int64_t c_gstride, void *stream);
+
 /* K5b weight gradient (MFMA, bf16 in / fp32 out): the backward of the projection above w.r.t. its
  *     weights (autograd of nn_modules.py:189-190,200 under loss.backward(), models.py:100)
  *
@@ -420,8 +436,9 @@ int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
  * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy
- * dst_t[c, r] (leading dimension dst_t_ld).  `descs` is a DEVICE array of n_desc descriptors;
- * padding columns of dst / dst_t are not written (allocate them zeroed).
+ * dst_t[c, r] (leading dimension dst_t_ld), and/or the fragment-ordered copy dst_p (see
+ * gsage_linear_nt_packed).  `descs` is a DEVICE array of n_desc descriptors; padding of dst / dst_t /
+ * dst_p is not written (allocate them zeroed).
  * max_elems = max rows*cols over the descriptors.  Being the first launch of a step it can also
  * advance two device counters: *tick0 += inc0, *tick1 += inc1 (either pointer may be NULL). */
 typedef struct {
@@ -429,6 +446,8 @@ typedef struct {
     uint16_t *dst;
     uint16_t *dst_t;
     int32_t rows, cols, dst_ld, dst_t_ld;
+    uint16_t *dst_p;       /* optional: the gsage_linear_nt_packed operand of THIS matrix (one group) */
+    int64_t kc_p;          /* its k chunks per column block: 4 * ceil(cols / 64) */
 } gsage_prep_desc;
 int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int64_t *tick0,
                        int64_t inc0, int64_t *tick1, int64_t inc1, void *stream);

@@ -55,6 +55,10 @@ SIGNATURES = {
     "gsage_scatter_add_rows": (_int, [_vp, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _i64, _vp]),
     "gsage_linear_nt": (_int, [_vp, _int, _i64, _vp, _int, _vp, _i64, _vp, _vp, _int, _i64, _i64,
                                _i64, _i64, _int, _int, _i64, _i64, _i64, _vp]),
+    "gsage_packed_weight_elems": (_i64, [_i64, _i64, _i32]),
+    "gsage_pack_weight": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "gsage_linear_nt_packed": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _int,
+                                      _int, _i64, _i64, _vp]),
     "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
                            _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),

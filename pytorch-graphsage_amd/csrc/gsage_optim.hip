@@ -185,6 +185,7 @@ k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0,
         const uint16_t b = f32_to_bf16(d.src[t]);
         if (d.dst) d.dst[(int64_t)r * d.dst_ld + c] = b;
         if (d.dst_t) d.dst_t[(int64_t)c * d.dst_t_ld + r] = b;
+        if (d.dst_p) d.dst_p[packed_offset(r, c, d.kc_p)] = b;
     }
 }
 

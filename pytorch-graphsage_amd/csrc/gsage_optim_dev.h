@@ -23,7 +23,16 @@ struct PrepDesc {
     uint16_t *dst;         // [rows, dst_ld] bf16 (may be null)
     uint16_t *dst_t;       // [cols, dst_t_ld] bf16 transposed copy (may be null)
     int32_t rows, cols, dst_ld, dst_t_ld;
+    uint16_t *dst_p;       // MFMA-fragment-ordered copy for k_linear_nt_packed (may be null)
+    int64_t kc_p;          // 16-wide k chunks per 32-column block of dst_p
 };
+
+// element (r, c) of a weight matrix inside its packed operand (include/gsage.h, gsage_linear_nt_packed)
+__device__ __forceinline__ int64_t packed_offset(int r, int c, int64_t kc_total)
+{
+    const int64_t slot = ((int64_t)(r >> 5) * kc_total + (c >> 4)) * 64 + (r & 31) + 32 * ((c >> 3) & 1);
+    return slot * 8 + (c & 7);
+}
 
 struct AdamParams {
     float *p, *g, *m, *v;
@@ -106,6 +115,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
                 const uint16_t b = f32_to_bf16(pn);
                 if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
                 if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
+                if (q.dst_p) q.dst_p[packed_offset(r, c, q.kc_p)] = b;
                 break;
             }
         }

@@ -147,7 +147,7 @@ class _ReduceDesc(ctypes.Structure):         # mirrors gsage_reduce_desc (includ
 class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/gsage.h)
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_ld", ctypes.c_int32),
-                ("dst_t_ld", ctypes.c_int32)]
+                ("dst_t_ld", ctypes.c_int32), ("dst_p", ctypes.c_void_p), ("kc_p", ctypes.c_int64)]
 
 
 def _r8(v):
@@ -294,7 +294,7 @@ class FusedMeanTrainStep(object):
         self.h = [l.output_dim_ for l in self.layers]
         self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
         self.rows = [self.off[L - l] for l in range(L)]           # R_l = rows of level l
-        self.w2, self.w2t, descs = [], [], []
+        self.w2, self.w2t, self.wp, descs = [], [], [], []
         for l, layer in enumerate(self.layers):
             h, din = self.h[l], self.din[l]
             assert tuple(layer.fc_x.weight.shape) == (h, din) == tuple(layer.fc_neib.weight.shape)
@@ -304,10 +304,18 @@ class FusedMeanTrainStep(object):
             w2t = torch.zeros(2, din, _r8(h), dtype=torch.bfloat16, device=dev) if l > 0 else None
             self.w2.append(w2)
             self.w2t.append(w2t)
+            # levels whose forward runs on K5 read the weights in MFMA fragment order
+            # (gsage_linear_nt_packed; needs whole-line operand rows); the seed-level kernel reads w2
+            lda = feats.ld if l == 0 else din
+            packed = lda % 64 == 0 and lda >= -(-din // 64) * 64
+            gstride = nat.lib().gsage_packed_weight_elems(h, din, 1)
+            wp = torch.zeros(2 * gstride, dtype=torch.bfloat16, device=dev) if packed else None
+            self.wp.append(wp)
             for g, prm in enumerate((layer.fc_x.weight, layer.fc_neib.weight)):
                 descs.append(_PrepDesc(prm.data_ptr(), w2[g].data_ptr(),
                                        w2t[g].data_ptr() if w2t is not None else None,
-                                       h, din, w2.shape[2], w2t.shape[2] if w2t is not None else 0))
+                                       h, din, w2.shape[2], w2t.shape[2] if w2t is not None else 0,
+                                       wp[g * gstride:].data_ptr() if packed else None, 4 * (-(-din // 64))))
         raw = bytes((_PrepDesc * len(descs))(*descs))
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
@@ -561,6 +569,12 @@ class FusedMeanTrainStep(object):
             delta = agg.data_ptr() - xbuf.data_ptr()
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
+            if self.wp[l] is not None:
+                ops._linear_packed_launch(xbuf.data_ptr(), lda, None, 0, self.wp[l].data_ptr(), None,
+                                          self.hout[l].data_ptr(), 2 * h, R, h, din,
+                                          nat.ACT_NONE if last else nat.ACT_RELU, 2, delta // esz, h,
+                                          nat.F32 if last else nat.BF16)
+                continue
             self._linear(xbuf.data_ptr(), lda, None, 0, self.w2[l].data_ptr(), self.w2[l].shape[2],
                          self.hout[l].data_ptr(), nat.F32 if last else nat.BF16, 2 * h, R, h, din,
                          nat.ACT_NONE if last else nat.ACT_RELU, delta // esz,

@@ -287,6 +287,29 @@ def _linear_launch(A, lda, a_rows, a_rows_g0, W, ldw, bias, C, ldc, M, N, K, act
                                         _stream()), "linear_nt")
 
 
+def pack_weight(W, K=None, out=None):
+    """[groups, N, ld] (or [N, ld]) fp32 / bf16 weights -> the MFMA-fragment-ordered bf16 operand of
+    gsage_linear_nt_packed (include/gsage.h).  K: logical inner size (default: the last dimension)."""
+    W3 = W if W.dim() == 3 else W.unsqueeze(0)
+    assert W3.stride(2) == 1 and W3.is_cuda
+    groups, N, _ = W3.shape
+    K = int(W3.shape[2] if K is None else K)
+    n = nat.lib().gsage_packed_weight_elems(N, K, groups)
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=W.device)
+    assert out.numel() >= n and out.dtype == torch.bfloat16
+    code = nat.BF16 if W3.dtype == torch.bfloat16 else nat.F32
+    assert W3.dtype in (torch.bfloat16, torch.float32)
+    nat.check(nat.lib().gsage_pack_weight(W3.data_ptr(), code, W3.stride(1), W3.stride(0) if groups > 1 else 0,
+                                          N, K, groups, out.data_ptr(), _stream()), "pack_weight")
+    return out
+
+
+def _linear_packed_launch(A, lda, a_rows, a_rows_g0, Wp, bias, C, ldc, M, N, K, act, groups, a_gs, c_gs, c_code):
+    nat.check(nat.lib().gsage_linear_nt_packed(A, lda, a_rows, a_rows_g0, Wp, bias, C, c_code, ldc, M, N, K,
+                                               act, groups, a_gs, c_gs, _stream()), "linear_nt_packed")
+
+
 def _prep_weight(W, cdt, epc):
     """[N, K] fp32 parameter -> [N, round_up(K, epc)] compute dtype, zero padded."""
     return _pad_cast(W.detach(), cdt, epc)

@@ -175,6 +175,44 @@ def test_linear_nt_mfma_layouts(dtype, M, N, K):
         close(outb.float().cpu().numpy(), _lin_ref(A, W, b, 1), "bf16 out", 2 ** -8, 2 ** -8)
 
 
+@pytest.mark.parametrize("M,N,K,groups", [(13312, 128, 602, 2), (100, 128, 602, 2), (513, 96, 256, 1),
+                                          (65, 41, 70, 1), (1000, 512, 640, 1), (77, 128, 64, 1),
+                                          (300, 256, 200, 2), (64, 128, 320, 1), (2000, 160, 1433, 1)])
+def test_linear_nt_packed_weight_operand(M, N, K, groups):
+    """gsage_linear_nt_packed (W in MFMA fragment order, loaded straight into registers) against fp64:
+    k-tile counts 1..23 (ring not full / exactly full / steady state + drain in every phase), ragged M
+    and N, grouped launches, fp32 and bf16 outputs, bias + activation."""
+    rng = np.random.RandomState(M + N + K + groups)
+    ld = -(-K // 64) * 64
+    A = np.zeros((groups, M, ld), dtype=np.float32)
+    A[:, :, :K] = bf16_round(rng.normal(size=(groups, M, K)))
+    W = bf16_round(rng.normal(size=(groups, N, K)) / np.sqrt(K))
+    b = rng.normal(size=(groups, N)).astype(np.float32)
+    At = torch.from_numpy(A).to(DEV).bfloat16().contiguous()
+    Wt = torch.from_numpy(W).to(DEV)
+    bt = torch.from_numpy(b).to(DEV)
+    for wsrc in (Wt, Wt.bfloat16()):                           # the packer takes fp32 or bf16 weights
+        Wp = ops.pack_weight(wsrc)
+        for act, bias, cdt in ((0, None, torch.float32), (1, bt, torch.float32), (2, bt, torch.bfloat16)):
+            C = torch.full((M, groups * N), -7.0, dtype=cdt, device=DEV)
+            ops._linear_packed_launch(At.data_ptr(), ld, None, 0, Wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      C.data_ptr(), groups * N, M, N, K, act, groups, M * ld, N,
+                                      nat.BF16 if cdt == torch.bfloat16 else nat.F32)
+            for g in range(groups):
+                ref = _lin_ref(A[g][:, :K], W[g], b[g] if bias is not None else None, act)
+                tol = (2 ** -8, 2 ** -8) if cdt == torch.bfloat16 else (2e-5, 2e-6)
+                close(C[:, g * N:(g + 1) * N].float().cpu().numpy(), ref, (M, N, K, g, act), *tol)
+    # row indirection on the A operand (group 0 only), as the fused projection uses it
+    if groups == 2:
+        rows = torch.from_numpy(rng.permutation(M)).to(DEV)
+        C = torch.zeros(M, 2 * N, dtype=torch.float32, device=DEV)
+        ops._linear_packed_launch(At.data_ptr(), ld, rows.data_ptr(), 1, Wp.data_ptr(), None, C.data_ptr(), 2 * N,
+                                  M, N, K, 0, 2, M * ld, N, nat.F32)
+        perm = rows.cpu().numpy()
+        close(C[:, :N].cpu().numpy(), _lin_ref(A[0][perm][:, :K], W[0], None, 0), "a_rows g0", 2e-5, 2e-6)
+        close(C[:, N:].cpu().numpy(), _lin_ref(A[1][:, :K], W[1], None, 0), "a_rows g1", 2e-5, 2e-6)
+
+
 def test_linear_identity_times_asymmetric():
     """A = I: output must be exactly W^T laid out [m, j] (guide: transpose-detecting check)."""
     K = 64

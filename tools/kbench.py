@@ -133,3 +133,40 @@ if 'gmulti' in which:
         t = timeit(f)
         rows = sum({"x": R0, "h1": B * f1, "h2": B * f1 * f2}[k] for k in order)
         print('gmulti %-12s: %.1f us (%.2f TB/s read)' % ('+'.join(order), t, rows * D * 2 / t / 1e6))
+
+if 'linp' in which:
+    # K5 at the layer-0 shape: LDS-DMA kernel against the packed-weight kernel
+    for M in (R0 * 8, R0, R0 // 4, 512):
+        XA = torch.randn(2, M, ld, device=dev).bfloat16()
+        XA[:, :, D:] = 0
+        H = torch.empty(M, 2 * h, dtype=torch.bfloat16, device=dev)
+        W2 = torch.zeros(2, h, 640, device=dev, dtype=torch.bfloat16)
+        W2[:, :, :D] = torch.randn(2, h, D, device=dev).bfloat16()
+        Wp = ops.pack_weight(W2, K=D)
+        def f0():
+            ops._linear_launch(XA.data_ptr(), ld, None, 0, W2.data_ptr(), 640, None, H.data_ptr(), 2 * h, M, h, D,
+                               1, 2, M * ld, h * 640, h, nat.BF16, nat.BF16)
+        def f1():
+            ops._linear_packed_launch(XA.data_ptr(), ld, None, 0, Wp.data_ptr(), None, H.data_ptr(), 2 * h, M, h, D,
+                                      1, 2, M * ld, h, nat.BF16)
+        f0(); ref = H.clone(); H.zero_(); f1()
+        err = (H.float() - ref.float()).abs().max().item()
+        t0, t1 = timeit(f0), timeit(f1)
+        fl = 2 * 2 * M * 640 * h / 1e6
+        print('linp M=%6d: dma %.1f us (%.0f TF/s)   packed %.1f us (%.0f TF/s)   max diff %.3g' % (M, t0, fl / t0, t1, fl / t1, err))
+
+if 'linpk' in which:
+    # K sweep: fixed cost vs cost per 64-wide k-tile, both K5 kernels
+    for M in (512, R0):
+        for K in (64, 256, 640, 1280, 2560):
+            XA = torch.randn(2, M, K, device=dev).bfloat16()
+            H = torch.empty(M, 2 * h, dtype=torch.bfloat16, device=dev)
+            W2 = torch.randn(2, h, K, device=dev).bfloat16()
+            Wp = ops.pack_weight(W2)
+            def f0():
+                ops._linear_launch(XA.data_ptr(), K, None, 0, W2.data_ptr(), K, None, H.data_ptr(), 2 * h, M, h, K,
+                                   1, 2, M * K, h * K, h, nat.BF16, nat.BF16)
+            def f1():
+                ops._linear_packed_launch(XA.data_ptr(), K, None, 0, Wp.data_ptr(), None, H.data_ptr(), 2 * h, M, h, K,
+                                          1, 2, M * K, h, nat.BF16)
+            print('linpk M=%6d K=%5d (%2d k-tiles): dma %.1f us   packed %.1f us' % (M, K, K // 64, timeit(f0), timeit(f1)))
