@@ -193,33 +193,43 @@ MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no spar
 
 def pool_kernel_roofline(gs, model, store, data, dev, reps=20, n_frontiers=4):
     """BASELINE configs[2] (max-pool): the dominant kernel is K3 (pooling MLP + bias + ReLU + segment
-    max fused, gather fused) on the hop-2 frontier -- MFMA-bound.  FLOPs = 2 * rows * D * hidden of the
-    contraction the reference runs as mlp(neibs) (nn_modules.py:224)."""
+    max fused) on the hop-2 frontier -- MFMA-bound.  FLOPs = 2 * rows * D * hidden of the contraction
+    the reference runs as mlp(neibs) (nn_modules.py:224).  Timed exactly as engine.FusedPoolTrainStep
+    launches it: gsage_pool_mlp_packed over the frontier's rows gathered beforehand (not timed)."""
     ops, nat = gs.ops, gs._native
     layer = list(model.agg_layers.children())[0]
     lin = layer.mlp[0]
     rng = np.random.RandomState(7)
     M, n = BATCH * FANOUT[0], FANOUT[1]
+    H = lin.weight.shape[0]
     fronts = []
     for _ in range(n_frontiers):
         ids0 = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=BATCH)]).to(dev)
-        fronts.append(model.train_sampler(model.train_sampler(ids0, n_samples=FANOUT[0]), n_samples=n))
-    run = lambda f: ops.pool_mlp(gs.RowRef(store, f), lin.weight, lin.bias, M, nat.POOL_MAX)
-    with torch.no_grad():
-        for f in fronts:
-            run(f)
-        torch.cuda.synchronize()
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for r in range(reps):
-            run(fronts[r % n_frontiers])
-        stop.record()
-        torch.cuda.synchronize()
-    # each call also converts the weight to bf16 (a 0.6 MB elementwise kernel): < 1 % of the launch
+        ids2 = model.train_sampler(model.train_sampler(ids0, n_samples=FANOUT[0]), n_samples=n)
+        fronts.append(ops.gather_mean(store, ids2, M * n, 1, out_dtype=torch.bfloat16, out_ld=store.ld))
+    wp = ops.pack_weight(lin.weight.detach().float().contiguous())
+    bias = lin.bias.detach().float().contiguous()
+    pooled = torch.empty(M, H, dtype=torch.float32, device=dev)
+    pooled_b = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    argmax = torch.empty(M, H, dtype=torch.int32, device=dev)
+
+    def run(rows):
+        nat.check(nat.lib().gsage_pool_mlp_packed(rows.data_ptr(), store.ld, None, wp.data_ptr(), bias.data_ptr(), M, n,
+                                                  H, FEAT_DIM, nat.POOL_MAX, pooled.data_ptr(), H, argmax.data_ptr(),
+                                                  pooled_b.data_ptr(), H, None, ops._stream()), "pool_mlp_packed")
+    for f in fronts:
+        run(f)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for r in range(reps):
+        run(fronts[r % n_frontiers])
+    stop.record()
+    torch.cuda.synchronize()
     dur_s = start.elapsed_time(stop) / 1e3 / reps
-    flops = 2.0 * M * n * FEAT_DIM * lin.weight.shape[0]
+    flops = 2.0 * M * n * FEAT_DIM * H
     achieved = flops / dur_s / 1e12
-    return {"bound": "mfma", "kernel": "k_linear_nt<bf16, POOL> (K3, hop 2: 128 000 rows x 602 -> 512)",
+    return {"bound": "mfma", "kernel": "k_pool_mlp_packed (K3, hop 2: 128 000 rows x 602 -> 512)",
             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
             "traffic": None, "alg_flops_per_launch": flops, "avg_launch_us": dur_s * 1e6}
 

@@ -273,6 +273,15 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
  * relu_mask (may be NULL; H % 32 == 0): [M*n, H/32] words, bit c%32 of word c/32 of row r = hidden
  * activation (r, c) > 0 -- all the mean pool's backward needs of the hidden layer. */
 
+/* K3 on the packed weight operand (bf16; see gsage_linear_nt_packed): one workgroup covers 64 rows x
+ * 256 hidden columns, so A is read once per 256 columns instead of once per 128, and W goes from L2
+ * straight into registers.  Same results and arguments as gsage_pool_mlp; Wp = gsage_pack_weight of
+ * the [H, K] weight; A rows must be whole 128-byte lines, zero padded up to round_up(K, 64). */
+int gsage_pool_mlp_packed(const void *A, int64_t lda, const int64_t *a_rows, const void *Wp,
+                          const float *bias, int64_t M, int32_t n, int64_t H, int64_t K, int pool,
+                          float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
+                          int64_t pooled_bf16_ld, uint32_t *relu_mask, void *stream);
+
 /* Backward routing of the max pool: the bf16 [M*n, ldo] gradient of the hidden activations,
  *     out[i*n + j, c] = (argmax[i, c] == j && pooled[i, c] > 0) ? g[i, c] : 0
  * (autograd of nn_modules.py:224-226,240: max picks one row per (segment, channel), ReLU passes

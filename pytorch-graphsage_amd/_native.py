@@ -80,6 +80,8 @@ SIGNATURES = {
                                _vp, _vp]),
     "gsage_pool_mlp": (_int, [_vp, _int, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _int,
                               _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "gsage_pool_mlp_packed": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _int, _vp, _i64, _vp, _vp,
+                                     _i64, _vp, _vp]),
     "gsage_pool_route_mean_bwd": (_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "gsage_pool_bias_partials": (_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp]),
     "gsage_pool_merge_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),

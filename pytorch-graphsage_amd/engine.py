@@ -917,23 +917,29 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         assert all(d % 64 == 0 for d in self.din[1:]), "hidden widths must be multiples of 32"
         descs = []
 
-        def copies(prm, need_t):
+        def copies(prm, need_t, packed=False):
             r, c = prm.shape
             w = torch.zeros(r, _r64(c), dtype=bf, device=dev)
             wt = torch.zeros(c, _r64(r), dtype=bf, device=dev) if need_t else None
+            # forward operands of K3 / K5 also in MFMA fragment order (gsage_*_packed)
+            wp = (torch.zeros(nat.lib().gsage_packed_weight_elems(r, c, 1), dtype=bf, device=dev)
+                  if packed else None)
             descs.append(_PrepDesc(prm.data_ptr(), w.data_ptr(), wt.data_ptr() if need_t else None, r, c,
-                                   w.shape[1], wt.shape[1] if need_t else 0))
-            return w, wt
+                                   w.shape[1], wt.shape[1] if need_t else 0,
+                                   wp.data_ptr() if packed else None, 4 * (-(-c // 64))))
+            return (w, wt, wp) if packed else (w, wt)
         self.wm, self.wx, self.wn, self.wmT, self.wxT, self.wnT = [], [], [], [], [], []
+        self.wm_p, self.wx_p, self.wn_p = [], [], []
         for l, layer in enumerate(self.layers):
             order = [self.pidx[id(p)] for p in (layer.mlp[0].weight, layer.mlp[0].bias, layer.fc_x.weight,
                                                 layer.fc_neib.weight)]
             assert order == list(range(order[0], order[0] + 4)), "unexpected parameter order"
-            wm, wmT = copies(layer.mlp[0].weight, l > 0)
-            wx, wxT = copies(layer.fc_x.weight, l > 0)
-            wn, wnT = copies(layer.fc_neib.weight, True)
+            wm, wmT, wm_p = copies(layer.mlp[0].weight, l > 0, True)
+            wx, wxT, wx_p = copies(layer.fc_x.weight, l > 0, True)
+            wn, wnT, wn_p = copies(layer.fc_neib.weight, True, True)
             self.wm.append(wm); self.wmT.append(wmT); self.wx.append(wx); self.wxT.append(wxT)
             self.wn.append(wn); self.wnT.append(wnT)
+            self.wm_p.append(wm_p); self.wx_p.append(wx_p); self.wn_p.append(wn_p)
         self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
         self.max_elems = max(d.rows * d.cols for d in descs)
@@ -1000,7 +1006,10 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None,
                               hops=hops)
 
-    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
+    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act, Wp=None):
+        if Wp is not None and lda % 64 == 0 and lda >= -(-K // 64) * 64:
+            ops._linear_packed_launch(A, lda, None, 0, Wp.data_ptr(), None, C, ldc, M, N, K, act, 1, 0, 0, c_code)
+            return
         ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
                            nat.BF16, c_code)
 
@@ -1013,19 +1022,25 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
                 is_max = self.pool_mode == nat.POOL_MAX
-                nat.check(lib.gsage_pool_mlp(
-                    nb[a0:].data_ptr(), nat.BF16, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
-                    layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
-                    self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
-                    self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1],
-                    None if is_max else self.argmax[l][a0:].data_ptr(), stream), "pool_mlp")
+                tail = (self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
+                        self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1],
+                        None if is_max else self.argmax[l][a0:].data_ptr(), stream)
+                if ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
+                    nat.check(lib.gsage_pool_mlp_packed(
+                        nb[a0:].data_ptr(), ldnb, None, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
+                        self.size[k], self.fan[k + 1], Hm, din, self.pool_mode, *tail), "pool_mlp_packed")
+                else:
+                    nat.check(lib.gsage_pool_mlp(
+                        nb[a0:].data_ptr(), nat.BF16, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
+                        layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
+                        *tail), "pool_mlp")
             x, ldx = self._x_operand(l, s)
             last = l == L - 1
             out, code = self.hout[l], (nat.F32 if last else nat.BF16)
             act = nat.ACT_NONE if last else nat.ACT_RELU
-            self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act)
+            self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act, self.wx_p[l])
             self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
-                       out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act)
+                       out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act, self.wn_p[l])
         C, D2 = m.fc.weight.shape
         tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
         nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), 2 * self.h[L - 1], m.fc.weight.data_ptr(),

@@ -213,6 +213,57 @@ def test_linear_nt_packed_weight_operand(M, N, K, groups):
         close(C[:, N:].cpu().numpy(), _lin_ref(A[1][:, :K], W[1], None, 0), "a_rows g1", 2e-5, 2e-6)
 
 
+@pytest.mark.parametrize("mode", ["max", "mean"])
+@pytest.mark.parametrize("M,n,D,H", [(1280, 10, 602, 512), (53, 25, 602, 512), (7, 1, 70, 130), (64, 3, 256, 64),
+                                     (3, 64, 40, 128), (33, 7, 1433, 1024), (10, 10, 128, 512)])
+def test_pool_mlp_packed_equals_pool_mlp(mode, M, n, D, H):
+    """gsage_pool_mlp_packed (64 rows x 512 hidden columns per workgroup, W from the fragment-ordered
+    operand) against gsage_pool_mlp: same k order inside every accumulator, so pooled values, argmax
+    and sign bits must agree exactly; row indirection included."""
+    rng = np.random.RandomState(M * 3 + n + D + H)
+    ld = -(-D // 64) * 64
+    R = 400
+    table = torch.zeros(R, ld, dtype=torch.bfloat16, device=DEV)
+    table[:, :D] = torch.from_numpy(rng.normal(size=(R, D)).astype(np.float32)).to(DEV).bfloat16()
+    W = torch.zeros(H, ld, dtype=torch.bfloat16, device=DEV)
+    W[:, :D] = torch.from_numpy((rng.normal(size=(H, D)) / np.sqrt(D)).astype(np.float32)).to(DEV).bfloat16()
+    b = torch.from_numpy(rng.normal(size=(H,)).astype(np.float32)).to(DEV)
+    ids = torch.from_numpy(rng.randint(0, R, size=M * n)).to(DEV)
+    rows = table[ids].contiguous()
+    Wp = ops.pack_weight(W, K=D)
+    pm = nat.POOL_MAX if mode == "max" else nat.POOL_MEAN
+    want_mask = mode == "mean" and H % 32 == 0
+
+    def run(packed, A, a_rows):
+        pooled = torch.full((M, H), -3.0, device=DEV)
+        pooled_b = torch.zeros(M, H, dtype=torch.bfloat16, device=DEV)
+        arg = torch.full((M, H), -1, dtype=torch.int32, device=DEV) if mode == "max" else None
+        mask = torch.zeros(M * n, H // 32, dtype=torch.int32, device=DEV) if want_mask else None
+        ap = arg.data_ptr() if arg is not None else None
+        mp = mask.data_ptr() if mask is not None else None
+        ar = a_rows.data_ptr() if a_rows is not None else None
+        if packed:
+            nat.check(nat.lib().gsage_pool_mlp_packed(A.data_ptr(), ld, ar, Wp.data_ptr(), b.data_ptr(), M, n, H, D, pm,
+                                                      pooled.data_ptr(), H, ap, pooled_b.data_ptr(), H, mp, None),
+                      "pool_mlp_packed")
+        else:
+            nat.check(nat.lib().gsage_pool_mlp(A.data_ptr(), nat.BF16, ld, ar, W.data_ptr(), ld, b.data_ptr(), M, n, H, D,
+                                               pm, pooled.data_ptr(), H, ap, pooled_b.data_ptr(), H, mp, None), "pool_mlp")
+        return pooled, pooled_b, arg, mask
+
+    ref = run(False, rows, None)
+    for A, a_rows in ((rows, None), (table, ids)):
+        got = run(True, A, a_rows)
+        for r, g_ in zip(ref, got):
+            if r is not None:
+                assert torch.equal(r, g_), (mode, M, n, D, H, a_rows is not None)
+    # and the reference values themselves against fp64 (guards both kernels)
+    hid = np.maximum(rows[:, :D].float().cpu().numpy().astype(np.float64) @ W[:, :D].float().cpu().numpy().astype(np.float64).T
+                     + b.cpu().numpy(), 0).reshape(M, n, H)
+    want = hid.max(1) if mode == "max" else hid.mean(1)
+    close(ref[0].cpu().numpy(), want, ("pool", mode), 2e-5, 2e-5)
+
+
 def test_linear_identity_times_asymmetric():
     """A = I: output must be exactly W^T laid out [m, j] (guide: transpose-detecting check)."""
     K = 64

@@ -170,3 +170,25 @@ if 'linpk' in which:
                 ops._linear_packed_launch(XA.data_ptr(), K, None, 0, Wp.data_ptr(), None, H.data_ptr(), 2 * h, M, h, K,
                                           1, 2, M * K, h, nat.BF16)
             print('linpk M=%6d K=%5d (%2d k-tiles): dma %.1f us   packed %.1f us' % (M, K, K // 64, timeit(f0), timeit(f1)))
+
+if 'pool' in which:
+    # K3 on the hop-2 / hop-1 frontier of the max-pool configuration: 64 x 128 tiles against the packed kernel
+    Hm = 512
+    Wm = torch.zeros(Hm, ld, dtype=torch.bfloat16, device=dev); Wm[:, :D] = (torch.randn(Hm, D, device=dev) / 25).bfloat16()
+    bm = torch.randn(Hm, device=dev) * 0.1
+    Wp = ops.pack_weight(Wm, K=D)
+    for M, n in ((B * f1, f2), (B, f1)):
+        rows = torch.zeros(M * n, ld, dtype=torch.bfloat16, device=dev); rows[:, :D] = torch.randn(M * n, D, device=dev).bfloat16()
+        pooled = torch.empty(M, Hm, device=dev); pb = torch.empty(M, Hm, dtype=torch.bfloat16, device=dev)
+        arg = torch.empty(M, Hm, dtype=torch.int32, device=dev)
+        def f0():
+            nat.check(L.gsage_pool_mlp(rows.data_ptr(), nat.BF16, ld, None, Wm.data_ptr(), ld, bm.data_ptr(), M, n, Hm, D,
+                                       nat.POOL_MAX, pooled.data_ptr(), Hm, arg.data_ptr(), pb.data_ptr(), Hm, None, ops._stream()))
+        def f1():
+            nat.check(L.gsage_pool_mlp_packed(rows.data_ptr(), ld, None, Wp.data_ptr(), bm.data_ptr(), M, n, Hm, D,
+                                              nat.POOL_MAX, pooled.data_ptr(), Hm, arg.data_ptr(), pb.data_ptr(), Hm, None, ops._stream()))
+        f0(); ref = pooled.clone(); pooled.zero_(); f1()
+        err = (pooled - ref).abs().max().item()
+        t0, t1 = timeit(f0, reps=10), timeit(f1, reps=10)
+        fl = 2.0 * M * n * D * Hm / 1e6
+        print('pool M=%6d n=%2d: tiles64x128 %.1f us (%.0f TF/s)   packed %.1f us (%.0f TF/s)   max diff %.3g' % (M, n, t0, fl / t0, t1, fl / t1, err))
