@@ -234,8 +234,9 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
  *     The reduction over M is split into ceil(M / rows_per_split) slices whose partial tiles are
  *     written to `slabs` (fp32 [slices, Ntot, ldk], caller-allocated) and summed deterministically
  *     into `out` (out == NULL: the slabs are left for gsage_finalize_grads).
- *     Needs ldc, lda, ldk % 4 == 0, Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0,
- *     n_per_group % 128 == 0 unless there is a single group. */
+ *     Needs ldc, lda % 8 == 0 and 16-byte aligned dC, A (16-byte lane loads), ldk % 4 == 0,
+ *     Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0, n_per_group % 128 == 0 unless there
+ *     is a single group. */
 int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
                 int64_t Ntot, int64_t K,
                 int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,

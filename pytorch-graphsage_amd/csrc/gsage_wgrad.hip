@@ -6,29 +6,30 @@
 //     dW_g[n, k] = sum_m dC[m, g*n_per_group + n] * A_g[m, k]          fp32 result
 //
 // Both operands are "M-major" (the reduction index m is the SLOW dimension of both matrices),
-// the opposite of what v_mfma_f32_32x32x16_bf16 wants (8 consecutive reduction elements per
-// lane).  Instead of transposing through LDS, each lane loads, for 8 consecutive rows m, the 8
-// bytes holding 4 adjacent columns, and re-packs them in registers with v_perm_b32 into four
-// operands -- one per column residue e -- so MFMA #e owns output rows n = 4*i + e (a fixed
+// the opposite of what the MFMA wants (8 consecutive reduction elements per lane).  Instead of
+// transposing through LDS, each lane loads, for 8 consecutive rows m, the 16 bytes holding 8 adjacent
+// columns, and re-packs them in registers with v_perm_b32 into eight operands -- one per column
+// residue e -- so MFMA (e, f) owns output rows n = 8*i + e and columns k = 8*j + f (a fixed
 // interleave of the output, undone for free in the epilogue's addressing).  Same trick on the A
-// side.  Every global load is a full, coalesced row segment (32 lanes x 8 B = 256 B).
+// side.  The MFMA is v_mfma_f32_16x16x32_bf16: 16 lanes x 8 columns span the 128-wide tile and the
+// four 16-lane groups take four 8-row groups, so one step is 32 rows and every global load is a
+// 16-byte lane load (256 B contiguous per 16 lanes).  (The first version used 32x32x16 with 8-byte
+// lane loads: twice the vector-memory instructions per row, and the texture addresser -- ~16 clocks per
+// wave-wide load whatever its width -- was what bound it.)
 //
-// Decomposition: workgroup tile = wave tile = 128 (n) x 128 (k) = 16 accumulators (256 AGPRs, one
+// Decomposition: workgroup tile = wave tile = 128 (n) x 128 (k) = 64 accumulators of 4 (256 AGPRs, one
 // wave per SIMD, one workgroup per CU).  The reduction over M is split across grid.x into
 // `rows_per_split` slices; inside a workgroup the four waves quarter the slice, then sum their tiles
-// through LDS (every wave parks its tile, then sums and stores an eighth of the output), so one fp32 partial tile per workgroup
-// goes to the slabs (deterministic; summed by k_reduce_slabs / gsage_finalize_grads -- no atomics).
-// MFMA-bound per wave, L2-bound overall.
+// through LDS (every wave parks its tile, then sums and stores a quarter of the output), so one fp32
+// partial tile per workgroup goes to the slabs (deterministic; summed by k_reduce_slabs /
+// gsage_finalize_grads -- no atomics).
 #include "gsage_common.h"
 
 namespace gsage {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradParams {
     const uint16_t *dC;
@@ -38,9 +39,9 @@ struct WgradParams {
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
 };
 
-// operand for column residue E out of eight 8-byte row segments
+// operand for column residue E (0..7) out of eight 16-byte row segments: element E of rows 0..7
 template <int E>
-__device__ __forceinline__ u32x4 pack_column(const u32x2 (&v)[8])
+__device__ __forceinline__ u32x4 pack_column(const u32x4 (&v)[8])
 {
     constexpr uint32_t sel = (E & 1) ? 0x07060302u : 0x05040100u;     // hi|hi : lo|lo halves
     u32x4 o;
@@ -50,135 +51,145 @@ __device__ __forceinline__ u32x4 pack_column(const u32x2 (&v)[8])
     return o;
 }
 
-__device__ __forceinline__ void mma_step(const u32x2 (&c_cur)[8], const u32x2 (&a_cur)[8],
-                                         f32x16_t (&acc)[4][4])
+template <int E>
+__device__ __forceinline__ void mma_row(const u32x4 (&c_cur)[8], const u32x4 (&opb)[8], f32x4 (&acc)[8][8])
 {
-    u32x4 opb[4], opa[4];
+    const u32x4 opa = pack_column<E>(c_cur);
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        acc[E][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, opa),
+                                                            __builtin_bit_cast(bf16x8_t, opb[f]), acc[E][f], 0, 0, 0);
+}
+
+// one 32-row step: lane l holds rows 8 (l >> 4) .. +7, columns 8 (l & 15) .. +7 of both operands
+__device__ __forceinline__ void mma_step(const u32x4 (&c_cur)[8], const u32x4 (&a_cur)[8], f32x4 (&acc)[8][8])
+{
+    u32x4 opb[8];
     opb[0] = pack_column<0>(a_cur);
     opb[1] = pack_column<1>(a_cur);
     opb[2] = pack_column<2>(a_cur);
     opb[3] = pack_column<3>(a_cur);
-    opa[0] = pack_column<0>(c_cur);
-    opa[1] = pack_column<1>(c_cur);
-    opa[2] = pack_column<2>(c_cur);
-    opa[3] = pack_column<3>(c_cur);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-            acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8_t, opa[e]), __builtin_bit_cast(bf16x8_t, opb[f]),
-                acc[e][f], 0, 0, 0);
+    opb[4] = pack_column<4>(a_cur);
+    opb[5] = pack_column<5>(a_cur);
+    opb[6] = pack_column<6>(a_cur);
+    opb[7] = pack_column<7>(a_cur);
+    mma_row<0>(c_cur, opb, acc);
+    mma_row<1>(c_cur, opb, acc);
+    mma_row<2>(c_cur, opb, acc);
+    mma_row<3>(c_cur, opb, acc);
+    mma_row<4>(c_cur, opb, acc);
+    mma_row<5>(c_cur, opb, acc);
+    mma_row<6>(c_cur, opb, acc);
+    mma_row<7>(c_cur, opb, acc);
 }
 
 // Software pipeline (one wave per SIMD has nothing else to hide latency with): phase s issues the
-// 16 loads of step s+2, then runs the 16 MFMAs of step s -- two steps (16 KiB per wave) stay in
-// flight.  3 register slots with static numbering (loop unrolled x3); vmcnt retires in order, so
-// a phase only waits for loads issued two phases earlier.  No selects on loaded data in here
-// (see the column-validity note in the kernel), so hipcc does not wait right after issue.
+// 16 loads of step s+1, then runs the 64 MFMAs of step s -- one step (16 KiB per wave) stays in
+// flight.  Two register slots with static numbering (loop unrolled x2); vmcnt retires in order, so a
+// phase only waits for the loads issued one phase earlier.  No selects on loaded data in here (see
+// the column-validity note in the kernel), so hipcc does not wait right after issue.
 __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint16_t *A,
                                                int64_t m_begin, int64_t m_end, int64_t n_off,
-                                               int64_t k_off, int half, f32x16_t (&acc)[4][4])
+                                               int64_t k_off, int rg, f32x4 (&acc)[8][8])
 {
-    u32x2 cb[3][8], ab[3][8];
-    const int64_t nfull = (m_end - m_begin) / 16;            // steps with 16 valid rows
-    const uint16_t *c_base = p.dC + (m_begin + 8 * half) * p.ldc + n_off;
-    const uint16_t *a_base = A + (m_begin + 8 * half) * p.lda + k_off;
-    auto load_data = [&](u32x2 (&cdst)[8], u32x2 (&adst)[8], int64_t step) {
-        const uint16_t *cp = c_base + step * 16 * p.ldc;
-        const uint16_t *ap = a_base + step * 16 * p.lda;
+    u32x4 cb[2][8], ab[2][8];
+    const int64_t nfull = (m_end - m_begin) / 32;            // steps with 32 valid rows
+    const uint16_t *c_base = p.dC + (m_begin + 8 * rg) * p.ldc + n_off;
+    const uint16_t *a_base = A + (m_begin + 8 * rg) * p.lda + k_off;
+    auto load_data = [&](u32x4 (&cdst)[8], u32x4 (&adst)[8], int64_t step) {
+        const uint16_t *cp = c_base + step * 32 * p.ldc;
+        const uint16_t *ap = a_base + step * 32 * p.lda;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            cdst[r] = *reinterpret_cast<const u32x2 *>(cp + r * p.ldc);
-            adst[r] = *reinterpret_cast<const u32x2 *>(ap + r * p.lda);
+            cdst[r] = *reinterpret_cast<const u32x4 *>(cp + r * p.ldc);
+            adst[r] = *reinterpret_cast<const u32x4 *>(ap + r * p.lda);
         }
     };
     if (nfull > 0) load_data(cb[0], ab[0], 0);
-    if (nfull > 1) load_data(cb[1], ab[1], 1);
-    for (int64_t s0 = 0; s0 < nfull; s0 += 3) {
+    for (int64_t s0 = 0; s0 < nfull; s0 += 2) {
 #pragma unroll
-        for (int ph = 0; ph < 3; ++ph) {
+        for (int ph = 0; ph < 2; ++ph) {
             const int64_t sidx = s0 + ph;
             if (sidx < nfull) {                                      // wave-uniform
-                if (sidx + 2 < nfull) load_data(cb[(ph + 2) % 3], ab[(ph + 2) % 3], sidx + 2);
+                if (sidx + 1 < nfull) load_data(cb[ph ^ 1], ab[ph ^ 1], sidx + 1);
                 mma_step(cb[ph], ab[ph], acc);
             }
         }
     }
-    // ragged tail (< 16 rows, last slice only): rows past the end contribute zeros
-    const int64_t m_tail = m_begin + nfull * 16;
+    // ragged tail (< 32 rows, last slice only): rows past the end contribute zeros
+    const int64_t m_tail = m_begin + nfull * 32;
     if (m_tail < m_end) {
-        u32x2 ct[8], at[8];
+        u32x4 ct[8], at[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int64_t m = m_tail + 8 * half + r;
+            const int64_t m = m_tail + 8 * rg + r;
             const bool ok = m < m_end;
             const int64_t mm = ok ? m : m_begin;
-            u32x2 c = *reinterpret_cast<const u32x2 *>(p.dC + mm * p.ldc + n_off);
-            u32x2 a = *reinterpret_cast<const u32x2 *>(A + mm * p.lda + k_off);
-            ct[r] = ok ? c : u32x2{0u, 0u};
-            at[r] = ok ? a : u32x2{0u, 0u};
+            u32x4 c = *reinterpret_cast<const u32x4 *>(p.dC + mm * p.ldc + n_off);
+            u32x4 a = *reinterpret_cast<const u32x4 *>(A + mm * p.lda + k_off);
+            ct[r] = ok ? c : u32x4{0u, 0u, 0u, 0u};
+            at[r] = ok ? a : u32x4{0u, 0u, 0u, 0u};
         }
         mma_step(ct, at, acc);
     }
 }
 
-// ---- in-workgroup reduction of the four waves' partial tiles (residue block E of the output) ------
-// D[i][j] of MFMA (E, f) is dW[n_base + 4i + E][k_base + 4j + f]; lane l holds j = l & 31 and
-// i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), so (f = 0..3) of one r is a float4 of the output row.
-// LDS slot of wave w: [r][lane] float4 -- consecutive lanes, consecutive 16-byte words.
-// LDS: two residue blocks per round, one parked copy per wave: slot (E & 1) * 4 + wave; a slot is
-// [r][lane] float4 -- consecutive lanes, consecutive 16-byte words.  Branch-free on purpose: every
-// wave parks both blocks of the round (with per-wave `if (wave == E)` special cases hipcc spilled
-// accumulators to scratch), then every wave sums and stores half of one block straight from LDS.
-constexpr int WGRAD_SLOT = 16 * 64 * 4;                     // floats per parked block
-constexpr size_t WGRAD_LDS_BYTES = 8 * WGRAD_SLOT * sizeof(float);
+// ---- in-workgroup reduction of the four waves' partial tiles ---------------------------------------
+// D[i][j] of MFMA (E, f) is dW[n_base + 8i + E][k_base + 8j + f]; lane l holds j = l & 15 and
+// i = 4 (l >> 4) + reg, so (f = 0..7) of one reg are eight consecutive floats of one output row.
+// Two rounds of four residue blocks; in a round every wave parks all four blocks (slot
+// (E & 3) * 4 + wave, laid out [reg][half][lane] float4 -- consecutive lanes, consecutive 16-byte
+// words), then wave w sums the four parked copies of block E = 4 * round + w in wave order
+// (deterministic) and stores it.  Branch-free on purpose: with per-wave `if (wave == E)` special
+// cases hipcc spilled accumulators to scratch.
+constexpr int WGRAD_SLOT = 8 * 64 * 4;                      // floats per parked block (8 KiB)
+constexpr size_t WGRAD_LDS_BYTES = 16 * WGRAD_SLOT * sizeof(float);
 
 template <int E>
-__device__ __forceinline__ void park_block(const f32x16_t (&acc)[4][4], float *lds, int wave, int lane)
+__device__ __forceinline__ void park_block(const f32x4 (&acc)[8][8], float *lds, int wave, int lane)
 {
-    float *slot = lds + ((E & 1) * 4 + wave) * WGRAD_SLOT;
+    float *slot = lds + ((E & 3) * 4 + wave) * WGRAD_SLOT;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const f32x4 v = {acc[E][0][r], acc[E][1][r], acc[E][2][r], acc[E][3][r]};
-        *reinterpret_cast<f32x4 *>(slot + ((r * 64 + lane) << 2)) = v;
-    }
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 v = {acc[E][4 * hh][reg], acc[E][4 * hh + 1][reg], acc[E][4 * hh + 2][reg],
+                             acc[E][4 * hh + 3][reg]};
+            *reinterpret_cast<f32x4 *>(slot + (((reg * 2 + hh) * 64 + lane) << 2)) = v;
+        }
 }
 
-// wave w sums the four parked copies of residue block E = 2 * round + (w & 1), accumulator rows
-// r in [8 * (w >> 1), +8), in wave order (deterministic), and stores them
-__device__ __forceinline__ void reduce_store_half(const float *lds, int round, int wave, const WgradParams &p,
-                                                  float *slab, int64_t n_base, int64_t k, int half, int lane)
+__device__ __forceinline__ void reduce_store(const float *lds, int round, int wave, const WgradParams &p,
+                                             float *slab, int64_t n_base, int64_t k0, int rg, int lane)
 {
-    const int E = 2 * round + (wave & 1);
-    const bool k_in = k + 3 < p.ldk;
-    const float *slot = lds + (wave & 1) * 4 * WGRAD_SLOT;
-    const int r0 = 8 * (wave >> 1);
+    const int E = 4 * round + wave;
+    const float *slot = lds + (wave * 4) * WGRAD_SLOT;
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = r0 + rr;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(slot + ((r * 64 + lane) << 2));
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t n = n_base + 8 * (4 * rg + reg) + E;
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-            v += *reinterpret_cast<const f32x4 *>(slot + q * WGRAD_SLOT + ((r * 64 + lane) << 2));
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int64_t n = n_base + 4 * i + E;
-        if (k_in && n < p.Ntot) *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int off = ((reg * 2 + hh) * 64 + lane) << 2;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(slot + off);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4 *>(slot + q * WGRAD_SLOT + off);
+            const int64_t k = k0 + 4 * hh;
+            if (k + 3 < p.ldk && n < p.Ntot) *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
+        }
     }
 }
 
 // One workgroup's share of problem p: M-slice bx, 128 x 128 output tile (by, bz).  The four waves
-// take a quarter of the slice each (whole 16-row steps), then meet in LDS: residue block E of the
-// tile is summed and stored by wave E.  Compared with one wave per tile and slice this quarters the
-// number of partial tiles that travel through HBM to gsage_finalize_grads for the same number of
-// busy SIMDs.
+// take a quarter of the slice each (whole 32-row steps), then meet in LDS.  Compared with one wave
+// per tile and slice this quarters the number of partial tiles that travel through HBM to
+// gsage_finalize_grads for the same number of busy SIMDs.
 __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx, int64_t by, int64_t bz,
                                                 float *lds)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the per-wave branches
-    const int ii = lane & 31;                                            // below must not become selects
-    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15;                                           // this lane's 8 columns
+    const int rg = lane >> 4;                                            // this lane's 8-row group
     const int64_t n_base = by * 128;
     const int64_t k_base = bz * 128;
     const int g = (int)(n_base / p.n_per_group);
@@ -186,7 +197,7 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 
     const int64_t m_begin = bx * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
-    const int64_t quarter = ((m_end - m_begin + 63) / 64) * 16;     // rows per wave, whole steps
+    const int64_t quarter = ((m_end - m_begin + 127) / 128) * 32;   // rows per wave, whole steps
     int64_t w_begin = m_begin + wave * quarter, w_end = w_begin + quarter;
     if (w_begin > m_end) w_begin = m_end;
     if (w_end > m_end) w_end = m_end;
@@ -195,33 +206,35 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
     // column 0 instead and its (garbage) accumulators are simply never stored -- output (n, k)
     // depends on column n of dC and column k of A only.  So the steady-state loop has no selects
     // on loaded data, and hipcc keeps the loads in flight instead of waiting right after issue.
-    const bool n_ok = n_base + 4 * ii + 3 < p.ldc && n_base + 4 * ii < p.Ntot;
-    const bool k_ok = k_base + 4 * ii + 3 < p.lda;
-    const int64_t n_off = n_ok ? n_base + 4 * ii : 0;
-    const int64_t k_off = k_ok ? k_base + 4 * ii : 0;
+    const bool n_ok = n_base + 8 * c16 + 7 < p.ldc && n_base + 8 * c16 < p.Ntot;
+    const bool k_ok = k_base + 8 * c16 + 7 < p.lda;
+    const int64_t n_off = n_ok ? n_base + 8 * c16 : 0;
+    const int64_t k_off = k_ok ? k_base + 8 * c16 : 0;
 
-    f32x16_t acc[4][4];
+    f32x4 acc[8][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+        for (int f = 0; f < 8; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, half, acc);
+    wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, rg, acc);
 
-    // two rounds of two residue blocks (8 x 16 KiB of LDS)
+    // two rounds of four residue blocks (16 x 8 KiB of LDS)
     float *slab = p.slabs + bx * p.Ntot * p.ldk;
-    const int64_t k = k_base + 4 * ii;
+    const int64_t k0 = k_base + 8 * c16;
     park_block<0>(acc, lds, wave, lane);
     park_block<1>(acc, lds, wave, lane);
-    lds_barrier();
-    reduce_store_half(lds, 0, wave, p, slab, n_base, k, half, lane);
-    lds_barrier();
     park_block<2>(acc, lds, wave, lane);
     park_block<3>(acc, lds, wave, lane);
     lds_barrier();
-    reduce_store_half(lds, 1, wave, p, slab, n_base, k, half, lane);
+    reduce_store(lds, 0, wave, p, slab, n_base, k0, rg, lane);
+    lds_barrier();
+    park_block<4>(acc, lds, wave, lane);
+    park_block<5>(acc, lds, wave, lane);
+    park_block<6>(acc, lds, wave, lane);
+    park_block<7>(acc, lds, wave, lane);
+    lds_barrier();
+    reduce_store(lds, 1, wave, p, slab, n_base, k0, rg, lane);
 }
 
 __global__ void __launch_bounds__(256, 1)
@@ -313,14 +326,15 @@ static int wgrad_fill(WgradParams &p, const void *dC, int64_t ldc, const void *A
 {
     GSAGE_REQUIRE(dC && A && slabs, "wgrad: null pointer");
     GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
-    GSAGE_REQUIRE(ldc % 4 == 0 && lda % 4 == 0 && ldk % 4 == 0, "wgrad: ldc, lda, ldk must be multiples of 4");
+    GSAGE_REQUIRE(ldc % 8 == 0 && lda % 8 == 0 && ldk % 4 == 0,
+                  "wgrad: ldc, lda must be multiples of 8 (16-byte row chunks), ldk of 4");
     GSAGE_REQUIRE(Ntot % 4 == 0 && Ntot <= ldc, "wgrad: Ntot must be a multiple of 4 and <= ldc");
     GSAGE_REQUIRE(ldk >= K && ldk <= lda + 3, "wgrad: need K <= ldk <= lda");
     GSAGE_REQUIRE(n_per_group > 0 && (n_per_group % 128 == 0 || n_per_group >= Ntot),
                   "wgrad: n_per_group must be a multiple of 128 (or a single group)");
     GSAGE_REQUIRE(rows_per_split >= 16 && rows_per_split % 16 == 0, "wgrad: rows_per_split must be a multiple of 16");
-    GSAGE_REQUIRE(((uintptr_t)dC % 8) == 0 && ((uintptr_t)A % 8) == 0 && ((uintptr_t)slabs % 16) == 0,
-                  "wgrad: misaligned pointer");
+    GSAGE_REQUIRE(((uintptr_t)dC % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)slabs % 16) == 0 &&
+                  (a_gstride % 8) == 0, "wgrad: misaligned pointer (16-byte lane loads)");
     p.dC = (const uint16_t *)dC; p.A = (const uint16_t *)A; p.slabs = slabs;
     p.ldc = ldc; p.lda = lda; p.a_gstride = a_gstride; p.M = M; p.Ntot = Ntot; p.K = K;
     p.n_per_group = n_per_group; p.ldk = ldk; p.rows_per_split = rows_per_split;

@@ -418,7 +418,7 @@ class _Linear(torch.autograd.Function):
             dx = _mm_f32(gc, wa)[:, :K].to(xdt)
         if ctx.needs_input_grad[1]:
             N = gc.shape[1]
-            if xa.dtype == torch.bfloat16 and N % 4 == 0 and xa.stride(0) % 4 == 0 and gc.shape[0] >= 64:
+            if xa.dtype == torch.bfloat16 and N % 8 == 0 and xa.stride(0) % 8 == 0 and gc.shape[0] >= 64:
                 # K5b: the library GEMM behind gc.t() @ xa ran at ~20 TF/s on these skinny shapes
                 dw = wgrad(gc.contiguous(), xa, xa.stride(0), 0, gc.shape[0], N, K, N)[0].to(wdt)
             else:
@@ -503,10 +503,10 @@ class _SageProject(torch.autograd.Function):
         gx, gn = gc[:, :h], gc[:, h:]
         dx = dagg = dwx = dwn = None
         fused_w = (cdt == torch.bfloat16 and ctx.grouped is not None and h % 128 == 0 and
-                   xa.stride(0) % 4 == 0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
+                   xa.stride(0) % 8 == 0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         # halves with different K (pool / attention aggregators): one K5b launch each -- the library
         # GEMM behind gx.t() @ xm ran at ~20 TF/s on these skinny, transposed operands
-        k5b_ok = cdt == torch.bfloat16 and h % 4 == 0 and gc.shape[0] >= 64 and gc.is_contiguous()
+        k5b_ok = cdt == torch.bfloat16 and h % 8 == 0 and gc.shape[0] >= 64 and gc.is_contiguous()
         if fused_w:
             # both weight gradients in one MFMA launch (x rows re-gathered when they were lazy)
             xm = xa if a_rows is None else _gather_mean_raw(xa, an.stride(0), a_rows, an.shape[0], 1,
@@ -520,12 +520,12 @@ class _SageProject(torch.autograd.Function):
                 xm = _gather_mean_raw(xa, Dx, a_rows, M, 1, cdt, _round_up(Dx, epc))
             else:
                 xm = xa
-            if k5b_ok and xm.stride(0) % 4 == 0:
+            if k5b_ok and xm.stride(0) % 8 == 0:
                 dwx = wgrad(gx, xm, xm.stride(0), 0, gc.shape[0], h, Dx, h)[0].to(wdt)
             else:
                 dwx = _mm_f32(gx.t(), xm)[:, :Dx].to(wdt)
         if ctx.needs_input_grad[3] and not fused_w:
-            if k5b_ok and an.stride(0) % 4 == 0:
+            if k5b_ok and an.stride(0) % 8 == 0:
                 dwn = wgrad(gn, an, an.stride(0), 0, gc.shape[0], h, Dn, h)[0].to(wdt)
             else:
                 dwn = _mm_f32(gn.t(), an)[:, :Dn].to(wdt)

@@ -367,7 +367,7 @@ def test_attn_aggregate_forward_backward():
 
 
 @pytest.mark.parametrize("M,N,K,groups", [(16, 128, 8, 1), (100, 128, 602, 2), (513, 128, 256, 2),
-                                          (1300, 4, 70, 1), (3000, 128, 1433, 2), (64, 128, 128, 1)])
+                                          (1300, 8, 70, 1), (3000, 128, 1433, 2), (64, 128, 128, 1), (37, 24, 200, 1)])
 def test_wgrad_mfma_vs_fp64(M, N, K, groups):
     """dW_g = dC_g^T @ A_g (K5b): exact in fp32 up to summation order on bf16-rounded operands."""
     rng = np.random.RandomState(M + N + K)
