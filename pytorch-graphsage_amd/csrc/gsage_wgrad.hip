@@ -85,9 +85,18 @@ __device__ __forceinline__ void mma_step(const u32x4 (&c_cur)[8], const u32x4 (&
 
 // Software pipeline (one wave per SIMD has nothing else to hide latency with): phase s issues the
 // 16 loads of step s+1, then runs the 64 MFMAs of step s -- one step (16 KiB per wave) stays in
-// flight.  Two register slots with static numbering (loop unrolled x2); vmcnt retires in order, so a
-// phase only waits for the loads issued one phase earlier.  No selects on loaded data in here (see
-// the column-validity note in the kernel), so hipcc does not wait right after issue.
+// flight.  Two register slots with static numbering (loop unrolled x2).
+// The loads are inline asm and the waits explicit: with ordinary loads the compiler's own wait
+// insertion has to merge the "more steps follow" and "last step" paths at every join and ends up
+// draining the loads it has just issued (vmcnt(13) ... vmcnt(0) where vmcnt(16) is right) -- the
+// pipeline then degenerates to load, wait, compute, one step at a time.  What the asm hides from the
+// compiler is replaced by hand: a wait before a slot is consumed, scheduling barriers so that nothing
+// that reads a slot moves above its wait and no load moves above the MFMAs still reading its target.
+__device__ __forceinline__ void load16_async(u32x4 &dst, const uint16_t *ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
 __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint16_t *A,
                                                int64_t m_begin, int64_t m_end, int64_t n_off,
                                                int64_t k_off, int rg, f32x4 (&acc)[8][8])
@@ -99,21 +108,30 @@ __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint1
     auto load_data = [&](u32x4 (&cdst)[8], u32x4 (&adst)[8], int64_t step) {
         const uint16_t *cp = c_base + step * 32 * p.ldc;
         const uint16_t *ap = a_base + step * 32 * p.lda;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            cdst[r] = *reinterpret_cast<const u32x4 *>(cp + r * p.ldc);
-            adst[r] = *reinterpret_cast<const u32x4 *>(ap + r * p.lda);
+            load16_async(cdst[r], cp + r * p.ldc);
+            load16_async(adst[r], ap + r * p.lda);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+    auto consume = [&](u32x4 (&c)[8], u32x4 (&a)[8], bool newer_in_flight) {
+        if (newer_in_flight) __builtin_amdgcn_s_waitcnt(0x4F70);     // vmcnt(16): the step issued after this one
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(c, a, acc);
+        __builtin_amdgcn_sched_barrier(0);
     };
     if (nfull > 0) load_data(cb[0], ab[0], 0);
     for (int64_t s0 = 0; s0 < nfull; s0 += 2) {
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const int64_t sidx = s0 + ph;
-            if (sidx < nfull) {                                      // wave-uniform
-                if (sidx + 1 < nfull) load_data(cb[ph ^ 1], ab[ph ^ 1], sidx + 1);
-                mma_step(cb[ph], ab[ph], acc);
-            }
+        const bool more1 = s0 + 1 < nfull, more2 = s0 + 2 < nfull;   // wave-uniform
+        if (more1) load_data(cb[1], ab[1], s0 + 1);
+        consume(cb[0], ab[0], more1);
+        if (more1) {
+            if (more2) load_data(cb[0], ab[0], s0 + 2);
+            consume(cb[1], ab[1], more2);
         }
     }
     // ragged tail (< 32 rows, last slice only): rows past the end contribute zeros
