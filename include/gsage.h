@@ -362,11 +362,23 @@ int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
  * operands of this level's gsage_wgrad --, preds [B,C], dH (bf16 [B*(1+n),256], ReLU mask of H
  * applied) and the fc.weight | fc.bias | loss partials (layout of gsage_head_ce, scratch size
  * gsage_mean_tail_ce_scratch).  Fixed widths: previous level 256, this level 2h = 256; n <= 32;
- * C <= 64. */
+ * C <= 64.
+ * gather (may be NULL): B / 4 workgroups of ~22 us of dependent phases leave half of the chip idle at
+ * B = 512, so n_workgroups extra workgroups of the same launch compute rows [0, rows) of a
+ * gsage_gather_mean segment (bf16 table and output, fan-out n = 10) -- part of the NEXT batch's
+ * level-0 gather, which that launch then skips.  Results are those of gsage_gather_mean. */
+typedef struct gsage_tail_gather_desc {
+    const void *table;
+    const int64_t *ids;
+    void *out;
+    int64_t ld, out_ld, D, rows;
+    int32_t n, n_workgroups;
+} gsage_tail_gather_desc;
 int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int64_t ldw2,
                        const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
                        const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
-                       void *dE, float *preds, void *dH, float *partial, void *stream);
+                       void *dE, float *preds, void *dH, float *partial,
+                       const gsage_tail_gather_desc *gather, void *stream);
 int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
 
 /* ------------------------------------------------------------------------------------------

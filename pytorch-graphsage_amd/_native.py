@@ -68,7 +68,7 @@ SIGNATURES = {
                              _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
     "gsage_mean_tail_ce": (_int, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i64,
-                                  _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsage_mean_tail_ce_scratch": (_i64, [_i32, _i32]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
@@ -158,6 +158,11 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
                 ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
                 ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
                 ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64)]
+
+
+class TailGatherDesc(ctypes.Structure):       # mirrors gsage_tail_gather_desc (include/gsage.h)
+    _fields_ = [("table", _vp), ("ids", _vp), ("out", _vp), ("ld", _i64), ("out_ld", _i64), ("D", _i64),
+                ("rows", _i64), ("n", _i32), ("n_workgroups", _i32)]
 
 
 class WgradDesc(ctypes.Structure):            # mirrors gsage_wgrad_desc (include/gsage.h)

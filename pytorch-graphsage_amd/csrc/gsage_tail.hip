@@ -78,11 +78,81 @@ constexpr size_t tail_lds_floats(int C)
            4 * TAIL_R + 2 * 8 * TAIL_R * TAIL_D;
 }
 
-// NBH = neighbour rows per half-wave lane (n <= 2 * NBH)
-template <int NBH>
-__global__ void __launch_bounds__(256)
-k_mean_tail_ce(const TailParams p)
+// ---- gather role ---------------------------------------------------------------------------------
+// B / 4 workgroups cannot fill the chip (128 of 256 CUs at B = 512) and each is a ~22 us chain of
+// dependent phases.  The CUs they leave idle take part of the NEXT batch's level-0 gather: rows
+// [0, rows) of one gather-mean segment (fan-out N), which the gather launch then skips.  One
+// workgroup per CU (the kernel's LDS footprint), so a lane keeps four work items = 4 N row requests
+// in flight; sums run in neighbour order like gather_mean_chunk (bit-identical means).
+struct TailGather {
+    const uint16_t *table;
+    const int64_t *ids;
+    uint16_t *out;
+    int64_t ld, out_ld;
+    int32_t rows, D, chunks, n_wg;       // n_wg = 0: no gather role in this launch
+};
+
+template <int N>
+__device__ __forceinline__ void tail_gather_role(const TailGather &g, int bx)
 {
+    const int64_t total = (int64_t)g.rows * g.chunks;
+    const int64_t S = (int64_t)g.n_wg * 256;
+    for (int64_t t0 = (int64_t)bx * 256 + threadIdx.x; t0 < total; t0 += 4 * S) {
+        int64_t row[4];
+        int32_t c0[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t t = t0 + u * S;
+            ok[u] = t < total;
+            if (!ok[u]) t = total - 1;
+            row[u] = t / g.chunks;
+            c0[u] = (int32_t)(t - row[u] * g.chunks) * 8;
+        }
+        int64_t id[4][N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < N; ++j) id[u][j] = g.ids[row[u] * N + j];
+        vec16 v[4][N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                v[u][j] = *reinterpret_cast<const vec16 *>(g.table + id[u][j] * g.ld + c0[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += tail_elem(v[u][j], e);
+            vec16 o;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float a = (c0[u] + e < g.D) ? acc[e] / (float)N : 0.f;
+                const float b = (c0[u] + e + 1 < g.D) ? acc[e + 1] / (float)N : 0.f;
+                o[e >> 1] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+            }
+            if (ok[u]) *reinterpret_cast<vec16 *>(g.out + row[u] * g.out_ld + c0[u]) = o;
+        }
+    }
+}
+
+// NBH = neighbour rows per half-wave lane (n <= 2 * NBH); GN = fan-out of the gather role (0: none)
+template <int NBH, int GN>
+__global__ void __launch_bounds__(256)
+k_mean_tail_ce(const TailParams p, const TailGather tg)
+{
+    if (GN > 0) {
+        const int n_tail = (p.B + TAIL_R - 1) / TAIL_R;
+        if ((int)blockIdx.x >= n_tail) {
+            tail_gather_role<(GN > 0 ? GN : 1)>(tg, (int)blockIdx.x - n_tail);
+            return;
+        }
+    }
     constexpr int R = TAIL_R, D = TAIL_D;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = p.C;
@@ -487,7 +557,8 @@ int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C)
 int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int64_t ldw2,
                        const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
                        const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
-                       void *dE, float *preds, void *dH, float *partial, void *stream)
+                       void *dE, float *preds, void *dH, float *partial, const gsage_tail_gather_desc *gather,
+                       void *stream)
 {
     GSAGE_REQUIRE(H && w2 && w2t && Wfc && bfc && targets && agg && dE && preds && dH && partial,
                   "mean_tail_ce: null pointer");
@@ -503,20 +574,38 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
     p.agg = (uint16_t *)agg; p.dE = (uint16_t *)dE; p.preds = preds; p.dH = (uint16_t *)dH;
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
+    TailGather tg = {};
+    const bool fused = gather && gather->rows > 0;
+    if (fused) {
+        GSAGE_REQUIRE(gather->n == 10, "mean_tail_ce: the gather role is built for fan-out 10");
+        GSAGE_REQUIRE(gather->table && gather->ids && gather->out && gather->D > 0 && gather->ld % 8 == 0 &&
+                      gather->out_ld % 8 == 0 && ceil_div(gather->D, 8) * 8 <= gather->ld &&
+                      ceil_div(gather->D, 8) * 8 <= gather->out_ld && gather->n_workgroups > 0 &&
+                      (((uintptr_t)gather->table | (uintptr_t)gather->out) & 15) == 0,
+                      "mean_tail_ce: bad gather descriptor");
+        tg.table = (const uint16_t *)gather->table; tg.ids = gather->ids; tg.out = (uint16_t *)gather->out;
+        tg.ld = gather->ld; tg.out_ld = gather->out_ld; tg.rows = (int32_t)gather->rows;
+        tg.D = (int32_t)gather->D; tg.chunks = (int32_t)ceil_div(gather->D, 8); tg.n_wg = gather->n_workgroups;
+    }
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
-    auto kern = n <= 16 ? k_mean_tail_ce<8> : k_mean_tail_ce<16>;
+    const int small = n <= 16;
+    void (*kern)(const TailParams, const TailGather) =
+        fused ? (small ? k_mean_tail_ce<8, 10> : k_mean_tail_ce<16, 10>)
+              : (small ? k_mean_tail_ce<8, 0> : k_mean_tail_ce<16, 0>);
     {   // more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
-        static bool raised[2] = {false, false};
-        if (!raised[n <= 16]) {
+        static bool raised[4] = {false, false, false, false};
+        const int slot = small + 2 * (int)fused;
+        if (!raised[slot]) {
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * tail_lds_floats(TAIL_CMAX) + 16)) != hipSuccess) {
                 set_error("mean_tail_ce: cannot raise the dynamic LDS limit");
                 return GSAGE_ELAUNCH;
             }
-            raised[n <= 16] = true;
+            raised[slot] = true;
         }
     }
-    launch(kern, dim3((B + TAIL_R - 1) / TAIL_R), dim3(256), lds, (hipStream_t)stream, p);
+    const unsigned n_tail = (unsigned)((B + TAIL_R - 1) / TAIL_R);
+    launch(kern, dim3(n_tail + (fused ? (unsigned)tg.n_wg : 0u)), dim3(256), lds, (hipStream_t)stream, p, tg);
     return check_launch("mean_tail_ce");
 }
 

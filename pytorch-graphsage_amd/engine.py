@@ -227,6 +227,7 @@ class FusedMeanTrainStep(object):
         self.nset = 2 if self.pipelined else 1
         self._front_ready, self._qstep = False, 0
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        self._tail_gather, self._tail_rows = None, 0
         self._reduce_op = None
         if ddp is not None:
             # averaging inside the collective saves a launch; fall back to divide-then-sum where
@@ -530,7 +531,7 @@ class FusedMeanTrainStep(object):
         d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
         return d
 
-    def _stage_gather(self, s, with_adam=False, ids=None, hops=None):
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
         launch; with_adam: the clip + Adam update of the batch just finished rides along; hops: so
         does the sampling of a later batch's frontier (a gsage_hops_desc writing ANOTHER buffer).
@@ -546,10 +547,13 @@ class FusedMeanTrainStep(object):
         # (tools/kbench.py gmulti: 36.1 us against 41.9 us for copies first at Reddit shapes)
         segs = []
         for k in range(L):
-            segs.append((st.data, ids[self.off[k + 1]:self.off[k + 2]], xa[1][self.off[k]:self.off[k + 1]],
-                         self.size[k], self.fan[k + 1]))
+            n, r0 = self.fan[k + 1], (skip_rows if k == L - 1 else 0)   # rows the seed-level launch gathered
+            if self.size[k] > r0:
+                segs.append((st.data, ids[self.off[k + 1] + r0 * n:self.off[k + 2]],
+                             xa[1][self.off[k] + r0:self.off[k + 1]], self.size[k] - r0, n))
         segs.append((st.data, ids[:R], xa[0], R, 1))
-        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None,
+        # (D = the real width: the pad columns of the operand buffers were zeroed once and stay zero)
+        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None,
                               hops=hops)
 
     def _stage_compute(self, s):
@@ -590,7 +594,9 @@ class FusedMeanTrainStep(object):
                 m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), C, tg.data_ptr(),
                 self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
                 self.agg[L - 1].data_ptr(), self.dc[L - 1].data_ptr(), self.preds.data_ptr(),
-                self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(), stream), "mean_tail_ce")
+                self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
+                ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, stream),
+                "mean_tail_ce")
         elif self.fused_head:
             C, D2 = m.fc.weight.shape
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
@@ -713,6 +719,12 @@ class FusedMeanTrainStep(object):
         # From here on the step is software-pipelined (see step_queue): two frontier buffers, batch
         # i+2 is sampled while batch i+1 is gathered and batch i is updated.
         self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
+        # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
+        # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
+        # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
+        self._tail_rows = self._tail_gather_rows()
+        if self._tail_rows and len(self.xa0_set) == 1:
+            self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
         self._front_ready, self._qstep = False, 0
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
         if self.g_main is not None:
@@ -723,24 +735,53 @@ class FusedMeanTrainStep(object):
             else:
                 # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
                 # gathers (see step_queue)
-                self.g_queue = [self._record(lambda: self._stage_compute(0))] * 2
+                self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
                 self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
                 self.g_opt = self._record(self._stage_opt)
         return self
 
+    def _tail_gather_rows(self):
+        """Rows of the last hop's neighbour means that the seed-level launch of the previous step
+        gathers (0: none).  Tuned at the Reddit shape: the launch is ~27 us long whatever it carries."""
+        if not getattr(self, "fused_tail", False) or self.L != 2 or self.fan[2] != 10:
+            return 0
+        n_idle = 256 - (self.B + 3) // 4                  # MI355X: 256 CUs, one seed-level workgroup each
+        if n_idle < 32:
+            return 0
+        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.4"))
+        self._tail_wgs = n_idle
+        return int(self.size[1] * min(max(frac, 0.0), 1.0))
+
     # the queue pipeline's pieces; par = parity of the step: batch i+1 is gathered from ids_q[1 - par]
-    # while batch i+2 is sampled into ids_q[par]
+    # (into operand set 1 - par when the sets alternate) while batch i+2 is sampled into ids_q[par]
+    def _qset(self, par):
+        return par if self._tail_rows else 0
+
     def _queue_prime(self):
         self._stage_sample(0, ids=self.ids_q[0])
         self._stage_sample(0, ids=self.ids_q[1], ahead=True)
         self._stage_gather(0, ids=self.ids_q[0])
 
     def _queue_front(self, par, with_adam):
-        self._stage_gather(0, with_adam=with_adam, ids=self.ids_q[1 - par],
-                           hops=self._hops_desc(self.ids_q[par], True))
+        self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
+                           hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
+
+    def _queue_compute(self, par):
+        if self._tail_rows:
+            L, st, nxt = self.L, self.store, self.ids_q[1 - par]
+            d = nat.TailGatherDesc()
+            d.table, d.ids = st.data.data_ptr(), nxt[self.off[L]:].data_ptr()
+            d.out = self.xa0_set[1 - par][1][self.off[L - 1]:].data_ptr()
+            d.ld, d.out_ld, d.D, d.rows = st.ld, st.ld, st.dim, self._tail_rows
+            d.n, d.n_workgroups = self.fan[L], self._tail_wgs
+            self._tail_gather = d
+        try:
+            self._stage_compute(self._qset(par))
+        finally:
+            self._tail_gather = None
 
     def _queue_step(self, par):
-        self._stage_compute(0)
+        self._queue_compute(par)
         self._queue_front(par, True)              # Adam(i) || gathers(i+1) || sampling(i+2)
 
     def step_queue(self):
@@ -773,7 +814,7 @@ class FusedMeanTrainStep(object):
         if rec:
             self.g_queue[par].replay()
         else:
-            self._stage_compute(0)
+            self._queue_compute(par)
         # Order matters: the collective is submitted BEFORE the gathers.  Submitted after them (from a
         # side stream that only waits for the gradients, which would hide the ~25 us the collective
         # call costs the host) it did not start until the 8 320-workgroup gather launch had been
@@ -997,13 +1038,14 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         self._install_reduce(rdesc)
 
     # ---- stages ----------------------------------------------------------------------------------------
-    def _stage_gather(self, s, with_adam=False, ids=None, hops=None):
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
         L, st = self.L, self.store
         if ids is None:
             ids = self.ids_set[s]
         segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1),
                 (st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1)]
-        ops.gather_mean_multi(segs, st.ld, st.ld, st.ld, adam=self._adam_desc() if with_adam else None,
+        # (D = the real width: the pad columns of the operand buffers were zeroed once and stay zero)
+        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None,
                               hops=hops)
 
     def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act, Wp=None):

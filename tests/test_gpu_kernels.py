@@ -611,8 +611,31 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
     nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
                                    Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
                                    agg.data_ptr(), dE.data_ptr(), preds.data_ptr(), dH.data_ptr(),
-                                   part.data_ptr(), None), "mean_tail_ce")
+                                   part.data_ptr(), None, None), "mean_tail_ce")
     torch.cuda.synchronize()
+    if B == 512:
+        # the same launch carrying a gather role on the CUs it leaves idle: every output of the seed
+        # level unchanged, the gathered means those of gsage_gather_mean, bit for bit
+        import ctypes
+        rngg = np.random.RandomState(3)
+        table = torch.zeros(5000, 640, dtype=torch.bfloat16, device=DEV)
+        table[:, :602] = torch.from_numpy(rngg.normal(size=(5000, 602)).astype(np.float32)).to(DEV).bfloat16()
+        store = gs.FeatureStore(table, 602)
+        rows = 1234
+        gids = torch.from_numpy(rngg.randint(0, 5000, size=rows * 10)).to(DEV)
+        ref = ops.gather_mean(store, gids, rows, 10, out_dtype=torch.bfloat16, out_ld=640)
+        out = torch.zeros(rows + 3, 640, dtype=torch.bfloat16, device=DEV)
+        d = nat.TailGatherDesc()
+        d.table, d.ids, d.out = table.data_ptr(), gids.data_ptr(), out.data_ptr()
+        d.ld, d.out_ld, d.D, d.rows, d.n, d.n_workgroups = 640, 640, 602, rows, 10, 128
+        outs = [torch.zeros_like(t) for t in (agg, dE, preds, dH, part)]
+        nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
+                                       Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
+                                       *[t.data_ptr() for t in outs], ctypes.addressof(d), None), "mean_tail_ce")
+        torch.cuda.synchronize()
+        for a, b_ in zip((agg, dE, preds, dH, part), outs):
+            assert torch.equal(a, b_)
+        assert torch.equal(out[:rows], ref) and float(out[rows:].float().abs().max()) == 0.0
     Hd = H.double().cpu()
     x, nb = Hd[:B], Hd[B:].view(B, n, 256)
     mean = nb.mean(1)

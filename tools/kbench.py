@@ -110,7 +110,7 @@ if 'tail' in which:
       def f():
           nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128, Wfc.data_ptr(),
                                          bfc.data_ptr(), C, tg.data_ptr(), None, 0, agg.data_ptr(), dE.data_ptr(),
-                                         preds.data_ptr(), dH.data_ptr(), part.data_ptr(), ops._stream()))
+                                         preds.data_ptr(), dH.data_ptr(), part.data_ptr(), None, ops._stream()))
       print('tail (B=%d n=%d): %.1f us' % (B, n, timeit(f)))
 
 if 'gmulti' in which:
