@@ -174,7 +174,8 @@ class FusedMeanTrainStep(object):
         K5            level 0: ONE grouped MFMA GEMM (x | agg against Wx | Wn), bf16 out
         seed level    segment mean + both projections + normalize/fc/CE + all gradients down to the
                       level-0 activations in one kernel (gsage_mean_tail_ce; generic models use K2 + K5
-                      + gsage_head_ce + K5/merge per level instead)
+                      + gsage_head_ce + K5/merge per level instead); in queue mode the CUs its B / 4
+                      workgroups leave idle gather the first part of the NEXT batch's last-hop means
         K5b           every level's weight gradient in one grouped launch (partial tiles -> slabs)
         finalise      partial tiles + head partials -> flat gradient bucket + norm partials; ticks the
                       step's device counters
