@@ -114,3 +114,29 @@ def test_product_never_touches_the_oracle_or_the_reference():
     assert "from oracle import" in body
     for f in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(root, f)).read() or f == "__graft_entry__.py"
+
+
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """Every struct that crosses the C ABI by address is declared twice (include/gsage.h and a
+    ctypes.Structure): sizes and field offsets must agree -- checked with the C compiler, no GPU."""
+    import subprocess
+    gs = pkg()
+    nat, eng = gs._native, gs.engine
+    mirrors = {"gsage_hops_desc": nat.HopsDesc, "gsage_adam_desc": nat.AdamDesc, "gsage_wgrad_desc": nat.WgradDesc,
+               "gsage_tail_gather_desc": nat.TailGatherDesc, "gsage_reduce_desc": eng._ReduceDesc,
+               "gsage_prep_desc": eng._PrepDesc}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gsage.h"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
