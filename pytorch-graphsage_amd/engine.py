@@ -743,15 +743,18 @@ class FusedMeanTrainStep(object):
 
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
-        gathers (0: none).  Tuned at the Reddit shape: the launch is ~27 us long whatever it carries."""
+        gathers (0: none)."""
         if not getattr(self, "fused_tail", False) or self.L != 2 or self.fan[2] != 10:
             return 0
-        n_idle = 256 - (self.B + 3) // 4                  # MI355X: 256 CUs, one seed-level workgroup each
+        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
+        n_idle = n_cu - (self.B + 3) // 4                 # one seed-level workgroup per CU
         if n_idle < 32:
             return 0
+        # what an idle CU moves while the ~27 us launch lasts does not depend on B: ~40 rows of ten
+        # neighbours each (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs)
         frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.4"))
         self._tail_wgs = n_idle
-        return int(self.size[1] * min(max(frac, 0.0), 1.0))
+        return min(int(self.size[1]), max(int(100.0 * frac * n_idle), 0))
 
     # the queue pipeline's pieces; par = parity of the step: batch i+1 is gathered from ids_q[1 - par]
     # (into operand set 1 - par when the sets alternate) while batch i+2 is sampled into ids_q[par]

@@ -163,12 +163,15 @@ def test_pipelined_engine_is_bit_identical_to_sequential(capture):
     assert torch.equal(outs[False][1], outs[True][1])
 
 
+@pytest.mark.parametrize("B,fans", [(24, (5, 3)), (40, (25, 10)), (800, (25, 10))])
 @pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
-def test_batch_queue_equals_per_step_copies(capture):
+def test_batch_queue_equals_per_step_copies(capture, B, fans):
     """step_queue (batch i+2 sampled and batch i+1 gathered in the launch that applies Adam(i)) is
-    the plain one-batch-at-a-time engine, bit for bit, across the queue's wrap-around."""
+    the plain one-batch-at-a-time engine, bit for bit, across the queue's wrap-around.  Fan-out
+    (25, 10) also moves hop-2 rows of the next batch into the seed-level launch: all of them at
+    B = 40 (the gather launch's segment disappears), about a tenth at B = 800 (56 idle CUs on an MI355X)."""
     adj, feats, rng = _problem(seed=4)
-    D, C, B, dims, fans = feats.shape[1], 5, 24, (128, 128), (5, 3)
+    D, C, dims = feats.shape[1], 5, (128, 128)
     store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
     ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
     tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
