@@ -12,7 +12,7 @@ all: hip oracle
 
 hip: $(PKG)/libgsage_hip.so
 
-$(PKG)/csrc/%.o: $(PKG)/csrc/%.hip $(PKG)/csrc/gsage_common.h include/gsage.h
+$(PKG)/csrc/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/gsage.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libgsage_hip.so: $(OBJ)

@@ -26,15 +26,9 @@
 // reduces max / mean over each group of `n` consecutive rows, so the [M*n, 512] hidden
 // activations of the reference never reach HBM.
 #include "gsage_common.h"
-
-#include <stdlib.h>
+#include "gsage_mma_dev.h"
 
 namespace gsage {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
 struct LinearParams {
     const void *A;
@@ -57,51 +51,6 @@ struct LinearParams {
     int32_t *argmax;
     uint32_t *relu_mask;   // optional [M, N/32] sign bits of the bias+ReLU'd tile (mean-pool backward)
 };
-
-constexpr int BM = 64;
-constexpr int BN = 128;
-constexpr int CH = 8;          // 16-byte chunks per tile row (128 bytes of K)
-
-__device__ __forceinline__ int lds_slot(int row, int ch)
-{
-    const int rp = (row & ~9) | ((row & 1) << 3) | ((row >> 3) & 1);     // swap bits 0 and 3
-    return rp * CH + (ch ^ (row & 7));
-}
-
-template <typename T>
-struct mma_chunk;
-
-template <>
-struct mma_chunk<uint16_t> {
-    __device__ static __forceinline__ void run(const vec16 &a, const vec16 &b, f32x16_t &acc)
-    {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-
-template <>
-struct mma_chunk<float> {
-    __device__ static __forceinline__ void run(const vec16 &a, const vec16 &b, f32x16_t &acc)
-    {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]),
-                                                       acc, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ float apply_act(float v, int act)
-{
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_TANH) {
-        // tanh(v) = sign(v) * (1 - 2 / (exp(2|v|) + 1)): full-precision expf, |err| ~ 1e-7
-        const float e = expf(2.f * fabsf(v));
-        const float t = 1.f - 2.f / (e + 1.f);
-        return v < 0.f ? -t : t;
-    }
-    return v;
-}
 
 // Epilogue shared by both K5 kernels: bias + activation, then the 64x128 tile goes through LDS
 // so that global memory sees full 16-byte row chunks (256 B contiguous per 16 lanes) instead of the
@@ -358,8 +307,6 @@ k_linear_nt(const LinearParams p)
 // Out-of-range rows are clamped (their outputs are never stored); the K tail relies on the
 // operands' zero padding, which is why rows must be whole lines (lda, ldw % (8*EPC) == 0).
 // -------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_void_t;
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(256)
@@ -491,487 +438,6 @@ k_linear_nt_dma(const LinearParams p)
     store_tile<ACT>(p, acc0, acc1, g, m0, n0, wm, wn, lane, tid, smem);
 }
 
-// -------------------------------------------------------------------------------------------------
-// K5 with a PACKED weight operand (bf16): W travels L2 -> registers directly, only A goes through LDS.
-//
-// The LDS-DMA kernel above is bound by bytes in flight: a tile needs ~1.3 us from issue to landing
-// (even from L2) and LDS capacity caps what a CU can have outstanding (2 workgroups x 2 tiles x 24 KiB).
-// Weights are written once per optimizer step, so the optimizer writes them in MFMA fragment order
-//     Wp[g][jb][kc][lane][8] = W_g[jb*32 + (lane & 31)][kc*16 + (lane >> 5)*8 .. +7]      (zero padded)
-// and a wave's B fragment of (32 columns, 16 k) is ONE fully coalesced 1 KiB load into registers:
-// no LDS traffic for W at all (it was 2/3 of the DMA bytes and 2/3 of the fragment reads), and the
-// register file holds the in-flight W tiles, so both rings can be deep (WP_R tiles in flight:
-// 8 KiB of A per tile in LDS, 16 VGPRs of W per tile and lane).
-// Wave w owns columns [32w, 32w+32) of the 64 x 128 tile and all 64 rows (two 32 x 32 accumulators);
-// the four waves read the same A fragments.
-// -------------------------------------------------------------------------------------------------
-constexpr int WP_R = 4;                       // tiles in flight per workgroup
-constexpr int WP_NBUF = WP_R + 1;             // A ring: the tile being read + WP_R in flight
-constexpr int WP_UNROLL = 24;                 // k-tiles of straight-line code (multiple of WP_R and PK_R)
-
-struct PackedParams {
-    const uint16_t *A;
-    const uint16_t *Wp;
-    const float *bias;
-    const int64_t *a_rows;
-    void *C;
-    int64_t lda, ldc;
-    int64_t M, N, K;
-    int64_t a_gstride, wp_gstride, c_gstride;
-    int32_t kc_total;        // 16-element k chunks per packed column block (= round_up(K, 64) / 16)
-    int32_t a_rows_group0_only;
-    int32_t c_dtype;
-};
-
-template <int ACT>
-__global__ void __launch_bounds__(256)
-k_linear_nt_packed(const PackedParams p)
-{
-    constexpr int EPC = 8;
-    constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
-    __shared__ vec16 smem[(BM * (BN + 4) * 4) / 16 > WP_NBUF * ATILE ? (BM * (BN + 4) * 4) / 16 : WP_NBUF * ATILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int g = blockIdx.z;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int64_t n0 = (int64_t)blockIdx.y * BN;
-    const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
-    const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
-    const int nk = (int)((p.K + 63) / 64);
-    // ragged N: a wave whose 32 columns do not exist computes the last existing block again (its
-    // results are never stored) -- no divergent region around the MFMAs
-    const int64_t jb_last = (p.N - 1) >> 5;
-    const int64_t jb = min((n0 >> 5) + wave, jb_last);
-    const vec16 *wp = reinterpret_cast<const vec16 *>(p.Wp + (int64_t)g * p.wp_gstride) +
-                      (jb * p.kc_total) * 64 + lane;
-
-    // A DMA assignment as in k_linear_nt_dma: instruction s fills rows 32*s + 8*wave + (lane >> 3)
-    const int cdst = lane & 7;
-    const uint16_t *a_src[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int R = 32 * s2 + 8 * wave + (lane >> 3);
-        const int row = (R & ~9) | ((R & 1) << 3) | ((R >> 3) & 1);
-        int64_t m = m0 + row;
-        if (m >= p.M) m = p.M - 1;
-        const int64_t r = a_rows ? a_rows[m] : m;
-        a_src[s2] = A + r * p.lda + (cdst ^ (row & 7)) * EPC;
-    }
-    const int a_dst0 = (8 * wave) * CH, a_dst1 = (32 + 8 * wave) * CH;
-
-    vec16 wr[WP_R][4];
-    // (scheduling barriers: the wait counts below assume that the six memory instructions of a tile
-    //  are not interleaved with another tile's -- left alone, the scheduler shuffles them)
-    auto issue_tile = [&](int kt, int buf, vec16 (&w)[4]) {
-        vec16 *base = smem + buf * ATILE;
-        const int64_t ko = (int64_t)kt * 64;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[0] + ko), (lds_void_t *)(base + a_dst0), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[1] + ko), (lds_void_t *)(base + a_dst1), 16, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) w[kk] = wp[(int64_t)(kt * 4 + kk) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    f32x16_t acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int arow0 = lane & 31, arow1 = arow0 + 32;
-
-    // Every tile is 6 vector-memory instructions per wave (2 DMA + 4 loads), issued in tile order and
-    // returning in order: "tile kt landed" == at most 6 * (tiles issued after it) still outstanding.
-    auto compute_tile = [&](int kt, const vec16 (&w)[4]) {
-        const vec16 *sA = smem + (kt % WP_NBUF) * ATILE;
-        vec16 fa0[4], fa1[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = kk * 2 + (lane >> 5);
-            fa0[kk] = sA[lds_slot(arow0, ch)];
-            fa1[kk] = sA[lds_slot(arow1, ch)];
-        }
-        // all eight fragment reads in flight together, then the MFMAs back to back
-        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            mma_chunk<uint16_t>::run(fa0[kk], w[kk], acc0);
-            mma_chunk<uint16_t>::run(fa1[kk], w[kk], acc1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    int kt = 0, phase = 0;
-    if (nk > WP_R) {
-#pragma unroll
-        for (int t = 0; t < WP_R; ++t) issue_tile(t, t, wr[t]);
-        // steady state: every step waits for ITS tile only (three later tiles stay in flight), computes
-        // it and refills its registers / the A buffer of the tile before it.  No conditional issue in
-        // here, and the waits are builtins (not inline asm): the compiler's own wait insertion can then
-        // prove that wr[s] is ready and adds no vmcnt(0) in front of the MFMAs.
-        //     simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
-        // The first WP_UNROLL tiles run as straight-line code: at a loop header the compiler's wait
-        // insertion merges the prologue's and the back edge's pending-load state conservatively and
-        // drains everything (vmcnt(0)) in front of the first MFMAs of every trip -- one full pipeline
-        // stall per WP_R tiles.  Longer reductions continue in the rolled loop.
-#pragma unroll
-        for (int u = 0; u < WP_UNROLL; ++u) {
-            if (kt + WP_R >= nk) { phase = u % WP_R; goto drain; }
-            __builtin_amdgcn_s_waitcnt(0x4F72);          // vmcnt(18)
-            __builtin_amdgcn_s_barrier();                // everybody's part of A(kt) landed; A(kt-1) is free
-            compute_tile(kt, wr[u % WP_R]);
-            issue_tile(kt + WP_R, (kt + WP_R) % WP_NBUF, wr[u % WP_R]);
-            ++kt;
-        }
-        for (;;) {
-#pragma unroll
-            for (int s = 0; s < WP_R; ++s) {
-                if (kt + WP_R >= nk) { phase = s; goto drain; }
-                __builtin_amdgcn_s_waitcnt(0x4F72);
-                __builtin_amdgcn_s_barrier();
-                compute_tile(kt, wr[s]);
-                issue_tile(kt + WP_R, (kt + WP_R) % WP_NBUF, wr[s]);
-                ++kt;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < WP_R; ++t)
-            if (t < nk) issue_tile(t, t, wr[t]);
-    }
-drain:
-    // the last (up to) WP_R tiles are all in flight and nothing is issued any more: one full wait
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int t = 0; t < WP_R; ++t) {
-        if (kt + t < nk) {
-            const int idx = (phase + t) % WP_R;
-#pragma unroll
-            for (int s = 0; s < WP_R; ++s)
-                if (idx == s) compute_tile(kt + t, wr[s]);
-        }
-    }
-
-    // ---- epilogue: bias + activation, tile through LDS, 16-byte row chunks to global ----------------
-    const float *bias = p.bias ? p.bias + (int64_t)g * p.N : nullptr;
-    const int esz = p.c_dtype == GSAGE_BF16 ? 2 : 4;
-    const int epc = 16 / esz;
-    const int64_t cbase = (int64_t)g * p.c_gstride + n0;
-    const bool wide = n0 + BN <= p.N && p.ldc % epc == 0 && cbase % epc == 0 && ((uintptr_t)p.C % 16) == 0;
-    const int jl = wave * 32 + (lane & 31);
-    const float bj = (bias && n0 + jl < p.N) ? bias[n0 + jl] : 0.f;
-    if (wide) {
-        __syncthreads();
-        const int ldt = BN + epc;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const f32x16_t &acc = rb ? acc1 : acc0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = apply_act(acc[r] + bj, ACT);
-                if (p.c_dtype == GSAGE_BF16)
-                    ((uint16_t *)smem)[i * ldt + jl] = f32_to_bf16(v);
-                else
-                    ((float *)smem)[i * ldt + jl] = v;
-            }
-        }
-        __syncthreads();
-        const int cpr = BN / epc;
-        for (int q = tid; q < BM * cpr; q += 256) {
-            const int row = q / cpr, ch = q - row * cpr;
-            const int64_t m = m0 + row;
-            if (m < p.M) {
-                const vec16 v = *reinterpret_cast<const vec16 *>((const char *)smem +
-                                                                 ((size_t)row * ldt + ch * epc) * esz);
-                *reinterpret_cast<vec16 *>((char *)p.C + ((size_t)m * p.ldc + cbase + ch * epc) * esz) = v;
-            }
-        }
-        return;
-    }
-    const int64_t j = n0 + jl;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const f32x16_t &acc = rb ? acc1 : acc0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < p.M && j < p.N) {
-                const float v = apply_act(acc[r] + bj, ACT);
-                const int64_t off = m * p.ldc + (int64_t)g * p.c_gstride + j;
-                if (p.c_dtype == GSAGE_BF16)
-                    ((uint16_t *)p.C)[off] = f32_to_bf16(v);
-                else
-                    ((float *)p.C)[off] = v;
-            }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// K3 with the packed weight operand: pooling MLP, 64 rows x (NW x 64) hidden columns per workgroup.
-//
-// The 64 x 128-tile K3 above reads every A tile once per 128 hidden columns (4 x 164 MB on the hop-2
-// frontier of the Reddit shape) and moves W through LDS.  Here wave w owns columns [64w, 64w + 64) and
-// all 64 rows (four 32 x 32 accumulators) and takes its B fragments from the packed operand straight
-// into registers (8 loads per k-tile); A (8 KiB per k-tile) goes through a four-buffer LDS-DMA ring.
-// Epilogue as in K3: bias + ReLU'd tile -> LDS (fp32), optional sign bits, segment max / mean down
-// the rows.  Measured on the hop-2 frontier (128 000 rows x 602 -> 512, tools/kbench.py pool):
-//     64 x 128 tiles, W through LDS (k_linear_nt POOL)            180 us   437 TF/s
-//     NW = 8: 512 columns, A read once, ONE workgroup per CU      156 us   506 TF/s
-//     NW = 4: 256 columns, A read twice, two workgroups per CU    130 us   606 TF/s   <- launched
-//     weight-stationary persistent variant (a wave keeps its 32 columns x 640 k in 160 registers,
-//     only A moves, column blocks of a row tile on one XCD)       133 us   595 TF/s   (removed)
-// One workgroup per CU loses to two even at half the A traffic: all eight waves stall at the same
-// barrier.  The weight-stationary variant moved no W at all and was no faster: its A stream (the
-// same tile requested by four workgroups in lock step) ran at 5.2 TB/s, i.e. every tile still paid
-// the full miss latency with only 4 x 8 KiB in flight per workgroup -- K3 is bound by how many bytes
-// a CU can have in flight towards HBM, not by L2 bandwidth or the matrix pipe (30 % busy).
-// -------------------------------------------------------------------------------------------------
-constexpr int PK_R = 3;                       // tiles in flight
-constexpr int PK_NBUF = PK_R + 1;
-
-struct PoolPackedParams {
-    const uint16_t *A;
-    const uint16_t *Wp;
-    const float *bias;
-    const int64_t *a_rows;
-    int64_t lda;
-    int64_t M, N, K;          // M = rows of A (= segments * pool_n)
-    int32_t kc_total;
-    int32_t pool_n, pool_groups, pool_mode;
-    float *pooled;
-    int64_t pooled_ld;
-    uint16_t *pooled_b;
-    int64_t pooled_b_ld;
-    int32_t *argmax;
-    uint32_t *relu_mask;
-};
-
-template <int NW>
-__global__ void __launch_bounds__(NW * 64)
-k_pool_mlp_packed(const PoolPackedParams p)
-{
-    constexpr int EPC = 8;
-    constexpr int PK_BN = NW * 64;
-    constexpr int PK_LDT = PK_BN + 8;                    // fp32 tile row: rows 4 apart land 32 banks apart
-    constexpr int NDMA = 8 / NW;                         // A DMA instructions per wave and tile
-    constexpr int WAIT_STEADY = NW == 8 ? 0x4F72 : 0x4F74;   // vmcnt((PK_R - 1) * (NDMA + 8)): 18 / 20
-    constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
-    __shared__ vec16 smem[(BM * PK_LDT * 4) / 16];       // fp32 output tile (130 KiB) >= A ring (32 KiB)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int rows_per_wg = p.pool_groups * p.pool_n;
-    const int64_t m0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t n0 = (int64_t)blockIdx.y * PK_BN;
-    const int nk = (int)((p.K + 63) / 64);
-    const int64_t jb_last = (p.N - 1) >> 5;
-    const int64_t jb0 = min((n0 >> 5) + wave * 2, jb_last), jb1 = min((n0 >> 5) + wave * 2 + 1, jb_last);
-    const vec16 *wp0 = reinterpret_cast<const vec16 *>(p.Wp) + (jb0 * p.kc_total) * 64 + lane;
-    const vec16 *wp1 = reinterpret_cast<const vec16 *>(p.Wp) + (jb1 * p.kc_total) * 64 + lane;
-
-    // A DMA: instruction d of wave w fills LDS rows 8 (NW d + w) + (lane >> 3), slot lane & 7, from the
-    // swizzled source
-    const uint16_t *a_src[NDMA];
-#pragma unroll
-    for (int d = 0; d < NDMA; ++d) {
-        const int R = 8 * (NW * d + wave) + (lane >> 3);
-        const int row = (R & ~9) | ((R & 1) << 3) | ((R >> 3) & 1);
-        int64_t m = m0 + min(row, rows_per_wg - 1);
-        if (m >= p.M) m = p.M - 1;
-        const int64_t r = p.a_rows ? p.a_rows[m] : m;
-        a_src[d] = p.A + r * p.lda + ((lane & 7) ^ (row & 7)) * EPC;
-    }
-    const int a_dst = (8 * wave) * CH;
-
-    vec16 wr[PK_R][2][4];
-    auto issue_tile = [&](int kt, int buf, vec16 (&w)[2][4]) {
-        vec16 *base = smem + buf * ATILE;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < NDMA; ++d)
-            __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[d] + (int64_t)kt * 64),
-                                             (lds_void_t *)(base + a_dst + 8 * NW * d * CH), 16, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            w[0][kk] = wp0[(int64_t)(kt * 4 + kk) * 64];
-            w[1][kk] = wp1[(int64_t)(kt * 4 + kk) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    f32x16_t acc[2][2];                                  // [row block][column block]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int arow0 = lane & 31, arow1 = arow0 + 32;
-
-    auto compute_tile = [&](int kt, const vec16 (&w)[2][4]) {
-        const vec16 *sA = smem + (kt % PK_NBUF) * ATILE;
-        vec16 fa0[4], fa1[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = kk * 2 + (lane >> 5);
-            fa0[kk] = sA[lds_slot(arow0, ch)];
-            fa1[kk] = sA[lds_slot(arow1, ch)];
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            mma_chunk<uint16_t>::run(fa0[kk], w[0][kk], acc[0][0]);
-            mma_chunk<uint16_t>::run(fa0[kk], w[1][kk], acc[0][1]);
-            mma_chunk<uint16_t>::run(fa1[kk], w[0][kk], acc[1][0]);
-            mma_chunk<uint16_t>::run(fa1[kk], w[1][kk], acc[1][1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // NDMA + 8 vector-memory instructions per tile and wave; see k_linear_nt_packed
-    int kt = 0, phase = 0;
-    if (nk > PK_R) {
-#pragma unroll
-        for (int t = 0; t < PK_R; ++t) issue_tile(t, t, wr[t]);
-        // straight-line for the first WP_UNROLL tiles (see k_linear_nt_packed), rolled beyond
-#pragma unroll
-        for (int u = 0; u < WP_UNROLL; ++u) {
-            if (kt + PK_R >= nk) { phase = u % PK_R; goto drain; }
-            __builtin_amdgcn_s_waitcnt(WAIT_STEADY);     // two later tiles stay in flight
-            __builtin_amdgcn_s_barrier();
-            compute_tile(kt, wr[u % PK_R]);
-            issue_tile(kt + PK_R, (kt + PK_R) % PK_NBUF, wr[u % PK_R]);
-            ++kt;
-        }
-        for (;;) {
-#pragma unroll
-            for (int s = 0; s < PK_R; ++s) {
-                if (kt + PK_R >= nk) { phase = s; goto drain; }
-                __builtin_amdgcn_s_waitcnt(WAIT_STEADY);
-                __builtin_amdgcn_s_barrier();
-                compute_tile(kt, wr[s]);
-                issue_tile(kt + PK_R, (kt + PK_R) % PK_NBUF, wr[s]);
-                ++kt;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < PK_R; ++t)
-            if (t < nk) issue_tile(t, t, wr[t]);
-    }
-drain:
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int t = 0; t < PK_R; ++t) {
-        if (kt + t < nk) {
-            const int idx = (phase + t) % PK_R;
-#pragma unroll
-            for (int s = 0; s < PK_R; ++s)
-                if (idx == s) compute_tile(kt + t, wr[s]);
-        }
-    }
-
-    // ---- epilogue: bias + ReLU'd tile -> LDS, sign bits, segment max / mean down the rows ----------
-    float *tile = reinterpret_cast<float *>(smem);
-    __syncthreads();                                     // the A ring is free
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int jl = wave * 64 + cb * 32 + (lane & 31);
-        const int64_t j = n0 + jl;
-        const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = acc[rb][cb][r] + bj;
-                tile[i * PK_LDT + jl] = v > 0.f ? v : 0.f;
-            }
-    }
-    __syncthreads();
-    if (p.relu_mask) {
-        // sign bits of the hidden activations: one task = 32 channels of one tile row
-        for (int task = tid; task < BM * (PK_BN / 32); task += NW * 64) {
-            const int i = task / (PK_BN / 32), q = task % (PK_BN / 32);
-            const int64_t row = m0 + i;
-            if (i < rows_per_wg && row < p.M && n0 + q * 32 < p.N) {
-                uint32_t bits = 0;
-#pragma unroll
-                for (int e0 = 0; e0 < 32; ++e0) {
-                    const int e = (e0 + i) & 31;           // rotate per row: spreads the LDS banks
-                    bits |= (tile[i * PK_LDT + q * 32 + e] > 0.f ? 1u : 0u) << e;
-                }
-                p.relu_mask[row * (p.N / 32) + (n0 >> 5) + q] = bits;
-            }
-        }
-    }
-    const int64_t j = n0 + tid;                          // thread t owns hidden column t of the tile
-    if (j < p.N) {
-        for (int sg = 0; sg < p.pool_groups; ++sg) {
-            const int64_t seg = (int64_t)blockIdx.x * p.pool_groups + sg;
-            if (seg * p.pool_n >= p.M) break;
-            const float *colp = tile + (sg * p.pool_n) * PK_LDT + tid;
-            float best = colp[0];
-            int arg = 0;
-            float sum = best;
-            for (int r = 1; r < p.pool_n; ++r) {
-                const float v = colp[r * PK_LDT];
-                sum += v;
-                if (v > best) { best = v; arg = r; }
-            }
-            if (p.pool_mode == GSAGE_POOL_MAX) {
-                p.pooled[seg * p.pooled_ld + j] = best;
-                if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(best);
-                if (p.argmax) p.argmax[seg * p.N + j] = arg;
-            } else {
-                p.pooled[seg * p.pooled_ld + j] = sum / (float)p.pool_n;
-                if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(sum / (float)p.pool_n);
-            }
-        }
-    }
-}
-
-// W [groups][N][ldw] (fp32 or bf16) -> packed operand; one thread per 16-byte lane slot
-template <typename TW>
-__global__ void __launch_bounds__(256)
-k_pack_weight(const TW *__restrict__ W, int64_t ldw, int64_t w_gstride, int64_t N, int64_t K,
-              int32_t kc_total, int32_t jb_total, int32_t groups, uint16_t *__restrict__ Wp)
-{
-    const int64_t total = (int64_t)groups * jb_total * kc_total * 64;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
-        const int lane = (int)(t & 63);
-        int64_t u = t >> 6;
-        const int kc = (int)(u % kc_total);
-        u /= kc_total;
-        const int jb = (int)(u % jb_total);
-        const int g = (int)(u / jb_total);
-        const int64_t j = (int64_t)jb * 32 + (lane & 31);
-        const int64_t k0 = (int64_t)kc * 16 + (lane >> 5) * 8;
-        uint16_t out[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = 0.f;
-            if (j < N && k0 + e < K) {
-                const TW w = W[(int64_t)g * w_gstride + j * ldw + k0 + e];
-                v = sizeof(TW) == 2 ? bf16_to_f32((uint16_t)w) : (float)w;
-            }
-            out[e] = f32_to_bf16(v);
-        }
-        vec16 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)out[2 * e] | ((uint32_t)out[2 * e + 1] << 16);
-        reinterpret_cast<vec16 *>(Wp)[t] = o;
-    }
-}
-
 static int check_operands(const char *who, const void *A, int dtype, int64_t lda, const void *W,
                           int64_t ldw, int64_t M, int64_t N, int64_t K)
 {
@@ -1053,62 +519,6 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     return check_launch("linear_nt");
 }
 
-int64_t gsage_packed_weight_elems(int64_t N, int64_t K, int32_t groups)
-{
-    return (int64_t)groups * ceil_div(N, 32) * (ceil_div(K, 64) * 4) * 64 * 8;
-}
-
-int gsage_pack_weight(const void *W, int dtype, int64_t ldw, int64_t w_gstride, int64_t N, int64_t K,
-                      int32_t groups, void *Wp, void *stream)
-{
-    GSAGE_REQUIRE(W && Wp && N > 0 && K > 0 && groups >= 1 && ldw >= K, "pack_weight: bad arguments");
-    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "pack_weight: bad dtype %d", dtype);
-    GSAGE_REQUIRE(((uintptr_t)Wp % 16) == 0, "pack_weight: output must be 16-byte aligned");
-    const int32_t kc = (int32_t)(ceil_div(K, 64) * 4), jb = (int32_t)ceil_div(N, 32);
-    const int64_t slots = (int64_t)groups * jb * kc * 64;
-    int64_t blocks = ceil_div(slots, 256);
-    if (blocks > 4096) blocks = 4096;
-    if (dtype == GSAGE_BF16)
-        launch(k_pack_weight<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-               (const uint16_t *)W, ldw, w_gstride, N, K, kc, jb, groups, (uint16_t *)Wp);
-    else
-        launch(k_pack_weight<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-               (const float *)W, ldw, w_gstride, N, K, kc, jb, groups, (uint16_t *)Wp);
-    return check_launch("pack_weight");
-}
-
-int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, int a_rows_group0_only,
-                           const void *Wp, const float *bias, void *C, int c_dtype, int64_t ldc,
-                           int64_t M, int64_t N, int64_t K, int act, int groups, int64_t a_gstride,
-                           int64_t c_gstride, void *stream)
-{
-    GSAGE_REQUIRE(A && Wp && C, "linear_nt_packed: null pointer");
-    GSAGE_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_nt_packed: bad sizes");
-    GSAGE_REQUIRE(c_dtype == GSAGE_BF16 || c_dtype == GSAGE_F32, "linear_nt_packed: bad c_dtype");
-    GSAGE_REQUIRE(groups >= 1 && groups <= 65535, "linear_nt_packed: bad group count");
-    GSAGE_REQUIRE(act >= ACT_NONE && act <= ACT_TANH, "linear_nt_packed: bad activation code");
-    // A rows must be whole 128-byte lines (zero padded up to round_up(K, 64)): the DMA streams lines
-    GSAGE_REQUIRE(lda % 64 == 0 && ceil_div(K, 64) * 64 <= lda && ((uintptr_t)A % 16) == 0 &&
-                  ((uintptr_t)Wp % 16) == 0, "linear_nt_packed: A rows must be whole zero-padded 128-byte lines");
-    if (M == 0) return GSAGE_OK;
-    PackedParams p;
-    p.A = (const uint16_t *)A; p.Wp = (const uint16_t *)Wp; p.bias = bias; p.a_rows = a_rows; p.C = C;
-    p.lda = lda; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
-    p.a_gstride = a_gstride; p.c_gstride = c_gstride;
-    p.kc_total = (int32_t)(ceil_div(K, 64) * 4);
-    p.wp_gstride = ceil_div(N, 32) * (int64_t)p.kc_total * 64 * 8;
-    p.a_rows_group0_only = a_rows_group0_only; p.c_dtype = c_dtype;
-    dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
-    hipStream_t s = (hipStream_t)stream;
-    if (act == ACT_RELU)
-        launch(k_linear_nt_packed<ACT_RELU>, grid, dim3(256), 0, s, p);
-    else if (act == ACT_TANH)
-        launch(k_linear_nt_packed<ACT_TANH>, grid, dim3(256), 0, s, p);
-    else
-        launch(k_linear_nt_packed<ACT_NONE>, grid, dim3(256), 0, s, p);
-    return check_launch("linear_nt_packed");
-}
-
 int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows, const void *W,
                    int64_t ldw, const float *bias, int64_t M, int32_t n, int64_t H, int64_t K,
                    int pool, float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
@@ -1135,31 +545,6 @@ int gsage_pool_mlp(const void *A, int dtype, int64_t lda, const int64_t *a_rows,
     else
         launch(k_linear_nt<float, true, ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("pool_mlp");
-}
-
-int gsage_pool_mlp_packed(const void *A, int64_t lda, const int64_t *a_rows, const void *Wp,
-                          const float *bias, int64_t M, int32_t n, int64_t H, int64_t K, int pool,
-                          float *pooled, int64_t pooled_ld, int32_t *argmax, void *pooled_bf16,
-                          int64_t pooled_bf16_ld, uint32_t *relu_mask, void *stream)
-{
-    GSAGE_REQUIRE(A && Wp && pooled && pooled_ld >= H, "pool_mlp_packed: bad pointers / output");
-    GSAGE_REQUIRE(M >= 0 && H > 0 && K > 0, "pool_mlp_packed: bad sizes");
-    GSAGE_REQUIRE(n >= 1 && n <= BM, "pool_mlp_packed: fanout must be in [1, %d]", BM);
-    GSAGE_REQUIRE(!relu_mask || H % 32 == 0, "pool_mlp_packed: relu_mask needs H % 32 == 0");
-    GSAGE_REQUIRE(!pooled_bf16 || pooled_bf16_ld >= H, "pool_mlp_packed: bad bf16 output");
-    GSAGE_REQUIRE(pool == GSAGE_POOL_MAX || pool == GSAGE_POOL_MEAN, "pool_mlp_packed: bad pool mode");
-    GSAGE_REQUIRE(lda % 64 == 0 && ceil_div(K, 64) * 64 <= lda && ((uintptr_t)A % 16) == 0 &&
-                  ((uintptr_t)Wp % 16) == 0, "pool_mlp_packed: A rows must be whole zero-padded 128-byte lines");
-    if (M == 0) return GSAGE_OK;
-    PoolPackedParams p;
-    p.A = (const uint16_t *)A; p.Wp = (const uint16_t *)Wp; p.bias = bias; p.a_rows = a_rows; p.lda = lda;
-    p.M = M * (int64_t)n; p.N = H; p.K = K; p.kc_total = (int32_t)(ceil_div(K, 64) * 4);
-    p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled; p.pooled_ld = pooled_ld;
-    p.pooled_b = (uint16_t *)pooled_bf16; p.pooled_b_ld = pooled_bf16_ld; p.argmax = argmax;
-    p.relu_mask = relu_mask;
-    dim3 grid((unsigned)ceil_div(M, p.pool_groups), (unsigned)ceil_div(H, 256), 1);
-    launch(k_pool_mlp_packed<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("pool_mlp_packed");
 }
 
 }  // extern "C"
