@@ -192,8 +192,9 @@ def test_batch_queue_equals_per_step_copies(capture, B, fans):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("B,fans", [(24, (5, 3)), (200, (25, 10))])
 @pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
-def test_data_parallel_queue_order_matches_single_process(capture):
+def test_data_parallel_queue_order_matches_single_process(capture, B, fans):
     """dist.py + engine.step_queue with a ONE-rank RCCL group: the exchange is an identity, so the
     software-pipelined order (next batch's sample/gather issued while the all-reduce is in flight,
     Adam afterwards) must reproduce the plain sequential engine.  The clip norm comes from a
@@ -201,7 +202,7 @@ def test_data_parallel_queue_order_matches_single_process(capture):
     import os
     import torch.distributed as dist
     adj, feats, rng = _problem(seed=6)
-    D, C, B, dims, fans = feats.shape[1], 5, 24, (128, 128), (5, 3)
+    D, C, dims = feats.shape[1], 5, (128, 128)     # fans (25, 10): the seed-level launch also gathers
     store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
     ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
     tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
