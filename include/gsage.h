@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSAGE_ABI_VERSION 1
+#define GSAGE_ABI_VERSION 2
 
 enum { GSAGE_F32 = 0, GSAGE_BF16 = 1 };
 enum {
@@ -139,6 +139,12 @@ typedef struct gsage_hops_desc {
     int64_t batch_base;
     int64_t n_batches;
     int32_t *err_flag;
+    /* sel (may be NULL): caller-supplied draws instead of Philox -- int32, this rank's samples of
+     * [hop 1 (B*fan[0]) | hop 2 | ...] back to back, each in [0, max_deg): the fused sampler then
+     * computes exactly gsage_sample_csr_sel per hop (parity level 1: replays the `sel` the reference
+     * drew at nn_modules.py:88).  With a seed queue the draws of batch b start at sel + b*sel_stride. */
+    const int32_t *sel;
+    int64_t sel_stride;
 } gsage_hops_desc;
 /* gsage_sample_hops_philox from a descriptor (the only way to pass batch_base). */
 int gsage_sample_hops(const gsage_hops_desc *hops, void *stream);
@@ -168,7 +174,8 @@ int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *i
                       int32_t n, int64_t D, void *out, int out_dtype, int64_t out_ld,
                       void *stream);
 
-/* Up to 8 gather+mean problems (e.g. all hops of one level) in one launch; bf16 in / bf16 out.
+/* Up to 8 gather+mean problems (e.g. all hops of one level) in one launch; bf16 in / bf16 out (or
+ * fp32 in / fp32 out: the exact-arithmetic parity mode).
  * tables / ids / outs / M / n are HOST arrays of n_seg entries holding DEVICE pointers and sizes;
  * segment s computes outs[s][i] = mean_j tables[s][ rows(i, j) ] exactly like gsage_gather_mean
  * (ids[s] == NULL: rows i*n+j of tables[s]).  All segments share ld, D, out_ld. */
@@ -237,7 +244,7 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
  *     Needs ldc, lda % 8 == 0 and 16-byte aligned dC, A (16-byte lane loads), ldk % 4 == 0,
  *     Ntot % 4 == 0, K <= ldk <= lda, rows_per_split % 16 == 0, n_per_group % 128 == 0 unless there
  *     is a single group. */
-int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
+int gsage_wgrad(const void *dC, int dtype, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
                 int64_t Ntot, int64_t K,
                 int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
                 int64_t out_gstride, void *stream);
@@ -254,7 +261,10 @@ typedef struct gsage_wgrad_desc {
     int64_t ldc, lda, a_gstride;
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
 } gsage_wgrad_desc;
-int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *stream);
+int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
+/* dtype (both entry points) = type of dC and A: GSAGE_BF16 (the MFMA kernel described above) or
+ * GSAGE_F32 (plain fp32 FMAs, same decomposition and slab layout: the exact-arithmetic parity mode in
+ * which the golden fixtures generated from the reference are replayed through the fused engines). */
 
 /* ------------------------------------------------------------------------------------------
  * K3  pooling MLP           replaces mlp(neibs) -> view(M,-1,H) -> max/mean over the fanout
@@ -290,13 +300,13 @@ int gsage_pool_mlp_packed(const void *A, int64_t lda, const int64_t *a_rows, con
  * H, ldo % 8 == 0. */
 int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
                          const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
-                         int64_t ldo, void *stream);
+                         int out_dtype, int64_t ldo, void *stream);
 
 /* Same for the mean pool: out[i*n + j, c] = relu_mask(i*n + j, c) ? g[i, c] / n : 0   (autograd of
  * nn_modules.py:224-226,252), plus -- when bias_part != NULL -- the MLP bias gradient as n_part
  * deterministic partial rows (summed by gsage_finalize_grads).  H % 32 == 0. */
 int gsage_pool_route_mean_bwd(const float *g, int64_t ldg, const uint32_t *relu_mask, int64_t M, int32_t n,
-                              int32_t H, void *out, int64_t ldo, float *bias_part, int32_t n_part,
+                              int32_t H, void *out, int out_dtype, int64_t ldo, float *bias_part, int32_t n_part,
                               void *stream);
 
 /* Bias gradient of the pooling MLP under the max pool: column sums of g * (pooled > 0) over the M
@@ -310,7 +320,7 @@ int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, i
  *     dH[m, c] = (Hprev[m, c] > 0) * ( (m < r_x ? DX[m, c] : 0) + (m >= r0 ? DN[m - r0, c] : 0) )
  * DX fp32 [r_x, ldx] = gradient through fc_x of the rows that were "x", DN fp32 [R - r0, ldn] =
  * gradient through the pooling MLP of the rows that were neighbours.  D % 4 == 0. */
-int gsage_pool_merge_bwd(const void *Hprev, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
+int gsage_pool_merge_bwd(const void *Hprev, int dtype, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
                          const float *DN, int64_t ldn, int64_t r0, void *dH, int64_t ldo, int64_t R,
                          int32_t D, void *stream);
 
@@ -378,7 +388,10 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
                        const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
                        const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
                        void *dE, float *preds, void *dH, float *partial,
-                       const gsage_tail_gather_desc *gather, void *stream);
+                       const gsage_tail_gather_desc *gather, int dtype, void *stream);
+/* dtype = storage type of H, w2, w2t, agg, dE, dH: GSAGE_BF16, or GSAGE_F32 -- the same kernel source
+ * instantiated on fp32 storage (every bf16 rounding point becomes a no-op; no gather role), used to
+ * replay the reference-generated golden fixtures through this kernel at fp32 tolerance. */
 int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
 
 /* ------------------------------------------------------------------------------------------
@@ -470,6 +483,8 @@ typedef struct {
     int32_t rows, cols, dst_ld, dst_t_ld;
     uint16_t *dst_p;       /* optional: the gsage_linear_nt_packed operand of THIS matrix (one group) */
     int64_t kc_p;          /* its k chunks per column block: 4 * ceil(cols / 64) */
+    int32_t dst_f32;       /* != 0: dst / dst_t are fp32 copies of the same layout (parity mode); dst_p unused */
+    int32_t reserved;
 } gsage_prep_desc;
 int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int64_t *tick0,
                        int64_t inc0, int64_t *tick1, int64_t inc1, void *stream);
@@ -481,7 +496,7 @@ int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int
  *     parent(m) = off[k-1] + (m - off[k]) / fan[k]
  * DG: fp32 [r_x, ldg] = the level above's (dX | dAgg); dH: bf16 [R, ldo].  off / fan: HOST arrays
  * of n_hops (<= 6) entries. */
-int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
+int gsage_bwd_merge(const void *H, int dtype, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
                     void *dH, int64_t ldo, int64_t R, int64_t r_x, int32_t D, int32_t n_hops,
                     const int64_t *off, const int32_t *fan, void *stream);
 

@@ -16,12 +16,37 @@ tolerance 1e-5 relative (fp32, different summation order only).
 
 The sampler step inside `forward` uses oracle/cpu.py (C) with an explicit `sel`, so the whole
 forward is a deterministic function of (weights, ids, sels).
+
+`rounding="bf16"` (mean / pool aggregators) additionally rounds to bf16 exactly where the fused
+engines store bf16 -- gathered rows, neighbour means, hidden-level outputs, the weight operand copies,
+and (through straight-through hooks) the gradients written between levels -- while every sum stays
+fp32/fp64 as in the kernels.  With rounding=None this file is the pinned fp32 oracle; the bf16 mode is
+the same code plus `_rb` calls, and lets the production (bf16) instantiation of the engines be checked
+to ~1e-3 instead of the ~3e-2 an fp32 oracle allows.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import cpu as ocpu
+
+
+class _RoundBF16(torch.autograd.Function):
+    """value -> bf16 -> fp32 in the forward, the same rounding on the gradient in the backward
+    (the engines store both the activation and its gradient in bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, round_grad):
+        ctx.round_grad = round_grad
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.round_grad else g), None
+
+
+def _rb(x, rounding, round_grad=False):
+    return _RoundBF16.apply(x, round_grad) if rounding == "bf16" else x
 
 
 def _act(name):
@@ -32,20 +57,36 @@ def _segments(x, neibs):
     return neibs.reshape(x.shape[0], -1, neibs.shape[1])
 
 
-def _combine(x, agg, w, act):
-    out = torch.cat([x @ w["fc_x.weight"].t(), agg @ w["fc_neib.weight"].t()], dim=1)
+def _combine(x, agg, w, act, rounding=None):
+    wx, wn = _rb(w["fc_x.weight"], rounding), _rb(w["fc_neib.weight"], rounding)
+    out = torch.cat([x @ wx.t(), agg @ wn.t()], dim=1)
     return _act(act)(out)
 
 
-def mean_aggregator(x, neibs, w, act):
-    return _combine(x, _segments(x, neibs).mean(dim=1), w, act)
+def mean_aggregator(x, neibs, w, act, rounding=None):
+    # the mean is a stored bf16 operand of the projection, and its gradient comes back in fp32
+    return _combine(x, _rb(_segments(x, neibs).mean(dim=1), rounding), w, act, rounding)
 
 
-def pool_aggregator(x, neibs, w, act, pool):
-    h = torch.relu(neibs @ w["mlp.0.weight"].t() + w["mlp.0.bias"])
+def pool_aggregator(x, neibs, w, act, pool, rounding=None):
+    h = torch.relu(neibs @ _rb(w["mlp.0.weight"], rounding).t() + w["mlp.0.bias"])
+    if rounding == "bf16":
+        # the hidden layer never leaves the chip in the forward; its GRADIENT is stored in bf16 (the
+        # dC operand of the MLP's weight gradient and of its input gradient)
+        h = _GradRound.apply(h)
     seg = _segments(x, h)
     agg = seg.max(dim=1)[0] if pool == "max" else seg.mean(dim=1)
-    return _combine(x, agg, w, act)
+    return _combine(x, _rb(agg, rounding), w, act, rounding)
+
+
+class _GradRound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
 
 
 def attention_aggregator(x, neibs, w, act):
@@ -59,13 +100,14 @@ def attention_aggregator(x, neibs, w, act):
     return _combine(x, agg, w, act)
 
 
-def aggregator(name, x, neibs, w, act):
+def aggregator(name, x, neibs, w, act, rounding=None):
     if name == "mean":
-        return mean_aggregator(x, neibs, w, act)
+        return mean_aggregator(x, neibs, w, act, rounding)
     if name == "max_pool":
-        return pool_aggregator(x, neibs, w, act, "max")
+        return pool_aggregator(x, neibs, w, act, "max", rounding)
     if name == "mean_pool":
-        return pool_aggregator(x, neibs, w, act, "mean")
+        return pool_aggregator(x, neibs, w, act, "mean", rounding)
+    assert rounding is None, "the bf16 rounding points are defined for the mean / pool engines"
     if name == "attention":
         return attention_aggregator(x, neibs, w, act)
     raise KeyError(name)
@@ -98,9 +140,14 @@ def split_weights(w):
 
 
 def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes,
-            acts=("relu", "identity")):
-    """models.py:71-91 with the sampler's `sel` supplied per hop."""
+            acts=None, rounding=None):
+    """models.py:71-91 with the sampler's `sel` supplied per hop.  acts: one activation name per
+    layer (default: the layer_specs of train.py:105-118 generalised in depth as models.py:85-86
+    allows -- ReLU on every layer but the last)."""
     prep_w, layers, fc = split_weights(w)
+    if acts is None:
+        acts = ["relu"] * (len(layers) - 1) + ["identity"]
+    assert len(acts) == len(layers) == len(fanouts)
     ids = torch.as_tensor(ids, dtype=torch.long)
     take = (lambda i: feats[i]) if feats is not None else (lambda i: None)
     hs = [prep(prep_name, ids, take(ids), prep_w, n_nodes, 0)]
@@ -110,9 +157,15 @@ def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_n
         cur = torch.from_numpy(nxt)
         hs.append(prep(prep_name, cur, take(cur), prep_w, n_nodes, hop + 1))
     for li, lw in enumerate(layers):
-        hs = [aggregator(agg_name, hs[k], hs[k + 1], lw, acts[li]) for k in range(len(hs) - 1)]
+        hs = [aggregator(agg_name, hs[k], hs[k + 1], lw, acts[li], rounding) for k in range(len(hs) - 1)]
+        if li < len(layers) - 1:
+            # hidden levels are stored (and their gradients written) in bf16; the last level stays fp32
+            hs = [_rb(h, rounding, round_grad=True) for h in hs]
     assert len(hs) == 1
-    out = F.normalize(hs[0], p=2, dim=1, eps=1e-12)
+    emb = hs[0]
+    if rounding == "bf16":
+        emb = _GradRound.apply(emb)       # the embedding stays fp32, its gradient is stored in bf16
+    out = F.normalize(emb, p=2, dim=1, eps=1e-12)
     return out @ fc["weight"].t() + fc["bias"]
 
 
@@ -163,11 +216,12 @@ class Adam(object):
 
 
 def train_step(w, opt, lr, task, ids, feats, targets, indptr, data, fanouts, sels, agg_name,
-               prep_name, n_nodes):
+               prep_name, n_nodes, acts=None, rounding=None):
     """models.py:97-104.  `w` is updated in place.  Returns dict(preds, loss, gradnorm, grads,
     clipped)."""
     params = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
-    preds = forward(params, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes)
+    preds = forward(params, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes,
+                    acts=acts, rounding=rounding)
     l = loss(task, preds, targets)
     l.backward()
     grads = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}

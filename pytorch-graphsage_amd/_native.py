@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
 F32, BF16 = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -59,16 +59,16 @@ SIGNATURES = {
     "gsage_pack_weight": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "gsage_linear_nt_packed": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _int,
                                       _int, _i64, _i64, _vp]),
-    "gsage_wgrad": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
+    "gsage_wgrad": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp,
                            _i64, _vp]),
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
-    "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
-    "gsage_wgrad_multi": (_int, [_i32, _vp, _vp]),
+    "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _int, _i64, _vp]),
+    "gsage_wgrad_multi": (_int, [_i32, _vp, _int, _vp]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
                              _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
     "gsage_mean_tail_ce": (_int, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i64,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "gsage_mean_tail_ce_scratch": (_i64, [_i32, _i32]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
@@ -76,15 +76,15 @@ SIGNATURES = {
     "gsage_finalize_partials": (_int, [_i32, _i64]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
-    "gsage_bwd_merge": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp,
+    "gsage_bwd_merge": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp,
                                _vp, _vp]),
     "gsage_pool_mlp": (_int, [_vp, _int, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _int,
                               _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "gsage_pool_mlp_packed": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _int, _vp, _i64, _vp, _vp,
                                      _i64, _vp, _vp]),
-    "gsage_pool_route_mean_bwd": (_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
+    "gsage_pool_route_mean_bwd": (_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _int, _i64, _vp, _i32, _vp]),
     "gsage_pool_bias_partials": (_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _vp]),
-    "gsage_pool_merge_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "gsage_pool_merge_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_aggregate": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
                                     _i64, _vp, _i64, _vp, _vp]),
     "gsage_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64, _i64,
@@ -149,7 +149,8 @@ class HopsDesc(ctypes.Structure):             # mirrors gsage_hops_desc (include
     _fields_ = [("rowptr", _vp), ("col", _vp), ("n_rows", _i64), ("ids", _vp), ("B", _i64),
                 ("n_hops", _i32), ("fan", _i32 * 5), ("max_deg", _u32), ("seed", _u64),
                 ("call_ctr", _vp), ("call_base", _u64), ("rank", _u64), ("seed_queue", _vp),
-                ("batch_idx", _vp), ("batch_base", _i64), ("n_batches", _i64), ("err_flag", _vp)]
+                ("batch_idx", _vp), ("batch_base", _i64), ("n_batches", _i64), ("err_flag", _vp),
+                ("sel", _vp), ("sel_stride", _i64)]
 
 
 class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include/gsage.h)

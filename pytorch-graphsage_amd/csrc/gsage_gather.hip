@@ -374,11 +374,12 @@ static int fill_multi(MultiSeg &q, int32_t &chunks, int32_t n_seg, const void *c
 {
     GSAGE_REQUIRE(n_seg >= 1 && n_seg <= 8, "gather_mean_multi: 1..8 segments");
     GSAGE_REQUIRE(tables && ids && outs && M && n, "gather_mean_multi: null pointer");
-    GSAGE_REQUIRE(dtype == GSAGE_BF16 && out_dtype == GSAGE_BF16,
-                  "gather_mean_multi: bf16 tables and outputs only");
-    GSAGE_REQUIRE(D > 0 && ld % 8 == 0 && out_ld % 8 == 0 && ceil_div(D, 8) * 8 <= ld &&
-                  ceil_div(D, 8) * 8 <= out_ld, "gather_mean_multi: needs 16-byte row chunks");
-    chunks = (int32_t)ceil_div(D, 8);
+    GSAGE_REQUIRE((dtype == GSAGE_BF16 || dtype == GSAGE_F32) && out_dtype == dtype,
+                  "gather_mean_multi: bf16 -> bf16 or fp32 -> fp32 (the exact-arithmetic parity mode)");
+    const int vec = dtype == GSAGE_BF16 ? 8 : 4;
+    GSAGE_REQUIRE(D > 0 && ld % vec == 0 && out_ld % vec == 0 && ceil_div(D, vec) * vec <= ld &&
+                  ceil_div(D, vec) * vec <= out_ld, "gather_mean_multi: needs 16-byte row chunks");
+    chunks = (int32_t)ceil_div(D, vec);
     q.n_seg = n_seg;
     q.first[0] = 0;
     for (int s = 0; s < 8; ++s) {
@@ -398,7 +399,7 @@ static int fill_multi(MultiSeg &q, int32_t &chunks, int32_t n_seg, const void *c
     for (int s = 0; s < n_seg; ++s)
         if (q.n[s] != 1) q.all_single = 0;
     for (int s = 0; s < 8; ++s) {
-        q.rpi[s] = (!q.all_single && s < n_seg && q.n[s] == 1) ? 4 : 1;
+        q.rpi[s] = (dtype == GSAGE_BF16 && !q.all_single && s < n_seg && q.n[s] == 1) ? 4 : 1;
         q.first[s + 1] = q.first[s] + ceil_div(q.M[s], (int64_t)q.rpi[s]) * chunks;
     }
     return GSAGE_OK;
@@ -413,8 +414,12 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
     int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
     if (rc != GSAGE_OK) return rc;
     if (q.first[n_seg] == 0) return GSAGE_OK;
-    launch(k_gather_mean_multi<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg])),
-                       dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
+    if (dtype == GSAGE_F32)
+        launch(k_gather_mean_multi<float, float, 4>, dim3(grid_for(q.first[n_seg])),
+               dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
+    else
+        launch(k_gather_mean_multi<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg])),
+               dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
     return check_launch("gather_mean_multi");
 }
 
@@ -447,8 +452,12 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
         if (rc != GSAGE_OK) return rc;
         n_smp = (int)ceil_div(hops->B, HOPS_SPW);
     }
-    launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
-           dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
+    if (dtype == GSAGE_F32)
+        launch(k_gather_multi_adam<float, float, 4>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
+    else
+        launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
     return check_launch("gather_mean_multi_adam");
 }
 

@@ -16,6 +16,28 @@ namespace gsage {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 4 consecutive columns of an activation row in storage type T (uint16_t = bf16, float = the
+// exact-arithmetic parity mode): load as fp32, store from fp32
+template <typename T> __device__ __forceinline__ f32x4 load4(const T *p);
+template <> __device__ __forceinline__ f32x4 load4<uint16_t>(const uint16_t *p)
+{
+    const uint2 h = *reinterpret_cast<const uint2 *>(p);
+    f32x4 r;
+    r[0] = bf16_to_f32((uint16_t)(h.x & 0xffff)); r[1] = bf16_to_f32((uint16_t)(h.x >> 16));
+    r[2] = bf16_to_f32((uint16_t)(h.y & 0xffff)); r[3] = bf16_to_f32((uint16_t)(h.y >> 16));
+    return r;
+}
+template <> __device__ __forceinline__ f32x4 load4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <typename T> __device__ __forceinline__ void store4(T *p, const f32x4 v);
+template <> __device__ __forceinline__ void store4<uint16_t>(uint16_t *p, const f32x4 v)
+{
+    uint2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2 *>(p) = o;
+}
+template <> __device__ __forceinline__ void store4<float>(float *p, const f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
 // partial[b] = sum over this block's grid-stride slice of g[i]^2
 __global__ void __launch_bounds__(256)
 k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partial)
@@ -182,10 +204,7 @@ k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0,
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
         const int r = (int)(t / d.cols), c = (int)(t - (int64_t)r * d.cols);
-        const uint16_t b = f32_to_bf16(d.src[t]);
-        if (d.dst) d.dst[(int64_t)r * d.dst_ld + c] = b;
-        if (d.dst_t) d.dst_t[(int64_t)c * d.dst_t_ld + r] = b;
-        if (d.dst_p) d.dst_p[packed_offset(r, c, d.kc_p)] = b;
+        prep_store(d, r, c, d.src[t]);
     }
 }
 
@@ -194,9 +213,9 @@ k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0,
 // hop k received the level above's x-gradient dX[m] if m < r_x, and -- when k >= 1 -- 1/fan[k] of
 // its parent's aggregate gradient dAgg[off[k-1] + (m - off[k]) / fan[k]].  dH = (H > 0) * that.
 struct MergeParams {
-    const uint16_t *H;       // [R, ldh] bf16 post-ReLU output of the level (for the mask)
+    const void *H;           // [R, ldh] bf16 (fp32 in parity mode) post-ReLU output of the level (for the mask)
     const float *DG;         // [r_x, ldg] fp32: cols [0, D) = dX, cols [dagg_off, dagg_off + D) = dAgg
-    uint16_t *dH;            // [R, ldo] bf16
+    void *dH;                // [R, ldo] same type as H
     int64_t ldh, ldg, ldo, dagg_off;
     int64_t R, r_x;
     int32_t D, n_hops;
@@ -204,6 +223,7 @@ struct MergeParams {
     int32_t fan[6];
 };
 
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_bwd_merge(const MergeParams q)
 {
@@ -225,13 +245,10 @@ k_bwd_merge(const MergeParams q)
             const float inv = 1.f / (float)q.fan[k];
             g += a * inv;
         }
-        const uint2 h = *reinterpret_cast<const uint2 *>(q.H + m * q.ldh + c);
-        const float h0 = bf16_to_f32((uint16_t)(h.x & 0xffff)), h1 = bf16_to_f32((uint16_t)(h.x >> 16));
-        const float h2 = bf16_to_f32((uint16_t)(h.y & 0xffff)), h3 = bf16_to_f32((uint16_t)(h.y >> 16));
-        uint2 o;
-        o.x = pack_bf16x2(h0 > 0.f ? g[0] : 0.f, h1 > 0.f ? g[1] : 0.f);
-        o.y = pack_bf16x2(h2 > 0.f ? g[2] : 0.f, h3 > 0.f ? g[3] : 0.f);
-        *reinterpret_cast<uint2 *>(q.dH + m * q.ldo + c) = o;
+        const f32x4 h = load4<T>((const T *)q.H + m * q.ldh + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = h[e] > 0.f ? g[e] : 0.f;
+        store4<T>((T *)q.dH + m * q.ldo + c, g);
     }
 }
 
@@ -239,6 +256,59 @@ k_bwd_merge(const MergeParams q)
 // hidden[i*n + j, c] receives g[i, c] iff row j won the max of (segment i, channel c) and the max
 // is positive (ReLU), else 0 -- autograd of nn_modules.py:224-226,240.  One thread = 8 channels of
 // one segment: reads 8 (g, pooled, argmax), writes n rows x 16 bytes of the bf16 operand of K5b.
+// fp32 variant of the two routing kernels (parity mode): one thread = 4 channels of one segment
+__global__ void __launch_bounds__(256)
+k_pool_route_bwd_f32(const float *__restrict__ g, int64_t ldg, const float *__restrict__ pooled, int64_t ldp,
+                     const int32_t *__restrict__ argmax, int64_t lda, int64_t M, int32_t n, int32_t H,
+                     float *__restrict__ out, int64_t ldo)
+{
+    const int chunks = H / 4;
+    const int64_t total = M * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / chunks;
+        const int c0 = (int)(t - i * chunks) * 4;
+        float gv[4];
+        int32_t am[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gv[e] = pooled[i * ldp + c0 + e] > 0.f ? g[i * ldg + c0 + e] : 0.f;
+            am[e] = argmax[i * lda + c0 + e];
+        }
+        for (int j = 0; j < n; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = am[e] == j ? gv[e] : 0.f;
+            *reinterpret_cast<f32x4 *>(out + (i * n + j) * ldo + c0) = o;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_pool_route_mean_bwd_f32(const float *__restrict__ g, int64_t ldg, const uint32_t *__restrict__ mask, int64_t M,
+                          int32_t n, int32_t H, float *__restrict__ out, int64_t ldo)
+{
+    const int chunks = H / 4;
+    const int words = H / 32;
+    const int64_t total = M * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float inv = 1.f / (float)n;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / chunks;
+        const int c0 = (int)(t - i * chunks) * 4;
+        float gv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = g[i * ldg + c0 + e] * inv;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t m = mask[(i * n + j) * words + (c0 >> 5)] >> (c0 & 31);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((m >> e) & 1u) ? gv[e] : 0.f;
+            *reinterpret_cast<f32x4 *>(out + (i * n + j) * ldo + c0) = o;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restrict__ pooled, int64_t ldp,
                  const int32_t *__restrict__ argmax, int64_t lda, int64_t M, int32_t n, int32_t H,
@@ -344,10 +414,11 @@ k_pool_bias_partials(const float *__restrict__ g, int64_t ldg, const float *__re
     *reinterpret_cast<f32x4 *>(part + (int64_t)blockIdx.x * H + c) = s;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_pool_merge_bwd(const uint16_t *__restrict__ Hp, int64_t ldh, const float *__restrict__ DX, int64_t ldx,
+k_pool_merge_bwd(const T *__restrict__ Hp, int64_t ldh, const float *__restrict__ DX, int64_t ldx,
                  int64_t r_x, const float *__restrict__ DN, int64_t ldn, int64_t r0,
-                 uint16_t *__restrict__ dH, int64_t ldo, int64_t R, int32_t D)
+                 T *__restrict__ dH, int64_t ldo, int64_t R, int32_t D)
 {
     const int chunks = D / 4;
     const int64_t total = R * chunks;
@@ -358,13 +429,10 @@ k_pool_merge_bwd(const uint16_t *__restrict__ Hp, int64_t ldh, const float *__re
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < r_x) v = *reinterpret_cast<const f32x4 *>(DX + m * ldx + c);
         if (m >= r0) v += *reinterpret_cast<const f32x4 *>(DN + (m - r0) * ldn + c);
-        const uint2 h = *reinterpret_cast<const uint2 *>(Hp + m * ldh + c);
-        const float h0 = bf16_to_f32((uint16_t)(h.x & 0xffff)), h1 = bf16_to_f32((uint16_t)(h.x >> 16));
-        const float h2 = bf16_to_f32((uint16_t)(h.y & 0xffff)), h3 = bf16_to_f32((uint16_t)(h.y >> 16));
-        uint2 o;
-        o.x = pack_bf16x2(h0 > 0.f ? v[0] : 0.f, h1 > 0.f ? v[1] : 0.f);
-        o.y = pack_bf16x2(h2 > 0.f ? v[2] : 0.f, h3 > 0.f ? v[3] : 0.f);
-        *reinterpret_cast<uint2 *>(dH + m * ldo + c) = o;
+        const f32x4 h = load4<T>(Hp + m * ldh + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+        store4<T>(dH + m * ldo + c, v);
     }
 }
 
@@ -449,9 +517,18 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
 
 int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64_t ldp,
                          const int32_t *argmax, int64_t lda, int64_t M, int32_t n, int32_t H, void *out,
-                         int64_t ldo, void *stream)
+                         int out_dtype, int64_t ldo, void *stream)
 {
     GSAGE_REQUIRE(g && pooled && argmax && out, "pool_route_bwd: null pointer");
+    GSAGE_REQUIRE(out_dtype == GSAGE_BF16 || out_dtype == GSAGE_F32, "pool_route_bwd: bad dtype");
+    if (out_dtype == GSAGE_F32) {
+        GSAGE_REQUIRE(M >= 0 && n > 0 && H > 0 && H % 4 == 0 && ldo % 4 == 0 && ldo >= H && ldg >= H && ldp >= H &&
+                      lda >= H && ((uintptr_t)out % 16) == 0, "pool_route_bwd: fp32 output needs H, ldo % 4 == 0");
+        if (M == 0) return GSAGE_OK;
+        launch(k_pool_route_bwd_f32, dim3(grid_for(M * (H / 4), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+               pooled, ldp, argmax, lda, M, n, H, (float *)out, ldo);
+        return check_launch("pool_route_bwd");
+    }
     GSAGE_REQUIRE(M >= 0 && n > 0 && H > 0 && H % 8 == 0 && ldo % 8 == 0 && ldo >= H &&
                   ((uintptr_t)out % 16) == 0, "pool_route_bwd: H and ldo must be multiples of 8, out 16-byte aligned");
     GSAGE_REQUIRE(ldg >= H && ldp >= H && lda >= H, "pool_route_bwd: leading dimension smaller than H");
@@ -462,16 +539,21 @@ int gsage_pool_route_bwd(const float *g, int64_t ldg, const float *pooled, int64
 }
 
 int gsage_pool_route_mean_bwd(const float *g, int64_t ldg, const uint32_t *relu_mask, int64_t M, int32_t n,
-                              int32_t H, void *out, int64_t ldo, float *bias_part, int32_t n_part,
+                              int32_t H, void *out, int out_dtype, int64_t ldo, float *bias_part, int32_t n_part,
                               void *stream)
 {
+    GSAGE_REQUIRE(out_dtype == GSAGE_BF16 || out_dtype == GSAGE_F32, "pool_route_mean_bwd: bad dtype");
     GSAGE_REQUIRE(g && relu_mask && out, "pool_route_mean_bwd: null pointer");
     GSAGE_REQUIRE(M >= 0 && n > 0 && H > 0 && H % 32 == 0 && ldo % 8 == 0 && ldo >= H && ldg >= H &&
                   ((uintptr_t)out % 16) == 0, "pool_route_mean_bwd: H % 32, ldo % 8, out 16-byte aligned");
     GSAGE_REQUIRE(!bias_part || (n_part >= 1 && n_part <= 1024), "pool_route_mean_bwd: bad n_part");
     if (M == 0) return GSAGE_OK;
-    launch(k_pool_route_mean_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
-           relu_mask, M, n, H, (uint16_t *)out, ldo);
+    if (out_dtype == GSAGE_F32)
+        launch(k_pool_route_mean_bwd_f32, dim3(grid_for(M * (H / 4), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+               relu_mask, M, n, H, (float *)out, ldo);
+    else
+        launch(k_pool_route_mean_bwd, dim3(grid_for(M * (H / 8), 8192)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+               relu_mask, M, n, H, (uint16_t *)out, ldo);
     int rc = check_launch("pool_route_mean_bwd");
     if (rc != GSAGE_OK || !bias_part) return rc;
     launch(k_pool_bias_partials_mean, dim3((unsigned)n_part, (unsigned)ceil_div(H, 256)), dim3(256), 0,
@@ -492,35 +574,43 @@ int gsage_pool_bias_partials(const float *g, int64_t ldg, const float *pooled, i
     return check_launch("pool_bias_partials");
 }
 
-int gsage_pool_merge_bwd(const void *Hprev, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
+int gsage_pool_merge_bwd(const void *Hprev, int dtype, int64_t ldh, const float *DX, int64_t ldx, int64_t r_x,
                          const float *DN, int64_t ldn, int64_t r0, void *dH, int64_t ldo, int64_t R,
                          int32_t D, void *stream)
 {
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "pool_merge_bwd: bad dtype");
     GSAGE_REQUIRE(Hprev && DX && DN && dH, "pool_merge_bwd: null pointer");
     GSAGE_REQUIRE(D > 0 && D % 4 == 0 && ldh % 4 == 0 && ldx % 4 == 0 && ldn % 4 == 0 && ldo % 4 == 0,
                   "pool_merge_bwd: D and leading dimensions must be multiples of 4");
     GSAGE_REQUIRE(R >= 0 && r_x >= 0 && r_x <= R && r0 >= 0 && r0 <= R, "pool_merge_bwd: bad row ranges");
     if (R == 0) return GSAGE_OK;
-    launch(k_pool_merge_bwd, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
-           (const uint16_t *)Hprev, ldh, DX, ldx, r_x, DN, ldn, r0, (uint16_t *)dH, ldo, R, D);
+    if (dtype == GSAGE_F32)
+        launch(k_pool_merge_bwd<float>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
+               (const float *)Hprev, ldh, DX, ldx, r_x, DN, ldn, r0, (float *)dH, ldo, R, D);
+    else
+        launch(k_pool_merge_bwd<uint16_t>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t *)Hprev, ldh, DX, ldx, r_x, DN, ldn, r0, (uint16_t *)dH, ldo, R, D);
     return check_launch("pool_merge_bwd");
 }
 
-int gsage_bwd_merge(const void *H, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
+int gsage_bwd_merge(const void *H, int dtype, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
                     void *dH, int64_t ldo, int64_t R, int64_t r_x, int32_t D, int32_t n_hops,
                     const int64_t *off, const int32_t *fan, void *stream)
 {
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "bwd_merge: bad dtype");
     GSAGE_REQUIRE(H && DG && dH && off && fan, "bwd_merge: null pointer");
     GSAGE_REQUIRE(n_hops >= 1 && n_hops <= 6, "bwd_merge: 1..6 hops");
     GSAGE_REQUIRE(D > 0 && D % 4 == 0 && ldh % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && dagg_off % 4 == 0,
                   "bwd_merge: D and leading dimensions must be multiples of 4");
     if (R == 0) return GSAGE_OK;
     MergeParams q;
-    q.H = (const uint16_t *)H; q.DG = DG; q.dH = (uint16_t *)dH; q.ldh = ldh; q.ldg = ldg; q.ldo = ldo;
+    q.H = H; q.DG = DG; q.dH = dH; q.ldh = ldh; q.ldg = ldg; q.ldo = ldo;
     q.dagg_off = dagg_off; q.R = R; q.r_x = r_x; q.D = D; q.n_hops = n_hops;
     for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }
-    launch(k_bwd_merge, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0,
-                       (hipStream_t)stream, q);
+    if (dtype == GSAGE_F32)
+        launch(k_bwd_merge<float>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, q);
+    else
+        launch(k_bwd_merge<uint16_t>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("bwd_merge");
 }
 

@@ -25,6 +25,8 @@ struct PrepDesc {
     int32_t rows, cols, dst_ld, dst_t_ld;
     uint16_t *dst_p;       // MFMA-fragment-ordered copy for k_linear_nt_packed (may be null)
     int64_t kc_p;          // 16-wide k chunks per 32-column block of dst_p
+    int32_t dst_f32;       // != 0: dst / dst_t are fp32 copies (exact-arithmetic parity mode; no dst_p)
+    int32_t reserved;
 };
 
 // element (r, c) of a weight matrix inside its packed operand (include/gsage.h, gsage_linear_nt_packed)
@@ -32,6 +34,20 @@ __device__ __forceinline__ int64_t packed_offset(int r, int c, int64_t kc_total)
 {
     const int64_t slot = ((int64_t)(r >> 5) * kc_total + (c >> 4)) * 64 + (r & 31) + 32 * ((c >> 3) & 1);
     return slot * 8 + (c & 7);
+}
+
+// store one (updated) weight into the operand copies of its descriptor
+__device__ __forceinline__ void prep_store(const PrepDesc &q, int r, int c, float w)
+{
+    if (q.dst_f32) {
+        if (q.dst) reinterpret_cast<float *>(q.dst)[(int64_t)r * q.dst_ld + c] = w;
+        if (q.dst_t) reinterpret_cast<float *>(q.dst_t)[(int64_t)c * q.dst_t_ld + r] = w;
+        return;
+    }
+    const uint16_t b = f32_to_bf16(w);
+    if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
+    if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
+    if (q.dst_p) q.dst_p[packed_offset(r, c, q.kc_p)] = b;
 }
 
 struct AdamParams {
@@ -112,10 +128,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             const int64_t o = i - (q.src - a.p);
             if (o >= 0 && o < (int64_t)q.rows * q.cols) {
                 const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
-                const uint16_t b = f32_to_bf16(pn);
-                if (q.dst) q.dst[(int64_t)r * q.dst_ld + c] = b;
-                if (q.dst_t) q.dst_t[(int64_t)c * q.dst_t_ld + r] = b;
-                if (q.dst_p) q.dst_p[packed_offset(r, c, q.kc_p)] = b;
+                prep_store(q, r, c, pn);
                 break;
             }
         }

@@ -187,7 +187,7 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
     GSAGE_REQUIRE(fan, "sample_hops_philox: null pointer");
     d.max_deg = max_deg; d.seed = seed; d.call_ctr = call_ctr; d.call_base = call_base; d.rank = rank;
     d.seed_queue = seed_queue; d.batch_idx = batch_idx; d.batch_base = 0; d.n_batches = n_batches;
-    d.err_flag = err_flag;
+    d.err_flag = err_flag; d.sel = nullptr; d.sel_stride = 0;
     return gsage_sample_hops(&d, stream);
 }
 

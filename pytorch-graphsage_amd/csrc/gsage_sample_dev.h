@@ -37,6 +37,8 @@ struct HopsParams {
     const int64_t *batch_idx;     // ... and the device word selecting the current one
     int64_t n_batches;
     int64_t batch_base;           // added to *batch_idx (sampling AHEAD of the counters, see k_gather_multi_adam)
+    const int32_t *sel;           // optional: caller-supplied sel [hop 1 | hop 2 | ...] instead of Philox
+    int64_t sel_stride;           // with a seed queue: sel of batch b starts at sel + b * sel_stride
     int64_t n_rows;
     int64_t off[6];               // first element of hop k in ids
     uint64_t g0[6];               // global sample index of this rank's first sample of hop k
@@ -59,8 +61,10 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
     int width = 1, widest = 1;
     for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
     int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
+    const int32_t *sel = p.sel;
     if (p.seed_queue) {           // take the seeds from the queue (and publish them as hop 0)
         const int64_t b = (int64_t)((uint64_t)(*p.batch_idx + p.batch_base) % (uint64_t)p.n_batches);
+        if (sel) sel += b * p.sel_stride;
         for (int t = threadIdx.x; t < nseed; t += 256) {
             const int64_t v = p.seed_queue[b * p.B + seed0 + t];
             cur[t] = v;
@@ -80,13 +84,18 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
         const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
         const int64_t local0 = (int64_t)seed0 * per_seed;             // first sample of this WG in hop k
         for (int64_t t = threadIdx.x; t < count; t += 256) {
-            const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
-            const uint64_t blk = g >> 2;
-            const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
-                                            (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
-            const uint32_t sel4 = (uint32_t)g & 3u;              // selects, not r.v[g & 3]: no scratch
-            const uint32_t w = sel4 == 0 ? r.v[0] : sel4 == 1 ? r.v[1] : sel4 == 2 ? r.v[2] : r.v[3];
-            const uint32_t s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
+            uint32_t s;
+            if (sel) {               // parity level 1: the reference's own draws (nn_modules.py:88), replayed
+                s = (uint32_t)sel[p.off[k] - p.off[1] + local0 + t];
+            } else {
+                const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
+                const uint64_t blk = g >> 2;
+                const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
+                                                (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
+                const uint32_t sel4 = (uint32_t)g & 3u;          // selects, not r.v[g & 3]: no scratch
+                const uint32_t w = sel4 == 0 ? r.v[0] : sel4 == 1 ? r.v[1] : sel4 == 2 ? r.v[2] : r.v[3];
+                s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
+            }
             const int64_t parent = cur[(uint32_t)t / n];
             const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
             nxt[t] = v;
@@ -109,6 +118,8 @@ inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
     p.rowptr = d.rowptr; p.col = d.col; p.ids = d.ids; p.call_ctr = d.call_ctr; p.err_flag = d.err_flag;
     p.seed_queue = d.seed_queue; p.batch_idx = d.batch_idx; p.n_batches = d.n_batches;
     p.batch_base = d.batch_base;
+    p.sel = d.sel; p.sel_stride = d.sel ? d.sel_stride : 0;
+    GSAGE_REQUIRE(!d.sel || d.sel_stride >= 0, "sample_hops: bad sel stride");
     p.n_rows = d.n_rows; p.call_base = d.call_base; p.n_hops = d.n_hops; p.B = (int32_t)d.B;
     p.max_deg = d.max_deg;
     p.seed_lo = (uint32_t)d.seed; p.seed_hi = (uint32_t)(d.seed >> 32);

@@ -31,19 +31,22 @@ constexpr int TAIL_D = 256;        // width of the previous level's rows and of 
 constexpr int TAIL_R = 4;          // seeds per workgroup (= waves per workgroup)
 constexpr int TAIL_CMAX = 64;
 
+// Storage type T of the activations and of the weight operand copies: uint16_t = bf16 (the
+// production path) or float (the exact-arithmetic parity mode: the SAME kernel source replayed on the
+// reference-generated golden fixtures at fp32 tolerance; every bf16 rounding point becomes a no-op).
 struct TailParams {
-    const uint16_t *H;       // previous level output, bf16 [B*(1+n), 256]: seeds first, then neighbours
-    const uint16_t *w2;      // bf16 [2, 128, ldw2]:  fc_x | fc_neib           (rows = outputs)
-    const uint16_t *w2t;     // bf16 [2, 256, ldw2t]: transposed copies        (rows = inputs)
+    const void *H;           // previous level output, T [B*(1+n), 256]: seeds first, then neighbours
+    const void *w2;          // T [2, 128, ldw2]:  fc_x | fc_neib           (rows = outputs)
+    const void *w2t;         // T [2, 256, ldw2t]: transposed copies        (rows = inputs)
     const float *Wfc;        // [C, 256]
     const float *bfc;        // [C]
     const int64_t *targets;
     const int64_t *batch_idx;
     int64_t n_batches;
-    uint16_t *agg;           // out: bf16 [B, 256] neighbour means (A operand of this level's K5b)
-    uint16_t *dE;            // out: bf16 [B, 256] d loss / d emb   (dC operand of this level's K5b)
+    void *agg;               // out: T [B, 256] neighbour means (A operand of this level's K5b)
+    void *dE;                // out: T [B, 256] d loss / d emb   (dC operand of this level's K5b)
     float *preds;            // out: [B, C] logits
-    uint16_t *dH;            // out: bf16 [B*(1+n), 256] gradient w.r.t. H (ReLU mask applied)
+    void *dH;                // out: T [B*(1+n), 256] gradient w.r.t. H (ReLU mask applied)
     float *partial;          // out: [grid, C*256 + C + 1] fc.weight / fc.bias / loss partials
     int64_t ldw2, ldw2t;
     int32_t B, n, C;
@@ -66,6 +69,38 @@ __device__ __forceinline__ float tail_elem(const vec16 v, int e)
 {
     const uint32_t w = v[e >> 1];
     return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+// eight consecutive elements of a row, as one lane holds them
+template <typename T> struct row8;
+template <> struct row8<uint16_t> {
+    vec16 v;
+    __device__ __forceinline__ void load(const uint16_t *p) { v = *(const vec16 *)p; }
+    __device__ __forceinline__ float get(int e) const { return tail_elem(v, e); }
+};
+template <> struct row8<float> {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 a, b;
+    __device__ __forceinline__ void load(const float *p) { a = *(const f4 *)p; b = *(const f4 *)(p + 4); }
+    __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
+};
+// the value a store of x in type T holds
+template <typename T> __device__ __forceinline__ float tail_round(float x);
+template <> __device__ __forceinline__ float tail_round<uint16_t>(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+template <> __device__ __forceinline__ float tail_round<float>(float x) { return x; }
+__device__ __forceinline__ void tail_store1(uint16_t *p, float x) { *p = f32_to_bf16(x); }
+__device__ __forceinline__ void tail_store1(float *p, float x) { *p = x; }
+__device__ __forceinline__ void tail_store8(uint16_t *p, const float (&x)[8])
+{
+    vec16 o;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) o[q >> 1] = pack_bf16x2(x[q], x[q + 1]);
+    *(vec16 *)p = o;
+}
+__device__ __forceinline__ void tail_store8(float *p, const float (&x)[8])
+{
+    *(float4 *)p = make_float4(x[0], x[1], x[2], x[3]);
+    *(float4 *)(p + 4) = make_float4(x[4], x[5], x[6], x[7]);
 }
 
 // fc.weight rows in LDS are padded to a multiple of 8 classes (zero rows): 8-class chunks need no
@@ -142,10 +177,12 @@ __device__ __forceinline__ void tail_gather_role(const TailGather &g, int bx)
 }
 
 // NBH = neighbour rows per half-wave lane (n <= 2 * NBH); GN = fan-out of the gather role (0: none)
-template <int NBH, int GN>
+template <typename T, int NBH, int GN>
 __global__ void __launch_bounds__(256)
 k_mean_tail_ce(const TailParams p, const TailGather tg)
 {
+    const T *const pH = (const T *)p.H, *const pw2 = (const T *)p.w2, *const pw2t = (const T *)p.w2t;
+    T *const pagg = (T *)p.agg, *const pdE = (T *)p.dE, *const pdH = (T *)p.dH;
     if (GN > 0) {
         const int n_tail = (p.B + TAIL_R - 1) / TAIL_R;
         if ((int)blockIdx.x >= n_tail) {
@@ -184,14 +221,15 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     const int64_t iwc = live ? iw : B - 1;        // clamped: loads stay unconditional
     const int64_t my_target = live ? tgt[iwc] : -1;
     const float my_bias = (lane < C) ? p.bfc[lane] : 0.f;
-    const vec16 xraw = *(const vec16 *)(p.H + iwc * D + cg * 8);
-    vec16 nb[NBH];
+    row8<T> xraw;
+    xraw.load(pH + iwc * D + cg * 8);
+    row8<T> nb[NBH];
     {
-        const uint16_t *base = p.H + (B + iwc * n) * D + cg * 8;
+        const T *base = pH + (B + iwc * n) * D + cg * 8;
 #pragma unroll
         for (int u = 0; u < NBH; ++u) {
             const int j = half + 2 * u;
-            nb[u] = *(const vec16 *)(base + (int64_t)(j < n ? j : n - 1) * D);
+            nb[u].load(base + (int64_t)(j < n ? j : n - 1) * D);
         }
     }
     {
@@ -231,20 +269,18 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
             const bool valid = half + 2 * u < n;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = valid ? tail_elem(nb[u], e) : 0.f;
+                const float f = valid ? nb[u].get(e) : 0.f;
                 s[e] += f;
                 mbits[u >> 2] |= (f > 0.f ? 1u : 0u) << ((u & 3) * 8 + e);
             }
         }
-        vec16 ab;
-        float af[8];
+        float af[8], am[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             s[e] += __shfl_xor(s[e], 32, 64);
-            const uint16_t b = f32_to_bf16(s[e] / (float)n);         // the GEMM operand is bf16
-            af[e] = live ? bf16_to_f32(b) : 0.f;
-            if (e & 1) ab[e >> 1] |= (uint32_t)b << 16; else ab[e >> 1] = b;
-            const float xf = tail_elem(xraw, e);
+            am[e] = tail_round<T>(s[e] / (float)n);                   // the GEMM operand has type T
+            af[e] = live ? am[e] : 0.f;
+            const float xf = xraw.get(e);
             xbits |= (xf > 0.f ? 1u : 0u) << e;
         }
         // pin the masks here: left alone the compiler sinks their computation to the stores at the
@@ -253,10 +289,10 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         for (int w = 0; w < (NBH + 3) / 4; ++w) asm volatile("" : "+v"(mbits[w]));
         asm volatile("" : "+v"(xbits));
         if (half == 0) {
-            if (live) *(vec16 *)(p.agg + iw * D + cg * 8) = ab;
+            if (live) tail_store8(pagg + iw * D + cg * 8, am);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                xs[wave * D + cg * 8 + e] = live ? tail_elem(xraw, e) : 0.f;
+                xs[wave * D + cg * 8 + e] = live ? xraw.get(e) : 0.f;
                 as[wave * D + cg * 8 + e] = af[e];
             }
         }
@@ -271,13 +307,13 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
         const int g = cg >> 4;
-        const uint16_t *wt = p.w2t + (int64_t)g * D * p.ldw2t + (cg & 15) * 8 + (int64_t)slot * 32 * p.ldw2t;
+        const T *wt = pw2t + (int64_t)g * D * p.ldw2t + (cg & 15) * 8 + (int64_t)slot * 32 * p.ldw2t;
         const float *in = (g ? as : xs) + slot * 32;
 #pragma unroll
         for (int kb = 0; kb < 32; kb += 16) {
-            vec16 w[16];
+            row8<T> w[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = *(const vec16 *)(wt + (int64_t)(kb + u) * p.ldw2t);
+            for (int u = 0; u < 16; ++u) w[u].load(wt + (int64_t)(kb + u) * p.ldw2t);
 #pragma unroll
             for (int u4 = 0; u4 < 16; u4 += 4) {
                 float4 iv[R];
@@ -287,7 +323,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
                 for (int uu = 0; uu < 4; ++uu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float wv = tail_elem(w[u4 + uu], e);
+                        const float wv = w[u4 + uu].get(e);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const float a = uu == 0 ? iv[r].x : uu == 1 ? iv[r].y : uu == 2 ? iv[r].z : iv[r].w;
@@ -421,9 +457,9 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = row0 + r;
-        const uint16_t gb = f32_to_bf16((dz[r] - z[r] * zdz[r]) / nrm[r]);
-        if (i < B) p.dE[i * D + t] = gb;
-        des[r * D + t] = (i < B) ? bf16_to_f32(gb) : 0.f;      // K5b and the products below see bf16
+        const float gb = tail_round<T>((dz[r] - z[r] * zdz[r]) / nrm[r]);
+        if (i < B) tail_store1(pdE + i * D + t, gb);
+        des[r * D + t] = (i < B) ? gb : 0.f;                   // K5b and the products below see type T
     }
     {
         float *out = p.partial + (int64_t)blockIdx.x * ((int64_t)C * D + C + 1);
@@ -441,16 +477,16 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int q = 0; q < 8; ++q) { ax[r][q] = 0.f; aa[r][q] = 0.f; }
-        const uint16_t *wx = p.w2 + (int64_t)slot * 16 * p.ldw2 + cg * 8;
-        const uint16_t *wn = wx + (int64_t)128 * p.ldw2;
+        const T *wx = pw2 + (int64_t)slot * 16 * p.ldw2 + cg * 8;
+        const T *wn = wx + (int64_t)128 * p.ldw2;
         const float *dx = des + slot * 16, *dn = des + 128 + slot * 16;
 #pragma unroll
         for (int cb = 0; cb < 16; cb += 8) {
-            vec16 a[8], b[8];
+            row8<T> a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a[u] = *(const vec16 *)(wx + (int64_t)(cb + u) * p.ldw2);
-                b[u] = *(const vec16 *)(wn + (int64_t)(cb + u) * p.ldw2);
+                a[u].load(wx + (int64_t)(cb + u) * p.ldw2);
+                b[u].load(wn + (int64_t)(cb + u) * p.ldw2);
             }
 #pragma unroll
             for (int u4 = 0; u4 < 8; u4 += 4) {
@@ -464,7 +500,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
                 for (int uu = 0; uu < 4; ++uu) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float fa = tail_elem(a[u4 + uu], q), fb = tail_elem(b[u4 + uu], q);
+                        const float fa = a[u4 + uu].get(q), fb = b[u4 + uu].get(q);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             const float gx = uu == 0 ? vx[r].x : uu == 1 ? vx[r].y : uu == 2 ? vx[r].z : vx[r].w;
@@ -505,27 +541,25 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
             gz[0] += a0.x; gz[1] += a0.y; gz[2] += a0.z; gz[3] += a0.w;
             gz[4] += a1.x; gz[5] += a1.y; gz[6] += a1.z; gz[7] += a1.w;
         }
-        uint16_t zb[8];
+        float zb[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zb[q] = f32_to_bf16(gz[q] * inv_n);
+        for (int q = 0; q < 8; ++q) zb[q] = gz[q] * inv_n;
         if (half == 0) {
-            vec16 o;
+            float o[8];
 #pragma unroll
-            for (int q = 0; q < 8; q += 2)
-                o[q >> 1] = pack_bf16x2(((xbits >> q) & 1u) ? gx[q] : 0.f, ((xbits >> (q + 1)) & 1u) ? gx[q + 1] : 0.f);
-            *(vec16 *)(p.dH + iw * D + cg * 8) = o;
+            for (int q = 0; q < 8; ++q) o[q] = ((xbits >> q) & 1u) ? gx[q] : 0.f;
+            tail_store8(pdH + iw * D + cg * 8, o);
         }
-        uint16_t *base = p.dH + (B + iw * n) * D + cg * 8;
+        T *base = pdH + (B + iw * n) * D + cg * 8;
 #pragma unroll
         for (int u = 0; u < NBH; ++u) {
             const int j = half + 2 * u;
             if (j < n) {
                 const uint32_t m = mbits[u >> 2] >> ((u & 3) * 8);
-                vec16 o;
+                float o[8];
 #pragma unroll
-                for (int q = 0; q < 8; q += 2)
-                    o[q >> 1] = (((m >> q) & 1u) ? (uint32_t)zb[q] : 0u) | ((((m >> (q + 1)) & 1u) ? (uint32_t)zb[q + 1] : 0u) << 16);
-                *(vec16 *)(base + (int64_t)j * D) = o;
+                for (int q = 0; q < 8; ++q) o[q] = ((m >> q) & 1u) ? zb[q] : 0.f;
+                tail_store8(base + (int64_t)j * D, o);
             }
         }
     }
@@ -558,8 +592,11 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
                        const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
                        const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
                        void *dE, float *preds, void *dH, float *partial, const gsage_tail_gather_desc *gather,
-                       void *stream)
+                       int dtype, void *stream)
 {
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "mean_tail_ce: bad dtype");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || !(gather && gather->rows > 0),
+                  "mean_tail_ce: the gather role exists for bf16 tables only");
     GSAGE_REQUIRE(H && w2 && w2t && Wfc && bfc && targets && agg && dE && preds && dH && partial,
                   "mean_tail_ce: null pointer");
     GSAGE_REQUIRE(B > 0 && n >= 1 && n <= 32 && C >= 1 && C <= TAIL_CMAX,
@@ -570,9 +607,9 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
                     (uintptr_t)dH) & 15) == 0, "mean_tail_ce: buffers must be 16-byte aligned");
     GSAGE_REQUIRE(!batch_idx || n_batches > 0, "mean_tail_ce: bad target queue");
     TailParams p;
-    p.H = (const uint16_t *)H; p.w2 = (const uint16_t *)w2; p.w2t = (const uint16_t *)w2t;
+    p.H = H; p.w2 = w2; p.w2t = w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
-    p.agg = (uint16_t *)agg; p.dE = (uint16_t *)dE; p.preds = preds; p.dH = (uint16_t *)dH;
+    p.agg = agg; p.dE = dE; p.preds = preds; p.dH = dH;
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
     TailGather tg = {};
     const bool fused = gather && gather->rows > 0;
@@ -590,11 +627,12 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
     const int small = n <= 16;
     void (*kern)(const TailParams, const TailGather) =
-        fused ? (small ? k_mean_tail_ce<8, 10> : k_mean_tail_ce<16, 10>)
-              : (small ? k_mean_tail_ce<8, 0> : k_mean_tail_ce<16, 0>);
+        dtype == GSAGE_F32 ? (small ? k_mean_tail_ce<float, 8, 0> : k_mean_tail_ce<float, 16, 0>)
+        : fused ? (small ? k_mean_tail_ce<uint16_t, 8, 10> : k_mean_tail_ce<uint16_t, 16, 10>)
+                : (small ? k_mean_tail_ce<uint16_t, 8, 0> : k_mean_tail_ce<uint16_t, 16, 0>);
     {   // more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
-        static bool raised[4] = {false, false, false, false};
-        const int slot = small + 2 * (int)fused;
+        static bool raised[6] = {false, false, false, false, false, false};
+        const int slot = dtype == GSAGE_F32 ? 4 + small : small + 2 * (int)fused;
         if (!raised[slot]) {
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * tail_lds_floats(TAIL_CMAX) + 16)) != hipSuccess) {

@@ -287,6 +287,82 @@ k_wgrad_multi(const WgradMulti q)
     wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds);
 }
 
+// ---- fp32 operands (exact-arithmetic parity mode) ---------------------------------------------------
+// Same decomposition and slab layout as the bf16 kernel (M-slice bx, 128 x 128 output tile (by, bz)),
+// plain fp32 FMAs: thread (ty, tx) owns an 8 x 8 block of the tile, eight rows of both operands are
+// staged in LDS per step.  This is the checker's path (golden fixtures replayed at 2e-4 through the
+// same engine that runs the bf16 kernels), not a throughput kernel.
+__device__ __forceinline__ void wgrad_workgroup_f32(const WgradParams &p, int64_t bx, int64_t by, int64_t bz,
+                                                    float *lds)
+{
+    const float *dC = reinterpret_cast<const float *>(p.dC);
+    const int64_t n_base = by * 128, k_base = bz * 128;
+    const int g = (int)(n_base / p.n_per_group);
+    const float *A = reinterpret_cast<const float *>(p.A) + (int64_t)g * p.a_gstride;
+    const int64_t m_begin = bx * p.rows_per_split;
+    const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
+    float *cs = lds, *as = lds + 8 * 128;
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    const int lr = t >> 5, lc = (t & 31) * 4;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 8) {
+        const int64_t m = m0 + lr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t n = n_base + lc + e, k = k_base + lc + e;
+            cs[lr * 128 + lc + e] = (m < m_end && n < p.Ntot) ? dC[m * p.ldc + n] : 0.f;
+            as[lr * 128 + lc + e] = (m < m_end && k < p.lda) ? A[m * p.lda + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float cv[8], av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { cv[i] = cs[r * 128 + ty * 8 + i]; av[i] = as[r * 128 + tx * 8 + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] += cv[i] * av[j];
+        }
+        __syncthreads();
+    }
+    float *slab = p.slabs + bx * p.Ntot * p.ldk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t n = n_base + ty * 8 + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k_base + tx * 8 + j;
+            if (n < p.Ntot && k < p.ldk) slab[n * p.ldk + k] = acc[i][j];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_wgrad_f32(const WgradParams p)
+{
+    __shared__ float lds[2 * 8 * 128];
+    wgrad_workgroup_f32(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+__global__ void __launch_bounds__(256)
+k_wgrad_multi_f32(const WgradMulti q)
+{
+    int s = 0;
+#pragma unroll
+    for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
+        if (j < q.n_prob && (int)blockIdx.x >= q.first[j]) s = j;
+    const int local = (int)blockIdx.x - q.first[s];
+    const int bx = local % q.S[s];
+    const int rest = local / q.S[s];
+    __shared__ float lds[2 * 8 * 128];
+    wgrad_workgroup_f32(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds);
+}
+
 // out_g[n_local * K + k] = sum_s slabs[s][g * n_per_group + n_local][k]
 __global__ void __launch_bounds__(256)
 k_reduce_slabs(const float *__restrict__ slabs, int32_t S, int64_t Ntot, int64_t K, int64_t ldk,
@@ -338,14 +414,16 @@ static int wgrad_raise_lds(K kernel, bool &done)
     return GSAGE_OK;
 }
 
-static int wgrad_fill(WgradParams &p, const void *dC, int64_t ldc, const void *A, int64_t lda,
+static int wgrad_fill(WgradParams &p, int dtype, const void *dC, int64_t ldc, const void *A, int64_t lda,
                       int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K, int64_t n_per_group,
                       int64_t rows_per_split, float *slabs, int64_t ldk)
 {
     GSAGE_REQUIRE(dC && A && slabs, "wgrad: null pointer");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "wgrad: bad dtype");
     GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
-    GSAGE_REQUIRE(ldc % 8 == 0 && lda % 8 == 0 && ldk % 4 == 0,
-                  "wgrad: ldc, lda must be multiples of 8 (16-byte row chunks), ldk of 4");
+    GSAGE_REQUIRE(dtype == GSAGE_F32 || (ldc % 8 == 0 && lda % 8 == 0), 
+                  "wgrad: ldc, lda must be multiples of 8 (16-byte row chunks)");
+    GSAGE_REQUIRE(ldk % 4 == 0, "wgrad: ldk must be a multiple of 4");
     GSAGE_REQUIRE(Ntot % 4 == 0 && Ntot <= ldc, "wgrad: Ntot must be a multiple of 4 and <= ldc");
     GSAGE_REQUIRE(ldk >= K && ldk <= lda + 3, "wgrad: need K <= ldk <= lda");
     GSAGE_REQUIRE(n_per_group > 0 && (n_per_group % 128 == 0 || n_per_group >= Ntot),
@@ -361,7 +439,7 @@ static int wgrad_fill(WgradParams &p, const void *dC, int64_t ldc, const void *A
 
 extern "C" {
 
-int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *stream)
+int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream)
 {
     GSAGE_REQUIRE(probs && n_prob >= 1 && n_prob <= WGRAD_MAX_PROBLEMS, "wgrad_multi: 1..%d problems",
                   WGRAD_MAX_PROBLEMS);
@@ -371,7 +449,7 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
     for (int s = 0; s < WGRAD_MAX_PROBLEMS; ++s) {
         if (s < n_prob) {
             const gsage_wgrad_desc &d = probs[s];
-            int rc = wgrad_fill(q.p[s], d.dC, d.ldc, d.A, d.lda, d.a_gstride, d.M, d.Ntot, d.K,
+            int rc = wgrad_fill(q.p[s], dtype, d.dC, d.ldc, d.A, d.lda, d.a_gstride, d.M, d.Ntot, d.K,
                                 d.n_per_group, d.rows_per_split, d.slabs, d.ldk);
             if (rc != GSAGE_OK) return rc;
             q.S[s] = (int32_t)ceil_div(d.M, d.rows_per_split);
@@ -383,6 +461,10 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
             q.first[s + 1] = q.first[s];
         }
     }
+    if (dtype == GSAGE_F32) {
+        launch(k_wgrad_multi_f32, dim3((unsigned)q.first[n_prob]), dim3(256), 0, (hipStream_t)stream, q);
+        return check_launch("wgrad_multi");
+    }
     static bool raised = false;
     int rc2 = wgrad_raise_lds(k_wgrad_multi, raised);
     if (rc2 != GSAGE_OK) return rc2;
@@ -390,19 +472,23 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, void *strea
     return check_launch("wgrad_multi");
 }
 
-int gsage_wgrad(const void *dC, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K,
-                int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk, float *out,
-                int64_t out_gstride, void *stream)
+int gsage_wgrad(const void *dC, int dtype, int64_t ldc, const void *A, int64_t lda, int64_t a_gstride, int64_t M,
+                int64_t Ntot, int64_t K, int64_t n_per_group, int64_t rows_per_split, float *slabs, int64_t ldk,
+                float *out, int64_t out_gstride, void *stream)
 {
     WgradParams p;
-    int rc0 = wgrad_fill(p, dC, ldc, A, lda, a_gstride, M, Ntot, K, n_per_group, rows_per_split, slabs, ldk);
+    int rc0 = wgrad_fill(p, dtype, dC, ldc, A, lda, a_gstride, M, Ntot, K, n_per_group, rows_per_split, slabs, ldk);
     if (rc0 != GSAGE_OK) return rc0;
     const int S = (int)ceil_div(M, rows_per_split);
     dim3 grid((unsigned)S, (unsigned)ceil_div(Ntot, 128), (unsigned)ceil_div(ldk, 128));
-    static bool raised = false;
-    int rc1 = wgrad_raise_lds(k_wgrad_bf16, raised);
-    if (rc1 != GSAGE_OK) return rc1;
-    launch(k_wgrad_bf16, grid, dim3(256), WGRAD_LDS_BYTES, (hipStream_t)stream, p);
+    if (dtype == GSAGE_F32) {
+        launch(k_wgrad_f32, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        static bool raised = false;
+        int rc1 = wgrad_raise_lds(k_wgrad_bf16, raised);
+        if (rc1 != GSAGE_OK) return rc1;
+        launch(k_wgrad_bf16, grid, dim3(256), WGRAD_LDS_BYTES, (hipStream_t)stream, p);
+    }
     int rc = check_launch("wgrad");
     if (rc != GSAGE_OK || out == nullptr) return rc;      // out == NULL: caller reduces the slabs
     int64_t blocks = ceil_div(Ntot * K, 256);

@@ -131,6 +131,8 @@ class CapturedTrainStep(object):
 import ctypes
 import os
 
+import numpy as np
+
 from . import ops
 from .nn_modules import IdentityPrep, MaxPoolAggregator, MeanAggregator, MeanPoolAggregator, \
     SparseUniformNeighborSampler, \
@@ -147,7 +149,8 @@ class _ReduceDesc(ctypes.Structure):         # mirrors gsage_reduce_desc (includ
 class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/gsage.h)
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_ld", ctypes.c_int32),
-                ("dst_t_ld", ctypes.c_int32), ("dst_p", ctypes.c_void_p), ("kc_p", ctypes.c_int64)]
+                ("dst_t_ld", ctypes.c_int32), ("dst_p", ctypes.c_void_p), ("kc_p", ctypes.c_int64),
+                ("dst_f32", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def _r8(v):
@@ -201,7 +204,9 @@ class FusedMeanTrainStep(object):
             return False
         if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
             return False
-        if feats.dtype != torch.bfloat16 or not feats.is_cuda:
+        # bf16 storage = the production path; fp32 storage = the exact-arithmetic parity mode (same
+        # engine, same kernel sources instantiated on fp32: golden fixtures replay at 2e-4)
+        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda:
             return False
         if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
             return False
@@ -243,6 +248,11 @@ class FusedMeanTrainStep(object):
                 self._reduce_op = torch.distributed.ReduceOp.SUM
         dev = feats.device
         self.dev = dev
+        # storage type of features, activations and weight operand copies
+        self.tdt = feats.dtype
+        self.code = nat.BF16 if self.tdt == torch.bfloat16 else nat.F32
+        self.esz = 2 if self.tdt == torch.bfloat16 else 4
+        self.sel, self.sel_queue = None, None     # caller-supplied sampler draws (set_sel / load_epoch)
         self.layers = list(model.agg_layers.children())
         L = self.L = len(self.layers)
         self.post = _split_activation(self.layers[-1].activation)[1]
@@ -302,14 +312,14 @@ class FusedMeanTrainStep(object):
             assert tuple(layer.fc_x.weight.shape) == (h, din) == tuple(layer.fc_neib.weight.shape)
             ix, inb = self.pidx[id(layer.fc_x.weight)], self.pidx[id(layer.fc_neib.weight)]
             assert inb == ix + 1, "fc_x / fc_neib must be adjacent in the parameter order"
-            w2 = torch.zeros(2, h, _r8(din), dtype=torch.bfloat16, device=dev)
-            w2t = torch.zeros(2, din, _r8(h), dtype=torch.bfloat16, device=dev) if l > 0 else None
+            w2 = torch.zeros(2, h, _r8(din), dtype=self.tdt, device=dev)
+            w2t = torch.zeros(2, din, _r8(h), dtype=self.tdt, device=dev) if l > 0 else None
             self.w2.append(w2)
             self.w2t.append(w2t)
             # levels whose forward runs on K5 read the weights in MFMA fragment order
             # (gsage_linear_nt_packed; needs whole-line operand rows); the seed-level kernel reads w2
             lda = feats.ld if l == 0 else din
-            packed = lda % 64 == 0 and lda >= -(-din // 64) * 64
+            packed = self.code == nat.BF16 and lda % 64 == 0 and lda >= -(-din // 64) * 64
             gstride = nat.lib().gsage_packed_weight_elems(h, din, 1)
             wp = torch.zeros(2 * gstride, dtype=torch.bfloat16, device=dev) if packed else None
             self.wp.append(wp)
@@ -317,13 +327,14 @@ class FusedMeanTrainStep(object):
                 descs.append(_PrepDesc(prm.data_ptr(), w2[g].data_ptr(),
                                        w2t[g].data_ptr() if w2t is not None else None,
                                        h, din, w2.shape[2], w2t.shape[2] if w2t is not None else 0,
-                                       wp[g * gstride:].data_ptr() if packed else None, 4 * (-(-din // 64))))
+                                       wp[g * gstride:].data_ptr() if packed else None, 4 * (-(-din // 64)),
+                                       int(self.code == nat.F32), 0))
         raw = bytes((_PrepDesc * len(descs))(*descs))
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
         self.max_elems = max(h * d for h, d in zip(self.h, self.din))
 
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.tdt, torch.float32
         # per-batch inputs of the compute stage, one set per batch in flight:
         #   ids   the concatenated frontier [hop 0 | hop 1 | ... | hop L]
         #   xa0   level-0 operands [x rows | neighbour means], gathered ONCE per step so the forward
@@ -440,23 +451,28 @@ class FusedMeanTrainStep(object):
             self.capture_mode = "graph"              # the stock-torch head cannot be recorded
         self._pool = None
         if self.capture_mode:
-            self.g_main = []
-            if self.pipelined:
-                self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
-                                for st_ in range(2)]
-
-            def main(st_):
-                if not self.pipelined:
-                    self._stage_sample_gather(0)
-                self._stage_compute(st_)
-                if ddp is None:
-                    self._stage_opt()
-            for st_ in range(self.nset):
-                self.g_main.append(self._record(lambda st_=st_: main(st_),
-                                                self.s_back if self.pipelined else None))
-            if ddp is not None:
-                self.g_opt = self._record(self._stage_opt, self.s_back if self.pipelined else None)
+            self._record_main()
         torch.cuda.synchronize()
+
+    def _record_main(self):
+        """(Re-)record the per-call command lists / graphs of __call__."""
+        ddp = self.ddp
+        self.g_main = []
+        if self.pipelined:
+            self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
+                            for st_ in range(2)]
+
+        def main(st_):
+            if not self.pipelined:
+                self._stage_sample_gather(0)
+            self._stage_compute(st_)
+            if ddp is None:
+                self._stage_opt()
+        for st_ in range(self.nset):
+            self.g_main.append(self._record(lambda st_=st_: main(st_),
+                                            self.s_back if self.pipelined else None))
+        if ddp is not None:
+            self.g_opt = self._record(self._stage_opt, self.s_back if self.pipelined else None)
 
     # ---- helpers ------------------------------------------------------------------------------
     def _record(self, fn, stream=None):
@@ -484,7 +500,7 @@ class FusedMeanTrainStep(object):
 
     def _linear(self, A, lda, a_rows, a_g0, W, ldw, C, c_dtype, ldc, M, N, K, act, a_gs, w_gs, c_gs):
         ops._linear_launch(A, lda, a_rows, a_g0, W, ldw, None, C, ldc, M, N, K, act, 2, a_gs, w_gs,
-                           c_gs, nat.BF16, c_dtype)
+                           c_gs, self.code, c_dtype)
 
     # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
     def _hops_desc(self, ids, ahead):
@@ -503,6 +519,10 @@ class FusedMeanTrainStep(object):
         d.batch_idx = self.batch_idx.data_ptr() if self.queue else None
         d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
         d.err_flag = self.csr.err_flag.data_ptr()
+        if self.queue and self.sel_queue is not None:
+            d.sel, d.sel_stride = self.sel_queue.data_ptr(), int(self.sel_queue.shape[1])
+        elif self.sel is not None:
+            d.sel, d.sel_stride = self.sel.data_ptr(), 0
         return d
 
     def _stage_sample(self, s, ids=None, ahead=False):
@@ -561,7 +581,7 @@ class FusedMeanTrainStep(object):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
         L, B, st, lib = self.L, self.B, self.store, nat.lib()
         stream = ops._stream()
-        esz = 2
+        esz = self.esz
         for l in range(L - 1 if self.fused_tail else L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             if l == 0:
@@ -581,7 +601,7 @@ class FusedMeanTrainStep(object):
                                           nat.F32 if last else nat.BF16)
                 continue
             self._linear(xbuf.data_ptr(), lda, None, 0, self.w2[l].data_ptr(), self.w2[l].shape[2],
-                         self.hout[l].data_ptr(), nat.F32 if last else nat.BF16, 2 * h, R, h, din,
+                         self.hout[l].data_ptr(), nat.F32 if last else self.code, 2 * h, R, h, din,
                          nat.ACT_NONE if last else nat.ACT_RELU, delta // esz,
                          h * self.w2[l].shape[2], h)
 
@@ -596,15 +616,15 @@ class FusedMeanTrainStep(object):
                 self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
                 self.agg[L - 1].data_ptr(), self.dc[L - 1].data_ptr(), self.preds.data_ptr(),
                 self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
-                ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, stream),
-                "mean_tail_ce")
+                ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
+                stream), "mean_tail_ce")
         elif self.fused_head:
             C, D2 = m.fc.weight.shape
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
             nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), self.hout[L - 1].stride(0),
                                         m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), tg.data_ptr(),
                                         B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
-                                        nat.BF16, self.dc[L - 1].stride(0), None, None, None,
+                                        self.code, self.dc[L - 1].stride(0), None, None, None,
                                         self.head_scratch.data_ptr(),
                                         self.batch_idx.data_ptr() if self.queue else None,
                                         self.queue[2] if self.queue else 0, stream), "head_ce")
@@ -631,7 +651,7 @@ class FusedMeanTrainStep(object):
     def _backward_levels(self, s):
         L, st, lib = self.L, self.store, nat.lib()
         stream = ops._stream()
-        esz = 2
+        esz = self.esz
         # (1) the chain of input gradients down the levels: dC[l] -> (dX | dAgg) -> mask/route -> dC[l-1]
         for l in range(L - 1, 0, -1):
             if self.fused_tail and l == L - 1:
@@ -643,7 +663,7 @@ class FusedMeanTrainStep(object):
                          self.dg[l].data_ptr(), nat.F32, 2 * din, R, din, h, nat.ACT_NONE, h,
                          din * w2t.shape[2], din)
             below = self.hout[l - 1]
-            nat.check(lib.gsage_bwd_merge(below.data_ptr(), below.stride(0), self.dg[l].data_ptr(),
+            nat.check(lib.gsage_bwd_merge(below.data_ptr(), self.code, below.stride(0), self.dg[l].data_ptr(),
                                           2 * din, din, self.dc[l - 1].data_ptr(),
                                           self.dc[l - 1].stride(0), self.rows[l - 1], R, din,
                                           L - l + 1, self.off_host, self.fan_host, stream),
@@ -704,7 +724,29 @@ class FusedMeanTrainStep(object):
         self.model.lr = self.model.lr_scheduler(progress)
         self.lr.fill_(float(self.model.lr))
 
-    def load_epoch(self, ids_epoch, targets_epoch):
+    def set_sel(self, sels):
+        """Replace the Philox draws of the sampler by caller-supplied ones for the following steps
+        (None: back to Philox).  sels: one integer array per hop, [M_k, fan_k] or flat, each value in
+        [0, max_deg) -- exactly what the reference draws with np.random.choice at nn_modules.py:88, so a
+        recorded reference step can be replayed through the engine (parity level 1).  Re-records the
+        command lists / graphs (their kernels now read the sel buffer); later set_sel calls with
+        same-sized draws only overwrite the buffer."""
+        if sels is None:
+            changed, self.sel = self.sel is not None, None
+        else:
+            flat = torch.cat([torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).reshape(-1)
+                              .to(device=self.dev, dtype=torch.int32) for x in sels])
+            assert flat.numel() == self.off[self.L + 1] - self.off[1], "sel must cover every sample of the frontier"
+            changed = self.sel is None
+            if changed:
+                self.sel = flat.clone()
+            else:
+                self.sel.copy_(flat)
+        if changed and self.g_main is not None:
+            torch.cuda.synchronize()
+            self._record_main()
+
+    def load_epoch(self, ids_epoch, targets_epoch, sel_epoch=None):
         """Device-resident batch queue: ids_epoch int64 [n_batches, B], targets_epoch int64
         [n_batches, B(,1)] on the GPU.  Afterwards `step_queue()` runs one train_step on the next batch
         of the queue (wrapping around) with no host->device or device->device copies at all.
@@ -716,6 +758,10 @@ class FusedMeanTrainStep(object):
         tq = targets_epoch.reshape(n_batches, self.B).contiguous()
         assert tq.dtype == torch.int64
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
+        self.sel_queue = None
+        if sel_epoch is not None:               # [n_batches, samples per frontier] recorded draws (see set_sel)
+            self.sel_queue = sel_epoch.to(device=self.dev, dtype=torch.int32).reshape(n_batches, -1).contiguous()
+            assert self.sel_queue.shape[1] == self.off[self.L + 1] - self.off[1]
         self.batch_idx.zero_()
         # From here on the step is software-pipelined (see step_queue): two frontier buffers, batch
         # i+2 is sampled while batch i+1 is gathered and batch i is updated.
@@ -744,7 +790,7 @@ class FusedMeanTrainStep(object):
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
         gathers (0: none)."""
-        if not getattr(self, "fused_tail", False) or self.L != 2 or self.fan[2] != 10:
+        if not getattr(self, "fused_tail", False) or self.L != 2 or self.fan[2] != 10 or self.code != nat.BF16:
             return 0
         n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
         n_idle = n_cu - (self.B + 3) // 4                 # one seed-level workgroup per CU
@@ -941,7 +987,7 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             return False
         if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
             return False
-        if feats.dtype != torch.bfloat16 or not feats.is_cuda or feats.ld % 64 != 0:
+        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda or feats.ld % 64 != 0:
             return False
         if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
             return False
@@ -952,7 +998,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
     # ---- construction ------------------------------------------------------------------------------
     def _init_levels(self, example_ids, example_targets):
         feats, dev, L = self.store, self.dev, self.L
-        bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+        bf, f32, i32 = self.tdt, torch.float32, torch.int32
+        is_bf = self.code == nat.BF16
         self.pool_mode = nat.POOL_MAX if type(self.layers[0]) is MaxPoolAggregator else nat.POOL_MEAN
         self.h = [l.output_dim_ for l in self.layers]
         self.Hm = [int(l.mlp[0].weight.shape[0]) for l in self.layers]
@@ -968,10 +1015,11 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             wt = torch.zeros(c, _r64(r), dtype=bf, device=dev) if need_t else None
             # forward operands of K3 / K5 also in MFMA fragment order (gsage_*_packed)
             wp = (torch.zeros(nat.lib().gsage_packed_weight_elems(r, c, 1), dtype=bf, device=dev)
-                  if packed else None)
+                  if packed and is_bf else None)
             descs.append(_PrepDesc(prm.data_ptr(), w.data_ptr(), wt.data_ptr() if need_t else None, r, c,
                                    w.shape[1], wt.shape[1] if need_t else 0,
-                                   wp.data_ptr() if packed else None, 4 * (-(-c // 64))))
+                                   wp.data_ptr() if wp is not None else None, 4 * (-(-c // 64)),
+                                   int(not is_bf), 0))
             return (w, wt, wp) if packed else (w, wt)
         self.wm, self.wx, self.wn, self.wmT, self.wxT, self.wnT = [], [], [], [], [], []
         self.wm_p, self.wx_p, self.wn_p = [], [], []
@@ -998,7 +1046,9 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
             last = l == L - 1
             self.pooled.append(torch.zeros(R, Hm, dtype=f32, device=dev))
-            self.pooled_b.append(torch.zeros(R, _r64(Hm), dtype=bf, device=dev))
+            # operand copy of `pooled` for the fc_neib projection and its weight gradient (parity mode:
+            # the fp32 result itself)
+            self.pooled_b.append(torch.zeros(R, _r64(Hm), dtype=bf, device=dev) if is_bf else self.pooled[l])
             # what the backward needs of the hidden layer: the winning row (max) / the ReLU sign bits (mean)
             self.argmax.append(torch.zeros(R, Hm, dtype=i32, device=dev) if self.pool_mode == nat.POOL_MAX
                                else torch.zeros(NR, Hm // 32, dtype=i32, device=dev))
@@ -1057,7 +1107,7 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             ops._linear_packed_launch(A, lda, None, 0, Wp.data_ptr(), None, C, ldc, M, N, K, act, 1, 0, 0, c_code)
             return
         ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
-                           nat.BF16, c_code)
+                           self.code, c_code)
 
     def _stage_compute(self, s):
         L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
@@ -1068,21 +1118,22 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
                 is_max = self.pool_mode == nat.POOL_MAX
+                is_bf = self.code == nat.BF16
                 tail = (self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
-                        self.pooled_b[l][r0:r1].data_ptr(), self.pooled_b[l].shape[1],
+                        self.pooled_b[l][r0:r1].data_ptr() if is_bf else None, self.pooled_b[l].shape[1],
                         None if is_max else self.argmax[l][a0:].data_ptr(), stream)
-                if ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
+                if self.wm_p[l] is not None and ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
                     nat.check(lib.gsage_pool_mlp_packed(
                         nb[a0:].data_ptr(), ldnb, None, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
                         self.size[k], self.fan[k + 1], Hm, din, self.pool_mode, *tail), "pool_mlp_packed")
                 else:
                     nat.check(lib.gsage_pool_mlp(
-                        nb[a0:].data_ptr(), nat.BF16, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
+                        nb[a0:].data_ptr(), self.code, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
                         layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
                         *tail), "pool_mlp")
             x, ldx = self._x_operand(l, s)
             last = l == L - 1
-            out, code = self.hout[l], (nat.F32 if last else nat.BF16)
+            out, code = self.hout[l], (nat.F32 if last else self.code)
             act = nat.ACT_NONE if last else nat.ACT_RELU
             self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act, self.wx_p[l])
             self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
@@ -1091,7 +1142,7 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
         nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), 2 * self.h[L - 1], m.fc.weight.data_ptr(),
                                     m.fc.bias.data_ptr(), tg.data_ptr(), B, C, D2, self.preds.data_ptr(),
-                                    self.dc[L - 1].data_ptr(), nat.BF16, 2 * self.h[L - 1], None, None, None,
+                                    self.dc[L - 1].data_ptr(), self.code, 2 * self.h[L - 1], None, None, None,
                                     self.head_scratch.data_ptr(),
                                     self.batch_idx.data_ptr() if self.queue else None,
                                     self.queue[2] if self.queue else 0, stream), "head_ce")
@@ -1103,22 +1154,22 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
             dc = self.dc[l]
             # d pooled = dC[:, h:] Wn
-            self._gemm(dc.data_ptr() + h * 2, 2 * h, self.wnT[l], self.dpool[l].data_ptr(), nat.F32, Hm, R, Hm, h,
-                       nat.ACT_NONE)
+            self._gemm(dc.data_ptr() + h * self.esz, 2 * h, self.wnT[l], self.dpool[l].data_ptr(), nat.F32, Hm, R, Hm,
+                       h, nat.ACT_NONE)
             for k in range(L - l):
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
                 if self.pool_mode == nat.POOL_MEAN:
                     nat.check(lib.gsage_pool_route_mean_bwd(self.dpool[l][r0:r1].data_ptr(), Hm,
                                                             self.argmax[l][a0:].data_ptr(), self.size[k],
-                                                            self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), Hm,
-                                                            self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
+                                                            self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), self.code,
+                                                            Hm, self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
                                                             stream), "pool_route_mean_bwd")
                     continue
                 nat.check(lib.gsage_pool_route_bwd(self.dpool[l][r0:r1].data_ptr(), Hm, self.pooled[l][r0:r1].data_ptr(),
                                                    Hm, self.argmax[l][r0:r1].data_ptr(), Hm, self.size[k],
-                                                   self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), Hm, stream),
-                          "pool_route_bwd")
+                                                   self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), self.code, Hm,
+                                                   stream), "pool_route_bwd")
                 nat.check(lib.gsage_pool_bias_partials(self.dpool[l][r0:r1].data_ptr(), Hm,
                                                        self.pooled[l][r0:r1].data_ptr(), Hm, self.size[k], Hm,
                                                        self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
@@ -1130,7 +1181,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                 self._gemm(self.ghc[l].data_ptr(), Hm, self.wmT[l], self.dnb[l].data_ptr(), nat.F32, din, NR, din,
                            Hm, nat.ACT_NONE)
                 below = self.hout[l - 1]
-                nat.check(lib.gsage_pool_merge_bwd(below.data_ptr(), below.stride(0), self.dxb[l].data_ptr(), din, R,
+                nat.check(lib.gsage_pool_merge_bwd(below.data_ptr(), self.code, below.stride(0), self.dxb[l].data_ptr(),
+                                                   din, R,
                                                    self.dnb[l].data_ptr(), din, self.off[1],
                                                    self.dc[l - 1].data_ptr(), self.dc[l - 1].stride(0),
                                                    self.rows[l - 1], din, stream), "pool_merge_bwd")

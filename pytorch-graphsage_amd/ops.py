@@ -317,7 +317,7 @@ def _prep_weight(W, cdt, epc):
 
 def gather_mean_multi(segments, ld, D, out_ld, adam=None, hops=None):
     """All hops of a level in one K2 launch.  segments: list of (table, ids|None, out, M, n) with
-    bf16 row-major tensors sharing ld / out_ld.  adam: optional _native.AdamDesc -- the clip + Adam
+    bf16 (or, parity mode, fp32) row-major tensors sharing ld / out_ld.  adam: optional _native.AdamDesc -- the clip + Adam
     update of the previous batch rides in the same launch; hops: optional _native.HopsDesc -- so does
     the frontier sampling of a later batch (gsage_gather_mean_multi_adam)."""
     k = len(segments)
@@ -326,13 +326,15 @@ def gather_mean_multi(segments, ld, D, out_ld, adam=None, hops=None):
     O = (ctypes.c_void_p * k)(*[s[2].data_ptr() for s in segments])
     Ms = (ctypes.c_int64 * k)(*[int(s[3]) for s in segments])
     ns = (ctypes.c_int32 * k)(*[int(s[4]) for s in segments])
+    code = _code(segments[0][0].dtype)
+    assert all(s[0].dtype == s[2].dtype == segments[0][0].dtype for s in segments)
     if adam is not None or hops is not None:
         nat.check(nat.lib().gsage_gather_mean_multi_adam(
-            k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16, out_ld,
+            k, T, I, O, Ms, ns, code, ld, D, code, out_ld,
             ctypes.addressof(adam) if adam is not None else None,
             ctypes.addressof(hops) if hops is not None else None, _stream()), "gather_mean_multi_adam")
         return
-    nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, nat.BF16, ld, D, nat.BF16, out_ld,
+    nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, code, ld, D, code, out_ld,
                                                 _stream()), "gather_mean_multi")
 
 
@@ -361,7 +363,7 @@ def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None, slabs=None, 
         slabs = torch.empty(S, Ntot, ldk, dtype=torch.float32, device=dC.device)
     if reduce and out is None:
         out = torch.empty(groups, n_per_group, K, dtype=torch.float32, device=dC.device)
-    nat.check(nat.lib().gsage_wgrad(_ptr(dC), dC.stride(0), _ptr(A), lda, a_gstride, M, Ntot, K,
+    nat.check(nat.lib().gsage_wgrad(_ptr(dC), _code(dC.dtype), dC.stride(0), _ptr(A), lda, a_gstride, M, Ntot, K,
                                     n_per_group, rps, _ptr(slabs), ldk, _ptr(out) if reduce else None,
                                     n_per_group * K, _stream()), "wgrad")
     return out if reduce else slabs
@@ -379,7 +381,9 @@ def wgrad_multi(problems):
         d.dC, d.A, d.slabs = _ptr(dC), _ptr(A), _ptr(slabs)
         d.ldc, d.lda, d.a_gstride = dC.stride(0), lda, a_gs
         d.M, d.Ntot, d.K, d.n_per_group, d.ldk, d.rows_per_split = M, Ntot, K, npg, ldk, rps
-    nat.check(nat.lib().gsage_wgrad_multi(len(problems), ctypes.cast(descs, ctypes.c_void_p), _stream()),
+    code = _code(problems[0][0].dtype)
+    assert all(prob[0].dtype == prob[1].dtype == problems[0][0].dtype for prob in problems)
+    nat.check(nat.lib().gsage_wgrad_multi(len(problems), ctypes.cast(descs, ctypes.c_void_p), code, _stream()),
               "wgrad_multi")
 
 
@@ -597,7 +601,7 @@ class _PoolMLP(torch.autograd.Function):
             g = g.contiguous()
             ghc = torch.empty(M * n, H, dtype=torch.bfloat16, device=g.device)
             nat.check(nat.lib().gsage_pool_route_bwd(_ptr(g), H, _ptr(pooled), H, _ptr(argmax), H, M, n, H,
-                                                     _ptr(ghc), H, _stream()), "pool_route_bwd")
+                                                     _ptr(ghc), nat.BF16, H, _stream()), "pool_route_bwd")
             if ctx.needs_input_grad[2]:
                 db = (g * (pooled > 0)).sum(dim=0)
             if ctx.needs_input_grad[1]:

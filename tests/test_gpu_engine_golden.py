@@ -1,0 +1,208 @@
+"""-m gpu: the reference-generated golden fixtures replayed through the FUSED engines -- the path
+bench.py times (engine.FusedMeanTrainStep / FusedPoolTrainStep), not the module-level path.
+
+Two instantiations of the same engine and kernel sources:
+  * fp32 storage ("parity mode"): every kernel of the step runs on fp32 operands (the seed-level
+    kernel, the multi-segment gather and K5 are the same templates instantiated on float; K5b has an
+    fp32 twin with the same slab layout), the sampler replays the `sel` the reference drew
+    (gsage_hops_desc.sel).  Predictions, pre-clip gradient norm, clipped gradients and the weights
+    after two Adam steps are compared with tests/golden/engine_kat.npz -- outputs of the reference's
+    own train_step (models.py:97-104) -- at fp32 tolerance.
+  * bf16 storage (production): compared with the oracle restated with the engines' bf16 rounding
+    points (oracle/torch_ref.py rounding="bf16"), same `sel`: bounds of a few 1e-3 instead of the few
+    1e-2 an fp32 oracle allows for a bf16 path.
+Each check fails if Adam, the clip, or one gradient term is skipped (see test_*_detects_*)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+from util import build_model, close, close_fro, close_rel, weights
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+DEV = "cuda"
+N_CASES = 6
+_LOG = os.environ.get("GSAGE_PARITY_LOG")
+
+
+def _note(key, **vals):
+    if _LOG:
+        with open(_LOG, "a") as f:
+            f.write(json.dumps(dict(key=key, **{k: float(v) for k, v in vals.items()})) + "\n")
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    yield
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    ops.set_compute_dtype("bf16")
+
+
+def _case(g, c, dtype):
+    p = "e%d_" % c
+    model, store, task = build_model(gs, g, p, device=DEV, feats_dtype=dtype)
+    fan = [int(v) for v in g[p + "fanouts"]]
+    ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+    tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+    sels = [[g[p + "s%d_sel%d" % (st, h)] for h in range(len(fan))] for st in range(2)]
+    return p, model, store, fan, ids, tg, sels
+
+
+def _engine(model, store, ids, tg, capture):
+    cls = gs.engine.fused_engine_for(model, store)
+    assert cls is not None, "fixture case not covered by a fused engine"
+    return cls(model, store, gs.ProblemLosses.classification, ids, tg, capture=capture)
+
+
+@pytest.mark.parametrize("capture", [False, "cmdlist"])
+@pytest.mark.parametrize("c", range(N_CASES))
+def test_fp32_engine_replays_reference_train_steps(c, capture):
+    g = load_golden("engine_kat.npz")
+    p, model, store, fan, ids, tg, sels = _case(g, c, "fp32")
+    w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    eng = _engine(model, store, ids, tg, capture)
+    before = gs._native.launch_count()
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        assert abs(float(eng.lr.item()) - float(g[p + "lr%d" % step])) < 1e-9
+        eng.set_sel(sels[step])
+        preds = eng(ids, tg).detach().cpu().numpy()
+        close(preds, g[p + "s%d_preds" % step], (c, step, "preds"), 2e-4, 2e-5)
+        gn, gn_ref = float(eng.gnorm.item()), float(g[p + "s%d_gradnorm" % step])
+        assert abs(gn - gn_ref) <= 2e-4 * max(1.0, gn_ref), (c, step, "gradnorm", gn, gn_ref)
+        _note("fp32/%d/%s/%d" % (c, capture, step), preds=np.abs(preds - g[p + "s%d_preds" % step]).max(),
+              gnorm=abs(gn - gn_ref))
+        if step == 0:
+            for k, v in model.named_parameters():          # p.grad holds the CLIPPED gradient, like the reference
+                close_rel(v.grad.cpu().numpy(), g[p + "s0_cg_" + k], (c, "clipped grad", k), 2e-4)
+    assert gs._native.launch_count() > before
+    err = 0.0
+    for k, v in model.state_dict().items():
+        ref = g[p + "w2_" + k]
+        e = float(np.abs(v.detach().cpu().numpy() - ref).max())
+        err = max(err, e)
+        # 2e-4 of the tensor's scale, and never more than 1 % of one Adam step (lr = 0.01)
+        assert e <= min(2e-4 * max(1.0, float(np.abs(ref).max())), 1e-4), (c, "weights after 2 steps", k, e)
+        # the update itself (not the weights, which barely move in two steps) must match
+        d_ref = ref - w0[k].cpu().numpy()
+        d_eng = v.detach().cpu().numpy() - w0[k].cpu().numpy()
+        close_fro(d_eng, d_ref, (c, "weight update", k), 5e-3)
+    _note("fp32/%d/%s/w2" % (c, capture), werr=err)
+    model.train_sampler.csr(DEV).check()
+
+
+@pytest.mark.parametrize("c", [0, 1, 3, 4])
+def test_fp32_engine_queue_mode_replays_reference(c):
+    """The software-pipelined queue order bench.py uses (batch i+2 sampled and batch i+1 gathered inside
+    the launch that applies Adam(i)) with the recorded draws as a device-resident sel queue."""
+    g = load_golden("engine_kat.npz")
+    p, model, store, fan, ids, tg, sels = _case(g, c, "fp32")
+    eng = _engine(model, store, ids, tg, "cmdlist")
+    sel_q = torch.stack([torch.cat([torch.from_numpy(np.asarray(x)).reshape(-1) for x in sels[st]]) for st in range(2)])
+    eng.load_epoch(torch.stack([ids, ids]), torch.stack([tg, tg]), sel_epoch=sel_q)
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        preds = eng.step_queue().detach().cpu().numpy()
+        close(preds, g[p + "s%d_preds" % step], (c, step, "preds"), 2e-4, 2e-5)
+    torch.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        ref = g[p + "w2_" + k]
+        e = float(np.abs(v.detach().cpu().numpy() - ref).max())
+        assert e <= min(2e-4 * max(1.0, float(np.abs(ref).max())), 1e-4), (c, "weights after 2 queue steps", k, e)
+
+
+def _oracle_bf16(g, p, store, fan, ids, tg, sels, steps=2):
+    from oracle import torch_ref as tref
+    aggn = str(g[p + "cfg"][0])
+    w = weights(g, p + "w0_")
+    opt = tref.Adam(weight_decay=float(g[p + "weight_decay"]))
+    fb = store.dense().cpu()                         # the bf16-rounded table, as fp32
+    out = []
+    for st in range(steps):
+        r = tref.train_step(w, opt, float(g[p + "lr%d" % st]), "classification", ids.cpu().numpy(), fb, tg.cpu(),
+                            g[p + "tadj_indptr"], g[p + "tadj_data"], fan,
+                            [np.asarray(x).astype(np.int64) for x in sels[st]], aggn, "identity",
+                            int(g[p + "adj_shape"][0]), rounding="bf16")
+        out.append(r)
+    return out, w
+
+
+@pytest.mark.parametrize("mode", ["call", "queue"])
+@pytest.mark.parametrize("c", range(N_CASES))
+def test_bf16_engine_against_rounding_aware_oracle(c, mode):
+    """The PRODUCTION instantiation (bf16 storage, packed-weight K5, MFMA K5b, seed-level kernel) with
+    the reference's recorded draws, against the oracle with the engines' bf16 rounding points."""
+    g = load_golden("engine_kat.npz")
+    p, model, store, fan, ids, tg, sels = _case(g, c, "bf16")
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref, w_ref = _oracle_bf16(g, p, store, fan, ids, tg, sels)
+    eng = _engine(model, store, ids, tg, "cmdlist")
+    if mode == "queue":
+        sel_q = torch.stack([torch.cat([torch.from_numpy(np.asarray(x)).reshape(-1) for x in sels[st]])
+                             for st in range(2)])
+        eng.load_epoch(torch.stack([ids, ids]), torch.stack([tg, tg]), sel_epoch=sel_q)
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        if mode == "queue":
+            preds = eng.step_queue().detach().cpu().numpy()
+        else:
+            eng.set_sel(sels[step])
+            preds = eng(ids, tg).detach().cpu().numpy()
+        torch.cuda.synchronize()
+        r = ref[step]
+        perr = float(np.abs(preds - r["preds"].numpy()).max())
+        close(preds, r["preds"].numpy(), (c, step, "preds vs bf16-aware oracle"), 3e-3, 3e-3)
+        # and against the reference's own fp32 outputs at the looser bound bf16 storage allows
+        close(preds, g[p + "s%d_preds" % step], (c, step, "preds vs reference"), 3e-2, 3e-2)
+        gn = float(eng.gnorm.item())
+        assert abs(gn - r["gradnorm"]) <= 5e-3 * max(1.0, r["gradnorm"]), (c, step, gn, r["gradnorm"])
+        gerr = 0.0
+        if step == 0 or mode == "call":
+            for k, v in model.named_parameters():
+                a, b = v.grad.cpu().numpy(), r["clipped"][k].numpy()
+                e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
+                gerr = max(gerr, e)
+                close_fro(a, b, (c, step, "clipped grad", k), 1e-2)
+        _note("bf16/%d/%s/%d" % (c, mode, step), preds=perr, gnorm=abs(gn - r["gradnorm"]), grad_fro=gerr)
+    # two Adam steps: compare the UPDATE (weights minus initial weights), which a skipped / wrong
+    # optimizer step or a sign error in any gradient term changes by O(1)
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        d_eng = v.detach().cpu().numpy() - w0[k].numpy()
+        d_ref = w_ref[k].numpy() - w0[k].numpy()
+        e = float(np.linalg.norm(d_eng - d_ref) / max(np.linalg.norm(d_ref), 1e-12))
+        worst = max(worst, e)
+        close_fro(d_eng, d_ref, (c, "weight update", k), 5e-2)
+    _note("bf16/%d/%s/w2" % (c, mode), upd_fro=worst)
+
+
+def test_checks_detect_a_skipped_update_and_a_dropped_gradient_term():
+    """The tolerances above are not vacuous: (a) weights that miss the second Adam step, (b) an update
+    computed without the neighbour half of the level-0 gradient both fail the same comparisons."""
+    g = load_golden("engine_kat.npz")
+    p, model, store, fan, ids, tg, sels = _case(g, 1, "fp32")
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    eng = _engine(model, store, ids, tg, False)
+    eng.set_progress(0.0)
+    eng.set_sel(sels[0])
+    eng(ids, tg)
+    torch.cuda.synchronize()
+    # (a) one step instead of two
+    k = "agg_layers.0.fc_x.weight"
+    d_ref = g[p + "w2_" + k] - w0[k].numpy()
+    d_one = model.state_dict()[k].detach().cpu().numpy() - w0[k].numpy()
+    with pytest.raises(AssertionError):
+        close_fro(d_one, d_ref, "one step is not two", 5e-3)
+    # (b) the clipped gradient with one term zeroed
+    kk = "agg_layers.0.fc_neib.weight"
+    bad = dict(model.named_parameters())[kk].grad.cpu().numpy() * 0.0
+    with pytest.raises(AssertionError):
+        close_rel(bad, g[p + "s0_cg_" + kk], "dropped term", 2e-4)

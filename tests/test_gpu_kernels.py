@@ -611,7 +611,7 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
     nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
                                    Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
                                    agg.data_ptr(), dE.data_ptr(), preds.data_ptr(), dH.data_ptr(),
-                                   part.data_ptr(), None, None), "mean_tail_ce")
+                                   part.data_ptr(), None, nat.BF16, None), "mean_tail_ce")
     torch.cuda.synchronize()
     if B == 512:
         # the same launch carrying a gather role on the CUs it leaves idle: every output of the seed
@@ -631,7 +631,7 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
         outs = [torch.zeros_like(t) for t in (agg, dE, preds, dH, part)]
         nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
                                        Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
-                                       *[t.data_ptr() for t in outs], ctypes.addressof(d), None), "mean_tail_ce")
+                                       *[t.data_ptr() for t in outs], ctypes.addressof(d), nat.BF16, None), "mean_tail_ce")
         torch.cuda.synchronize()
         for a, b_ in zip((agg, dE, preds, dH, part), outs):
             assert torch.equal(a, b_)

@@ -24,6 +24,17 @@ def close(a, b, what, rtol=1e-5, atol=2e-6):
     assert err <= (atol + rtol) * scale, (what, "max abs err %g at scale %g" % (err, scale))
 
 
+def close_rel(a, b, what, tol):
+    """max |a - b| <= tol * max |b|: element-wise, relative to the tensor's own scale (not to 1.0, so
+    it stays meaningful for gradients and updates of magnitude 1e-2)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(np.abs(b).max())
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale + 1e-12, (what, "max abs err %g vs scale %g" % (err, scale))
+
+
 def close_fro(a, b, what, tol):
     """Norm-wise check for low-precision gradients: a bf16 forward can flip the ReLU mask of a
     pre-activation that is ~0, which moves single gradient entries by O(1) -- bounded in
@@ -61,7 +72,7 @@ ACTS = {"relu": F.relu, "identity": (lambda x: x)}
 def build_model(gs, g, p, device="cpu", feats_dtype=None):
     """GSSupervised for golden model case `p` with the recorded initial weights."""
     aggn, prepn, task, sched = [str(s) for s in g[p + "cfg"]]
-    has_feats = bool(int(g[p + "has_feats"]))
+    has_feats = bool(int(g[p + "has_feats"])) if (p + "has_feats") in g.files else True
     fan = [int(v) for v in g[p + "fanouts"]]
     odims = [int(v) for v in g[p + "out_dims"]]
     adj, tadj = csr_of(g, p + "adj_"), csr_of(g, p + "tadj_")
@@ -77,10 +88,8 @@ def build_model(gs, g, p, device="cpu", feats_dtype=None):
         prep_class=gs.prep_lookup[prepn], aggregator_class=gs.aggregator_lookup[aggn],
         input_dim=g[p + "feats"].shape[1] if has_feats else None, n_nodes=adj.shape[0],
         n_classes=int(g[p + "n_classes"]),
-        layer_specs=[{"n_train_samples": fan[0], "n_val_samples": fan[0], "output_dim": odims[0],
-                      "activation": F.relu},
-                     {"n_train_samples": fan[1], "n_val_samples": fan[1], "output_dim": odims[1],
-                      "activation": lambda x: x}],
+        layer_specs=[{"n_train_samples": fan[l], "n_val_samples": fan[l], "output_dim": odims[l],
+                      "activation": F.relu if l < len(fan) - 1 else (lambda x: x)} for l in range(len(fan))],
         lr_init=0.01, lr_schedule=sched, weight_decay=float(g[p + "weight_decay"]))
     model.load_state_dict(weights(g, p + "w0_"))
     model = model.to(device)

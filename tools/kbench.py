@@ -37,7 +37,7 @@ if 'wgrad' in which:
         S = (R0 + rps - 1) // rps
         slabs = torch.empty(S, 2 * h, 604, device=dev)
         def f():
-            nat.check(L.gsage_wgrad(dC.data_ptr(), 2 * h, XA.data_ptr(), ld, R0 * ld, R0, 2 * h, D, h, rps,
+            nat.check(L.gsage_wgrad(dC.data_ptr(), nat.BF16, 2 * h, XA.data_ptr(), ld, R0 * ld, R0, 2 * h, D, h, rps,
                                     slabs.data_ptr(), 604, None, h * D, ops._stream()))
         print('wgrad L0 rps=%d S=%d (%d workgroups): %.1f us' % (rps, S, S * 10, timeit(f)))
 
@@ -110,7 +110,7 @@ if 'tail' in which:
       def f():
           nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128, Wfc.data_ptr(),
                                          bfc.data_ptr(), C, tg.data_ptr(), None, 0, agg.data_ptr(), dE.data_ptr(),
-                                         preds.data_ptr(), dH.data_ptr(), part.data_ptr(), None, ops._stream()))
+                                         preds.data_ptr(), dH.data_ptr(), part.data_ptr(), None, nat.BF16, ops._stream()))
       print('tail (B=%d n=%d): %.1f us' % (B, n, timeit(f)))
 
 if 'gmulti' in which:
