@@ -13,17 +13,31 @@ lognormal degrees clipped to [1, 21 657], D=602 bf16 features, 41 classes; graph
 resident in HBM before the timed region.  Timing: W untimed steps, then exactly K steps between
 barrier + torch.cuda.synchronize() on both sides, max over ranks; rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself
+(re-executes under torch.distributed.run on 127.0.0.1) and prints the one line of rank 0.
+
+The timed region is repeated (R times exactly K steps, each between barrier + synchronize) until it
+has run for >= 0.5 s; `value` comes from the MEDIAN repeat (K = 20 steps is ~2 ms: one repeat is
+noise), min / max are in config.timing.
+
 Extra objects on the line (tier contract, section 4 of the task):
-  roofline     the dominant kernel = the hop-2 k_gather_mean launch (250 of the 276 rows/seed):
-               algorithmic bytes = B*f1*f2*D*2 per launch / its mean duration, HIP events on the
-               launch stream, fresh frontier per launch; peak = 8 TB/s HBM3E.
-  cpu_baseline the oracle (oracle/torch_ref.py + oracle/gsage_oracle.c: a port of the reference's
-               CPU op sequence) timed on this host's cores on a bounded sample of the same workload.
+  roofline     the step's dominant launch, timed IN PLACE: the command list of the queue-mode step is
+               re-recorded with HIP-event marks around k_gather_multi_adam (the launch that gathers
+               the next batch's level-0 rows, with Adam and the sampler riding along) and around the
+               seed-level launch that carries the rest of those gathers; achieved = the frontier rows
+               that launch reads x D x 2 B / its mean duration over real steps (fresh frontier every
+               step, events on the stream the step runs on); peak = 8 TB/s HBM3E.  `step` adds the
+               whole-step figure (all 276 rows/seed / ms_per_step).
+  cpu_baseline the OpenMP C restatement of train_step (oracle/gsage_train_omp.c) on all host cores,
+               bounded sample; `torch_port` = the plain-torch port of the reference's op sequence
+               (oracle/torch_ref.py) at a fixed thread count.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -97,14 +111,17 @@ def rows_per_seed(fanout):
     return n
 
 
-def cpu_baseline(data, budget_s=15.0, batch=BATCH):
-    """Oracle train_step (port of the reference CPU path) on the host cores, bounded sample."""
+def cpu_baseline(data, budget_s=12.0, batch=BATCH):
+    """train_step on the host cores, bounded sample of the bench workload (same graph, features,
+    shapes, fp32).  Primary figure: the OpenMP C restatement (oracle/gsage_train_omp.c, all cores --
+    SURVEY 8(d)(i)); second figure: the plain-torch port of the reference's op sequence
+    (oracle/torch_ref.py) at a FIXED thread count (min(32, cores): more oversubscribes its gathers)."""
     from oracle import cpu as ocpu
     from oracle import torch_ref as tref
     ncpu = os.cpu_count() or 1
     adj = data["adj"]
     indptr, dat = adj.indptr.astype(np.int64), adj.data.astype(np.int64)
-    feats = torch.from_numpy(data["feats_np"]())
+    feats_np = data["feats_np"]()
     gen = torch.Generator().manual_seed(0)
     D, h = FEAT_DIM, HIDDEN[0]
     w = {"agg_layers.0.fc_x.weight": torch.randn(h, D, generator=gen) / 25,
@@ -113,79 +130,130 @@ def cpu_baseline(data, budget_s=15.0, batch=BATCH):
          "agg_layers.1.fc_neib.weight": torch.randn(h, 2 * h, generator=gen) / 16,
          "fc.weight": torch.randn(N_CLASSES, 2 * h, generator=gen) / 16,
          "fc.bias": torch.zeros(N_CLASSES)}
-    opt = tref.Adam()
     rng = np.random.RandomState(0)
     stream = ocpu.LegacyMT19937(123 ** 2)
 
-    def one_step():
+    def batch_inputs():
         ids = data["train_ids"][rng.randint(0, len(data["train_ids"]), size=batch)]
-        tg = torch.from_numpy(data["targets"][ids])
         sels = [stream.choice(adj.shape[1], (batch, FANOUT[0])),
                 stream.choice(adj.shape[1], (batch * FANOUT[0], FANOUT[1]))]
-        tref.train_step(w, opt, 0.01, "classification", ids, feats, tg, indptr, dat, FANOUT, sels,
-                        "mean", "identity", adj.shape[0])
+        return ids, data["targets"][ids], sels
 
-    # torch's default (one thread per hardware thread) oversubscribes this gather-heavy step on
-    # big hosts; give the CPU its best thread count from a short probe, then time with it.
-    one_step()                                       # page faults, lazy init
-    best, cores = None, 1
-    for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
-        torch.set_num_threads(th)
-        one_step()
-        t = time.time()
-        one_step()
-        dt1 = time.time() - t
-        if best is None or dt1 < best:
-            best, cores = dt1, th
-    torch.set_num_threads(cores)
-    done, t0 = 0, time.time()
-    while True:
-        one_step()
-        done += 1
-        if done >= 3 and time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return {"value": done * batch / dt, "unit": "seed-nodes/sec", "cores": cores, "kind": "port",
-            "sample": "%d train_steps of %d seeds (oracle/torch_ref.py fp32 + C sampler, "
-                      "torch %d of %d host threads, %.1f s)" % (done, batch, cores, ncpu, dt)}
+    def timed(step, budget):
+        step()                                       # page faults, lazy init
+        done, t0 = 0, time.time()
+        while True:
+            step()
+            done += 1
+            if done >= 3 and time.time() - t0 > budget:
+                break
+        return done, time.time() - t0
+
+    trainer = ocpu.MeanTrainerOMP({k: v.numpy() for k, v in w.items()}, FANOUT)
+    omp_threads = ocpu.omp_threads()
+
+    def omp_step():
+        ids, tg, sels = batch_inputs()
+        trainer.step(0.01, ids, feats_np, tg, indptr, dat, sels)
+    n_omp, dt_omp = timed(omp_step, budget_s * 0.6)
+
+    feats = torch.from_numpy(feats_np)
+    opt = tref.Adam()
+    threads = min(32, ncpu)
+    torch.set_num_threads(threads)
+
+    def torch_step():
+        ids, tg, sels = batch_inputs()
+        tref.train_step(w, opt, 0.01, "classification", ids, feats, torch.from_numpy(tg), indptr, dat, FANOUT,
+                        sels, "mean", "identity", adj.shape[0])
+    n_t, dt_t = timed(torch_step, budget_s * 0.4)
+    return {"value": n_omp * batch / dt_omp, "unit": "seed-nodes/sec", "cores": omp_threads, "kind": "port",
+            "sample": "%d train_steps of %d seeds, fp32, OpenMP C restatement (oracle/gsage_train_omp.c) on %d "
+                      "threads of %d host threads, %.1f s" % (n_omp, batch, omp_threads, ncpu, dt_omp),
+            "torch_port": {"value": n_t * batch / dt_t, "cores": threads,
+                           "sample": "%d train_steps, oracle/torch_ref.py fp32 + C sampler, torch %d threads "
+                                     "(fixed), %.1f s" % (n_t, threads, dt_t)}}
 
 
-def dominant_kernel_roofline(gs, model, store, data, dev, reps=40, n_frontiers=8):
-    """Mean duration of the hop-2 k_gather_mean launch on fresh frontiers, HIP events on the launch
-    stream (torch's current stream is the stream ops.py launches on)."""
+def dominant_kernel_roofline(eng, store, n_steps=64):
+    """Roofline object of the step's dominant launch, measured in place.
+
+    The queue-mode command lists are re-recorded with HIP-event marks (gsage_cmdlist_mark) around
+    k_gather_multi_adam -- the launch that gathers the next batch's level-0 rows (Adam of the current
+    batch and the sampler of the batch after ride along) -- and around the seed-level launch whose
+    spare workgroups gather the first part of the last hop.  n_steps real steps follow (every step a
+    fresh frontier, the events are recorded on the stream the step runs on, one host sync per step to
+    read them).  achieved = algorithmic bytes of the rows the launch reads (rows x D x sizeof) / mean
+    duration.  `traffic`: HBM bytes per launch of the same kernel from the rocprofv3 PMC passes
+    committed under profiles/ (FETCH_SIZE / WRITE_SIZE, guide's gfx950 corrections) when the workload is
+    the default one, else null."""
+    eng.instrument(True)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        eng.step_queue()
+    torch.cuda.synchronize()
+    g_ms, t_ms = [], []
+    for _ in range(n_steps):
+        eng.step_queue()
+        d = eng.last_launch_ms()
+        g_ms.append(d["gather"])
+        t_ms.append(d.get("seed_level", 0.0))
+    eng.instrument(False)
+    torch.cuda.synchronize()
+    elem = store.data.element_size()
+    rows_g, rows_t = eng.gather_launch_rows()
+    g_us, t_us = float(np.mean(g_ms)) * 1e3, float(np.mean(t_ms)) * 1e3
+    alg = rows_g * store.dim * elem
+    achieved = alg / (g_us * 1e-6) / 1e9
+    traffic, twrite, src = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_gather_launch.json")
+    if os.path.exists(pmc) and elem == 2 and (eng.B, tuple(eng.fan[1:]), store.dim) == (BATCH, FANOUT, FEAT_DIM):
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic, twrite, src = rec.get("hbm_read_bytes_per_launch"), rec.get("hbm_write_bytes_per_launch"), \
+            "profiles/r02_pmc_gather_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    out = {"bound": "hbm", "kernel": "k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_write": twrite, "traffic_source": src,
+           "alg_bytes_per_launch": alg, "rows_per_launch": rows_g, "avg_launch_us": g_us,
+           "timed_steps": n_steps, "method": "HIP events recorded in the step's command list around the launch"}
+    if rows_t:
+        out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
+                                    "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * store.dim * elem,
+                                    "avg_launch_us": t_us}
+    return out
+
+
+def standalone_gather_probe(gs, model, store, data, dev, fanout, B, reps=40, n_frontiers=8):
+    """Fallback roofline object when the step is not the queue-mode fused mean engine (data-parallel
+    runs, other engines): the last hop's gather+mean as ONE stand-alone k_gather_mean launch on fresh
+    frontiers, HIP events on the launch stream.  Labelled as a probe: it is not a kernel of the step."""
     ops = gs.ops
     rng = np.random.RandomState(7)
     fronts = []
     for _ in range(n_frontiers):
-        ids0 = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=BATCH)]).to(dev)
-        ids1 = model.train_sampler(ids0, n_samples=FANOUT[0])
-        fronts.append(model.train_sampler(ids1, n_samples=FANOUT[1]))
-    M = BATCH * FANOUT[0]
-    cdt = ops.torch_dtype()
+        ids = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=B)]).to(dev)
+        M = B
+        for f in fanout[:-1]:
+            ids = model.train_sampler(ids, n_samples=f)
+            M *= f
+        fronts.append(model.train_sampler(ids, n_samples=fanout[-1]))
+    cdt = store.data.dtype
     for f in fronts:                                   # warm
-        ops.gather_mean(store, f, M, FANOUT[1], out_dtype=cdt, out_ld=store.ld)
+        ops.gather_mean(store, f, M, fanout[-1], out_dtype=cdt, out_ld=store.ld)
     torch.cuda.synchronize()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for r in range(reps):
-        ops.gather_mean(store, fronts[r % n_frontiers], M, FANOUT[1], out_dtype=cdt, out_ld=store.ld)
+        ops.gather_mean(store, fronts[r % n_frontiers], M, fanout[-1], out_dtype=cdt, out_ld=store.ld)
     stop.record()
     torch.cuda.synchronize()
     dur_s = start.elapsed_time(stop) / 1e3 / reps
-    elem = store.data.element_size()
-    alg_bytes = BATCH * FANOUT[0] * FANOUT[1] * FEAT_DIM * elem
-    achieved = alg_bytes / dur_s / 1e9
-    # HBM bytes per launch of the same kernel from the PMC pass committed under profiles/
-    # (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only valid for the default workload
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
-    if os.path.exists(pmc) and elem == 2:
-        with open(pmc) as f:
-            traffic = json.load(f).get("hbm_read_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "k_gather_mean (hop 2: 250 of 276 rows/seed)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "alg_bytes_per_launch": alg_bytes, "avg_launch_us": dur_s * 1e6}
+    alg = M * fanout[-1] * store.dim * store.data.element_size()
+    achieved = alg / dur_s / 1e9
+    return {"bound": "hbm", "kernel": "k_gather_mean (stand-alone probe of the last hop, NOT a launch of the step)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_us": dur_s * 1e6}
 
 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
@@ -234,6 +302,30 @@ def pool_kernel_roofline(gs, model, store, data, dev, reps=20, n_frontiers=4):
             "traffic": None, "alg_flops_per_launch": flops, "avg_launch_us": dur_s * 1e6}
 
 
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (one process per
+    GPU under torch.distributed.run, rendezvous on 127.0.0.1) with the same arguments; rank 0 prints the
+    line.  With fewer than N GPUs visible the run only makes sense as a test of the data-parallel path:
+    GSAGE_DIST_BACKEND=gloo lets the ranks share the visible GPU (RCCL refuses duplicate devices)."""
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < n and env.get("GSAGE_DIST_BACKEND") != "gloo":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set GSAGE_DIST_BACKEND=gloo to let the "
+                         "ranks share one GPU for a functional test)" % (n, n_dev))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,8 +350,15 @@ def main():
                     help="copy each batch into the engine's static buffers per step instead of walking "
                          "a device-resident batch queue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="repeat the K-step timed region until it has run this many seconds in total")
+    ap.add_argument("--extra", type=str, default="max_pool",
+                    help="comma-separated additional aggregators measured after the main line (N=1 only) "
+                         "and reported under `extra`; '' for none")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import __graft_entry__
     __graft_entry__.ensure_built()
@@ -269,7 +368,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher (bench.py then starts the ranks itself)" % (args.gpus, world, args.gpus))
     ddp = gs.dist.init_from_env(cuda=True)
     rank = ddp.rank if ddp is not None else 0
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -281,81 +382,109 @@ def main():
     fanout = tuple(int(v) for v in args.fanout.split(","))
     hidden = tuple(int(v) for v in args.hidden.split(","))
     assert len(fanout) == len(hidden)
-    model = build_model(gs, data["adj"], aggregator=args.aggregator, rng="philox", fanout=fanout,
-                        hidden=hidden).to(dev)
-    if ddp is not None:
-        gs.dist.attach(model, ddp, seed=123)
-    model.train_sampler.csr(dev)                       # upload the CSR before timing
-    loss_fn = gs.ProblemLosses.classification
     B = args.batch_size
-
-    # seed batches resident in HBM before the timed region; rank r owns rows [r*B, (r+1)*B)
+    loss_fn = gs.ProblemLosses.classification
+    if args.no_graph:
+        args.launch = "eager"
     total = args.steps + args.warmup
     rng = np.random.RandomState(1234)
+    # seed batches resident in HBM before the timed region; rank r owns columns [r*B, (r+1)*B)
     pick = rng.randint(0, len(data["train_ids"]), size=(total, world * B))
     ids_all = torch.from_numpy(data["train_ids"][pick][:, rank * B:(rank + 1) * B]).to(dev)
     tg_all = torch.from_numpy(data["targets"][data["train_ids"][pick]][:, rank * B:(rank + 1) * B]).to(dev)
-
-    if args.no_graph:
-        args.launch = "eager"
-    use_graph = args.launch != "eager"
-    step_fn = None
-    engine = args.engine
-    fused_cls = gs.engine.fused_engine_for(model, store)
-    if engine == "fused" and fused_cls is None:
-        engine = "autograd"
-    if engine == "fused":
-        step_fn = fused_cls(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
-                                               capture=args.launch if use_graph else False,
-                                               pipelined=args.pipeline)
-    elif use_graph:
-        try:
-            step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
-        except Exception as e:                          # report, then measure eager launches
-            if rank == 0:
-                print("graph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
-            use_graph = False
-    if step_fn is None:
-        def step_fn(ids, tg):
-            return model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
-    queued = engine == "fused" and not args.pipeline and not args.per_step_copy
-    if queued:
-        # the whole run's seed batches live in HBM (as the task's timing rule prescribes) and the
-        # graph walks them through a device-side batch index: no per-step copies
-        step_fn.load_epoch(ids_all, tg_all)
-        run_step = lambda k: step_fn.step_queue()
-    else:
-        run_step = lambda k: step_fn(ids_all[k], tg_all[k])
 
     def sync():
         if ddp is not None:
             ddp.barrier()
         torch.cuda.synchronize()
 
-    launches0 = gs._native.launch_count()
-    for k in range(args.warmup):
-        run_step(k)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, total):
-        run_step(k)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if hasattr(step_fn, "flush"):
-        step_fn.flush()          # pipelined engine: the timed region ran exactly K sample/gather
-        torch.cuda.synchronize()  # stages and K compute stages; this drains the last compute stage
-    if ddp is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    model.train_sampler.csr(dev).check()
+    def measure(aggregator, min_time):
+        """Build model + engine for `aggregator`, warm up, time R x exactly K steps.  Returns a dict."""
+        model = build_model(gs, data["adj"], aggregator=aggregator, rng="philox", fanout=fanout,
+                            hidden=hidden).to(dev)
+        if ddp is not None:
+            gs.dist.attach(model, ddp, seed=123)
+        model.train_sampler.csr(dev)                       # upload the CSR before timing
+        use_graph = args.launch != "eager"
+        step_fn, engine = None, args.engine
+        fused_cls = gs.engine.fused_engine_for(model, store)
+        if engine == "fused" and fused_cls is None:
+            engine = "autograd"
+        if engine == "fused":
+            step_fn = fused_cls(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
+                                capture=args.launch if use_graph else False, pipelined=args.pipeline)
+        elif use_graph:
+            try:
+                step_fn = gs.engine.CapturedTrainStep(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp)
+            except Exception as e:                          # report, then measure eager launches
+                if rank == 0:
+                    print("graph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
+                use_graph = False
+        if step_fn is None:
+            def step_fn(ids, tg):
+                return model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+        queued = engine == "fused" and not args.pipeline and not args.per_step_copy
+        if queued:
+            # the whole run's seed batches live in HBM (as the task's timing rule prescribes) and the
+            # step walks them through a device-side batch index: no per-step copies
+            step_fn.load_epoch(ids_all, tg_all)
+            run_step = lambda k: step_fn.step_queue()
+        else:
+            run_step = lambda k: step_fn(ids_all[k % total], tg_all[k % total])
+
+        for k in range(args.warmup):
+            run_step(k)
+        sync()
+        times, launches, k = [], [], args.warmup
+        while True:
+            l0 = gs._native.launch_count()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):                 # EXACTLY K steps per timed repeat
+                run_step(k)
+                k += 1
+            sync()
+            dt = time.perf_counter() - t0
+            if hasattr(step_fn, "flush") and args.pipeline:
+                step_fn.flush()      # pipelined engine: drain the last compute stage (outside the clock)
+                torch.cuda.synchronize()
+            if ddp is not None:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dt = float(t.item())
+            times.append(dt)
+            launches.append((gs._native.launch_count() - l0) / args.steps)
+            stop = sum(times) >= min_time or len(times) >= 200
+            if ddp is not None:                         # every rank must take the same decision
+                flag = torch.tensor([1 if stop else 0], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                stop = bool(flag.item())
+            if stop:
+                break
+        model.train_sampler.csr(dev).check()
+        med = float(np.median(times))
+        return {"model": model, "step_fn": step_fn, "engine": engine, "queued": queued, "use_graph": use_graph,
+                "elapsed": med, "times": times, "launches_per_step": float(np.median(launches))}
+
+    res = measure(args.aggregator, args.min_time)
+    elapsed, step_fn, model = res["elapsed"], res["step_fn"], res["model"]
+    elem = store.data.element_size()
 
     if rank == 0:
         value = args.steps * B * world / elapsed
-        if args.aggregator == "max_pool" and fanout == FANOUT and B == BATCH:
+        fused_mean_queue = (res["queued"] and ddp is None and isinstance(step_fn, gs.engine.FusedMeanTrainStep)
+                            and not isinstance(step_fn, gs.engine.FusedPoolTrainStep)
+                            and getattr(step_fn, "capture_mode", None) == "cmdlist")
+        if args.aggregator in ("max_pool", "mean_pool") and fanout == FANOUT and B == BATCH:
             roof = pool_kernel_roofline(gs, model, store, data, dev)
+        elif fused_mean_queue:
+            roof = dominant_kernel_roofline(step_fn, store)
         else:
-            roof = dominant_kernel_roofline(gs, model, store, data, dev)
+            roof = standalone_gather_probe(gs, model, store, data, dev, fanout, B)
+        step_alg = rows_per_seed(fanout) * FEAT_DIM * elem * B
+        roof["step"] = {"alg_bytes_per_step": step_alg, "ms_per_step": elapsed / args.steps * 1e3,
+                        "achieved": step_alg / (elapsed / args.steps) / 1e9,
+                        "frac": step_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
         line = {
             "metric": "seed-nodes/sec", "value": value, "unit": "seed-nodes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -368,15 +497,37 @@ def main():
                                       "" if (args.aggregator, fanout, hidden) == ("mean", FANOUT, HIDDEN)
                                       else " variant", data["nnz"]),
                        "batch_per_gpu": B, "global_batch": B * world, "rng": "philox",
-                       "engine": engine,
-                       "launch": (getattr(step_fn, "capture_mode", None) or ("graph" if use_graph else "eager")),
-                       "pipelined": bool(engine == "fused" and args.pipeline), "batch_queue": bool(queued), "parallelism": "dp%d" % world,
-                       "kernel_launches_per_step": (gs._native.launch_count() - launches0) / max(total, 1)
-                       if args.launch != "graph" else None},
+                       "engine": res["engine"],
+                       "launch": (getattr(step_fn, "capture_mode", None) or ("graph" if res["use_graph"] else "eager")),
+                       "pipelined": bool(res["engine"] == "fused" and args.pipeline),
+                       "batch_queue": bool(res["queued"]), "parallelism": "dp%d" % world,
+                       "ranks": world, "collective": (torch.distributed.get_backend() if ddp is not None else None),
+                       "kernel_launches_per_step": res["launches_per_step"] if args.launch != "graph" else None,
+                       "timing": {"repeats": len(res["times"]), "steps_per_repeat": args.steps,
+                                  "median_s": elapsed, "min_s": min(res["times"]), "max_s": max(res["times"]),
+                                  "value_from": "median repeat"}},
             "frac_of_hbm_gather_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (
-                rows_per_seed(fanout) * FEAT_DIM * store.data.element_size())),
+                rows_per_seed(fanout) * FEAT_DIM * elem)),
             "roofline": roof,
         }
+        # other BASELINE configurations on the same graph, so that the driver's run measures them too
+        extra = {}
+        if world == 1:
+            del res, step_fn, model
+            torch.cuda.empty_cache()
+            for agg in [a for a in args.extra.split(",") if a and a != args.aggregator]:
+                r2 = measure(agg, min(args.min_time, 0.3))
+                e2 = r2["elapsed"]
+                rec = {"config": "BASELINE configs[2] shape on one GPU" if agg == "max_pool" else agg,
+                       "ms_per_step": e2 / args.steps * 1e3, "value": args.steps * B / e2,
+                       "unit": "seed-nodes/sec", "engine": type(r2["step_fn"]).__name__,
+                       "kernel_launches_per_step": r2["launches_per_step"], "repeats": len(r2["times"])}
+                if agg in ("max_pool", "mean_pool") and fanout == FANOUT and B == BATCH:
+                    rec["roofline"] = pool_kernel_roofline(gs, r2["model"], store, data, dev)
+                extra[agg] = rec
+                del r2
+                torch.cuda.empty_cache()
+        line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)
         else:

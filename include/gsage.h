@@ -73,8 +73,16 @@ int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
  * around an RCCL collective on another stream) at no cost.  Host-side calls (gsage_mt_*) and the
  * one-time LDS-limit setup of a kernel are not recordable: run one un-recorded step first.
  * ---------------------------------------------------------------------------------------- */
+/*   gsage_cmdlist_mark(slot)        [host] while recording: the list records HIP event `slot` (0..15) at
+ *                                    this point of every replay (on the replay's stream).
+ *   gsage_cmdlist_elapsed(l,a,b,&ms) [host] waits for mark b of the last replay and returns the time
+ *                                    between marks a and b: how bench.py times ONE kernel of a step in
+ *                                    place, on the stream it runs on (measurement only: a list with
+ *                                    marks pays an event record per mark). */
 int gsage_cmdlist_begin(void);
 int gsage_cmdlist_end(void **list);
+int gsage_cmdlist_mark(int slot);
+int gsage_cmdlist_elapsed(const void *list, int slot_a, int slot_b, float *ms);
 int64_t gsage_cmdlist_size(const void *list);
 int gsage_cmdlist_replay(const void *list, void *stream);
 void gsage_cmdlist_destroy(void *list);
@@ -499,6 +507,23 @@ int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int
 int gsage_bwd_merge(const void *H, int dtype, int64_t ldh, const float *DG, int64_t ldg, int64_t dagg_off,
                     void *dH, int64_t ldo, int64_t R, int64_t r_x, int32_t D, int32_t n_hops,
                     const int64_t *off, const int32_t *fan, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metrics of the train / eval log     replaces ProblemMetrics, problem.py:44-64 (sklearn f1_score on
+ *                                     host copies of predictions and targets, called per batch at
+ *                                     train.py:150)
+ *
+ *   gsage_metric_f1: out[0] = micro-F1, out[1] = macro-F1 of
+ *       classification (multilabel == 0): argmax_c logits[i, c] against targets int64 [B]; the macro
+ *                      mean runs over the classes that occur in targets or predictions (sklearn's label set)
+ *       multilabel     (multilabel != 0): logits[i, c] > 0 against targets [B, ldy] (float32 when
+ *                      targets_f32, else int64; non-zero = positive); macro over all C labels
+ *     counts: int32 scratch [3 * C] (tp | fp | fn per class, integer atomics: exact).
+ *   gsage_metric_mae: out[0] = mean |y_true[i] - y_pred[i]| over n elements (problem.py:62-64).
+ * ---------------------------------------------------------------------------------------- */
+int gsage_metric_f1(const float *logits, int64_t ld, const void *targets, int multilabel, int targets_f32,
+                    int64_t ldy, int64_t B, int32_t C, int32_t *counts, float *out, void *stream);
+int gsage_metric_mae(const float *y_true, const float *y_pred, int64_t n, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -140,10 +140,12 @@ def split_weights(w):
 
 
 def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes,
-            acts=None, rounding=None):
+            acts=None, rounding=None, frontier=None):
     """models.py:71-91 with the sampler's `sel` supplied per hop.  acts: one activation name per
     layer (default: the layer_specs of train.py:105-118 generalised in depth as models.py:85-86
-    allows -- ReLU on every layer but the last)."""
+    allows -- ReLU on every layer but the last).  frontier (optional): the sampled ids of every hop
+    [hop 1, hop 2, ...] given directly instead of (indptr, data, sels) -- for graphs too large to
+    hand to the CPU, whose samples are checked against the sampler's definition separately."""
     prep_w, layers, fc = split_weights(w)
     if acts is None:
         acts = ["relu"] * (len(layers) - 1) + ["identity"]
@@ -153,7 +155,11 @@ def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_n
     hs = [prep(prep_name, ids, take(ids), prep_w, n_nodes, 0)]
     cur = ids
     for hop, n in enumerate(fanouts):
-        nxt = ocpu.sample_csr_sel(indptr, data, cur.numpy(), int(n), sels[hop])
+        if frontier is not None:
+            nxt = np.asarray(frontier[hop], dtype=np.int64).reshape(-1)
+            assert nxt.shape[0] == cur.shape[0] * int(n)
+        else:
+            nxt = ocpu.sample_csr_sel(indptr, data, cur.numpy(), int(n), sels[hop])
         cur = torch.from_numpy(nxt)
         hs.append(prep(prep_name, cur, take(cur), prep_w, n_nodes, hop + 1))
     for li, lw in enumerate(layers):
@@ -216,12 +222,12 @@ class Adam(object):
 
 
 def train_step(w, opt, lr, task, ids, feats, targets, indptr, data, fanouts, sels, agg_name,
-               prep_name, n_nodes, acts=None, rounding=None):
+               prep_name, n_nodes, acts=None, rounding=None, frontier=None):
     """models.py:97-104.  `w` is updated in place.  Returns dict(preds, loss, gradnorm, grads,
     clipped)."""
     params = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
     preds = forward(params, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_nodes,
-                    acts=acts, rounding=rounding)
+                    acts=acts, rounding=rounding, frontier=frontier)
     l = loss(task, preds, targets)
     l.backward()
     grads = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}

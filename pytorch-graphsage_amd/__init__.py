@@ -10,12 +10,12 @@ surface of bkj/pytorch-graphsage.  Directory name has a hyphen: import it with
                               same names and interfaces as the reference's files
     dist.py, engine.py        RCCL data-parallel gradient sync, hipGraph-captured train step
 """
-from . import _native, dist, engine, nn_modules, ops, optim, store                                   # noqa: F401
+from . import _native, dist, engine, helpers, nn_modules, ops, optim, problem, store               # noqa: F401
 from .helpers import set_seeds, to_numpy                            # noqa: F401
 from .lr import LRSchedule                                          # noqa: F401
 from .models import GSSupervised                                    # noqa: F401
 from .nn_modules import aggregator_lookup, prep_lookup, sampler_lookup   # noqa: F401
-from .problem import NodeProblem, ProblemLosses, ProblemMetrics     # noqa: F401
+from .problem import DeviceMetrics, NodeProblem, ProblemLosses, ProblemMetrics, batch_metric   # noqa: F401
 from .store import DeviceCSR, FeatureStore, RowRef                  # noqa: F401
 
 __all__ = ["GSSupervised", "NodeProblem", "aggregator_lookup", "prep_lookup", "sampler_lookup",

@@ -32,6 +32,8 @@ SIGNATURES = {
     "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "gsage_cmdlist_begin": (_int, []),
     "gsage_cmdlist_end": (_int, [ctypes.POINTER(_vp)]),
+    "gsage_cmdlist_mark": (_int, [_int]),
+    "gsage_cmdlist_elapsed": (_int, [_vp, _int, _int, ctypes.POINTER(_f32)]),
     "gsage_cmdlist_size": (_i64, [_vp]),
     "gsage_cmdlist_replay": (_int, [_vp, _vp]),
     "gsage_cmdlist_destroy": (None, [_vp]),
@@ -87,6 +89,8 @@ SIGNATURES = {
     "gsage_pool_merge_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_aggregate": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
                                     _i64, _vp, _i64, _vp, _vp]),
+    "gsage_metric_f1": (_int, [_vp, _i64, _vp, _int, _int, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "gsage_metric_mae": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "gsage_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64, _i64,
                               _vp, _i64, _vp, _i64, _vp]),
 }
@@ -188,6 +192,12 @@ class CommandList(object):
 
     def replay(self, stream):
         check(lib().gsage_cmdlist_replay(self._h, stream), "cmdlist_replay")
+
+    def elapsed_ms(self, slot_a, slot_b):
+        """Time between two gsage_cmdlist_mark events of the last replay (blocks until mark b)."""
+        ms = _f32(0.0)
+        check(lib().gsage_cmdlist_elapsed(self._h, slot_a, slot_b, ctypes.byref(ms)), "cmdlist_elapsed")
+        return float(ms.value)
 
     def __del__(self):
         if self._h and _LIB is not None:

@@ -47,8 +47,16 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // kernels a replay costs the host one hipLaunchKernel per node (~2-3 us) instead of ~10-16 us per
 // graph launch PLUS an 8-15 us start-up gap on the device at every graph boundary, which matters
 // when a step has to be cut into several pieces around a collective (engine.py, data-parallel).
+constexpr int CMDLIST_MARKS = 16;
 struct CmdList {
     std::vector<std::function<void(hipStream_t)>> nodes;
+    hipEvent_t marks[CMDLIST_MARKS] = {};      // gsage_cmdlist_mark: events recorded between kernels
+    int64_t n_marks = 0;                       // mark nodes in `nodes` (not counted as kernel launches)
+    ~CmdList()
+    {
+        for (int i = 0; i < CMDLIST_MARKS; ++i)
+            if (marks[i]) (void)hipEventDestroy(marks[i]);
+    }
 };
 extern thread_local CmdList *t_recording;
 

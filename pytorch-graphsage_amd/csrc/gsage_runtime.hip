@@ -74,7 +74,8 @@ int gsage_cmdlist_end(void **list)
 
 int64_t gsage_cmdlist_size(const void *list)
 {
-    return list ? (int64_t)((const CmdList *)list)->nodes.size() : -1;
+    const CmdList *l = (const CmdList *)list;
+    return l ? (int64_t)l->nodes.size() - l->n_marks : -1;
 }
 
 int gsage_cmdlist_replay(const void *list, void *stream)
@@ -89,7 +90,41 @@ int gsage_cmdlist_replay(const void *list, void *stream)
         set_error("cmdlist_replay: %s", hipGetErrorString(e));
         return GSAGE_ELAUNCH;
     }
-    g_launches.fetch_add(l->nodes.size(), std::memory_order_relaxed);
+    g_launches.fetch_add(l->nodes.size() - (size_t)l->n_marks, std::memory_order_relaxed);
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_mark(int slot)
+{
+    GSAGE_REQUIRE(t_recording, "cmdlist_mark: no recording in progress on this thread");
+    GSAGE_REQUIRE(slot >= 0 && slot < CMDLIST_MARKS, "cmdlist_mark: slot must be in [0, %d)", CMDLIST_MARKS);
+    CmdList *l = t_recording;
+    if (!l->marks[slot] && hipEventCreate(&l->marks[slot]) != hipSuccess) {
+        (void)hipGetLastError();
+        l->marks[slot] = nullptr;
+        set_error("cmdlist_mark: hipEventCreate failed");
+        return GSAGE_ELAUNCH;
+    }
+    hipEvent_t ev = l->marks[slot];
+    l->nodes.emplace_back([ev](hipStream_t s) { (void)hipEventRecord(ev, s); });
+    l->n_marks += 1;
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_elapsed(const void *list, int slot_a, int slot_b, float *ms)
+{
+    GSAGE_REQUIRE(list && ms, "cmdlist_elapsed: null pointer");
+    GSAGE_REQUIRE(slot_a >= 0 && slot_a < CMDLIST_MARKS && slot_b >= 0 && slot_b < CMDLIST_MARKS,
+                  "cmdlist_elapsed: bad slot");
+    const CmdList *l = (const CmdList *)list;
+    GSAGE_REQUIRE(l->marks[slot_a] && l->marks[slot_b], "cmdlist_elapsed: mark not recorded in this list");
+    hipError_t e = hipEventSynchronize(l->marks[slot_b]);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, l->marks[slot_a], l->marks[slot_b]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("cmdlist_elapsed: %s", hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
     return GSAGE_OK;
 }
 

@@ -32,6 +32,9 @@ class DataParallel(object):
         """Equal contiguous slices; the (< world) left-over seeds of a batch are dropped so every
         rank has the same M (keeps the mean exact and the compat-mode stream aligned)."""
         per = ids.shape[0] // self.world
+        if per < 1:
+            raise ValueError("data-parallel batch of %d seeds cannot be split over %d ranks: every rank would "
+                             "train on an empty batch (NaN loss)" % (ids.shape[0], self.world))
         lo, hi = self.rank * per, (self.rank + 1) * per
         if targets is None:
             return ids[lo:hi]

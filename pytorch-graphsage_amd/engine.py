@@ -609,6 +609,7 @@ class FusedMeanTrainStep(object):
         if self.fused_tail:
             C = m.fc.weight.shape[0]
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+            self._mark(2)
             nat.check(lib.gsage_mean_tail_ce(
                 self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
                 self.w2[L - 1].shape[2], self.w2t[L - 1].data_ptr(), self.w2t[L - 1].shape[2],
@@ -618,6 +619,7 @@ class FusedMeanTrainStep(object):
                 self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
                 ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
                 stream), "mean_tail_ce")
+            self._mark(3)
         elif self.fused_head:
             C, D2 = m.fc.weight.shape
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
@@ -773,6 +775,10 @@ class FusedMeanTrainStep(object):
         if self._tail_rows and len(self.xa0_set) == 1:
             self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
         self._front_ready, self._qstep = False, 0
+        self._record_queue()
+        return self
+
+    def _record_queue(self):
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
         if self.g_main is not None:
             torch.cuda.synchronize()
@@ -785,7 +791,34 @@ class FusedMeanTrainStep(object):
                 self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
                 self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
                 self.g_opt = self._record(self._stage_opt)
-        return self
+
+    def instrument(self, on=True):
+        """Measurement only (bench.py's roofline object): re-record the queue-mode command lists with
+        HIP-event marks around the step's dominant launch -- the one that gathers the next batch's
+        level-0 rows (marks 0/1) -- and around the seed-level launch that carries the first part of
+        those gathers (marks 2/3).  `last_launch_ms()` then returns their durations for the step just
+        replayed, timed in place on the stream the step runs on."""
+        assert self.queue is not None and self.capture_mode == "cmdlist" and self.ddp is None
+        self._marks = bool(on)
+        self._record_queue()
+
+    def last_launch_ms(self):
+        cl = self.g_queue[(self._qstep - 1) % 2].cl
+        out = {"gather": cl.elapsed_ms(0, 1)}
+        if self.fused_tail:
+            out["seed_level"] = cl.elapsed_ms(2, 3)
+        return out
+
+    def _mark(self, slot):
+        if getattr(self, "_marks", False) and self.capture_mode == "cmdlist":
+            nat.check(nat.lib().gsage_cmdlist_mark(slot), "cmdlist_mark")
+
+    def gather_launch_rows(self):
+        """(rows the queue-mode gather launch reads, rows the seed-level launch's gather role reads) per
+        step: every sampled frontier row is read exactly once, by one of the two."""
+        total = self.off[self.L + 1]
+        tail = self._tail_rows * self.fan[self.L]
+        return total - tail, tail
 
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
@@ -813,8 +846,10 @@ class FusedMeanTrainStep(object):
         self._stage_gather(0, ids=self.ids_q[0])
 
     def _queue_front(self, par, with_adam):
+        self._mark(0)
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
                            hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
+        self._mark(1)
 
     def _queue_compute(self, par):
         if self._tail_rows:

@@ -93,13 +93,15 @@ class GSSupervised(nn.Module):
 
     def _flat_optimizer(self):
         """On the GPU the optimizer built in __init__ (torch.optim.Adam, never stepped yet) is replaced,
-        on the first train_step, by optim.FlatAdam: same arithmetic, Parameters and gradients become
+        on the first train_step, by optim.FlatAdam (its state_dict keeps torch.optim.Adam's format, so
+        checkpoints interchange; a reference to the ORIGINAL optimizer object taken before the first step
+        goes stale -- hold `model.optimizer` instead): same arithmetic, Parameters and gradients become
         views of flat buckets, clip + Adam become two launches.  An optimizer assigned from outside,
         one that has state already, CPU parameters or GSAGE_TORCH_ADAM=1 keep the stock route."""
         opt = self.optimizer
         if isinstance(opt, FlatAdam):
-            if not opt.owns():                    # somebody re-pointed the Parameters (e.g. a fused engine)
-                opt._attach()
+            if not opt.owns():                    # somebody re-pointed the Parameters (e.g. a fused engine):
+                opt._attach()                     # take them back WITH their current values
             return opt
         if opt is not self._init_optimizer or opt.state or os.environ.get("GSAGE_TORCH_ADAM", "0") == "1":
             return None

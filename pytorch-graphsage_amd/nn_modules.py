@@ -339,7 +339,7 @@ class AttentionAggregator(nn.Module, AggregatorMixin):
             st = t.store
             ids = t.ids.contiguous().view(-1)
             buf = ops._gather_mean_raw(st.data, st.ld, ids, int(ids.shape[0]), 1, torch.bfloat16, st.ld)
-            return buf[:, :st.dim]
+            return ops.mark_zero_padded(buf[:, :st.dim])
         return _as_tensor(t)
 
     def _att(self, t):

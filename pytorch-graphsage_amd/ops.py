@@ -77,13 +77,27 @@ def _mm_f32(a, b):
     return torch.mm(a.float(), b.float())
 
 
-def _pad_cast(t, dtype, mult):
-    """[M, D] -> contiguous [M, round_up(D, mult)] of `dtype`, zero padded (no copy if already so)."""
+def mark_zero_padded(view):
+    """Tag a [:, :D] view of a buffer THIS library filled (rows gathered with their zero padding) so
+    that _pad_cast may hand it to the GEMM kernels as is."""
+    view._gsage_zero_padded = True
+    return view
+
+
+def _trusted(t):
+    return bool(getattr(t, "_gsage_zero_padded", False))
+
+
+def _pad_cast(t, dtype, mult, trusted=False):
+    """[M, D] -> contiguous [M, round_up(D, mult)] of `dtype`, zero padded (no copy if already so).
+    The GEMM kernels read whole padded rows, so a strided [:, :D] view is passed through only when the
+    caller vouches for its pad columns (`trusted`: buffers this library produced, see
+    mark_zero_padded); a user tensor sliced out of a wider buffer is copied into a zeroed one."""
     M, D = t.shape
     ld = _round_up(D, mult)
     if t.dtype == dtype and ld == D and t.is_contiguous():
         return t
-    if t.dtype == dtype and t.stride(1) == 1 and t.stride(0) == ld and t.data_ptr() % 16 == 0:
+    if trusted and t.dtype == dtype and t.stride(1) == 1 and t.stride(0) == ld and t.data_ptr() % 16 == 0:
         return t              # [:, :D] view of rows that are already padded (pad columns zero: gathered rows)
     out = torch.zeros(M, ld, dtype=dtype, device=t.device) if ld != D else \
         torch.empty(M, ld, dtype=dtype, device=t.device)
@@ -396,7 +410,7 @@ class _Linear(torch.autograd.Function):
         epc = 8 if cdt == torch.bfloat16 else 4
         M, K = x.shape
         N = W.shape[0]
-        xa = _pad_cast(x.detach(), cdt, 8 * epc)          # whole 128-byte rows: LDS-DMA GEMM path
+        xa = _pad_cast(x.detach(), cdt, 8 * epc, _trusted(x))   # whole 128-byte rows: LDS-DMA GEMM path
         wa = _prep_weight(W, cdt, 8 * epc)
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
         bf = b.detach().float().contiguous() if b is not None else None
@@ -456,7 +470,7 @@ class _SageProject(torch.autograd.Function):
         h = Wx.shape[0]
         M = agg.shape[0]
         Dn = Wn.shape[1]
-        an = _pad_cast(agg.detach(), cdt, 8 * epc)
+        an = _pad_cast(agg.detach(), cdt, 8 * epc, _trusted(agg))
         if x_ids is not None:
             Dx = x_dim
             if x_table.dtype != cdt or x_table.stride(0) % epc != 0:
@@ -466,7 +480,7 @@ class _SageProject(torch.autograd.Function):
                 xa, a_rows = x_table, x_ids
         else:
             Dx = x.shape[1]
-            xa, a_rows = _pad_cast(x.detach(), cdt, 8 * epc), None
+            xa, a_rows = _pad_cast(x.detach(), cdt, 8 * epc, _trusted(x)), None
         out = torch.empty(M, 2 * h, dtype=out_dtype, device=agg.device)
         esz = xa.element_size()
         delta = an.data_ptr() - xa.data_ptr()
@@ -575,7 +589,7 @@ class _PoolMLP(torch.autograd.Function):
                 A, a_rows = table, ids
         else:
             K = neibs.shape[1]
-            A, a_rows = _pad_cast(neibs.detach(), cdt, epc), None
+            A, a_rows = _pad_cast(neibs.detach(), cdt, epc, _trusted(neibs)), None
         wa = _prep_weight(Wm, cdt, epc)
         bf = bm.detach().float().contiguous()
         pooled = torch.empty(M, H, dtype=torch.float32, device=A.device)

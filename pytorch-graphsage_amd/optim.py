@@ -46,9 +46,17 @@ class FlatAdam(object):
 
     # ---- views ----------------------------------------------------------------------------------
     def _attach(self):
-        for p, o, n in zip(self.params, self.offsets, self.sizes):
-            p.data = self.flat_p[o:o + n].view_as(p)
-            p.grad = self.flat_g[o:o + n].view_as(p)
+        """Make the Parameters (and their .grad) views of this optimizer's buckets.  A Parameter that
+        currently lives elsewhere (first attach, or something re-pointed it since -- a fused engine
+        trains through buckets of its own) brings its LIVE value along: the bucket must never resurrect
+        the weights it held before somebody else trained them."""
+        es = self.flat_p.element_size()
+        with torch.no_grad():
+            for p, o, n in zip(self.params, self.offsets, self.sizes):
+                if p.data_ptr() != self.flat_p.data_ptr() + o * es:
+                    self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + n].view_as(p)
+                p.grad = self.flat_g[o:o + n].view_as(p)
 
     def owns(self, params=None):
         """True while every Parameter (and its .grad) still is the view this optimizer made."""
@@ -87,12 +95,40 @@ class FlatAdam(object):
         self.clip_and_step(max_norm=3.0e38)           # no clipping
 
     def state_dict(self):
-        return {"m": self.flat_m.clone(), "v": self.flat_v.clone(), "step": self.step_count.clone(),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.Adam's format ({"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups":
+        [...]}): a checkpoint written here loads into the torch.optim.Adam the reference builds
+        (models.py:69) and vice versa."""
+        state = {}
+        if int(self.step_count.item()) > 0:
+            step = self.step_count.to(torch.float32).reshape(())
+            for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.sizes)):
+                state[i] = {"step": step.clone(), "exp_avg": self.flat_m[o:o + n].view_as(p).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + n].view_as(p).clone()}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(len(self.params)))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.flat_m.copy_(sd["m"])
-        self.flat_v.copy_(sd["v"])
-        self.step_count.copy_(sd["step"])
+        if "state" not in sd:                          # round-1 format of this class: flat buckets
+            self.flat_m.copy_(sd["m"])
+            self.flat_v.copy_(sd["v"])
+            self.step_count.copy_(sd["step"])
+        else:
+            st = sd["state"]
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            steps = set()
+            for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.sizes)):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    continue
+                self.flat_m[o:o + n].copy_(e["exp_avg"].reshape(-1))
+                self.flat_v[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+                steps.add(int(e["step"]))
+            assert len(steps) <= 1, "FlatAdam keeps one step count: per-parameter counts differ (%r)" % (steps,)
+            self.step_count.fill_(steps.pop() if steps else 0)
         for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})

@@ -66,6 +66,57 @@ class ProblemMetrics:
         return float(np.abs(y_true - y_pred).mean())
 
 
+class DeviceMetrics:
+    """ProblemMetrics for CUDA tensors: the counting / reduction runs on the device
+    (csrc/gsage_metrics.hip), 8 bytes come back for the log line instead of the [B, C] predictions
+    going to the host and through sklearn on every batch (train.py:150)."""
+
+    @staticmethod
+    def _f1(y_true, preds, multilabel):
+        from . import _native as nat
+        preds = preds.detach().float().contiguous()
+        B, C = preds.shape
+        f32 = bool(multilabel and y_true.dtype.is_floating_point)
+        y = y_true.detach().contiguous().float() if f32 else y_true.detach().contiguous().long()
+        y = y.view(B, C) if multilabel else y.view(-1)
+        assert y.shape[0] == B
+        counts = torch.empty(3 * C, dtype=torch.int32, device=preds.device)
+        out = torch.empty(2, dtype=torch.float32, device=preds.device)
+        nat.check(nat.lib().gsage_metric_f1(preds.data_ptr(), preds.stride(0), y.data_ptr(), int(multilabel),
+                                            int(f32), C if multilabel else 0, B, C, counts.data_ptr(),
+                                            out.data_ptr(), ops._stream()), "metric_f1")
+        micro, macro = out.tolist()
+        return {"micro": float(micro), "macro": float(macro)}
+
+    @staticmethod
+    def multilabel_classification(y_true, y_pred):
+        return DeviceMetrics._f1(y_true, y_pred, True)
+
+    @staticmethod
+    def classification(y_true, y_pred):
+        return DeviceMetrics._f1(y_true, y_pred, False)
+
+    @staticmethod
+    def regression_mae(y_true, y_pred):
+        from . import _native as nat
+        a = y_true.detach().float().contiguous().view(-1)
+        b = y_pred.detach().float().contiguous().view(-1)
+        assert a.shape == b.shape, "regression_mae: y_true and y_pred must have the same number of elements"
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        nat.check(nat.lib().gsage_metric_mae(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
+                                             ops._stream()), "metric_mae")
+        return float(out.item())
+
+
+def batch_metric(task, y_true, y_pred):
+    """problem.metric_fn for a batch that may live on the GPU: CUDA tensors are scored by the device
+    kernels, anything else by the reference's host route (ProblemMetrics on numpy copies)."""
+    if torch.is_tensor(y_pred) and y_pred.is_cuda:
+        return getattr(DeviceMetrics, task)(y_true.to(y_pred.device), y_pred)
+    to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return getattr(ProblemMetrics, task)(to_np(y_true), to_np(y_pred))
+
+
 def parse_csr_matrix(x):
     """(v, r, c) triple -> csr_matrix with inferred shape (problem.py:70-72)."""
     v, r, c = x

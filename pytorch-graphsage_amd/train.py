@@ -35,7 +35,7 @@ else:
     gs = importlib.import_module(__package__)
 
 GSSupervised, NodeProblem = gs.GSSupervised, gs.NodeProblem
-set_seeds, to_numpy = gs.set_seeds, gs.to_numpy
+set_seeds, to_numpy, batch_metric = gs.set_seeds, gs.to_numpy, gs.batch_metric
 aggregator_lookup, prep_lookup, sampler_lookup = gs.aggregator_lookup, gs.prep_lookup, gs.sampler_lookup
 
 
@@ -52,13 +52,34 @@ def dumps(obj):
     return json.dumps(_round5(obj), separators=(",", ":"))
 
 
+def check_samplers(model):
+    """The GPU sampler maps an id outside the adjacency to the dummy node and raises a device flag
+    instead of synchronising per call; the reference (and host mode) raise IndexError on the spot.  Read
+    the flags here -- once per evaluation, so no sync is added to a train step."""
+    for s in (model.train_sampler, model.val_sampler):
+        for csr in getattr(s, "_dev", {}).values():          # the device copies a sparse sampler has made
+            csr.check()
+
+
 def evaluate(model, problem, mode='val'):
     assert mode in ['test', 'val']
     preds, acts = [], []
-    for (ids, targets, _) in problem.iterate(mode=mode, shuffle=False):
-        preds.append(to_numpy(model(ids, problem.feats, train=False)))
-        acts.append(to_numpy(targets))
-    return problem.metric_fn(np.vstack([a.reshape(a.shape[0], -1) for a in acts]), np.vstack(preds))
+    # every rank evaluates the WHOLE fold: draw the samples a single process would (rank offset off)
+    shard = getattr(model.val_sampler, "shard", None)
+    if shard is not None:
+        model.val_sampler.shard = (0, 1)
+    try:
+        for (ids, targets, _) in problem.iterate(mode=mode, shuffle=False):
+            preds.append(model(ids, problem.feats, train=False).detach())
+            acts.append(targets.reshape(targets.shape[0], -1))
+    finally:
+        if shard is not None:
+            model.val_sampler.shard = shard
+    check_samplers(model)
+    if preds and preds[0].is_cuda:
+        # scored on the device (problem.DeviceMetrics): the fold's predictions never travel to the host
+        return batch_metric(problem.task, torch.cat(acts), torch.cat(preds))
+    return problem.metric_fn(np.vstack([to_numpy(a) for a in acts]), np.vstack([to_numpy(p) for p in preds]))
 
 
 def parse_args(argv=None):
@@ -149,7 +170,7 @@ def main(argv=None):
             model.set_progress((epoch + epoch_progress) / args.epochs)
             preds = model.train_step(ids=ids, feats=problem.feats, targets=targets,
                                      loss_fn=problem.loss_fn)
-            train_metric = problem.metric_fn(to_numpy(targets), to_numpy(preds))
+            train_metric = batch_metric(problem.task, targets, preds)      # on the device when the batch is
             if ddp is None or ddp.rank == 0:
                 print(dumps({"epoch": epoch, "epoch_progress": epoch_progress,
                              "train_metric": train_metric, "val_metric": val_metric,
@@ -201,7 +222,7 @@ def train_fused(args, problem, model, ddp, start_time):
             step.set_progress((epoch + b / n_batches) / args.epochs)
             preds = step.step_queue()
             if (b % max(args.log_interval, 1) == 0 or b == n_batches - 1) and rank == 0:
-                train_metric = problem.metric_fn(to_numpy(tgs[b].view(B, 1)), to_numpy(preds))
+                train_metric = batch_metric(problem.task, tgs[b].view(B, 1), preds)
                 print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
                              "val_metric": val_metric, "time": time() - start_time}))
                 sys.stdout.flush()

@@ -95,3 +95,88 @@ def test_gather_rows_beyond_2_31_bytes():
     mean = ops.gather_mean(store, ids, 4096, 5, out_dtype=torch.float32)
     want = table[ids].float().view(4096, 5, D).mean(1)
     assert float((mean - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1)
+
+
+def test_three_layer_engine_step_at_papers_scale():
+    """BASELINE configs[4] at full structural scale: 8.4 M nodes, 2.5e9 edges (row offsets beyond 2^31:
+    int64 rowptr), 128-d bf16 features, mean aggregator, THREE layers, fan-out 15/10/5 -- one fused
+    engine step on a graph built on the device.  Checked through properties that do not depend on size:
+      * the engine's frontier == three per-hop launches of the stand-alone sampler with the same Philox
+        (seed, call) -- which tests above tie to the definition out = col[rowptr[id] + sel % deg];
+      * the step itself against the oracle (bf16 rounding points) fed that frontier and the frontier's
+        feature rows: predictions, gradient norm, clipped gradients, and the Adam update."""
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs a large-memory GPU")
+    import sys
+    from scipy import sparse
+    from torch.nn import functional as F
+    from oracle import torch_ref as tref
+    from util import close, close_fro
+    n_rows, D, C, B, fans, dims = (1 << 23) + 1, 128, 41, 64, (15, 10, 5), (128, 128, 128)
+    deg = torch.randint(200, 401, (n_rows,), dtype=torch.int64, device=DEV)
+    deg[0] = 0
+    deg[3::1000] = 0
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=DEV)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(rowptr[-1])
+    assert nnz > 2 ** 31
+    col = torch.randint(1, n_rows, (nnz,), dtype=torch.int32, device=DEV)
+    big = gs.DeviceCSR(rowptr, col, n_rows, 4096)
+    table = torch.zeros(n_rows, D, dtype=torch.bfloat16, device=DEV)
+    table[1:] = torch.randn(n_rows - 1, D, device=DEV).bfloat16()
+    store = gs.FeatureStore(table, D)
+
+    # the model is built on a placeholder adjacency (the plugin API takes a scipy matrix, which a
+    # 2.5e9-edge graph is not going to be); the sampler's device CSR is then the big graph
+    tiny = sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
+    torch.manual_seed(11)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": F.relu if i < 2 else (lambda x: x)} for i, (f, h) in enumerate(zip(fans, dims))]
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=tiny,
+                            train_adj=tiny, prep_class=gs.prep_lookup["identity"],
+                            aggregator_class=gs.aggregator_lookup["mean"], input_dim=D, n_nodes=n_rows,
+                            n_classes=C, layer_specs=specs, lr_init=0.01, weight_decay=1e-4).to(DEV)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    model.train_sampler.seed = 31
+    model.train_sampler.csr(DEV)
+    key = next(iter(model.train_sampler._dev))
+    model.train_sampler._dev[key] = big
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ids = (n_rows - 1 - torch.randint(0, 2_000_000, (B,), generator=g)).to(DEV)      # far end: offsets > 2^31
+    assert int(rowptr[ids].min()) > 2 ** 31
+    tg = torch.randint(0, C, (B, 1), generator=g).to(DEV)
+    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids, tg, capture="cmdlist")
+    assert eng.csr is big and eng.L == 3
+    preds = eng(ids, tg).detach().cpu().numpy()
+    torch.cuda.synchronize()
+    big.check()
+
+    # (1) frontier == per-hop sampler launches with the engine's (seed, call index)
+    front = eng.ids_set[0]
+    cur, off, hops = ids, B, []
+    for k, f in enumerate(fans):
+        ref = ops.sample_csr(big, cur, f, philox={"seed": 31, "call_base": k})
+        assert torch.equal(front[off:off + ref.numel()], ref), "hop %d" % (k + 1)
+        hops.append(ref.cpu().numpy())
+        cur, off = ref, off + ref.numel()
+    assert off == B * (1 + 15 + 150 + 750)
+
+    # (2) the step against the oracle on the frontier's rows (ids relabelled to a compact table)
+    uniq, inv = np.unique(np.concatenate([ids.cpu().numpy()] + hops), return_inverse=True)
+    small = table[torch.from_numpy(uniq).to(DEV)].float().cpu()
+    sizes = [B] + [h.shape[0] for h in hops]
+    parts = np.split(inv, np.cumsum(sizes)[:-1])
+    w = {k: v.clone() for k, v in w0.items()}
+    r = tref.train_step(w, tref.Adam(weight_decay=1e-4), 0.01, "classification", parts[0], small, tg.cpu(), None,
+                        None, fans, None, "mean", "identity", n_rows, rounding="bf16", frontier=parts[1:])
+    close(preds, r["preds"].numpy(), "preds vs oracle (papers scale)", 3e-3, 3e-3)
+    gn = float(eng.gnorm.item())
+    assert abs(gn - r["gradnorm"]) <= 5e-3 * max(1.0, r["gradnorm"])
+    for k, v in model.named_parameters():
+        close_fro(v.grad.cpu().numpy(), r["clipped"][k].numpy(), ("clipped grad", k), 1e-2)
+        d_eng = v.detach().cpu().numpy() - w0[k].numpy()
+        d_ref = w[k].numpy() - w0[k].numpy()
+        close_fro(d_eng, d_ref, ("Adam update", k), 5e-2)

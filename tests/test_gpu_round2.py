@@ -1,0 +1,174 @@
+"""-m gpu: round-2 additions that are not engine parity (tests/test_gpu_engine_golden.py):
+  * optimizer hand-over eager -> fused -> eager keeps the trained weights
+  * FlatAdam checkpoints interchange with torch.optim.Adam
+  * ops._pad_cast copies a user view whose pad columns it cannot vouch for
+  * dense UniformNeighborSampler golden vectors on the GPU
+  * bench.py --gpus 2 starts its own ranks (gloo exchange on the one GPU of the box)
+  * device-side metrics against the golden metric fixtures"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+from torch.nn import functional as F
+
+from conftest import ROOT, load_golden, pkg
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    yield
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    ops.set_compute_dtype("bf16")
+
+
+def _small(seed=0, n=400, D=40, C=5):
+    rng = np.random.RandomState(seed)
+    deg = rng.randint(0, 20, size=n + 1)
+    deg[0], deg[n] = 0, 3
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    data = rng.randint(1, n + 1, size=int(indptr[-1]))
+    adj = sparse.csr_matrix((data, gs.store.row_positions(indptr), indptr), shape=(n + 1, int(deg.max())))
+    feats = rng.normal(size=(n + 1, D)).astype(np.float32)
+    feats[0] = 0
+    torch.manual_seed(1)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": 5, "n_val_samples": 5, "output_dim": 128, "activation": F.relu},
+             {"n_train_samples": 3, "n_val_samples": 3, "output_dim": 128, "activation": lambda x: x}]
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj,
+                            train_adj=adj, prep_class=gs.prep_lookup["identity"],
+                            aggregator_class=gs.aggregator_lookup["mean"], input_dim=D, n_nodes=n + 1,
+                            n_classes=C, layer_specs=specs, lr_init=0.01).to(DEV)
+    ids = torch.from_numpy(rng.randint(1, n + 1, size=32)).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(32, 1))).to(DEV)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    return model, store, ids, tg
+
+
+def test_eager_fused_eager_keeps_the_trained_weights():
+    """train_step (FlatAdam takes the Parameters) -> fused engine (re-points them at its own buckets and
+    trains) -> train_step again: FlatAdam must take the Parameters back WITH the engine's weights, not
+    resurrect the copy it held before the engine ran."""
+    model, store, ids, tg = _small()
+    loss_fn = gs.ProblemLosses.classification
+    model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+    assert isinstance(model.optimizer, gs.optim.FlatAdam) and model.optimizer.owns()
+    eng = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids, tg, capture=False)
+    for _ in range(3):
+        eng(ids, tg)
+    torch.cuda.synchronize()
+    assert not model.optimizer.owns()
+    after_engine = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    stale = model.optimizer.flat_p.clone()
+    model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+    torch.cuda.synchronize()
+    assert model.optimizer.owns()
+    for k, v in model.state_dict().items():
+        # one Adam step of lr 0.01 away from the engine's weights, not back at the pre-engine copy
+        assert float((v - after_engine[k]).abs().max()) <= 0.0101, k
+    moved = torch.cat([v.reshape(-1) for v in after_engine.values()])
+    assert float((moved - stale).abs().max()) > 0.015      # the engine really had moved them
+
+
+def test_flat_adam_state_dict_interchanges_with_torch_adam():
+    model, store, ids, tg = _small(seed=3)
+    loss_fn = gs.ProblemLosses.classification
+    twin = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for _ in range(2):
+        model.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+    fa = model.optimizer
+    assert isinstance(fa, gs.optim.FlatAdam)
+    sd = fa.state_dict()
+    assert set(sd) == {"state", "param_groups"} and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    # torch.optim.Adam accepts it ...
+    params = [torch.nn.Parameter(p.detach().clone()) for p in model.parameters()]
+    ta = torch.optim.Adam(params, lr=0.01)
+    ta.load_state_dict(sd)
+    assert float(ta.state[params[0]]["step"]) == 2.0
+    assert torch.equal(ta.state[params[0]]["exp_avg"], sd["state"][0]["exp_avg"])
+    # ... and FlatAdam accepts torch's
+    m2, _, _, _ = _small(seed=3)
+    m2.load_state_dict(twin)
+    m2.train_step(ids=ids, feats=store, targets=tg, loss_fn=loss_fn)
+    m2.optimizer.load_state_dict(ta.state_dict())
+    assert int(m2.optimizer.step_count.item()) == 2
+    assert torch.equal(m2.optimizer.flat_m, fa.flat_m) and torch.equal(m2.optimizer.flat_v, fa.flat_v)
+
+
+def test_pad_cast_copies_views_it_cannot_vouch_for():
+    """K5 reads whole padded rows: a [:, :D] slice of a wider USER buffer whose pad columns hold data
+    must be copied into a zeroed buffer, a slice of a library-gathered buffer may pass as is."""
+    wide = torch.randn(64, 64, device=DEV).bfloat16()
+    view = wide[:, :40]
+    out = ops._pad_cast(view, torch.bfloat16, 64)
+    assert out.data_ptr() != view.data_ptr() and float(out[:, 40:].float().abs().max()) == 0.0
+    assert ops._pad_cast(ops.mark_zero_padded(view), torch.bfloat16, 64, True).data_ptr() == view.data_ptr()
+    W = torch.randn(16, 40, device=DEV)
+    y = ops.linear(view, W, out_dtype=torch.float32)
+    ref = view.float() @ W.bfloat16().float().t()
+    assert float((y - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+def test_dense_sampler_golden_on_gpu():
+    """UniformNeighborSampler (nn_modules.py:19-49: train.py:55's default sampler) with the adjacency and
+    the ids on the GPU: the reference's outputs for the reference's seeds, bit for bit."""
+    g = load_golden("dense_sampler_kat.npz")
+    adj = torch.from_numpy(g["adj"]).to(DEV)
+    s = gs.sampler_lookup["uniform_neighbor_sampler"](adj=adj)
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        gs.helpers.set_seeds(int(g[p + "seed"]))
+        out = s(torch.from_numpy(g[p + "ids"]).to(DEV), n_samples=int(g[p + "n"]))
+        assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[p + "out"]), c
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under
+    torch.distributed.run (2 ranks sharing this box's GPU, gloo exchange) and rank 0 prints one line."""
+    env = dict(os.environ, GSAGE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--no-cpu-baseline", "--min-time", "0", "--extra", ""], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2 and rec["config"]["collective"] == "gloo"
+    assert rec["config"]["global_batch"] == 1024 and rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_device_metrics_match_the_reference_fixture():
+    """problem.DeviceMetrics (csrc/gsage_metrics.hip) on the inputs of misc_kat.npz: the micro / macro F1
+    and MAE the reference's ProblemMetrics (sklearn) returned."""
+    g = load_golden("misc_kat.npz")
+    y = torch.from_numpy(g["cls_y"]).to(DEV)
+    lg = torch.from_numpy(g["cls_logits"]).to(DEV)
+    m = gs.DeviceMetrics.classification(y, lg)
+    assert abs(m["micro"] - float(g["cls_micro"])) < 1e-6 and abs(m["macro"] - float(g["cls_macro"])) < 1e-6
+    # a class that nobody has or predicts does not enter the macro mean (sklearn's label set)
+    lg2 = torch.cat([lg, torch.full((lg.shape[0], 3), -50.0, device=DEV)], dim=1)
+    m2 = gs.DeviceMetrics.classification(y, lg2)
+    assert abs(m2["macro"] - float(g["cls_macro"])) < 1e-6
+    for cast in (torch.int64, torch.float32):
+        ym = torch.from_numpy(g["ml_y"]).to(DEV).to(cast)
+        mm = gs.DeviceMetrics.multilabel_classification(ym, torch.from_numpy(g["ml_logits"]).to(DEV))
+        assert abs(mm["micro"] - float(g["ml_micro"])) < 1e-6 and abs(mm["macro"] - float(g["ml_macro"])) < 1e-6
+    mae = gs.DeviceMetrics.regression_mae(torch.from_numpy(g["mae_y"]).to(DEV), torch.from_numpy(g["mae_pred"]).to(DEV))
+    assert abs(mae - float(g["mae"])) < 1e-5 * max(1.0, float(g["mae"]))
+    # dispatcher: CUDA -> device kernels, host tensors -> the reference's sklearn route, same numbers
+    host = gs.batch_metric("classification", torch.from_numpy(g["cls_y"]), torch.from_numpy(g["cls_logits"]))
+    dev = gs.batch_metric("classification", y, lg)
+    assert abs(host["micro"] - dev["micro"]) < 1e-6 and abs(host["macro"] - dev["macro"]) < 1e-6

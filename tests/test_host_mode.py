@@ -247,3 +247,15 @@ def test_train_py_cli_runs_on_cpu(tmp_path, capsys, sampler, sparse_adj):
     assert per_batch[0]["val_metric"] is None and per_batch[-1]["val_metric"] is not None
     assert set(lines[-2]) == {"epoch", "train_metric", "val_metric", "time"}
     assert set(lines[-1]) == {"test_f1"} and set(lines[-1]["test_f1"]) == {"micro", "macro"}
+
+
+def test_shard_refuses_batches_smaller_than_the_world():
+    """A chunk with fewer seeds than ranks would give every rank an empty batch (NaN loss averaged
+    into every replica): dist.DataParallel.shard raises instead."""
+    import pytest
+    gs = pkg()
+    dp = gs.dist.DataParallel(rank=1, world=4, device=torch.device("cpu"), owns_group=False)
+    ids = torch.arange(10)
+    assert dp.shard(ids).tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        dp.shard(torch.arange(3))

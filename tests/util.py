@@ -35,6 +35,22 @@ def close_rel(a, b, what, tol):
     assert err <= tol * scale + 1e-12, (what, "max abs err %g vs scale %g" % (err, scale))
 
 
+def close_update(w, w_ref, w0, what, tol_fro=5e-3, tol_elem=1e-4):
+    """Weights after Adam steps (lr = 0.01) against the reference's.  Adam's update
+    lr * m / (sqrt(v) + 1e-8) is ill-conditioned exactly where a gradient entry (plus weight decay)
+    cancels to ~1e-8 -- there an fp32 summation-order difference moves the weight by a fraction of lr
+    -- so the check is (a) the UPDATE w - w0 matches in norm to tol_fro (a skipped or wrong optimizer
+    step, a missing gradient term or a sign error changes it by O(1)), and (b) all but a handful of
+    entries (1e-4 of the tensor, at least 2) match to tol_elem = 1 % of one step."""
+    w, w_ref, w0 = (np.asarray(t, dtype=np.float64) for t in (w, w_ref, w0))
+    assert w.shape == w_ref.shape == w0.shape, (what, w.shape, w_ref.shape)
+    d, d_ref = w - w0, w_ref - w0
+    err = float(np.linalg.norm(d - d_ref)) / max(float(np.linalg.norm(d_ref)), 1e-12)
+    assert err <= tol_fro, (what, "update differs by %g of its norm" % err)
+    bad = int((np.abs(w - w_ref) > tol_elem).sum())
+    assert bad <= max(2, int(1e-4 * w.size)), (what, "%d of %d entries off by more than %g" % (bad, w.size, tol_elem))
+
+
 def close_fro(a, b, what, tol):
     """Norm-wise check for low-precision gradients: a bf16 forward can flip the ReLU mask of a
     pre-activation that is ~0, which moves single gradient entries by O(1) -- bounded in

@@ -11,28 +11,37 @@ rocminfo 2>/dev/null | grep -m2 -E "gfx|Compute Unit" ; nproc
 for w in $WHAT; do
   case $w in
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout 600 -p no:cacheprovider > $OUT/tests.log 2>&1
+      rm -f $OUT/parity_errors.jsonl
+      GSAGE_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl timeout 1700 python -m pytest tests -m gpu -q --tb=short --timeout 900 -p no:cacheprovider --durations=8 > $OUT/tests.log 2>&1
       echo "== tests rc=$?"; tail -60 $OUT/tests.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
       echo "== smoke rc=$?"; tail -5 $OUT/smoke.log ;;
     bench)
-      timeout 600 python bench.py --steps 50 --warmup 10 --no-graph --no-cpu-baseline > $OUT/bench_eager.log 2>&1
-      echo "== bench eager rc=$?"; tail -3 $OUT/bench_eager.log
       timeout 900 python bench.py > $OUT/bench.log 2>&1
       echo "== bench rc=$?"; tail -3 $OUT/bench.log ;;
+    bench20)
+      timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1
+      echo "== bench20 rc=$?"; tail -2 $OUT/bench20.log ;;
     prof)
       rm -rf $OUT/prof
-      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r --output-format csv -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/prof.log 2>&1
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r --output-format csv -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --extra '' > $OUT/prof.log 2>&1
       echo "== prof rc=$?"; tail -3 $OUT/prof.log
       find $OUT/prof -name "*kernel_stats*.csv" | head -3
       f=$(find $OUT/prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -25 "$f"
       # keep the merged-back payload small
       find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete ;;
     pmc)
-      rm -rf $OUT/pmc
-      timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc -o f --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc.log 2>&1
-      echo "== pmc rc=$?"; tail -3 $OUT/pmc.log
-      find $OUT/pmc -name "*.csv" | head; find $OUT/pmc -name "*kernel_trace*.csv" -size +20M -delete ;;
+      # FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), each with its calibration run
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf $OUT/pmc_$c $OUT/pmc_cal_$c
+        timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o f --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extra '' --min-time 0 > $OUT/pmc_$c.log 2>&1
+        echo "== pmc $c rc=$?"; tail -2 $OUT/pmc_$c.log
+        timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_cal_$c -o f --output-format csv -- python tools/pmc_calib.py > $OUT/pmc_cal_$c.log 2>&1
+        echo "== pmc calib $c rc=$?"; tail -1 $OUT/pmc_cal_$c.log
+        a=$(find $OUT/pmc_$c -name "*counter_collection.csv" | head -1); b=$(find $OUT/pmc_cal_$c -name "*counter_collection.csv" | head -1)
+        [ -n "$a" ] && python tools/pmc_summary.py "$a" $b > $OUT/pmc_$c.json && head -40 $OUT/pmc_$c.json
+        find $OUT/pmc_$c $OUT/pmc_cal_$c -name "*.csv" -size +8M -delete
+      done ;;
   esac
 done
