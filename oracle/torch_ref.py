@@ -69,11 +69,13 @@ def mean_aggregator(x, neibs, w, act, rounding=None):
 
 
 def pool_aggregator(x, neibs, w, act, pool, rounding=None):
-    h = torch.relu(neibs @ _rb(w["mlp.0.weight"], rounding).t() + w["mlp.0.bias"])
+    pre = neibs @ _rb(w["mlp.0.weight"], rounding).t()
     if rounding == "bf16":
-        # the hidden layer never leaves the chip in the forward; its GRADIENT is stored in bf16 (the
-        # dC operand of the MLP's weight gradient and of its input gradient)
-        h = _GradRound.apply(h)
+        # the hidden layer never leaves the chip in the forward; its GRADIENT is stored in bf16 as the
+        # dC operand of the MLP's weight gradient and of its input gradient -- the bias gradient is
+        # summed from the unrounded fp32 values (gsage_pool_bias_partials / _mean)
+        pre = _GradRound.apply(pre)
+    h = torch.relu(pre + w["mlp.0.bias"])
     seg = _segments(x, h)
     agg = seg.max(dim=1)[0] if pool == "max" else seg.mean(dim=1)
     return _combine(x, _rb(agg, rounding), w, act, rounding)

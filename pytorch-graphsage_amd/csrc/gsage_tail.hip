@@ -102,6 +102,16 @@ __device__ __forceinline__ void tail_store8(float *p, const float (&x)[8])
     *(float4 *)p = make_float4(x[0], x[1], x[2], x[3]);
     *(float4 *)(p + 4) = make_float4(x[4], x[5], x[6], x[7]);
 }
+// the same for values that tail_round<T> produced (or zero): bf16 is then the upper half of the word,
+// no rounding arithmetic per stored element (a lane stores up to 17 rows)
+__device__ __forceinline__ void tail_store8_exact(uint16_t *p, const float (&x)[8])
+{
+    vec16 o;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) o[q >> 1] = (__float_as_uint(x[q]) >> 16) | (__float_as_uint(x[q + 1]) & 0xffff0000u);
+    *(vec16 *)p = o;
+}
+__device__ __forceinline__ void tail_store8_exact(float *p, const float (&x)[8]) { tail_store8(p, x); }
 
 // fc.weight rows in LDS are padded to a multiple of 8 classes (zero rows): 8-class chunks need no
 // per-class guards, and every buffer behind them stays 16-byte aligned for ds_read_b128
@@ -110,7 +120,7 @@ constexpr int tail_cpad(int C) { return (C + 7) & ~7; }
 constexpr size_t tail_lds_floats(int C)
 {
     return (size_t)tail_cpad(C) * (TAIL_D + 1) + 4 * TAIL_R * TAIL_D + 4 * TAIL_R * TAIL_CMAX + TAIL_R * TAIL_CMAX +
-           4 * TAIL_R + 2 * 8 * TAIL_R * TAIL_D;
+           4 * TAIL_R + 4 + 2 * 8 * TAIL_R * TAIL_D;
 }
 
 // ---- gather role ---------------------------------------------------------------------------------
@@ -203,7 +213,8 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     float *part = des + R * D;                    // [4][R][64]
     float *dls = part + 4 * R * TAIL_CMAX;        // [R][64]
     float *red = dls + R * TAIL_CMAX;             // [4*R]
-    float *big = red + 4 * R;                     // [2][8][R][256] split-reduction partial sums
+    float *lss = red + 4 * R;                     // [R] per-seed loss terms
+    float *big = lss + 4;                         // [2][8][R][256] split-reduction partial sums
     big = (float *)(((uintptr_t)big + 15) & ~(uintptr_t)15);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -289,7 +300,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         for (int w = 0; w < (NBH + 3) / 4; ++w) asm volatile("" : "+v"(mbits[w]));
         asm volatile("" : "+v"(xbits));
         if (half == 0) {
-            if (live) tail_store8(pagg + iw * D + cg * 8, am);
+            if (live) tail_store8_exact(pagg + iw * D + cg * 8, am);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xs[wave * D + cg * 8 + e] = live ? xraw.get(e) : 0.f;
@@ -309,13 +320,16 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         const int g = cg >> 4;
         const T *wt = pw2t + (int64_t)g * D * p.ldw2t + (cg & 15) * 8 + (int64_t)slot * 32 * p.ldw2t;
         const float *in = (g ? as : xs) + slot * 32;
+        // weight rows in flight per lane: 16 x 16 B (bf16); the fp32 instantiation takes half as many
+        // rows per batch so that it needs no more registers (it must not spill, see the note on dls)
+        constexpr int WB = sizeof(T) == 2 ? 16 : 8;
 #pragma unroll
-        for (int kb = 0; kb < 32; kb += 16) {
-            row8<T> w[16];
+        for (int kb = 0; kb < 32; kb += WB) {
+            row8<T> w[WB];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u].load(wt + (int64_t)(kb + u) * p.ldw2t);
+            for (int u = 0; u < WB; ++u) w[u].load(wt + (int64_t)(kb + u) * p.ldw2t);
 #pragma unroll
-            for (int u4 = 0; u4 < 16; u4 += 4) {
+            for (int u4 = 0; u4 < WB; u4 += 4) {
                 float4 iv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) iv[r] = *(const float4 *)(in + r * D + kb + u4);
@@ -399,7 +413,9 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         for (int r = 0; r < R; ++r) part[(wave * R + r) * TAIL_CMAX + lane] = s[r];
     }
     lds_barrier();
-    float acc_db = 0.f, acc_loss = 0.f;
+    // (d logits and the loss terms go to LDS at once and stay there until the partials are written at
+    // the end: as per-lane accumulators they lived across the whole input-gradient phase, and in the fp32
+    // instantiation hipcc spilled them to AGPRs INSIDE a divergent region -- lanes outside it lost them)
     {
         const int r = wave;                                   // R == 4 waves: wave r <-> row r
         const int64_t i = row0 + r;
@@ -414,8 +430,9 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         const float dl = ok ? (ex / den - ((int64_t)lane == my_target ? 1.f : 0.f)) * invB : 0.f;
         dls[r * TAIL_CMAX + lane] = dl;
         if (ok) p.preds[i * C + lane] = logit;
-        if (i < B && (int64_t)lane == my_target) acc_loss += -(logit - mx - logf(den));
-        acc_db += dl;
+        const int tl = (my_target >= 0 && my_target < C) ? (int)my_target : 0;
+        const float lt = __shfl(logit, tl, 64);                   // the target's logit (wave-uniform index)
+        if (lane == 0) lss[r] = (i < B && my_target >= 0 && my_target < C) ? -(lt - mx - logf(den)) : 0.f;
     }
     lds_barrier();
     float dz[R], zdz[R];
@@ -480,16 +497,17 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         const T *wx = pw2 + (int64_t)slot * 16 * p.ldw2 + cg * 8;
         const T *wn = wx + (int64_t)128 * p.ldw2;
         const float *dx = des + slot * 16, *dn = des + 128 + slot * 16;
+        constexpr int CB = sizeof(T) == 2 ? 8 : 4;
 #pragma unroll
-        for (int cb = 0; cb < 16; cb += 8) {
-            row8<T> a[8], b[8];
+        for (int cb = 0; cb < 16; cb += CB) {
+            row8<T> a[CB], b[CB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < CB; ++u) {
                 a[u].load(wx + (int64_t)(cb + u) * p.ldw2);
                 b[u].load(wn + (int64_t)(cb + u) * p.ldw2);
             }
 #pragma unroll
-            for (int u4 = 0; u4 < 8; u4 += 4) {
+            for (int u4 = 0; u4 < CB; u4 += 4) {
                 float4 vx[R], vn[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -543,7 +561,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         }
         float zb[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zb[q] = gz[q] * inv_n;
+        for (int q = 0; q < 8; ++q) zb[q] = tail_round<T>(gz[q] * inv_n);
         if (half == 0) {
             float o[8];
 #pragma unroll
@@ -559,20 +577,16 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
                 float o[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) o[q] = ((m >> q) & 1u) ? zb[q] : 0.f;
-                tail_store8(base + (int64_t)j * D, o);
+                tail_store8_exact(base + (int64_t)j * D, o);
             }
         }
     }
     // ---- 6. fc.bias / loss partials ----------------------------------------------------------------
-    part[wave * TAIL_CMAX + lane] = acc_db;
-    const float l = tail_wave_sum(acc_loss);
-    if (lane == 0) red[wave] = l;
-    lds_barrier();
-    if (wave == 0) {
+    if (wave == 0) {              // dls / lss: written before the barriers of the phases above, never since
         float *out = p.partial + (int64_t)blockIdx.x * ((int64_t)C * D + C + 1);
         if (lane < C)
-            out[C * D + lane] = (part[lane] + part[TAIL_CMAX + lane]) + (part[2 * TAIL_CMAX + lane] + part[3 * TAIL_CMAX + lane]);
-        if (lane == 0) out[C * D + C] = (red[0] + red[1]) + (red[2] + red[3]);
+            out[C * D + lane] = (dls[lane] + dls[TAIL_CMAX + lane]) + (dls[2 * TAIL_CMAX + lane] + dls[3 * TAIL_CMAX + lane]);
+        if (lane == 0) out[C * D + C] = (lss[0] + lss[1]) + (lss[2] + lss[3]);
     }
 }
 

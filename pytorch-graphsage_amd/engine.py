@@ -804,7 +804,7 @@ class FusedMeanTrainStep(object):
 
     def last_launch_ms(self):
         cl = self.g_queue[(self._qstep - 1) % 2].cl
-        out = {"gather": cl.elapsed_ms(0, 1)}
+        out = {"gather": cl.elapsed_ms(0, 1), "event_overhead": cl.elapsed_ms(4, 5)}
         if self.fused_tail:
             out["seed_level"] = cl.elapsed_ms(2, 3)
         return out
@@ -850,6 +850,8 @@ class FusedMeanTrainStep(object):
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
                            hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
         self._mark(1)
+        self._mark(4)          # an empty interval: what one event record itself adds to a bracketed launch
+        self._mark(5)
 
     def _queue_compute(self, par):
         if self._tail_rows:
@@ -1022,7 +1024,9 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
             return False
         if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
             return False
-        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda or feats.ld % 64 != 0:
+        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda:
+            return False
+        if feats.ld % (64 if feats.dtype == torch.bfloat16 else 4) != 0:      # whole lines for the LDS-DMA kernels
             return False
         if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
             return False

@@ -28,7 +28,7 @@ def test_device_and_library():
     info = nat.device_info()
     assert info is not None and info["arch"].startswith("gfx950"), info
     assert info["wave_size"] == 64
-    assert nat.lib().gsage_abi_version() == 1
+    assert nat.lib().gsage_abi_version() == nat.ABI_VERSION
 
 
 def test_sampler_sel_bit_exact_all_golden_cases():
