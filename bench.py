@@ -178,8 +178,8 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
 def dominant_kernel_roofline(eng, store, n_steps=64):
     """Roofline object of the step's dominant launch, measured in place.
 
-    The queue-mode command lists are re-recorded with HIP-event marks (gsage_cmdlist_mark) around
-    k_gather_multi_adam -- the launch that gathers the next batch's level-0 rows (Adam of the current
+    The queue-mode command lists are re-recorded with HIP start / stop events attached to the dispatch
+    (gsage_cmdlist_time_next) of k_gather_multi_adam -- the launch that gathers the next batch's level-0 rows (Adam of the current
     batch and the sampler of the batch after ride along) -- and around the seed-level launch whose
     spare workgroups gather the first part of the last hop.  n_steps real steps follow (every step a
     fresh frontier, the events are recorded on the stream the step runs on, one host sync per step to
@@ -192,22 +192,17 @@ def dominant_kernel_roofline(eng, store, n_steps=64):
     for _ in range(4):
         eng.step_queue()
     torch.cuda.synchronize()
-    g_ms, t_ms, o_ms = [], [], []
+    g_ms, t_ms = [], []
     for _ in range(n_steps):
         eng.step_queue()
         d = eng.last_launch_ms()
         g_ms.append(d["gather"])
         t_ms.append(d.get("seed_level", 0.0))
-        o_ms.append(d["event_overhead"])
     eng.instrument(False)
     torch.cuda.synchronize()
     elem = store.data.element_size()
     rows_g, rows_t = eng.gather_launch_rows()
-    # an interval between two event records contains one record's own processing: the empty interval
-    # recorded in the same list measures it, and it is subtracted from the bracketed launches
-    o_us = float(np.mean(o_ms)) * 1e3
-    g_raw_us, t_raw_us = float(np.mean(g_ms)) * 1e3, float(np.mean(t_ms)) * 1e3
-    g_us, t_us = g_raw_us - o_us, max(t_raw_us - o_us, 0.0)
+    g_us, t_us = float(np.mean(g_ms)) * 1e3, float(np.mean(t_ms)) * 1e3
     alg = rows_g * store.dim * elem
     achieved = alg / (g_us * 1e-6) / 1e9
     traffic, twrite, src = None, None, None
@@ -221,9 +216,9 @@ def dominant_kernel_roofline(eng, store, n_steps=64):
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_write": twrite, "traffic_source": src,
            "alg_bytes_per_launch": alg, "rows_per_launch": rows_g, "avg_launch_us": g_us,
-           "avg_launch_us_raw": g_raw_us, "event_overhead_us": o_us, "timed_steps": n_steps,
-           "method": "HIP events recorded in the step's command list around the launch, minus the empty "
-                     "event interval recorded in the same list"}
+           "timed_steps": n_steps,
+           "method": "HIP start/stop events attached to the launch's dispatch inside the step's command list "
+                     "(hipExtLaunchKernel), one read per step"}
     if rows_t:
         out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
                                     "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * store.dim * elem,

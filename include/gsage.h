@@ -82,6 +82,11 @@ int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
 int gsage_cmdlist_begin(void);
 int gsage_cmdlist_end(void **list);
 int gsage_cmdlist_mark(int slot);
+/*   gsage_cmdlist_time_next(a, b)    [host] while recording: the NEXT recorded kernel is dispatched with
+ *                                    start event a and stop event b attached to the dispatch itself
+ *                                    (hipExtLaunchKernel): gsage_cmdlist_elapsed(l, a, b) is then that
+ *                                    kernel's own duration -- no event packets before or after it. */
+int gsage_cmdlist_time_next(int slot_a, int slot_b);
 int gsage_cmdlist_elapsed(const void *list, int slot_a, int slot_b, float *ms);
 int64_t gsage_cmdlist_size(const void *list);
 int gsage_cmdlist_replay(const void *list, void *stream);

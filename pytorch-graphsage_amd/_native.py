@@ -33,6 +33,7 @@ SIGNATURES = {
     "gsage_cmdlist_begin": (_int, []),
     "gsage_cmdlist_end": (_int, [ctypes.POINTER(_vp)]),
     "gsage_cmdlist_mark": (_int, [_int]),
+    "gsage_cmdlist_time_next": (_int, [_int, _int]),
     "gsage_cmdlist_elapsed": (_int, [_vp, _int, _int, ctypes.POINTER(_f32)]),
     "gsage_cmdlist_size": (_i64, [_vp]),
     "gsage_cmdlist_replay": (_int, [_vp, _vp]),

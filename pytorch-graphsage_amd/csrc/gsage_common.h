@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
@@ -52,6 +53,7 @@ struct CmdList {
     std::vector<std::function<void(hipStream_t)>> nodes;
     hipEvent_t marks[CMDLIST_MARKS] = {};      // gsage_cmdlist_mark: events recorded between kernels
     int64_t n_marks = 0;                       // mark nodes in `nodes` (not counted as kernel launches)
+    int time_a = -1, time_b = -1;              // gsage_cmdlist_time_next: events for the next recorded kernel
     ~CmdList()
     {
         for (int i = 0; i < CMDLIST_MARKS; ++i)
@@ -67,6 +69,18 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
     static_assert(sizeof...(KArgs) == sizeof...(Args), "launch: argument count mismatch");
     if (t_recording) {
         std::tuple<KArgs...> packed(static_cast<KArgs>(args)...);
+        if (t_recording->time_a >= 0) {
+            // gsage_cmdlist_time_next: this kernel's dispatch carries a start and a stop event (the
+            // timestamps of the dispatch itself, what a kernel trace reports), nothing else changes
+            hipEvent_t ea = t_recording->marks[t_recording->time_a], eb = t_recording->marks[t_recording->time_b];
+            t_recording->time_a = t_recording->time_b = -1;
+            t_recording->nodes.emplace_back([kernel, grid, block, lds, packed, ea, eb](hipStream_t s) {
+                std::apply([&](const KArgs &...a) {
+                    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, ea, eb, 0u, a...);
+                }, packed);
+            });
+            return;
+        }
         t_recording->nodes.emplace_back([kernel, grid, block, lds, packed](hipStream_t s) {
             std::apply([&](const KArgs &...a) { hipLaunchKernelGGL(kernel, grid, block, lds, s, a...); },
                        packed);

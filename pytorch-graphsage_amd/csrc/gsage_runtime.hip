@@ -111,6 +111,24 @@ int gsage_cmdlist_mark(int slot)
     return GSAGE_OK;
 }
 
+int gsage_cmdlist_time_next(int slot_a, int slot_b)
+{
+    GSAGE_REQUIRE(t_recording, "cmdlist_time_next: no recording in progress on this thread");
+    GSAGE_REQUIRE(slot_a >= 0 && slot_a < CMDLIST_MARKS && slot_b >= 0 && slot_b < CMDLIST_MARKS && slot_a != slot_b,
+                  "cmdlist_time_next: two different slots in [0, %d)", CMDLIST_MARKS);
+    CmdList *l = t_recording;
+    for (int slot : {slot_a, slot_b})
+        if (!l->marks[slot] && hipEventCreate(&l->marks[slot]) != hipSuccess) {
+            (void)hipGetLastError();
+            l->marks[slot] = nullptr;
+            set_error("cmdlist_time_next: hipEventCreate failed");
+            return GSAGE_ELAUNCH;
+        }
+    l->time_a = slot_a;
+    l->time_b = slot_b;
+    return GSAGE_OK;
+}
+
 int gsage_cmdlist_elapsed(const void *list, int slot_a, int slot_b, float *ms)
 {
     GSAGE_REQUIRE(list && ms, "cmdlist_elapsed: null pointer");

@@ -609,7 +609,7 @@ class FusedMeanTrainStep(object):
         if self.fused_tail:
             C = m.fc.weight.shape[0]
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
-            self._mark(2)
+            self._time_next(2, 3)
             nat.check(lib.gsage_mean_tail_ce(
                 self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
                 self.w2[L - 1].shape[2], self.w2t[L - 1].data_ptr(), self.w2t[L - 1].shape[2],
@@ -619,7 +619,6 @@ class FusedMeanTrainStep(object):
                 self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
                 ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
                 stream), "mean_tail_ce")
-            self._mark(3)
         elif self.fused_head:
             C, D2 = m.fc.weight.shape
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
@@ -794,24 +793,25 @@ class FusedMeanTrainStep(object):
 
     def instrument(self, on=True):
         """Measurement only (bench.py's roofline object): re-record the queue-mode command lists with
-        HIP-event marks around the step's dominant launch -- the one that gathers the next batch's
-        level-0 rows (marks 0/1) -- and around the seed-level launch that carries the first part of
-        those gathers (marks 2/3).  `last_launch_ms()` then returns their durations for the step just
-        replayed, timed in place on the stream the step runs on."""
+        HIP start / stop events attached to the dispatch of the step's dominant launch -- the one that
+        gathers the next batch's level-0 rows (events 0/1) -- and of the seed-level launch that carries
+        the first part of those gathers (events 2/3).  `last_launch_ms()` then returns their durations
+        for the step just replayed: timed in place, on the stream the step runs on."""
         assert self.queue is not None and self.capture_mode == "cmdlist" and self.ddp is None
         self._marks = bool(on)
         self._record_queue()
 
     def last_launch_ms(self):
         cl = self.g_queue[(self._qstep - 1) % 2].cl
-        out = {"gather": cl.elapsed_ms(0, 1), "event_overhead": cl.elapsed_ms(4, 5)}
+        out = {"gather": cl.elapsed_ms(0, 1)}
         if self.fused_tail:
             out["seed_level"] = cl.elapsed_ms(2, 3)
         return out
 
-    def _mark(self, slot):
+    def _time_next(self, a, b):
+        """While recording an instrumented list: attach start / stop events a, b to the next kernel."""
         if getattr(self, "_marks", False) and self.capture_mode == "cmdlist":
-            nat.check(nat.lib().gsage_cmdlist_mark(slot), "cmdlist_mark")
+            nat.check(nat.lib().gsage_cmdlist_time_next(a, b), "cmdlist_time_next")
 
     def gather_launch_rows(self):
         """(rows the queue-mode gather launch reads, rows the seed-level launch's gather role reads) per
@@ -846,12 +846,9 @@ class FusedMeanTrainStep(object):
         self._stage_gather(0, ids=self.ids_q[0])
 
     def _queue_front(self, par, with_adam):
-        self._mark(0)
+        self._time_next(0, 1)
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
                            hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
-        self._mark(1)
-        self._mark(4)          # an empty interval: what one event record itself adds to a bracketed launch
-        self._mark(5)
 
     def _queue_compute(self, par):
         if self._tail_rows:
