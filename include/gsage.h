@@ -79,6 +79,14 @@ int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
  *                                    between marks a and b: how bench.py times ONE kernel of a step in
  *                                    place, on the stream it runs on (measurement only: a list with
  *                                    marks pays an event record per mark). */
+/*   gsage_stream_create_masked      [host] a HIP stream whose kernels run on the compute units set in
+ *                                    cu_mask only (bit n = CU n of the device, `words` x 32 bits): how
+ *                                    the engines give the weight-independent, HBM-bound gathers of the
+ *                                    NEXT batch and the latency-bound forward / backward chain of the
+ *                                    current batch disjoint halves of the chip, so that the two really
+ *                                    run side by side.  gsage_stream_destroy frees it. */
+int gsage_stream_create_masked(const uint32_t *cu_mask, int32_t words, void **stream);
+int gsage_stream_destroy(void *stream);
 int gsage_cmdlist_begin(void);
 int gsage_cmdlist_end(void **list);
 int gsage_cmdlist_mark(int slot);

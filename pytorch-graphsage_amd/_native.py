@@ -30,6 +30,8 @@ SIGNATURES = {
     "gsage_last_error": (ctypes.c_char_p, []),
     "gsage_launch_count": (_u64, []),
     "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "gsage_stream_create_masked": (_int, [_vp, _i32, ctypes.POINTER(_vp)]),
+    "gsage_stream_destroy": (_int, [_vp]),
     "gsage_cmdlist_begin": (_int, []),
     "gsage_cmdlist_end": (_int, [ctypes.POINTER(_vp)]),
     "gsage_cmdlist_mark": (_int, [_int]),
@@ -222,6 +224,17 @@ class _Recorder(object):
         if et is None:
             check(rc, "cmdlist_end")
         return False
+
+
+def masked_stream(cu_bits):
+    """HIP stream restricted to the CUs whose indices are in cu_bits -> raw stream handle (int)."""
+    words = (max(cu_bits) + 32) // 32
+    mask = (_u32 * words)()
+    for b in cu_bits:
+        mask[b // 32] |= 1 << (b % 32)
+    h = _vp()
+    check(lib().gsage_stream_create_masked(mask, words, ctypes.byref(h)), "stream_create_masked")
+    return h.value
 
 
 def device_info():

@@ -440,7 +440,7 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
     if (adam) {
         rc = fill_adam(a, *adam);
         if (rc != GSAGE_OK) return rc;
-        n_adam = adam_grid(adam->n, 2048);
+        n_adam = adam_grid(a.n_prep > 0 ? ceil_div(adam->n, 4) : adam->n, 2048);
         GSAGE_REQUIRE(!hops || (adam->tick1 != (int64_t *)hops->call_ctr && adam->tick2 != (int64_t *)hops->batch_idx) ||
                       (!adam->tick1 && !adam->tick2),
                       "gather_mean_multi_adam: the update may not tick a counter the sampler reads");

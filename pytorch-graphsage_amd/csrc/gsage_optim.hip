@@ -480,7 +480,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     AdamParams a;
     rc = fill_adam(a, d);
     if (rc != GSAGE_OK) return rc;
-    launch(k_adam_clip, dim3(adam_grid(n, 2048)), dim3(256), 0, s, a);
+    launch(k_adam_clip, dim3(adam_grid(a.n_prep > 0 ? ceil_div(n, 4) : n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;
     if (!step_is_current) {

@@ -110,26 +110,40 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         }
         return;
     }
-    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride) {
-        float g = a.g[i] * coef;
-        if (clipped) a.g[i] = g;                        // clipped gradient stays visible (p.grad)
-        float p = a.p[i];
-        if (a.weight_decay != 0.f) g += a.weight_decay * p;
-        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
-        const float pn = p - step_size * (m / denom);
-        a.p[i] = pn;
-        // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
-        for (int d = 0; d < a.n_prep; ++d) {
-            const PrepDesc &q = a.prep[d];
-            const int64_t o = i - (q.src - a.p);
-            if (o >= 0 && o < (int64_t)q.rows * q.cols) {
-                const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
-                prep_store(q, r, c, pn);
-                break;
+    // four elements per thread and trip, their 16 loads in flight together: a quarter of the workgroups
+    // (each a chain of dependent round trips: partials -> norm -> loads -> stores) for the same update
+    for (int64_t i0 = (int64_t)bx * 256 + threadIdx.x; i0 < a.n; i0 += 4 * stride) {
+        float gv[4], pv[4], mv[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            const int64_t ic = i < a.n ? i : i0;
+            gv[u] = a.g[ic]; pv[u] = a.p[ic]; mv[u] = a.m[ic]; vv[u] = a.v[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= a.n) continue;
+            float g = gv[u] * coef;
+            if (clipped) a.g[i] = g;                    // clipped gradient stays visible (p.grad)
+            const float p = pv[u];
+            if (a.weight_decay != 0.f) g += a.weight_decay * p;
+            const float m = a.beta1 * mv[u] + (1.f - a.beta1) * g;
+            const float v = a.beta2 * vv[u] + (1.f - a.beta2) * g * g;
+            a.m[i] = m;
+            a.v[i] = v;
+            const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
+            const float pn = p - step_size * (m / denom);
+            a.p[i] = pn;
+            // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
+            for (int d = 0; d < a.n_prep; ++d) {
+                const PrepDesc &q = a.prep[d];
+                const int64_t o = i - (q.src - a.p);
+                if (o >= 0 && o < (int64_t)q.rows * q.cols) {
+                    const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
+                    prep_store(q, r, c, pn);
+                    break;
+                }
             }
         }
     }

@@ -151,4 +151,28 @@ void gsage_cmdlist_destroy(void *list)
     delete (CmdList *)list;
 }
 
+int gsage_stream_create_masked(const uint32_t *cu_mask, int32_t words, void **stream)
+{
+    GSAGE_REQUIRE(cu_mask && words > 0 && stream, "stream_create_masked: bad arguments");
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("stream_create_masked: %s", hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
+    *stream = (void *)s;
+    return GSAGE_OK;
+}
+
+int gsage_stream_destroy(void *stream)
+{
+    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("stream_destroy failed");
+        return GSAGE_ELAUNCH;
+    }
+    return GSAGE_OK;
+}
+
 }  // extern "C"

@@ -314,17 +314,20 @@ class FusedMeanTrainStep(object):
             assert inb == ix + 1, "fc_x / fc_neib must be adjacent in the parameter order"
             w2 = torch.zeros(2, h, _r8(din), dtype=self.tdt, device=dev)
             w2t = torch.zeros(2, din, _r8(h), dtype=self.tdt, device=dev) if l > 0 else None
+            tail_level = self._will_fuse_tail(example_targets) and l == L - 1
             self.w2.append(w2)
             self.w2t.append(w2t)
             # levels whose forward runs on K5 read the weights in MFMA fragment order
             # (gsage_linear_nt_packed; needs whole-line operand rows); the seed-level kernel reads w2
             lda = feats.ld if l == 0 else din
-            packed = self.code == nat.BF16 and lda % 64 == 0 and lda >= -(-din // 64) * 64
+            # the fragment-ordered copy feeds K5's forward; the seed-level kernel reads w2 / w2t instead
+            packed = (self.code == nat.BF16 and lda % 64 == 0 and lda >= -(-din // 64) * 64 and not tail_level)
             gstride = nat.lib().gsage_packed_weight_elems(h, din, 1)
             wp = torch.zeros(2 * gstride, dtype=torch.bfloat16, device=dev) if packed else None
             self.wp.append(wp)
             for g, prm in enumerate((layer.fc_x.weight, layer.fc_neib.weight)):
-                descs.append(_PrepDesc(prm.data_ptr(), w2[g].data_ptr(),
+                # (a copy nobody reads is not refreshed: w2 serves the unpacked K5 and the seed-level kernel)
+                descs.append(_PrepDesc(prm.data_ptr(), w2[g].data_ptr() if (not packed or tail_level) else None,
                                        w2t[g].data_ptr() if w2t is not None else None,
                                        h, din, w2.shape[2], w2t.shape[2] if w2t is not None else 0,
                                        wp[g * gstride:].data_ptr() if packed else None, 4 * (-(-din // 64)),
@@ -354,19 +357,28 @@ class FusedMeanTrainStep(object):
         self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
 
 
+    def _will_fuse_head(self, example_targets):
+        from .problem import ProblemLosses
+        C, D2 = self.model.fc.weight.shape
+        probe = torch.randn(3, 4, device=self.dev)
+        ident = self.post is None or torch.equal(self.post(probe), probe)
+        return bool(self.loss_fn is ProblemLosses.classification and ident and C <= 64 and D2 <= 1024 and
+                    example_targets.dtype == torch.int64)
+
+    def _will_fuse_tail(self, example_targets):
+        """The seed level (segment mean + GEMM + head + input gradients + mask/route) as ONE kernel?"""
+        L = self.L
+        hs = [l.output_dim_ for l in self.layers]
+        return bool(type(self) is FusedMeanTrainStep and self._will_fuse_head(example_targets) and L >= 2 and
+                    2 * hs[L - 2] == 256 and 2 * hs[L - 1] == 256 and self.fan[1] <= 32 and
+                    os.environ.get("GSAGE_NO_FUSED_TAIL", "0") != "1")
+
     def _init_head(self, loss_fn, example_targets):
         """Classification head as one fused kernel pair when it applies (else stock torch autograd)."""
-        from .problem import ProblemLosses
         model, dev, L, B = self.model, self.dev, self.L, self.B
         C, D2 = model.fc.weight.shape
-        probe = torch.randn(3, 4, device=dev)
-        ident = self.post is None or torch.equal(self.post(probe), probe)
-        self.fused_head = (loss_fn is ProblemLosses.classification and ident and C <= 64 and
-                           D2 <= 1024 and example_targets.dtype == torch.int64)
-        # the seed level (segment mean + GEMM + head + input gradients + mask/route) as ONE kernel
-        self.fused_tail = bool(self.fused_head and L >= 2 and self.din[L - 1] == 256 and
-                               2 * self.h[L - 1] == 256 and self.fan[1] <= 32 and
-                               os.environ.get("GSAGE_NO_FUSED_TAIL", "0") != "1")
+        self.fused_head = self._will_fuse_head(example_targets)
+        self.fused_tail = self._will_fuse_tail(example_targets)
         if self.fused_head:
             assert nat.lib().gsage_head_ce_scratch(B, C, D2) == nat.lib().gsage_mean_tail_ce_scratch(B, C) \
                 or not self.fused_tail
