@@ -396,7 +396,7 @@ int64_t gsage_head_ce_scratch(int32_t B, int32_t C, int32_t D);
  * C <= 64.
  * gather (may be NULL): B / 4 workgroups of ~22 us of dependent phases leave half of the chip idle at
  * B = 512, so n_workgroups extra workgroups of the same launch compute rows [0, rows) of a
- * gsage_gather_mean segment (bf16 table and output, fan-out n = 10) -- part of the NEXT batch's
+ * gsage_gather_mean segment (bf16 table and output, fan-out n = 5, 10 or 15) -- part of the NEXT batch's
  * level-0 gather, which that launch then skips.  Results are those of gsage_gather_mean. */
 typedef struct gsage_tail_gather_desc {
     const void *table;

@@ -628,7 +628,8 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     TailGather tg = {};
     const bool fused = gather && gather->rows > 0;
     if (fused) {
-        GSAGE_REQUIRE(gather->n == 10, "mean_tail_ce: the gather role is built for fan-out 10");
+        GSAGE_REQUIRE(gather->n == 5 || gather->n == 10 || gather->n == 15,
+                      "mean_tail_ce: the gather role is built for fan-outs 5, 10 and 15");
         GSAGE_REQUIRE(gather->table && gather->ids && gather->out && gather->D > 0 && gather->ld % 8 == 0 &&
                       gather->out_ld % 8 == 0 && ceil_div(gather->D, 8) * 8 <= gather->ld &&
                       ceil_div(gather->D, 8) * 8 <= gather->out_ld && gather->n_workgroups > 0 &&
@@ -640,13 +641,16 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     }
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
     const int small = n <= 16;
+    const int gn = fused ? gather->n : 0;
     void (*kern)(const TailParams, const TailGather) =
         dtype == GSAGE_F32 ? (small ? k_mean_tail_ce<float, 8, 0> : k_mean_tail_ce<float, 16, 0>)
-        : fused ? (small ? k_mean_tail_ce<uint16_t, 8, 10> : k_mean_tail_ce<uint16_t, 16, 10>)
-                : (small ? k_mean_tail_ce<uint16_t, 8, 0> : k_mean_tail_ce<uint16_t, 16, 0>);
+        : gn == 10 ? (small ? k_mean_tail_ce<uint16_t, 8, 10> : k_mean_tail_ce<uint16_t, 16, 10>)
+        : gn == 5 ? (small ? k_mean_tail_ce<uint16_t, 8, 5> : k_mean_tail_ce<uint16_t, 16, 5>)
+        : gn == 15 ? (small ? k_mean_tail_ce<uint16_t, 8, 15> : k_mean_tail_ce<uint16_t, 16, 15>)
+                   : (small ? k_mean_tail_ce<uint16_t, 8, 0> : k_mean_tail_ce<uint16_t, 16, 0>);
     {   // more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
-        static bool raised[6] = {false, false, false, false, false, false};
-        const int slot = dtype == GSAGE_F32 ? 4 + small : small + 2 * (int)fused;
+        static bool raised[10] = {false, false, false, false, false, false, false, false, false, false};
+        const int slot = dtype == GSAGE_F32 ? 8 + small : small + 2 * (gn == 10 ? 1 : gn == 5 ? 2 : gn == 15 ? 3 : 0);
         if (!raised[slot]) {
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * tail_lds_floats(TAIL_CMAX) + 16)) != hipSuccess) {

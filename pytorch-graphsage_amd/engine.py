@@ -835,17 +835,19 @@ class FusedMeanTrainStep(object):
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
         gathers (0: none)."""
-        if not getattr(self, "fused_tail", False) or self.L != 2 or self.fan[2] != 10 or self.code != nat.BF16:
+        if not getattr(self, "fused_tail", False) or self.fan[self.L] not in (5, 10, 15) or self.code != nat.BF16:
             return 0
         n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
         n_idle = n_cu - (self.B + 3) // 4                 # one seed-level workgroup per CU
         if n_idle < 32:
             return 0
-        # what an idle CU moves while the ~27 us launch lasts does not depend on B: ~40 rows of ten
-        # neighbours each (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs)
+        # what an idle CU moves while the ~27 us launch lasts does not depend on B: ~480 KB, i.e. ~40
+        # means of ten 1.2 KB rows (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs);
+        # other row sizes / fan-outs get the same bytes per idle CU
         frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.4"))
         self._tail_wgs = n_idle
-        return min(int(self.size[1]), max(int(100.0 * frac * n_idle), 0))
+        per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
+        return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
 
     # the queue pipeline's pieces; par = parity of the step: batch i+1 is gathered from ids_q[1 - par]
     # (into operand set 1 - par when the sets alternate) while batch i+2 is sampled into ids_q[par]

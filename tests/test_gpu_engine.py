@@ -163,7 +163,8 @@ def test_pipelined_engine_is_bit_identical_to_sequential(capture):
     assert torch.equal(outs[False][1], outs[True][1])
 
 
-@pytest.mark.parametrize("B,fans", [(24, (5, 3)), (40, (25, 10)), (800, (25, 10))])
+@pytest.mark.parametrize("B,fans", [(24, (5, 3)), (40, (25, 10)), (800, (25, 10)), (40, (6, 5)), (40, (7, 15)),
+                                    (24, (4, 3, 5))])
 @pytest.mark.parametrize("capture", [False, "cmdlist", "graph"])
 def test_batch_queue_equals_per_step_copies(capture, B, fans):
     """step_queue (batch i+2 sampled and batch i+1 gathered in the launch that applies Adam(i)) is
@@ -171,7 +172,7 @@ def test_batch_queue_equals_per_step_copies(capture, B, fans):
     (25, 10) also moves hop-2 rows of the next batch into the seed-level launch: all of them at
     B = 40 (the gather launch's segment disappears), about a tenth at B = 800 (56 idle CUs on an MI355X)."""
     adj, feats, rng = _problem(seed=4)
-    D, C, dims = feats.shape[1], 5, (128, 128)
+    D, C, dims = feats.shape[1], 5, (128,) * len(fans)
     store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
     ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
     tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
@@ -189,6 +190,8 @@ def test_batch_queue_equals_per_step_copies(capture, B, fans):
             for k in range(7):
                 preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
         res.append((torch.stack(preds), eng.flat_p.clone()))
+        if queued and fans[-1] in (5, 10, 15):
+            assert eng._tail_rows > 0              # the seed-level launch carried part of the last hop's means
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
