@@ -304,6 +304,98 @@ def pool_kernel_roofline(gs, model, store, data, dev, reps=20, n_frontiers=4):
             "traffic": None, "alg_flops_per_launch": flops, "avg_launch_us": dur_s * 1e6}
 
 
+def _lognormal_graph(gs, n_nodes, mu, sigma, max_deg, seed=0):
+    from scipy import sparse
+    rng = np.random.default_rng(seed)
+    deg = np.clip(np.exp(rng.normal(mu, sigma, size=n_nodes + 1)).astype(np.int64), 1, max_deg)
+    deg[0], deg[1] = 0, max_deg
+    indptr = np.zeros(n_nodes + 2, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    data = rng.integers(1, n_nodes + 1, size=int(indptr[-1]), dtype=np.int32)
+    adj = sparse.csr_matrix((data, gs.store.row_positions(indptr), indptr), shape=(n_nodes + 1, max_deg))
+    adj.has_sorted_indices = True
+    return adj, rng
+
+
+def _timed_steps(step, n_warm, n_steps):
+    for k in range(n_warm):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n_warm, n_warm + n_steps):
+        step(k)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_steps
+
+
+def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=8_000_000, B=BATCH):
+    """BASELINE configs[4] at its SHAPE on one GPU: mean aggregator, three layers, fan-out 15/10/5, 128-d
+    bf16 features, synthetic graph of n_nodes nodes (~28 neighbours on average; the full 111 M-node table is
+    28 GB and would fit, building a 3.2e9-edge CSR on the host takes minutes).  Parity of this shape:
+    tests/test_gpu_large.py (8.4 M nodes, int64 row offsets) and the 3-layer golden fixtures."""
+    from torch.nn import functional as F
+    adj, rng = _lognormal_graph(gs, n_nodes, 2.6, 1.2, 30_000)
+    feats = torch.zeros(n_nodes + 1, 128, dtype=torch.bfloat16, device=dev)
+    feats[1:] = torch.randn(n_nodes, 128, device=dev).bfloat16()
+    store = gs.FeatureStore(feats, 128)
+    fan, dims = (15, 10, 5), (128, 128, 128)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": (lambda x: x) if i == 2 else F.relu} for i, (f, h) in enumerate(zip(fan, dims))]
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+                            prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup["mean"],
+                            input_dim=128, n_nodes=adj.shape[0], n_classes=N_CLASSES, layer_specs=specs,
+                            lr_init=0.01).to(dev)
+    model.train_sampler.seed = 123
+    model.train_sampler.csr(dev)
+    total = steps + warmup
+    ids = torch.from_numpy(rng.integers(1, n_nodes + 1, size=(total, B))).to(dev)
+    tg = torch.from_numpy(rng.integers(0, N_CLASSES, size=(total, B, 1))).to(dev)
+    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids[0], tg[0])
+    eng.load_epoch(ids, tg)
+    dt = _timed_steps(lambda k: eng.step_queue(), warmup, steps)
+    model.train_sampler.csr(dev).check()
+    rows = 1 + 15 + 150 + 750
+    return {"config": "BASELINE configs[4] shape at %d nodes (nnz=%d): mean, 3 layers, fan-out 15/10/5, 128-d bf16 "
+                      "features, one GPU" % (n_nodes, adj.nnz),
+            "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec", "engine": "FusedMeanTrainStep",
+            "alg_bytes_per_seed": rows * 128 * 2,
+            "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2))}
+
+
+def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH):
+    """BASELINE configs[3] at its SHAPE on one GPU: Pokec-sized graph (1.63 M nodes, ~6e7 edges), no features,
+    trainable 64-d node embeddings (node_embedding prep), attention aggregator (hidden 32), fan-out 20/15,
+    regression_mae.  The step keeps the reference's DENSE embedding-gradient semantics: clip and Adam run
+    over the whole 418 MB table every step (dense_table_bytes_per_step is that mandatory traffic)."""
+    from torch.nn import functional as F
+    N = 1_632_803
+    adj, rng = _lognormal_graph(gs, N, 3.0, 1.1, 8_763)
+    fan, dims = (20, 15), (128, 128)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": (lambda x: x) if i == 1 else F.relu} for i, (f, h) in enumerate(zip(fan, dims))]
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+                            prep_class=gs.prep_lookup["node_embedding"],
+                            aggregator_class=gs.aggregator_lookup["attention"], input_dim=None,
+                            n_nodes=adj.shape[0], n_classes=1, layer_specs=specs, lr_init=0.01).to(dev)
+    model.train_sampler.seed = 123
+    model.train_sampler.csr(dev)
+    total = steps + warmup
+    ids = torch.from_numpy(rng.integers(1, N + 1, size=(total, B))).to(dev)
+    tg = torch.from_numpy(rng.integers(15, 60, size=(total, B, 1)).astype(np.float32)).to(dev)
+    loss_fn = gs.ProblemLosses.regression_mae
+    step_fn = gs.engine.CapturedTrainStep(model, None, loss_fn, ids[0], tg[0])
+    dt = _timed_steps(lambda k: step_fn(ids[k], tg[k]), warmup, steps)
+    model.train_sampler.csr(dev).check()
+    rows = 1 + 20 + 300
+    return {"config": "BASELINE configs[3] shape on one GPU: Pokec-sized graph (N=%d, nnz=%d), node_embedding(64) + "
+                      "attention(32), fan-out 20/15, regression_mae" % (N, adj.nnz),
+            "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec",
+            "engine": "CapturedTrainStep (native K4 / K5 / K5b / K6 kernels under autograd, hipGraph)",
+            "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2)}
+
+
 def _free_port():
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
@@ -355,9 +447,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool",
-                    help="comma-separated additional aggregators measured after the main line (N=1 only) "
-                         "and reported under `extra`; '' for none")
+    ap.add_argument("--extra", type=str, default="max_pool,papers,pokec",
+                    help="comma-separated additional configurations measured after the main line (N=1 only) and "
+                         "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
+                         "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -517,7 +610,8 @@ def main():
         if world == 1:
             del res, step_fn, model
             torch.cuda.empty_cache()
-            for agg in [a for a in args.extra.split(",") if a and a != args.aggregator]:
+            names = [a for a in args.extra.split(",") if a and a != args.aggregator]
+            for agg in [a for a in names if a not in ("papers", "pokec")]:
                 r2 = measure(agg, min(args.min_time, 0.3))
                 e2 = r2["elapsed"]
                 rec = {"config": "BASELINE configs[2] shape on one GPU" if agg == "max_pool" else agg,
@@ -529,6 +623,15 @@ def main():
                 extra[agg] = rec
                 del r2
                 torch.cuda.empty_cache()
+            store = None                         # the other shapes bring their own graphs and tables
+            torch.cuda.empty_cache()
+            for name, fn in (("papers", extra_papers), ("pokec", extra_pokec)):
+                if name in names:
+                    try:
+                        extra[name] = fn(gs, dev)
+                    except Exception as e:                      # never lose the main line to an extra
+                        extra[name] = {"error": repr(e)}
+                    torch.cuda.empty_cache()
         line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)

@@ -87,6 +87,17 @@ int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
  *                                    run side by side.  gsage_stream_destroy frees it. */
 int gsage_stream_create_masked(const uint32_t *cu_mask, int32_t words, void **stream);
 int gsage_stream_destroy(void *stream);
+/*   gsage_event_create / _destroy   [host] a HIP event without timing, for ordering between streams.
+ *   gsage_cmdlist_replay_pair       [host] one step of a two-stream pipeline in one call: on stream b
+ *                                    {wait for event wait_b; replay list_b; record record_b}, then on
+ *                                    stream a {wait for wait_a; replay list_a; record record_a}; finally
+ *                                    then_wait_stream (may be NULL) is made to wait for record_b
+ *                                    (then_wait_on_b != 0) or record_a.  Events / lists may be NULL. */
+int gsage_event_create(void **event);
+void gsage_event_destroy(void *event);
+int gsage_cmdlist_replay_pair(const void *list_a, void *stream_a, void *wait_a, void *record_a,
+                              const void *list_b, void *stream_b, void *wait_b, void *record_b,
+                              void *then_wait_stream, int then_wait_on_b);
 int gsage_cmdlist_begin(void);
 int gsage_cmdlist_end(void **list);
 int gsage_cmdlist_mark(int slot);

@@ -32,6 +32,9 @@ SIGNATURES = {
     "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "gsage_stream_create_masked": (_int, [_vp, _i32, ctypes.POINTER(_vp)]),
     "gsage_stream_destroy": (_int, [_vp]),
+    "gsage_event_create": (_int, [ctypes.POINTER(_vp)]),
+    "gsage_event_destroy": (None, [_vp]),
+    "gsage_cmdlist_replay_pair": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "gsage_cmdlist_begin": (_int, []),
     "gsage_cmdlist_end": (_int, [ctypes.POINTER(_vp)]),
     "gsage_cmdlist_mark": (_int, [_int]),
@@ -234,6 +237,12 @@ def masked_stream(cu_bits):
         mask[b // 32] |= 1 << (b % 32)
     h = _vp()
     check(lib().gsage_stream_create_masked(mask, words, ctypes.byref(h)), "stream_create_masked")
+    return h.value
+
+
+def new_event():
+    h = _vp()
+    check(lib().gsage_event_create(ctypes.byref(h)), "event_create")
     return h.value
 
 

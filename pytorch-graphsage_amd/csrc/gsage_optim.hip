@@ -48,7 +48,17 @@ k_grad_sqnorm(const float *__restrict__ g, int64_t n, float *__restrict__ partia
     if ((n & 3) == 0 && ((uintptr_t)g & 15) == 0) {                     // 16-byte lanes
         typedef float v4 __attribute__((ext_vector_type(4)));
         const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        // four 16-byte loads in flight per lane: with one, the 418 MB gradient of a trainable embedding
+        // table (Pokec) streamed at 2.2 TB/s
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            v4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const v4 *>(g)[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+        }
+        for (; i < n4; i += stride) {
             const v4 v = reinterpret_cast<const v4 *>(g)[i];
             s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
@@ -322,11 +332,29 @@ k_pool_route_bwd(const float *__restrict__ g, int64_t ldg, const float *__restri
         const int c0 = (int)(t - i * chunks) * 8;
         uint16_t gb[8];
         int32_t am[8];
+        if (((ldg | ldp | lda) & 3) == 0 && ((((uintptr_t)g | (uintptr_t)pooled | (uintptr_t)argmax) & 15) == 0)) {
+            // 6 x 16-byte loads instead of 24 x 4-byte ones
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            f32x4 gv[2], pv[2];
+            i32x4 av[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool on = pooled[i * ldp + c0 + e] > 0.f;
-            gb[e] = on ? f32_to_bf16(g[i * ldg + c0 + e]) : (uint16_t)0;
-            am[e] = argmax[i * lda + c0 + e];
+            for (int h = 0; h < 2; ++h) {
+                gv[h] = *reinterpret_cast<const f32x4 *>(g + i * ldg + c0 + 4 * h);
+                pv[h] = *reinterpret_cast<const f32x4 *>(pooled + i * ldp + c0 + 4 * h);
+                av[h] = *reinterpret_cast<const i32x4 *>(argmax + i * lda + c0 + 4 * h);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gb[e] = pv[e >> 2][e & 3] > 0.f ? f32_to_bf16(gv[e >> 2][e & 3]) : (uint16_t)0;
+                am[e] = av[e >> 2][e & 3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool on = pooled[i * ldp + c0 + e] > 0.f;
+                gb[e] = on ? f32_to_bf16(g[i * ldg + c0 + e]) : (uint16_t)0;
+                am[e] = argmax[i * lda + c0 + e];
+            }
         }
         for (int j = 0; j < n; ++j) {
             vec16 o;

@@ -165,6 +165,53 @@ int gsage_stream_create_masked(const uint32_t *cu_mask, int32_t words, void **st
     return GSAGE_OK;
 }
 
+int gsage_event_create(void **event)
+{
+    GSAGE_REQUIRE(event, "event_create: null pointer");
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("event_create failed");
+        return GSAGE_ELAUNCH;
+    }
+    *event = (void *)e;
+    return GSAGE_OK;
+}
+
+void gsage_event_destroy(void *event)
+{
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+int gsage_cmdlist_replay_pair(const void *list_a, void *stream_a, void *wait_a, void *record_a,
+                              const void *list_b, void *stream_b, void *wait_b, void *record_b,
+                              void *then_wait_stream, int then_wait_on_b)
+{
+    GSAGE_REQUIRE(!t_recording, "cmdlist_replay_pair: cannot replay while recording");
+    GSAGE_REQUIRE(stream_a && stream_b && stream_a != stream_b, "cmdlist_replay_pair: needs two different streams");
+    hipError_t e = hipSuccess;
+    int rc = GSAGE_OK;
+    // stream b first: it carries the longer, latency-bound chain
+    if (wait_b) e = hipStreamWaitEvent((hipStream_t)stream_b, (hipEvent_t)wait_b, 0);
+    if (e == hipSuccess && list_b) rc = gsage_cmdlist_replay(list_b, stream_b);
+    if (rc != GSAGE_OK) return rc;
+    if (e == hipSuccess && record_b) e = hipEventRecord((hipEvent_t)record_b, (hipStream_t)stream_b);
+    if (e == hipSuccess && wait_a) e = hipStreamWaitEvent((hipStream_t)stream_a, (hipEvent_t)wait_a, 0);
+    if (e == hipSuccess && list_a) rc = gsage_cmdlist_replay(list_a, stream_a);
+    if (rc != GSAGE_OK) return rc;
+    if (e == hipSuccess && record_a) e = hipEventRecord((hipEvent_t)record_a, (hipStream_t)stream_a);
+    if (e == hipSuccess && then_wait_stream) {
+        hipEvent_t ev = (hipEvent_t)(then_wait_on_b ? record_b : record_a);
+        if (ev) e = hipStreamWaitEvent((hipStream_t)then_wait_stream, ev, 0);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("cmdlist_replay_pair: %s", hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
+    return GSAGE_OK;
+}
+
 int gsage_stream_destroy(void *stream)
 {
     if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {

@@ -213,8 +213,23 @@ class FusedMeanTrainStep(object):
         return all(l.output_dim_ % 8 == 0 for l in layers)
 
     def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
-                 warmup=2, pipelined=False):
-        assert type(self).supports(model, feats), "configuration not covered by this fused engine"
+                 warmup=2, pipelined=False, gather_cus=None):
+        """gather_cus (queue mode, single GPU, command lists): run the weight-independent half of the step
+        -- sampling of batch i+2 and the level-0 gathers of batch i+1 -- on a stream restricted to that many
+        compute units while the forward / backward / update chain of batch i runs on a stream restricted
+        to the others (see _split_* below).  None: GSAGE_GATHER_CUS from the environment, else off."""
+        if not type(self).supports(model, feats):
+            raise ValueError("%s does not cover this (model, feature store): see %s.supports"
+                             % (type(self).__name__, type(self).__name__))
+        if not (torch.is_tensor(example_ids) and example_ids.is_cuda and example_ids.dtype == torch.int64
+                and example_ids.dim() == 1):
+            raise ValueError("example_ids must be a CUDA int64 vector of seed ids (one batch)")
+        if not (torch.is_tensor(example_targets) and example_targets.is_cuda
+                and int(example_targets.shape[0]) == int(example_ids.shape[0])):
+            raise ValueError("example_targets must be a CUDA tensor with one row per seed")
+        if gather_cus is None:
+            gather_cus = int(os.environ.get("GSAGE_GATHER_CUS", "0"))
+        self.gather_cus = int(gather_cus) if (ddp is None and not pipelined and type(self) is FusedMeanTrainStep) else 0
         self._init_common(model, feats, loss_fn, example_ids, example_targets, ddp, pipelined)
         self._init_levels(example_ids, example_targets)
         self._init_head(loss_fn, example_targets)
@@ -399,12 +414,19 @@ class FusedMeanTrainStep(object):
             parts = [(2 * h, 0)] if h % 128 == 0 else [(h, 0), (h, 1)]
             bufs = []
             for ntot, g in parts:
-                rps, S, ldk = ops.wgrad_plan(R, ntot, din)
+                rps, S, ldk = ops.wgrad_plan(R, ntot, din, self._wg_target())
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs.append(buf)
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[ix + g], S, ntot, din, ldk))
             self.slabs.append(bufs)
         self._install_reduce(rdesc)
+
+    def _wg_target(self):
+        """K5b workgroups to plan for: the chip, or the chain's share of it in split mode."""
+        if not self.gather_cus:
+            return 240
+        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
+        return max(32, n_cu - self.gather_cus - 8)
 
     def _install_reduce(self, rdesc):
         """Append the head's gradient source, check that every parameter is covered, upload."""
@@ -515,20 +537,21 @@ class FusedMeanTrainStep(object):
                            c_gs, self.code, c_dtype)
 
     # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
-    def _hops_desc(self, ids, ahead):
+    def _hops_desc(self, ids, ahead, counters=None):
         """gsage_hops_desc that samples a whole frontier into `ids`; ahead=True: the batch AFTER the
         one the device counters point at (call_base / batch_base offsets, the counters themselves
-        are not touched)."""
+        are not touched).  counters: (philox call counter, batch index) to read instead of the step's own."""
         L = self.L
+        ctr, bidx = counters if counters is not None else (self.counter, self.batch_idx)
         d = nat.HopsDesc()
         d.rowptr, d.col, d.n_rows = self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows
         d.ids, d.B, d.n_hops = ids.data_ptr(), self.B, L
         for k in range(5):
             d.fan[k] = int(self.fan[k + 1]) if k < L else 1
         d.max_deg, d.seed = self.csr.max_deg, self.sampler.seed
-        d.call_ctr, d.call_base, d.rank = self.counter.data_ptr(), (L if ahead else 0), self.sampler.shard[0]
+        d.call_ctr, d.call_base, d.rank = ctr.data_ptr(), (L if ahead else 0), self.sampler.shard[0]
         d.seed_queue = self.queue[0].data_ptr() if self.queue else None
-        d.batch_idx = self.batch_idx.data_ptr() if self.queue else None
+        d.batch_idx = bidx.data_ptr() if self.queue else None
         d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
         d.err_flag = self.csr.err_flag.data_ptr()
         if self.queue and self.sel_queue is not None:
@@ -537,9 +560,9 @@ class FusedMeanTrainStep(object):
             d.sel, d.sel_stride = self.sel.data_ptr(), 0
         return d
 
-    def _stage_sample(self, s, ids=None, ahead=False):
+    def _stage_sample(self, s, ids=None, ahead=False, counters=None):
         """K1: every hop in one launch, frontier written in place into the concatenated ids."""
-        d = self._hops_desc(self.ids_set[s] if ids is None else ids, ahead)
+        d = self._hops_desc(self.ids_set[s] if ids is None else ids, ahead, counters)
         nat.check(nat.lib().gsage_sample_hops(ctypes.addressof(d), ops._stream()), "sample_hops")
 
     def _stage_sample_gather(self, s):
@@ -690,11 +713,11 @@ class FusedMeanTrainStep(object):
             aggl = self.xa0_set[s][1] if l == 0 else self.agg[l]
             delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
             if h % 128 == 0:
-                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0]))
+                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0], self._wg_target()))
             else:
                 for g in range(2):
                     probs.append((dc[:, g * h:], xbuf if g == 0 else aggl, lda, 0, R, h, din, h,
-                                  self.slabs[l][g]))
+                                  self.slabs[l][g], self._wg_target()))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)
@@ -736,6 +759,7 @@ class FusedMeanTrainStep(object):
     def set_progress(self, progress):
         self.model.lr = self.model.lr_scheduler(progress)
         self.lr.fill_(float(self.model.lr))
+        self._user_dirty = True           # split mode: the chain stream must see this write
 
     def set_sel(self, sels):
         """Replace the Philox draws of the sampler by caller-supplied ones for the following steps
@@ -765,11 +789,21 @@ class FusedMeanTrainStep(object):
         of the queue (wrapping around) with no host->device or device->device copies at all.
         Needs the fused classification head and the sequential (non-pipelined) mode; the graph is
         re-captured because its kernels now read the queue."""
-        assert self.fused_head and not self.pipelined and self.ddp is None or self.fused_head and not self.pipelined
+        if not self.fused_head:
+            raise ValueError("load_epoch needs the fused classification head (classification loss, <= 64 classes, "
+                             "int64 targets); this model runs per batch through __call__")
+        if self.pipelined:
+            raise ValueError("load_epoch is the sequential engine's queue mode; build the engine without pipelined=True")
+        if ids_epoch.dim() != 2 or int(ids_epoch.shape[1]) != self.B or ids_epoch.dtype != torch.int64:
+            raise ValueError("ids_epoch must be int64 [n_batches, %d], got %s %s"
+                             % (self.B, ids_epoch.dtype, tuple(ids_epoch.shape)))
         n_batches = int(ids_epoch.shape[0])
-        assert tuple(ids_epoch.shape) == (n_batches, self.B) and ids_epoch.dtype == torch.int64
+        if targets_epoch.dtype != torch.int64 or targets_epoch.numel() != n_batches * self.B:
+            raise ValueError("targets_epoch must be int64 class ids, one per seed: [n_batches, %d(, 1)], got %s %s"
+                             % (self.B, targets_epoch.dtype, tuple(targets_epoch.shape)))
+        if not (ids_epoch.is_cuda and targets_epoch.is_cuda):
+            raise ValueError("the epoch queue lives in HBM: pass CUDA tensors")
         tq = targets_epoch.reshape(n_batches, self.B).contiguous()
-        assert tq.dtype == torch.int64
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
         self.sel_queue = None
         if sel_epoch is not None:               # [n_batches, samples per frontier] recorded draws (see set_sel)
@@ -782,15 +816,74 @@ class FusedMeanTrainStep(object):
         # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
         # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
-        self._tail_rows = self._tail_gather_rows()
-        if self._tail_rows and len(self.xa0_set) == 1:
+        self.split = bool(self.gather_cus and self.capture_mode == "cmdlist" and self.ddp is None)
+        self._tail_rows = 0 if self.split else self._tail_gather_rows()
+        if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
             self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
         self._front_ready, self._qstep = False, 0
+        if self.split:
+            self._split_setup()
         self._record_queue()
         return self
 
+    # ---- split mode: gathers and chain side by side on disjoint halves of the chip ------------------
+    # The level-0 gathers of batch i+1 (170 MB of HBM reads, no weights involved) and the chain of batch i
+    # (K5 -> seed level -> K5b -> finalise -> Adam: ~65 us of latency-bound launches that move little)
+    # want different things from the chip, and on one stream they can only take turns.  Two streams
+    # alone do not help (tools/overlap2_check.py, round 1): the chain's kernels own their CUs through
+    # registers / LDS and a gather squeezed in beside them runs at a fraction of its bandwidth.  So each
+    # gets CUs of its own (hipExtStreamCreateWithCUMask): `gather_cus` for the gathers (they need ~96
+    # to finish inside the chain's time), the rest for the chain.  Per step: the gather stream waits
+    # for chain(i-1) (whose K5 / K5b read the operand buffers it is about to overwrite), gathers batch
+    # i+1 and samples batch i+2; the chain stream waits for the gathers of batch i.  The sampler reads
+    # counters of its own, advanced on the gather stream (the chain's finalisation ticks the step's).
+    def _split_setup(self):
+        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
+        assert 16 <= self.gather_cus <= n_cu - 32, "gather_cus out of range"
+        if getattr(self, "_sG", None) is None:
+            self._sG = nat.masked_stream(range(self.gather_cus))
+            self._sC = nat.masked_stream(range(self.gather_cus, n_cu))
+            self._evG = [nat.new_event() for _ in range(2)]
+            self._evC = [nat.new_event() for _ in range(2)]
+            self.g_ctr = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.g_bidx = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.g_ctr.zero_()
+        self.g_bidx.zero_()
+        self._user_dirty = True
+
+    def _split_prime(self):
+        c = (self.g_ctr, self.g_bidx)
+        self._stage_sample(0, ids=self.ids_q[0], counters=c)
+        self._stage_sample(0, ids=self.ids_q[1], ahead=True, counters=c)
+        self._stage_gather(0, ids=self.ids_q[0])
+        self._split_tick(2)
+
+    def _split_tick(self, n):
+        lib, st = nat.lib(), ops._stream()
+        nat.check(lib.gsage_counter_add(self.g_ctr.data_ptr(), n * self.L, st), "counter_add")
+        nat.check(lib.gsage_counter_add(self.g_bidx.data_ptr(), n, st), "counter_add")
+
+    def _split_front(self, par):
+        """gather stream, step i (par = i % 2): gathers of batch i+1 || sampling of batch i+2."""
+        self._time_next(0, 1)
+        self._stage_gather(1 - par, ids=self.ids_q[1 - par],
+                           hops=self._hops_desc(self.ids_q[par], False, (self.g_ctr, self.g_bidx)))
+        self._split_tick(1)
+
+    def _split_chain(self, par):
+        """chain stream, step i: everything that needs the current weights, then the update."""
+        self._tail_gather = None
+        self._stage_compute(par)
+        self._stage_opt()
+
     def _record_queue(self):
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        if getattr(self, "split", False):
+            torch.cuda.synchronize()
+            self.g_prime = self._record(self._split_prime)
+            self.g_qfront = [self._record(lambda par=par: self._split_front(par)) for par in range(2)]
+            self.g_queue = [self._record(lambda par=par: self._split_chain(par)) for par in range(2)]
+            return
         if self.g_main is not None:
             torch.cuda.synchronize()
             self.g_prime = self._record(self._queue_prime)
@@ -814,8 +907,9 @@ class FusedMeanTrainStep(object):
         self._record_queue()
 
     def last_launch_ms(self):
-        cl = self.g_queue[(self._qstep - 1) % 2].cl
-        out = {"gather": cl.elapsed_ms(0, 1)}
+        par = (self._qstep - 1) % 2
+        cl = self.g_queue[par].cl
+        out = {"gather": (self.g_qfront[par].cl if self.split else cl).elapsed_ms(0, 1)}
         if self.fused_tail:
             out["seed_level"] = cl.elapsed_ms(2, 3)
         return out
@@ -894,6 +988,8 @@ class FusedMeanTrainStep(object):
         it returns; the first call after load_epoch() additionally samples batches 0 and 1 and
         gathers batch 0."""
         assert self.queue is not None, "call load_epoch() first"
+        if getattr(self, "split", False):
+            return self._step_queue_split()
         rec = self.g_queue is not None
         if not self._front_ready:
             if rec:
@@ -927,6 +1023,28 @@ class FusedMeanTrainStep(object):
             self.g_opt.replay()
         else:
             self._stage_opt()
+        return self.preds
+
+    def _step_queue_split(self):
+        user = torch.cuda.current_stream()
+        if not self._front_ready:
+            self.g_prime.replay()                       # on the caller's stream, once per epoch
+            torch.cuda.synchronize()
+            self._front_ready = True
+        i = self._qstep
+        par = i % 2
+        self._qstep += 1
+        if self._user_dirty:                            # e.g. set_progress wrote the learning rate
+            ev = torch.cuda.Event()
+            ev.record(user)
+            for h in (self._sC, self._sG):
+                torch.cuda.ExternalStream(h).wait_event(ev)
+            self._user_dirty = False
+        vp = ctypes.c_void_p
+        nat.check(nat.lib().gsage_cmdlist_replay_pair(
+            self.g_qfront[par].cl._h, vp(self._sG), vp(self._evC[1 - par]) if i > 0 else None, vp(self._evG[par]),
+            self.g_queue[par].cl._h, vp(self._sC), vp(self._evG[1 - par]) if i > 0 else None, vp(self._evC[par]),
+            vp(user.cuda_stream), 1), "cmdlist_replay_pair")
         return self.preds
 
     def _load(self, s, ids, targets):

@@ -283,3 +283,38 @@ def test_captured_autograd_engine_runs_and_advances_samples():
     b = eng(ids, tg).clone()
     assert torch.isfinite(a).all() and not torch.equal(a, b)     # new samples + updated weights
     assert int(eng.counter.item()) == 4
+
+
+@pytest.mark.parametrize("B,fans", [(40, (25, 10)), (24, (4, 3, 5))])
+def test_split_mode_equals_single_stream(B, fans):
+    """gather_cus: the gathers of batch i+1 / sampling of batch i+2 on a CU-masked stream, the chain of batch
+    i on the complementary one (engine._split_*).  Same kernels on the same data in the same order per
+    stream, so the results are those of the plain per-call engine built with the same K5b plan, bit for bit,
+    across the queue's wrap-around."""
+    adj, feats, rng = _problem(seed=8)
+    D, C, dims = feats.shape[1], 5, (128,) * len(fans)
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
+    tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
+    res = []
+    for queued in (False, True):
+        model = _model(adj, D, C, dims, fans)
+        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0], tg_all[0],
+                                           capture="cmdlist", gather_cus=96)
+        preds = []
+        if queued:
+            eng.load_epoch(ids_all, tg_all)
+            assert eng.split
+            for k in range(7):
+                if k == 3:
+                    eng.set_progress(0.5)            # a write from the caller's stream between steps
+                preds.append(eng.step_queue().clone())
+        else:
+            for k in range(7):
+                if k == 3:
+                    eng.set_progress(0.5)
+                preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(preds), eng.flat_p.clone()))
+        model.train_sampler.csr(DEV).check()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
