@@ -191,6 +191,13 @@ void gsage_mt_destroy(void *mt);
 void gsage_mt_seed(void *mt, uint32_t seed);
 /* np.random.choice(high, count) -> int32 out[count]; returns 32-bit words consumed. */
 int64_t gsage_mt_choice_i32(void *mt, int64_t high, int64_t count, int32_t *out);
+/* The same np.random.choice(high, count) with the stream ON THE DEVICE: `state` = 625 device words (the
+ * 624 MT19937 state words + the position, numpy's np.random.get_state()[1], [2]); the launch consumes
+ * exactly the words numpy would, leaves state / position where numpy would, and writes int32 out[count]
+ * (device).  One workgroup (the recurrence is sequential; refill, tempering and the order-preserving
+ * rejection are parallel inside it).  Not recordable into a graph-free command list restriction: it IS an
+ * ordinary kernel launch and can be recorded like any other. */
+int gsage_mt_choice_device(uint32_t *state, int64_t high, int64_t count, int32_t *out, void *stream);
 /* np.random.permutation(n) -> int64 out[n]. */
 void gsage_mt_permutation(void *mt, int64_t n, int64_t *out);
 

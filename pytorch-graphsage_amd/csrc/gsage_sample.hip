@@ -66,6 +66,108 @@ k_sample_hops(const HopsParams p)
     sample_hops_workgroup(p, blockIdx.x, frontier);
 }
 
+// ---- the legacy MT19937 stream ON THE DEVICE ------------------------------------------------------
+// Compat mode draws `sel` from numpy's global legacy stream, exactly as the reference does at
+// nn_modules.py:88 (np.random.choice(high, size) = masked rejection over 32-bit words: v = word & mask,
+// accepted if v <= high - 1).  On the host that is ~1 ms of numpy per 512-seed Reddit batch plus a 560 KB
+// H2D copy per step.  MT19937 is a sequential recurrence, but one refill of its 624 words splits into
+// three data-parallel phases (word k needs words k+1 and (k+397) mod 624: for k < 227 both are old, for
+// 227 <= k < 454 the second one was produced in the first phase, and so on), tempering is per word, and
+// the order-preserving rejection is a prefix sum over acceptance flags.  One workgroup owns the stream:
+// state and position live in device memory between launches, so a training run hands the stream over
+// once per epoch instead of once per sampler call.
+//   st[0..623] = state words, st[624] = position (624 = refill before the next word)
+constexpr uint32_t MT_N = 624, MT_M = 397;
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t hi, uint32_t lo)
+{
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// one refill of the 624 state words in LDS (256 threads)
+__device__ __forceinline__ void mt_refill(uint32_t *s)
+{
+    const int t = threadIdx.x;
+    // phases [0,227) [227,454) [454,623): every operand of a phase is final before the phase starts
+    for (int base = 0; base < 623; base += 227) {
+        const int k = base + t;
+        const bool on = t < 227 && k < 623;
+        uint32_t v = 0;
+        if (on) v = s[(k + MT_M) % MT_N] ^ mt_mix(s[k], s[k + 1]);
+        __syncthreads();
+        if (on) s[k] = v;
+        __syncthreads();
+    }
+    if (t == 0) s[623] = s[396] ^ mt_mix(s[623], s[0]);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t count, int32_t *__restrict__ out)
+{
+    __shared__ uint32_t s[MT_N];
+    __shared__ int wave_tot[4];
+    __shared__ int cut;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int k = t; k < (int)MT_N; k += 256) s[k] = st[k];
+    uint32_t idx = st[MT_N];
+    __syncthreads();
+    int64_t produced = 0;
+    while (produced < count) {
+        if (idx >= MT_N) {
+            mt_refill(s);
+            idx = 0;
+        }
+        // the next (up to) 256 words, in order
+        const uint32_t pos = idx + (uint32_t)t;
+        const bool have = pos < MT_N;
+        const uint32_t v = have ? (mt_temper(s[pos]) & mask) : 0u;
+        const int acc = (have && v <= top) ? 1 : 0;
+        int incl = acc;                                          // inclusive prefix inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        if (t == 0) cut = -1;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += wave_tot[w];
+            total += wave_tot[w];
+        }
+        incl += before;
+        const int64_t need = count - produced;
+        if (acc && (int64_t)incl <= need) out[produced + incl - 1] = (int32_t)v;
+        if (acc && (int64_t)incl == need) cut = t;                 // the word that completes the request
+        __syncthreads();
+        const int c = cut;
+        const uint32_t n_here = MT_N - idx < 256u ? MT_N - idx : 256u;
+        if ((int64_t)total >= need) {
+            idx += (uint32_t)c + 1u;
+            produced = count;
+        } else {
+            idx += n_here;
+            produced += total;
+        }
+        __syncthreads();                                           // wave_tot / cut are reused
+    }
+    for (int k = t; k < (int)MT_N; k += 256) st[k] = s[k];
+    if (t == 0) st[MT_N] = idx;
+}
+
 static inline int grid_for(int64_t work_items)
 {
     int64_t blocks = ceil_div(work_items, 256);
@@ -225,6 +327,22 @@ int64_t gsage_mt_choice_i32(void *mt, int64_t high, int64_t count, int32_t *out)
     const uint32_t mask = LegacyStream::mask_for(top);
     for (int64_t i = 0; i < count; ++i) out[i] = (int32_t)st->bounded(top, mask, &words);
     return words;
+}
+
+int gsage_mt_choice_device(uint32_t *state, int64_t high, int64_t count, int32_t *out, void *stream)
+{
+    GSAGE_REQUIRE(state && (out || count == 0) && count >= 0, "mt_choice_device: null pointer / negative count");
+    GSAGE_REQUIRE(high >= 1 && high <= 0x100000000LL, "mt_choice_device: high must be in [1, 2^32]");
+    if (count == 0) return GSAGE_OK;
+    if (high == 1) {                               // numpy draws nothing for a range of one value
+        GSAGE_REQUIRE(hipMemsetAsync(out, 0, sizeof(int32_t) * (size_t)count, (hipStream_t)stream) == hipSuccess,
+                      "mt_choice_device: memset failed");
+        return GSAGE_OK;
+    }
+    const uint32_t top = (uint32_t)(high - 1);
+    launch(k_mt_choice, dim3(1), dim3(256), 0, (hipStream_t)stream, state, top, LegacyStream::mask_for(top), count,
+           out);
+    return check_launch("mt_choice_device");
 }
 
 void gsage_mt_permutation(void *mt, int64_t n, int64_t *out)

@@ -83,6 +83,16 @@ class SparseUniformNeighborSampler(object):
         if self.rng == "compat":
             # the reference's own draw (nn_modules.py:88).  Data-parallel: every rank draws the
             # whole job's matrix from the same stream and keeps its rows (dist.py).
+            from .helpers import legacy_stream
+            if ids.is_cuda and legacy_stream.enabled:
+                # the same words, consumed on the device (gsage_mt_choice_device): no host draw, no H2D
+                st = legacy_stream.acquire(ids.device)
+                full = torch.empty(M * world * n_samples, dtype=torch.int32, device=ids.device)
+                nat.check(nat.lib().gsage_mt_choice_device(st.data_ptr(), csr.max_deg, full.numel(),
+                                                           full.data_ptr(), ops._stream()), "mt_choice_device")
+                sel = full[rank * M * n_samples:(rank + 1) * M * n_samples]
+                return ops.sample_csr(csr, ids, n_samples, sel=sel)
+            legacy_stream.release()
             sel = np.random.choice(csr.max_deg, (M * world, n_samples))[rank * M:(rank + 1) * M]
             sel = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32))
             if ids.is_cuda:

@@ -212,6 +212,8 @@ class NodeProblem(object):
         nodes = self.nodes[mode]
         order = np.arange(nodes.shape[0])
         if shuffle:
+            from .helpers import legacy_stream
+            legacy_stream.release()                       # the shuffle is a HOST draw from the shared stream
             order = np.random.permutation(order)          # global legacy stream (problem.py:146)
         n_chunks = order.shape[0] // batch_size + 1       # never exactly batch_size (quirk 6)
         for chunk_id, chunk in enumerate(np.array_split(order, n_chunks)):

@@ -144,6 +144,10 @@ def main(argv=None):
     set_seeds(args.seed)
     gs.ops.set_compute_dtype(args.precision)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = args.rng
+    # compat mode on the GPU: the sampler consumes numpy's legacy stream on the device (same words, same
+    # order; helpers.LegacyStreamOnDevice) instead of drawing on the host and copying `sel` over
+    gs.helpers.legacy_stream.enabled = bool(args.cuda and args.rng == 'compat' and
+                                            os.environ.get("GSAGE_HOST_SEL", "0") != "1")
 
     ddp = gs.dist.init_from_env(args.cuda)            # no-op outside torch.distributed.run
     problem = NodeProblem(problem_path=args.problem_path, cuda=args.cuda)
@@ -179,6 +183,7 @@ def main(argv=None):
         model.eval()
         val_metric = evaluate(model, problem, mode='val')
 
+    gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host
     print('-- done --', file=sys.stderr)
     if ddp is None or ddp.rank == 0:
         print(dumps({"epoch": epoch, "train_metric": train_metric, "val_metric": val_metric,
@@ -204,6 +209,7 @@ def train_fused(args, problem, model, ddp, start_time):
     dev = torch.device('cuda')
 
     def epoch_batches():
+        gs.helpers.legacy_stream.release()
         order = np.random.permutation(np.arange(nodes.shape[0]))[:n_batches * B * world]     # problem.py:146
         mids = nodes[order].reshape(n_batches, world, B)[:, rank]
         ids = torch.from_numpy(np.ascontiguousarray(mids)).to(dev)

@@ -172,3 +172,60 @@ def test_device_metrics_match_the_reference_fixture():
     host = gs.batch_metric("classification", torch.from_numpy(g["cls_y"]), torch.from_numpy(g["cls_logits"]))
     dev = gs.batch_metric("classification", y, lg)
     assert abs(host["micro"] - dev["micro"]) < 1e-6 and abs(host["macro"] - dev["macro"]) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [0, 123, 15129])
+def test_device_legacy_stream_equals_numpy(seed):
+    """gsage_mt_choice_device consumes numpy's legacy MT19937 stream on the GPU: the same values as
+    np.random.choice(high, count) call after call (refills, rejection, requests that end mid-block), and the
+    stream continues on the host exactly where numpy would be."""
+    from conftest import pkg as _pkg
+    hp = _pkg().helpers
+    nat = gs._native
+    np.random.seed(seed)
+    ref = np.random.RandomState(seed)
+    ls = hp.LegacyStreamOnDevice()
+    st = ls.acquire(torch.device(DEV))
+    for high, count in ((21657, 1000), (8, 64), (1, 5), (2 ** 31 - 1, 10), (21657, 140800), (4, 3), (700, 623),
+                        (2 ** 32, 300), (3, 1)):
+        out = torch.full((count,), -7, dtype=torch.int32, device=DEV)
+        nat.check(nat.lib().gsage_mt_choice_device(st.data_ptr(), high, count, out.data_ptr(), ops._stream()), "mt")
+        want = ref.randint(0, high, size=count, dtype=np.int64) if high > 2 ** 31 else ref.choice(high, count)
+        got = out.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(got, np.asarray(want, dtype=np.int64)), (seed, high, count)
+    ls.release()
+    assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=8), ref.randint(0, 2 ** 31 - 1, size=8))
+    # a host draw while the device holds the stream is an error, not a silent fork of the sequence
+    ls.acquire(torch.device(DEV))
+    np.random.randint(0, 10)
+    with pytest.raises(RuntimeError):
+        ls.release()
+
+
+def test_stream_kat_with_the_stream_on_the_device():
+    """The reference's epoch shuffle + sampled frontier (stream_kat.npz), with the sampler's draws generated
+    on the GPU (helpers.legacy_stream.enabled): bit-identical, including the words left in the stream."""
+    from util import csr_of
+    hp = gs.helpers
+    g = load_golden("stream_kat.npz")
+    adj = csr_of(g, "g_")
+    s = gs.sampler_lookup["sparse_uniform_neighbor_sampler"](adj=adj, rng="compat")
+    nodes = g["nodes"]
+    hp.legacy_stream.enabled = True
+    try:
+        gs.set_seeds(int(g["seed"]) ** 2)
+        order = np.random.permutation(np.arange(nodes.shape[0]))
+        before = gs._native.launch_count()
+        for b, chunk in enumerate(np.array_split(order, nodes.shape[0] // 64 + 1)):
+            ids = torch.from_numpy(nodes[chunk]).to(DEV)
+            h1 = s(ids, n_samples=5)
+            h2 = s(h1, n_samples=3)
+            assert hp.legacy_stream.on_device
+            assert np.array_equal(h1.cpu().numpy(), g["b%d_h1" % b])
+            assert np.array_equal(h2.cpu().numpy(), g["b%d_h2" % b])
+        assert gs._native.launch_count() > before
+        hp.legacy_stream.release()
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g["tail"])
+    finally:
+        hp.legacy_stream.drop()
+        hp.legacy_stream.enabled = False
