@@ -28,9 +28,9 @@ Extra objects on the line (tier contract, section 4 of the task):
                that launch reads x D x 2 B / its mean duration over real steps (fresh frontier every
                step, events on the stream the step runs on); peak = 8 TB/s HBM3E.  `step` adds the
                whole-step figure (all 276 rows/seed / ms_per_step).
-  cpu_baseline the OpenMP C restatement of train_step (oracle/gsage_train_omp.c) on all host cores,
-               bounded sample; `torch_port` = the plain-torch port of the reference's op sequence
-               (oracle/torch_ref.py) at a fixed thread count.
+  cpu_baseline two CPU restatements of train_step on the host, bounded sample each: the OpenMP C one
+               (oracle/gsage_train_omp.c, all cores, plain loops) and the plain-torch port of the reference's
+               op sequence (oracle/torch_ref.py, MKL GEMMs, fixed thread count); `value` is the faster.
 """
 import argparse
 import importlib
@@ -167,12 +167,18 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
         tref.train_step(w, opt, 0.01, "classification", ids, feats, torch.from_numpy(tg), indptr, dat, FANOUT,
                         sels, "mean", "identity", adj.shape[0])
     n_t, dt_t = timed(torch_step, budget_s * 0.4)
-    return {"value": n_omp * batch / dt_omp, "unit": "seed-nodes/sec", "cores": omp_threads, "kind": "port",
-            "sample": "%d train_steps of %d seeds, fp32, OpenMP C restatement (oracle/gsage_train_omp.c) on %d "
-                      "threads of %d host threads, %.1f s" % (n_omp, batch, omp_threads, ncpu, dt_omp),
-            "torch_port": {"value": n_t * batch / dt_t, "cores": threads,
-                           "sample": "%d train_steps, oracle/torch_ref.py fp32 + C sampler, torch %d threads "
-                                     "(fixed), %.1f s" % (n_t, threads, dt_t)}}
+    omp = {"value": n_omp * batch / dt_omp, "cores": omp_threads,
+           "sample": "%d train_steps of %d seeds, fp32, OpenMP C restatement (oracle/gsage_train_omp.c: plain "
+                     "loops, no BLAS) on %d threads of %d host threads, %.1f s" % (n_omp, batch, omp_threads, ncpu, dt_omp)}
+    tp = {"value": n_t * batch / dt_t, "cores": threads,
+          "sample": "%d train_steps of %d seeds, fp32, oracle/torch_ref.py (the reference's op sequence on stock "
+                    "torch CPU kernels: MKL GEMMs) + C sampler, torch %d threads (fixed), %.1f s"
+                    % (n_t, batch, threads, dt_t)}
+    best, other, names = (tp, omp, ("torch_port", "openmp_c")) if tp["value"] >= omp["value"] else \
+        (omp, tp, ("openmp_c", "torch_port"))
+    # `value` = the FASTER of the two restatements (a slow baseline flatters nobody); both are listed
+    return {"value": best["value"], "unit": "seed-nodes/sec", "cores": best["cores"], "kind": "port",
+            "which": names[0], "sample": best["sample"], names[1]: other}
 
 
 def dominant_kernel_roofline(eng, store, n_steps=64):
