@@ -180,3 +180,86 @@ def test_three_layer_engine_step_at_papers_scale():
         d_eng = v.detach().cpu().numpy() - w0[k].numpy()
         d_ref = w[k].numpy() - w0[k].numpy()
         close_fro(d_eng, d_ref, ("Adam update", k), 5e-2)
+
+
+def test_attention_embedding_step_at_pokec_scale():
+    """BASELINE configs[3] at full structural scale: a Pokec-sized graph (1.63 M nodes, ~6.5e7 edges) built on
+    the device, NO features, trainable 64-d node embeddings (node_embedding prep: a 418 MB table whose dense
+    gradient / clip / Adam semantics are the reference's), attention aggregators, fan-out 20/15,
+    regression_mae (with its [B,1]-vs-[B] broadcast).  One train_step of the product's module path in fp32
+    against the oracle fed the same frontier: the frontier is tied to the sampler's definition by per-hop
+    launches, the oracle runs on the touched embedding rows only (with zero Adam state an untouched row
+    does not move -- asserted on the GPU side), everything else is compared at fp32 tolerance."""
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs a large-memory GPU")
+    from scipy import sparse
+    from torch.nn import functional as F
+    from oracle import torch_ref as tref
+    from util import close, close_rel
+    N, B, fans, dims = 1_632_803, 48, (20, 15), (128, 128)
+    n_rows = N + 1
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    deg = torch.randint(10, 71, (n_rows,), dtype=torch.int64, device=DEV, generator=gen)
+    deg[0] = 0
+    deg[5::997] = 0
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=DEV)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(1, n_rows, (int(rowptr[-1]),), dtype=torch.int32, device=DEV, generator=gen)
+    big = gs.DeviceCSR(rowptr, col, n_rows, 128)
+    tiny = sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
+    ops.set_compute_dtype("fp32")
+    try:
+        torch.manual_seed(21)
+        gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+        specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+                  "activation": F.relu if i < 1 else (lambda x: x)} for i, (f, h) in enumerate(zip(fans, dims))]
+        model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=tiny,
+                                train_adj=tiny, prep_class=gs.prep_lookup["node_embedding"],
+                                aggregator_class=gs.aggregator_lookup["attention"], input_dim=None, n_nodes=n_rows,
+                                n_classes=1, layer_specs=specs, lr_init=0.01).to(DEV)
+        gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+        model.train_sampler.seed = 17
+        model.train_sampler.csr(DEV)
+        model.train_sampler._dev[next(iter(model.train_sampler._dev))] = big
+        table0 = model.prep.embedding.weight.detach().clone()
+        assert tuple(table0.shape) == (n_rows + 1, 64)
+        w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k != "prep.embedding.weight"}
+        g = torch.Generator(device="cpu").manual_seed(9)
+        ids = torch.randint(1, n_rows, (B,), generator=g).to(DEV)
+        tg = (30 + 8 * torch.randn(B, 1, generator=g)).to(DEV)
+        loss_fn = gs.ProblemLosses.regression_mae
+        before = nat.launch_count()
+        preds = model.train_step(ids=ids, feats=None, targets=tg, loss_fn=loss_fn).detach().cpu()
+        torch.cuda.synchronize()
+        assert nat.launch_count() - before > 10
+        big.check()
+        # the frontier the step sampled: Philox (seed 17, calls 0 and 1), per-hop launches
+        h1 = ops.sample_csr(big, ids, fans[0], philox={"seed": 17, "call_base": 0})
+        h2 = ops.sample_csr(big, h1, fans[1], philox={"seed": 17, "call_base": 1})
+        hops = [h1.cpu().numpy(), h2.cpu().numpy()]
+        # compact embedding table: touched rows + the spare row every seed reads at layer 0 (nn_modules.py:145-149)
+        touched = np.unique(np.concatenate([ids.cpu().numpy(), hops[0], hops[1], np.array([n_rows])]))
+        remap = {int(v): i for i, v in enumerate(touched)}
+        rl = lambda a: np.array([remap[int(v)] for v in a], dtype=np.int64)
+        w = {k: v.clone() for k, v in w0.items()}
+        w["prep.embedding.weight"] = table0[torch.from_numpy(touched).to(DEV)].cpu()
+        r = tref.train_step(w, tref.Adam(), 0.01, "regression_mae", rl(ids.cpu().numpy()), None, tg.cpu(), None, None,
+                            fans, None, "attention", "node_embedding", remap[n_rows], frontier=[rl(hops[0]), rl(hops[1])])
+        close(preds.numpy(), r["preds"].numpy(), "preds vs oracle (Pokec scale)", 2e-4, 2e-4)
+        gn = float(model.optimizer.grad_norm.item())
+        assert abs(gn - r["gradnorm"]) <= 2e-4 * max(1.0, r["gradnorm"]), (gn, r["gradnorm"])
+        sd = model.state_dict()
+        for k, v in w.items():
+            if k == "prep.embedding.weight":
+                continue
+            close_rel(sd[k].detach().cpu().numpy() - w0[k].numpy(), v.numpy() - w0[k].numpy(), ("update", k), 2e-2)
+        new_rows = sd["prep.embedding.weight"][torch.from_numpy(touched).to(DEV)].cpu().numpy()
+        old_rows = table0[torch.from_numpy(touched).to(DEV)].cpu().numpy()
+        upd, upd_ref = new_rows - old_rows, w["prep.embedding.weight"].numpy() - old_rows
+        assert np.linalg.norm(upd - upd_ref) <= 2e-2 * np.linalg.norm(upd_ref)
+        # dense semantics: every row is visited by clip + Adam, and with zero moments an untouched row stays put
+        mask = torch.ones(n_rows + 1, dtype=torch.bool, device=DEV)
+        mask[torch.from_numpy(touched).to(DEV)] = False
+        assert torch.equal(sd["prep.embedding.weight"][mask], table0[mask])
+    finally:
+        ops.set_compute_dtype("bf16")
