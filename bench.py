@@ -369,12 +369,14 @@ def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=8_000_000, B=BATCH):
             "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2))}
 
 
-def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH):
+def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None):
     """BASELINE configs[3] at its SHAPE on one GPU: Pokec-sized graph (1.63 M nodes, ~6e7 edges), no features,
     trainable 64-d node embeddings (node_embedding prep), attention aggregator (hidden 32), fan-out 20/15,
     regression_mae.  The step keeps the reference's DENSE embedding-gradient semantics: clip and Adam run
     over the whole 418 MB table every step (dense_table_bytes_per_step is that mandatory traffic)."""
     from torch.nn import functional as F
+    if precision:
+        gs.ops.set_compute_dtype(precision)
     N = 1_632_803
     adj, rng = _lognormal_graph(gs, N, 3.0, 1.1, 8_763)
     fan, dims = (20, 15), (128, 128)
@@ -573,8 +575,7 @@ def main():
 
     if rank == 0:
         value = args.steps * B * world / elapsed
-        fused_mean_queue = (res["queued"] and ddp is None and isinstance(step_fn, gs.engine.FusedMeanTrainStep)
-                            and not isinstance(step_fn, gs.engine.FusedPoolTrainStep)
+        fused_mean_queue = (res["queued"] and ddp is None and type(step_fn) is gs.engine.FusedMeanTrainStep
                             and getattr(step_fn, "capture_mode", None) == "cmdlist")
         if args.aggregator in ("max_pool", "mean_pool") and fanout == FANOUT and B == BATCH:
             roof = pool_kernel_roofline(gs, model, store, data, dev)

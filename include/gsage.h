@@ -387,6 +387,25 @@ int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *n
                    const int64_t *ids, int64_t M, int32_t n, int64_t Ha, int64_t D, float *dna,
                    int64_t dna_ld, float *dxa, int64_t dxa_ld, void *stream);
 
+/* Glue of the native attention train step (engine.FusedAttnTrainStep): what autograd ran as separate cast /
+ * add / tanh-backward / expand kernels between K4, K5 and K5b.
+ *   gsage_add_cast        dst[m, c] = T(a[m, c] + (b ? b[m, c] : 0))             (fp32 in, bf16 / fp32 out)
+ *   gsage_tanh_bwd        out[m, c] = T(g[m, c] * (1 - hid[m, c]^2))             (the att MLP's tanh, nn_modules.py:294)
+ *   gsage_attn_merge_bwd  input gradient of an attention level (autograd of nn_modules.py:307-317 w.r.t. x and
+ *                         neibs), rows = hops concatenated (hop k from off[k], fan[k] children per parent):
+ *       dIn[m] = mask(m) * ( DATT[m] + (m < r_x ? DX[m] : 0) + (hop(m) >= 1 ? ws[m - off[1]] * DAGG[parent(m)] : 0) )
+ *       DATT: through att(.), every row; DX: through fc_x; ws: the softmax weights of every (parent, child) pair
+ *       in hop order (the ws outputs of gsage_attn_aggregate, back to back); mask = (H[m, c] > 0) when H is given
+ *       (the ReLU of the level below), else 1. */
+int gsage_add_cast(const float *a, int64_t lda, const float *b, int64_t ldb, void *dst, int dst_dtype, int64_t ldd,
+                   int64_t M, int64_t D, void *stream);
+int gsage_tanh_bwd(const float *g, int64_t ldg, const void *hid, int dtype, int64_t ldh, void *out, int64_t ldo,
+                   int64_t M, int64_t D, void *stream);
+int gsage_attn_merge_bwd(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt, const float *DX,
+                         int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg, const float *ws, void *out,
+                         int out_dtype, int64_t ldo, int64_t R, int32_t D, int32_t n_hops, const int64_t *off,
+                         const int32_t *fan, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Classification head, forward + backward   replaces F.normalize(dim=1) -> fc -> F.cross_entropy
  *                                            (models.py:90-91, problem.py:34) and their autograd

@@ -239,9 +239,153 @@ k_attn_bwd_wide(const float *__restrict__ g, int64_t g_ld, const float *__restri
     }
 }
 
+// ---- glue of the native attention train step (engine.FusedAttnTrainStep) ------------------------------
+// Element-wise kernels between K4 / K5 / K5b: what autograd ran as a cast, an add, a tanh backward and
+// four scatter / expand kernels per level (52 casts and 34 adds per Pokec-shaped step).
+__device__ __forceinline__ void store_as(uint16_t *p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void store_as(float *p, float v) { *p = v; }
+__device__ __forceinline__ float load_as(const uint16_t *p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float load_as(const float *p) { return *p; }
+
+// dst[m, c] = T(a[m, c] (+ b[m, c]))
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_add_cast(const float *__restrict__ a, int64_t lda, const float *__restrict__ b, int64_t ldb, T *__restrict__ dst,
+           int64_t ldd, int64_t M, int32_t D)
+{
+    const int64_t total = M * D, stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t m = t / D;
+        const int c = (int)(t - m * D);
+        float v = a[m * lda + c];
+        if (b) v += b[m * ldb + c];
+        store_as(dst + m * ldd + c, v);
+    }
+}
+
+// out[m, c] = T(g[m, c] * (1 - hid[m, c]^2))      (backward of the att MLP's tanh, nn_modules.py:294)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_tanh_bwd(const float *__restrict__ g, int64_t ldg, const T *__restrict__ hid, int64_t ldh, T *__restrict__ out,
+           int64_t ldo, int64_t M, int32_t D)
+{
+    const int64_t total = M * D, stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t m = t / D;
+        const int c = (int)(t - m * D);
+        const float h = load_as(hid + m * ldh + c);
+        store_as(out + m * ldo + c, g[m * ldg + c] * (1.f - h * h));
+    }
+}
+
+// Input gradient of an attention level, all of its sources in one pass (autograd of nn_modules.py:307-317
+// w.r.t. x and neibs): rows are the hops concatenated (hop k starts at off[k], fan[k] children per parent)
+//   dIn[m] = mask(m) * ( DATT[m]                                   through att(.) -- every row
+//                      + (m < r_x ? DX[m] : 0)                     through fc_x -- rows that were "x"
+//                      + (hop(m) >= 1 ? ws[m - off[1]] * DAGG[parent(m)] : 0) )   the weighted sum of raw rows
+//   mask(m) = H ? (H[m, c] > 0) : 1     (ReLU of the level below; none for a prep output)
+struct AttnMergeParams {
+    const void *H;
+    const float *DATT, *DX, *DAGG, *ws;
+    void *out;
+    int64_t ldh, ldatt, ldx, ldagg, ldo;
+    int64_t R, r_x;
+    int32_t D, n_hops;
+    int64_t off[6];
+    int32_t fan[6];
+};
+
+template <typename TH, typename TO>
+__global__ void __launch_bounds__(256)
+k_attn_merge_bwd(const AttnMergeParams q)
+{
+    const int64_t total = q.R * q.D, stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t m = t / q.D;
+        const int c = (int)(t - m * q.D);
+        float v = q.DATT[m * q.ldatt + c];
+        if (m < q.r_x && q.DX) v += q.DX[m * q.ldx + c];
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 6; ++j)
+            if (j < q.n_hops && m >= q.off[j]) k = j;
+        if (k >= 1) {
+            const int64_t parent = q.off[k - 1] + (m - q.off[k]) / q.fan[k];
+            v += q.ws[m - q.off[1]] * q.DAGG[parent * q.ldagg + c];
+        }
+        if (q.H && !(load_as((const TH *)q.H + m * q.ldh + c) > 0.f)) v = 0.f;
+        store_as((TO *)q.out + m * q.ldo + c, v);
+    }
+}
+
+static inline int ew_grid(int64_t items)
+{
+    int64_t b = ceil_div(items, 256);
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
 }  // namespace gsage
 
 using namespace gsage;
+
+extern "C" int gsage_add_cast(const float *a, int64_t lda, const float *b, int64_t ldb, void *dst, int dst_dtype,
+                              int64_t ldd, int64_t M, int64_t D, void *stream)
+{
+    GSAGE_REQUIRE(a && dst && M >= 0 && D > 0 && lda >= D && ldd >= D && (!b || ldb >= D), "add_cast: bad arguments");
+    GSAGE_REQUIRE(dst_dtype == GSAGE_BF16 || dst_dtype == GSAGE_F32, "add_cast: bad dtype");
+    if (M == 0) return GSAGE_OK;
+    if (dst_dtype == GSAGE_BF16)
+        launch(k_add_cast<uint16_t>, dim3(ew_grid(M * D)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+               (uint16_t *)dst, ldd, M, (int32_t)D);
+    else
+        launch(k_add_cast<float>, dim3(ew_grid(M * D)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+               (float *)dst, ldd, M, (int32_t)D);
+    return check_launch("add_cast");
+}
+
+extern "C" int gsage_tanh_bwd(const float *g, int64_t ldg, const void *hid, int dtype, int64_t ldh, void *out,
+                              int64_t ldo, int64_t M, int64_t D, void *stream)
+{
+    GSAGE_REQUIRE(g && hid && out && M >= 0 && D > 0 && ldg >= D && ldh >= D && ldo >= D, "tanh_bwd: bad arguments");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "tanh_bwd: bad dtype");
+    if (M == 0) return GSAGE_OK;
+    if (dtype == GSAGE_BF16)
+        launch(k_tanh_bwd<uint16_t>, dim3(ew_grid(M * D)), dim3(256), 0, (hipStream_t)stream, g, ldg,
+               (const uint16_t *)hid, ldh, (uint16_t *)out, ldo, M, (int32_t)D);
+    else
+        launch(k_tanh_bwd<float>, dim3(ew_grid(M * D)), dim3(256), 0, (hipStream_t)stream, g, ldg, (const float *)hid,
+               ldh, (float *)out, ldo, M, (int32_t)D);
+    return check_launch("tanh_bwd");
+}
+
+extern "C" int gsage_attn_merge_bwd(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt,
+                                    const float *DX, int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg,
+                                    const float *ws, void *out, int out_dtype, int64_t ldo, int64_t R, int32_t D,
+                                    int32_t n_hops, const int64_t *off, const int32_t *fan, void *stream)
+{
+    GSAGE_REQUIRE(DATT && DAGG && ws && out && off && fan, "attn_merge_bwd: null pointer");
+    GSAGE_REQUIRE(n_hops >= 2 && n_hops <= 6 && R >= 0 && r_x >= 0 && r_x <= R && D > 0, "attn_merge_bwd: bad sizes");
+    GSAGE_REQUIRE((out_dtype == GSAGE_BF16 || out_dtype == GSAGE_F32) && (!H || h_dtype == GSAGE_BF16 || h_dtype == GSAGE_F32),
+                  "attn_merge_bwd: bad dtype");
+    if (R == 0) return GSAGE_OK;
+    AttnMergeParams q;
+    q.H = H; q.DATT = DATT; q.DX = DX; q.DAGG = DAGG; q.ws = ws; q.out = out;
+    q.ldh = ldh; q.ldatt = ldatt; q.ldx = ldx; q.ldagg = ldagg; q.ldo = ldo; q.R = R; q.r_x = r_x; q.D = D;
+    q.n_hops = n_hops;
+    for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }
+    const dim3 grid(ew_grid(R * D));
+    hipStream_t s = (hipStream_t)stream;
+    const bool hb = H && h_dtype == GSAGE_BF16;
+    if (out_dtype == GSAGE_BF16) {
+        if (hb || !H) launch(k_attn_merge_bwd<uint16_t, uint16_t>, grid, dim3(256), 0, s, q);
+        else launch(k_attn_merge_bwd<float, uint16_t>, grid, dim3(256), 0, s, q);
+    } else {
+        if (hb) launch(k_attn_merge_bwd<uint16_t, float>, grid, dim3(256), 0, s, q);
+        else launch(k_attn_merge_bwd<float, float>, grid, dim3(256), 0, s, q);
+    }
+    return check_launch("attn_merge_bwd");
+}
+
 
 template <typename T, int VEC>
 static bool attn_wide_ok(const void *table, int64_t ld, int64_t D)

@@ -1370,10 +1370,219 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         self._stage_finalize(s)
 
 
+class FusedAttnTrainStep(FusedMeanTrainStep):
+    """train_step for attention aggregators (reference nn_modules.py:289-321; BASELINE config 4's aggregator)
+    with no autograd and no framework glue, on the machinery of FusedMeanTrainStep (flat buckets, fused
+    multi-hop sampler, head kernel, finalisation + Adam, command lists, batch queue).  Level l turns the rows
+    of hops 0 .. L-l ("In") into the rows of hops 0 .. L-l-1:
+
+      forward    K5   hid = tanh(In W0^T);  K5  a = hid W2^T        att(.) ONCE per row: the reference applies the
+                                                                    same MLP to a row as "x" and as a neighbour
+                 K4   per hop: scores <a_child, a_parent>, softmax over the fan-out, agg = sum w * raw child row
+                 K5   out[:, :h] = act(In[:rows_x] Wx^T);  K5  out[:, h:] = act(agg Wn^T)
+      backward   K5   d agg = dC[:, h:] Wn
+                 K4'  per hop: d a(child), d a(parent)  (softmax backward inside)
+                 K5   (d a W2), tanh backward -> d hid;   l > 0: K5 d In(att) = d hid W0, K5 dX = dC[:, :h] Wx,
+                      one merge kernel adds them to ws * d agg(parent) and applies the ReLU mask -> dC of level l-1
+                 K5b  fc_x, fc_neib, att.0, att.2 weight gradients of every level in one grouped launch
+    Level 0 reads its rows from ONE buffer gathered per step (all hops, next batch, beside Adam and K1): the att
+    MLP, K4, the x projection and two of the four weight gradients all want plain row-major operands."""
+
+    HA_LD = 64            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
+    WG_TARGET = 120       # K5b workgroups per problem (eight problems share the launch)
+
+    @staticmethod
+    def supports(model, feats):
+        from .nn_modules import AttentionAggregator
+        layers = list(model.agg_layers.children())
+        if not layers or not all(type(l) is AttentionAggregator and l.combine_fn is concat_combine for l in layers):
+            return False
+        codes = [_split_activation(l.activation)[0] for l in layers]
+        if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
+            return False
+        if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
+            return False
+        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda or feats.ld % 8 != 0:
+            return False
+        if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
+            return False
+        if any(not (2 <= fn.keywords["n_samples"] <= 32) for fn in model.train_sample_fns) or len(layers) > 4:
+            return False                                     # K4 keeps a parent's softmax in one wave's lanes
+        ha = {int(l.att[0].weight.shape[0]) for l in layers}
+        return all(l.output_dim_ % 8 == 0 for l in layers) and ha <= {32} and \
+            all(tuple(l.att[2].weight.shape) == (32, 32) for l in layers)
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _init_levels(self, example_ids, example_targets):
+        feats, dev, L = self.store, self.dev, self.L
+        T, f32 = self.tdt, torch.float32
+        self.Ha = 32
+        self.h = [l.output_dim_ for l in self.layers]
+        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
+        self.ldin = [feats.ld] + [2 * h for h in self.h[:-1]]
+        self.rows = [self.off[L - l] for l in range(L)]              # x rows of level l
+        self.rall = [self.off[L - l + 1] for l in range(L)]          # all input rows of level l
+        assert all(d % 8 == 0 for d in self.ldin)
+        descs = []
+
+        def copies(prm, need_t):
+            r, c = prm.shape
+            w = torch.zeros(r, _r64(c), dtype=T, device=dev)
+            wt = torch.zeros(c, _r64(r), dtype=T, device=dev) if need_t else None
+            descs.append(_PrepDesc(prm.data_ptr(), w.data_ptr(), wt.data_ptr() if need_t else None, r, c, w.shape[1],
+                                   wt.shape[1] if need_t else 0, None, 0, int(self.code == nat.F32), 0))
+            return w, wt
+        self.w0, self.w0T, self.w2, self.w2T, self.wx, self.wxT, self.wn, self.wnT = ([] for _ in range(8))
+        for l, layer in enumerate(self.layers):
+            a, b = copies(layer.att[0].weight, l > 0); self.w0.append(a); self.w0T.append(b)
+            a, b = copies(layer.att[2].weight, True); self.w2.append(a); self.w2T.append(b)
+            a, b = copies(layer.fc_x.weight, l > 0); self.wx.append(a); self.wxT.append(b)
+            a, b = copies(layer.fc_neib.weight, True); self.wn.append(a); self.wnT.append(b)
+        self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
+        self.n_desc = len(descs)
+        self.max_elems = max(d.rows * d.cols for d in descs)
+
+        # level-0 rows of every hop, gathered once per step (one set per batch in flight)
+        self.g0_set = [torch.zeros(self.rall[0], feats.ld, dtype=T, device=dev) for _ in range(self.nset)]
+        Ha, HL = self.Ha, self.HA_LD
+        z = lambda *shape, dt=f32: torch.zeros(*shape, dtype=dt, device=dev)
+        self.hid, self.a, self.agg, self.aggc, self.ws, self.hout, self.dc = ([] for _ in range(7))
+        self.dagg, self.dan, self.dax, self.da, self.dhg, self.dhid, self.datt, self.dx = ([] for _ in range(8))
+        for l in range(L):
+            R, RA, ld, h = self.rows[l], self.rall[l], self.ldin[l], self.h[l]
+            last = l == L - 1
+            self.hid.append(z(RA, HL, dt=T)); self.a.append(z(RA, Ha))
+            self.agg.append(z(R, ld)); self.aggc.append(z(R, ld, dt=T)); self.ws.append(z(RA - self.off[1]))
+            self.hout.append(z(R, 2 * h, dt=f32 if last else T)); self.dc.append(z(R, 2 * h, dt=T))
+            self.dagg.append(z(R, ld)); self.dan.append(z(RA, Ha)); self.dax.append(z(RA, Ha))
+            self.da.append(z(RA, HL, dt=T)); self.dhg.append(z(RA, Ha)); self.dhid.append(z(RA, HL, dt=T))
+            self.datt.append(z(RA, ld) if l > 0 else None); self.dx.append(z(R, ld) if l > 0 else None)
+        self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
+        self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
+
+    def _init_head(self, loss_fn, example_targets):
+        super(FusedAttnTrainStep, self)._init_head(loss_fn, example_targets)
+        self.fused_tail = False
+
+    def _in(self, l, s):
+        """input rows of level l (all hops it reads) and their leading dimension"""
+        return (self.g0_set[s], self.ldin[0]) if l == 0 else (self.hout[l - 1], self.ldin[l])
+
+    def _wg_problems(self, l, s):
+        """(dC, A, lda, M, Ntot, K, parameter) of the four weight gradients of level l"""
+        inp, ld = self._in(l, s)
+        h, Ha, D, layer = self.h[l], self.Ha, self.din[l], self.layers[l]
+        return [(self.dc[l][:, :h], inp, ld, self.rows[l], h, D, layer.fc_x.weight),
+                (self.dc[l][:, h:], self.aggc[l], ld, self.rows[l], h, D, layer.fc_neib.weight),
+                (self.da[l], self.hid[l], self.HA_LD, self.rall[l], Ha, Ha, layer.att[2].weight),
+                (self.dhid[l], inp, ld, self.rall[l], Ha, D, layer.att[0].weight)]
+
+    def _init_reduce(self):
+        dev, f32 = self.dev, torch.float32
+        rdesc, self.slabs = [], []
+        for l in range(self.L):
+            bufs = []
+            for (dC, A, lda, M, ntot, K, prm) in self._wg_problems(l, 0):
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET)
+                buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
+                bufs.append(buf)
+                rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
+            self.slabs.append(bufs)
+        self._install_reduce(rdesc)
+
+    # ---- stages ----------------------------------------------------------------------------------------
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
+        st = self.store
+        if ids is None:
+            ids = self.ids_set[s]
+        segs = [(st.data, ids[:self.rall[0]], self.g0_set[s], self.rall[0], 1)]
+        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None, hops=hops)
+
+    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
+        ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
+                           self.code, c_code)
+
+    def _stage_compute(self, s):
+        L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
+        Ha, HL, esz = self.Ha, self.HA_LD, self.esz
+        for l in range(L):
+            R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
+            inp, ld = self._in(l, s)
+            self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RA, Ha, D, nat.ACT_TANH)
+            self._gemm(self.hid[l].data_ptr(), HL, self.w2[l], self.a[l].data_ptr(), nat.F32, Ha, RA, Ha, Ha, nat.ACT_NONE)
+            for k in range(L - l):
+                r0, c0 = self.off[k], self.off[k + 1]
+                nat.check(lib.gsage_attn_aggregate(
+                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, inp[c0:].data_ptr(), self.code, ld,
+                    None, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
+                    self.ws[l][c0 - self.off[1]:].data_ptr(), stream), "attn_aggregate")
+            nat.check(lib.gsage_add_cast(self.agg[l].data_ptr(), ld, None, 0, self.aggc[l].data_ptr(), self.code, ld, R, D,
+                                         stream), "add_cast")
+            last = l == L - 1
+            out, code = self.hout[l], (nat.F32 if last else self.code)
+            act = nat.ACT_NONE if last else nat.ACT_RELU
+            self._gemm(inp.data_ptr(), ld, self.wx[l], out.data_ptr(), code, 2 * h, R, h, D, act)
+            self._gemm(self.aggc[l].data_ptr(), ld, self.wn[l], out.data_ptr() + h * out.element_size(), code, 2 * h,
+                       R, h, D, act)
+        if self.fused_head:
+            C, D2 = m.fc.weight.shape
+            tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+            nat.check(lib.gsage_head_ce(self.hout[L - 1].data_ptr(), 2 * self.h[L - 1], m.fc.weight.data_ptr(),
+                                        m.fc.bias.data_ptr(), tg.data_ptr(), B, C, D2, self.preds.data_ptr(),
+                                        self.dc[L - 1].data_ptr(), self.code, 2 * self.h[L - 1], None, None, None,
+                                        self.head_scratch.data_ptr(),
+                                        self.batch_idx.data_ptr() if self.queue else None,
+                                        self.queue[2] if self.queue else 0, stream), "head_ce")
+        else:
+            self._torch_head(s)
+        self._backward_levels(s)
+
+    def _backward_levels(self, s):
+        L, lib, stream = self.L, nat.lib(), ops._stream()
+        Ha, HL, esz = self.Ha, self.HA_LD, self.esz
+        for l in range(L - 1, -1, -1):
+            R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
+            inp, ld = self._in(l, s)
+            dc = self.dc[l]
+            # d agg = dC[:, h:] Wn
+            self._gemm(dc.data_ptr() + h * esz, 2 * h, self.wnT[l], self.dagg[l].data_ptr(), nat.F32, ld, R, D, h,
+                       nat.ACT_NONE)
+            for k in range(L - l):
+                r0, c0 = self.off[k], self.off[k + 1]
+                nat.check(lib.gsage_attn_bwd(
+                    self.dagg[l][r0:].data_ptr(), ld, self.ws[l][c0 - self.off[1]:].data_ptr(),
+                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, inp[c0:].data_ptr(), self.code, ld,
+                    None, self.size[k], self.fan[k + 1], Ha, D, self.dan[l][c0:].data_ptr(), Ha,
+                    self.dax[l][r0:].data_ptr(), Ha, stream), "attn_bwd")
+            # d a = (as a child) + (as a parent); hop 0 is never a child, the last hop never a parent (zeros)
+            nat.check(lib.gsage_add_cast(self.dan[l].data_ptr(), Ha, self.dax[l].data_ptr(), Ha, self.da[l].data_ptr(),
+                                         self.code, HL, RA, Ha, stream), "add_cast")
+            self._gemm(self.da[l].data_ptr(), HL, self.w2T[l], self.dhg[l].data_ptr(), nat.F32, Ha, RA, Ha, Ha,
+                       nat.ACT_NONE)
+            nat.check(lib.gsage_tanh_bwd(self.dhg[l].data_ptr(), Ha, self.hid[l].data_ptr(), self.code, HL,
+                                         self.dhid[l].data_ptr(), HL, RA, Ha, stream), "tanh_bwd")
+            if l > 0:
+                self._gemm(self.dhid[l].data_ptr(), HL, self.w0T[l], self.datt[l].data_ptr(), nat.F32, ld, RA, D, Ha,
+                           nat.ACT_NONE)
+                self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dx[l].data_ptr(), nat.F32, ld, R, D, h, nat.ACT_NONE)
+                below = self.hout[l - 1]
+                nat.check(lib.gsage_attn_merge_bwd(
+                    below.data_ptr(), self.code, below.stride(0), self.datt[l].data_ptr(), ld, self.dx[l].data_ptr(), ld,
+                    R, self.dagg[l].data_ptr(), ld, self.ws[l].data_ptr(), self.dc[l - 1].data_ptr(), self.code,
+                    self.dc[l - 1].stride(0), RA, D, L - l + 1, self.off_host, self.fan_host, stream), "attn_merge_bwd")
+        probs = []
+        for l in range(L - 1, -1, -1):
+            for (dC, A, lda, M, ntot, K, prm), slab in zip(self._wg_problems(l, s), self.slabs[l]):
+                probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.WG_TARGET))
+        for i in range(0, len(probs), 8):
+            ops.wgrad_multi(probs[i:i + 8])
+        self._stage_finalize(s)
+
+
 def fused_engine_for(model, feats):
     """The fused train-step engine that covers (model, feats), or None (callers then fall back to
     GSSupervised.train_step, optionally captured by CapturedTrainStep)."""
-    for cls in (FusedMeanTrainStep, FusedPoolTrainStep):
+    for cls in (FusedMeanTrainStep, FusedPoolTrainStep, FusedAttnTrainStep):
         if cls.supports(model, feats):
             return cls
     return None

@@ -199,3 +199,65 @@ def test_checks_detect_a_skipped_update_and_a_dropped_gradient_term():
     bad = dict(model.named_parameters())[kk].grad.cpu().numpy() * 0.0
     with pytest.raises(AssertionError):
         close_rel(bad, g[p + "s0_cg_" + kk], "dropped term", 2e-4)
+
+
+@pytest.mark.parametrize("capture", [False, "cmdlist"])
+def test_fp32_attention_engine_replays_reference_train_steps(capture):
+    """engine.FusedAttnTrainStep (native attention step: K4 forward / backward, the att MLP on K5, K5b, the merge
+    kernel -- no autograd) on the reference's attention / identity / classification fixture (model_kat case 6):
+    two train steps in fp32 storage with the recorded draws, against the reference's predictions, clipped
+    gradients of BOTH steps and weights after each Adam update."""
+    g = load_golden("model_kat.npz")
+    p = "c6_"
+    assert [str(v) for v in g[p + "cfg"]][:3] == ["attention", "identity", "classification"]
+    model, store, task = build_model(gs, g, p, device=DEV, feats_dtype="fp32")
+    fan = [int(v) for v in g[p + "fanouts"]]
+    ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+    tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cls = gs.engine.fused_engine_for(model, store)
+    assert cls is gs.engine.FusedAttnTrainStep
+    eng = cls(model, store, gs.ProblemLosses.classification, ids, tg, capture=capture)
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        eng.set_sel([g[p + "s%d_sel%d" % (step, h)] for h in range(len(fan))])
+        preds = eng(ids, tg).detach().cpu().numpy()
+        close(preds, g[p + "s%d_preds" % step], (step, "preds"), 2e-4, 2e-5)
+        gn = float(eng.gnorm.item())
+        assert abs(gn - float(g[p + "s%d_gradnorm" % step])) <= 2e-4 * max(1.0, float(g[p + "s%d_gradnorm" % step]))
+        for k, v in model.named_parameters():
+            close_rel(v.grad.cpu().numpy(), g[p + "s%d_cg_%s" % (step, k)], (step, "clipped grad", k), 2e-4)
+        for k, v in model.state_dict().items():
+            close_update(v.detach().cpu().numpy(), g[p + "w%d_%s" % (step + 1, k)], w0[k].numpy(), (step, "weights", k))
+    model.train_sampler.csr(DEV).check()
+
+
+def test_bf16_attention_engine_matches_reference_and_queue_mode():
+    """The bf16 instantiation of the same engine: against the reference's fp32 outputs at bf16 tolerance, and
+    its queue mode (gathers of batch i+1 + sampling of batch i+2 beside Adam(i)) == per-call mode, bit for bit."""
+    g = load_golden("model_kat.npz")
+    p = "c6_"
+    fan = [int(v) for v in g[p + "fanouts"]]
+    outs = []
+    for queued in (False, True):
+        model, store, task = build_model(gs, g, p, device=DEV, feats_dtype="bf16")
+        ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+        tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+        eng = gs.engine.FusedAttnTrainStep(model, store, gs.ProblemLosses.classification, ids, tg, capture="cmdlist")
+        sels = [[g[p + "s%d_sel%d" % (st, h)] for h in range(len(fan))] for st in range(2)]
+        preds = []
+        if queued:
+            sel_q = torch.stack([torch.cat([torch.from_numpy(np.asarray(x)).reshape(-1) for x in sels[st]])
+                                 for st in range(2)])
+            eng.load_epoch(torch.stack([ids, ids]), torch.stack([tg, tg]), sel_epoch=sel_q)
+            for st in range(2):
+                preds.append(eng.step_queue().clone())
+        else:
+            for st in range(2):
+                eng.set_sel(sels[st])
+                preds.append(eng(ids, tg).clone())
+        torch.cuda.synchronize()
+        outs.append((torch.stack(preds), eng.flat_p.clone()))
+        for st in range(2):
+            close(preds[st].cpu().numpy(), g[p + "s%d_preds" % st], (queued, st, "preds vs reference"), 4e-2, 4e-2)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

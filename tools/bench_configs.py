@@ -16,11 +16,12 @@ ap.add_argument("config", choices=["pokec", "papers"])
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--papers-nodes", type=int, default=8_000_000)
+ap.add_argument("--precision", type=str, default=None)
 args = ap.parse_args()
 dev = torch.device("cuda")
 gs.ops.set_compute_dtype("bf16")
 gs.ops.warmup(dev)
 if args.config == "pokec":
-    print(json.dumps(bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup)))
+    print(json.dumps(bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup, precision=args.precision)))
 else:
     print(json.dumps(bench.extra_papers(gs, dev, steps=args.steps, warmup=args.warmup, n_nodes=args.papers_nodes)))
