@@ -369,7 +369,7 @@ def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=8_000_000, B=BATCH):
             "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2))}
 
 
-def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None):
+def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fused"):
     """BASELINE configs[3] at its SHAPE on one GPU: Pokec-sized graph (1.63 M nodes, ~6e7 edges), no features,
     trainable 64-d node embeddings (node_embedding prep), attention aggregator (hidden 32), fan-out 20/15,
     regression_mae.  The step keeps the reference's DENSE embedding-gradient semantics: clip and Adam run
@@ -393,15 +393,20 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None):
     ids = torch.from_numpy(rng.integers(1, N + 1, size=(total, B))).to(dev)
     tg = torch.from_numpy(rng.integers(15, 60, size=(total, B, 1)).astype(np.float32)).to(dev)
     loss_fn = gs.ProblemLosses.regression_mae
-    step_fn = gs.engine.CapturedTrainStep(model, None, loss_fn, ids[0], tg[0])
+    cls = gs.engine.fused_engine_for(model, None) if engine == "fused" else None
+    if cls is not None:
+        step_fn = cls(model, None, loss_fn, ids[0], tg[0], capture="graph")
+        how = "%s (native attention step: K4 / K5 / K5b / K6, no autograd below the head), hipGraph" % cls.__name__
+    else:
+        step_fn = gs.engine.CapturedTrainStep(model, None, loss_fn, ids[0], tg[0])
+        how = "CapturedTrainStep (native K4 / K5 / K5b / K6 kernels under autograd, hipGraph)"
     dt = _timed_steps(lambda k: step_fn(ids[k], tg[k]), warmup, steps)
     model.train_sampler.csr(dev).check()
     rows = 1 + 20 + 300
     return {"config": "BASELINE configs[3] shape on one GPU: Pokec-sized graph (N=%d, nnz=%d), node_embedding(64) + "
                       "attention(32), fan-out 20/15, regression_mae" % (N, adj.nnz),
             "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec",
-            "engine": "CapturedTrainStep (native K4 / K5 / K5b / K6 kernels under autograd, hipGraph)",
-            "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2)}
+            "engine": how, "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2)}
 
 
 def _free_port():
@@ -455,7 +460,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool,papers,pokec",
+    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec",
                     help="comma-separated additional configurations measured after the main line (N=1 only) and "
                          "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
                          "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
@@ -621,7 +626,9 @@ def main():
             for agg in [a for a in names if a not in ("papers", "pokec")]:
                 r2 = measure(agg, min(args.min_time, 0.3))
                 e2 = r2["elapsed"]
-                rec = {"config": "BASELINE configs[2] shape on one GPU" if agg == "max_pool" else agg,
+                rec = {"config": {"max_pool": "BASELINE configs[2] shape on one GPU",
+                                  "attention": "attention aggregators on the Reddit-shaped graph (config 4's aggregator "
+                                               "on config 2's data), native engine"}.get(agg, agg),
                        "ms_per_step": e2 / args.steps * 1e3, "value": args.steps * B / e2,
                        "unit": "seed-nodes/sec", "engine": type(r2["step_fn"]).__name__,
                        "kernel_launches_per_step": r2["launches_per_step"], "repeats": len(r2["times"])}

@@ -464,6 +464,8 @@ int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
  * increments *step afterwards; != 0: *step was already advanced for this update (by
  * gsage_prep_weights' / gsage_finalize_grads' tick) and is left alone.  partial: fp32 scratch of
  * gsage_adam_partials(n) elements.  norm_out (may be NULL) receives the pre-clip gradient norm.
+ * (step_is_current & 2: the caller consumes g in this call and zeroes it next -- a scatter-added
+ * embedding-table gradient --, so the clipped values are not written back.)
  * n_partial_ready > 0: `partial` already holds that many squared-norm partials (written by
  * gsage_finalize_grads) and the norm pass is skipped.  prep_descs (DEVICE array of n_prep
  * gsage_prep_desc whose src point into p; may be NULL): the bf16 operand copies of the updated
@@ -525,6 +527,17 @@ int gsage_finalize_grads(const void *descs, int32_t n_desc, int64_t max_elems, f
                          float *partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
                          int64_t *tick2, int64_t inc2, void *stream);
 int gsage_finalize_partials(int32_t n_desc, int64_t max_elems);
+/* Pieces of the same tail for a bucket that holds a trainable embedding table (NodeEmbeddingPrep, config 4:
+ * a dense 418 MB gradient by the reference's semantics):
+ *   gsage_grad_sqnorm      partial[b] = sum of g[i]^2 over block b's slice (n_partial <= 1024 blocks): squared-norm
+ *                          partials of a bucket slice, to sit next to gsage_finalize_grads' in one `partial` array
+ *   gsage_zero_rows        table[ids[r], 0:D] = 0: undoes a gsage_scatter_add_rows once the optimizer has consumed
+ *                          it -- the gradient table is zeroed by touching the rows that were written, not all of it
+ *   gsage_colsum_partials  part[b, c] = sum_{i = b, b + n_part, ...} src[i, c]: a Linear's bias gradient as
+ *                          deterministic partial rows (summed by gsage_finalize_grads, S = n_part, stride = D) */
+int gsage_grad_sqnorm(const float *g, int64_t n, float *partial, int32_t n_partial, void *stream);
+int gsage_zero_rows(float *table, int64_t ld, const int64_t *ids, int64_t M, int64_t D, void *stream);
+int gsage_colsum_partials(const float *src, int64_t ld, int64_t M, int32_t D, float *part, int32_t n_part, void *stream);
 int gsage_adam_partials(int64_t n);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:

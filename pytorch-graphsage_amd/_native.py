@@ -83,6 +83,9 @@ SIGNATURES = {
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_partials": (_int, [_i32, _i64]),
+    "gsage_grad_sqnorm": (_int, [_vp, _i64, _vp, _i32, _vp]),
+    "gsage_zero_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _vp]),
+    "gsage_colsum_partials": (_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
     "gsage_bwd_merge": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp,

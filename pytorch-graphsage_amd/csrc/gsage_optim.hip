@@ -200,6 +200,49 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
 
 __global__ void k_step_inc(int64_t *step) { *step += 1; }
 
+// table[ids[r], 0:D] = 0: undoes a scatter-add (gsage_scatter_add_rows) once the optimizer has consumed it, so
+// that a dense gradient table is zeroed by touching the rows that were written instead of all of it
+__global__ void __launch_bounds__(256)
+k_zero_rows(float *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M, int32_t chunks)
+{
+    const int64_t total = M * chunks, stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t r = t / chunks;
+        const int c = (int)(t - r * chunks) * 4;
+        *reinterpret_cast<f32x4 *>(table + ids[r] * ld + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// part[b, c] = sum over rows i = b, b + n_part, ... of src[i, c]   (bias gradient of a Linear: column sums)
+// A workgroup = 256 / DW row lanes x DW columns (DW = D rounded up to a power of two <= 256): every thread
+// streams rows, four loads in flight, the row lanes meet in LDS in a fixed order.
+__global__ void __launch_bounds__(256)
+k_colsum_partials(const float *__restrict__ src, int64_t ld, int64_t M, int32_t D, int32_t DW, float *__restrict__ part)
+{
+    __shared__ float red[256];
+    const int lanes = 256 / DW;                       // row lanes per workgroup
+    const int c = blockIdx.y * DW + (threadIdx.x % DW), rl = threadIdx.x / DW;
+    const int64_t step = (int64_t)gridDim.x * lanes;
+    float s = 0.f;
+    if (c < D) {
+        int64_t i = (int64_t)blockIdx.x + (int64_t)rl * gridDim.x;     // rows b, b + n_part, ... split over the lanes
+        for (; i + 3 * step < M; i += 4 * step) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[(i + u * step) * ld + c];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; i < M; i += step) s += src[i * ld + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += red[l * DW + (threadIdx.x % DW)];
+        part[(int64_t)blockIdx.x * D + c] = t;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_prep_weights(const PrepDesc *__restrict__ descs, int64_t *tick0, int64_t inc0, int64_t *tick1,
                int64_t inc1)
@@ -489,6 +532,10 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
                          int32_t n_partial_ready, const void *prep_descs, int32_t n_prep,
                          int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2, void *stream)
 {
+    // step_is_current & 2: the caller consumes the gradient here (it is about to be zeroed): do not write the
+    // clipped values back (a trainable embedding table: 418 MB of stores per clipped step at Pokec's size)
+    const int discard = (step_is_current & 2) != 0;
+    step_is_current &= 1;
     gsage_adam_desc d;
     d.p = p; d.g = g; d.m = m; d.v = v; d.n = n; d.partial = partial; d.lr = lr; d.step = step;
     d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay; d.max_norm = max_norm;
@@ -508,6 +555,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     AdamParams a;
     rc = fill_adam(a, d);
     if (rc != GSAGE_OK) return rc;
+    a.discard_clipped = discard;
     launch(k_adam_clip, dim3(adam_grid(a.n_prep > 0 ? ceil_div(n, 4) : n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;
@@ -516,6 +564,33 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
         rc = check_launch("step_inc");
     }
     return rc;
+}
+
+int gsage_grad_sqnorm(const float *g, int64_t n, float *partial, int32_t n_partial, void *stream)
+{
+    GSAGE_REQUIRE(g && partial && n > 0 && n_partial >= 1 && n_partial <= 1024, "grad_sqnorm: bad arguments");
+    launch(k_grad_sqnorm, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+    return check_launch("grad_sqnorm");
+}
+
+int gsage_zero_rows(float *table, int64_t ld, const int64_t *ids, int64_t M, int64_t D, void *stream)
+{
+    GSAGE_REQUIRE(table && ids && M >= 0 && D > 0 && D % 4 == 0 && ld % 4 == 0 && ld >= D &&
+                  ((uintptr_t)table % 16) == 0, "zero_rows: needs 16-byte rows (D, ld multiples of 4)");
+    if (M == 0) return GSAGE_OK;
+    launch(k_zero_rows, dim3(grid_for(M * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, table, ld, ids, M,
+           (int32_t)(D / 4));
+    return check_launch("zero_rows");
+}
+
+int gsage_colsum_partials(const float *src, int64_t ld, int64_t M, int32_t D, float *part, int32_t n_part, void *stream)
+{
+    GSAGE_REQUIRE(src && part && M >= 0 && D > 0 && ld >= D && n_part >= 1 && n_part <= 1024, "colsum_partials: bad arguments");
+    int32_t DW = 1;
+    while (DW < D && DW < 256) DW <<= 1;
+    launch(k_colsum_partials, dim3((unsigned)n_part, (unsigned)ceil_div(D, DW)), dim3(256), 0, (hipStream_t)stream, src,
+           ld, M, D, DW, part);
+    return check_launch("colsum_partials");
 }
 
 int gsage_prep_weights(const void *descs, int32_t n_desc, int64_t max_elems, int64_t *tick0,

@@ -63,6 +63,7 @@ struct AdamParams {
     int32_t n_prep;
     int64_t *tick1, *tick2;        // optional counters advanced at kernel start (not read here)
     int64_t inc1, inc2;
+    int32_t discard_clipped;       // != 0: the clipped gradient is not written back (the caller zeroes g next)
 };
 
 // one workgroup of the clip + Adam update: grid-stride slice bx of gx
@@ -86,7 +87,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
     }
 
     const int64_t stride = (int64_t)gx * 256;
-    const bool clipped = coef < 1.f;                    // (block-uniform) unclipped gradients are not rewritten
+    const bool clipped = coef < 1.f && !a.discard_clipped;   // (block-uniform) unclipped gradients are not rewritten
     if (a.n_prep == 0 && (a.n & 3) == 0 &&
         ((((uintptr_t)a.p | (uintptr_t)a.g | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0)) {
         // big plain buckets (a trainable embedding table): 16-byte lanes, no operand copies to refresh
@@ -169,6 +170,7 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.norm_out = d.norm_out; a.n = d.n; a.n_partial = d.n_partial_ready; a.beta1 = d.beta1;
     a.beta2 = d.beta2; a.eps = d.eps; a.weight_decay = d.weight_decay; a.max_norm = d.max_norm;
     a.step_off = d.step_is_current ? 0 : 1;
+    a.discard_clipped = 0;
     return GSAGE_OK;
 }
 

@@ -255,16 +255,16 @@ class FusedMeanTrainStep(object):
             # the backend has no AVG
             self._reduce_op = torch.distributed.ReduceOp.AVG
             try:
-                probe = torch.ones(8, device=feats.device)
+                probe = torch.ones(8, device=next(model.parameters()).device)
                 torch.distributed.all_reduce(probe, op=self._reduce_op)
                 if abs(float(probe[0]) - 1.0) > 1e-6:
                     raise RuntimeError("AVG returned %r" % float(probe[0]))
             except Exception:
                 self._reduce_op = torch.distributed.ReduceOp.SUM
-        dev = feats.device
+        dev = feats.device if feats is not None else next(model.parameters()).device
         self.dev = dev
         # storage type of features, activations and weight operand copies
-        self.tdt = feats.dtype
+        self.tdt = feats.dtype if feats is not None else ops.torch_dtype()
         self.code = nat.BF16 if self.tdt == torch.bfloat16 else nat.F32
         self.esz = 2 if self.tdt == torch.bfloat16 else 4
         self.sel, self.sel_queue = None, None     # caller-supplied sampler draws (set_sel / load_epoch)
@@ -444,7 +444,8 @@ class FusedMeanTrainStep(object):
             rdesc.append(_ReduceDesc(self.head_stage.data_ptr(), 0, self.poff[ifc], 1, 1, Cc * D2c + Cc,
                                      Cc * D2c + Cc))
         covered = sum(d.rows * d.cols for d in rdesc)
-        assert covered == self.flat_p.numel(), "every parameter must be covered by a gradient source"
+        uncovered = self._uncovered() if hasattr(self, "_uncovered") else 0     # e.g. a scatter-added embedding table
+        assert covered + uncovered == self.flat_p.numel(), "every parameter must be covered by a gradient source"
         self.rdescs = torch.frombuffer(bytearray(bytes((_ReduceDesc * len(rdesc))(*rdesc))),
                                        dtype=torch.uint8).to(dev)
         self.n_rdesc = len(rdesc)
@@ -491,6 +492,10 @@ class FusedMeanTrainStep(object):
     def _record_main(self):
         """(Re-)record the per-call command lists / graphs of __call__."""
         ddp = self.ddp
+        if self.capture_mode == "graph":
+            # re-recording: let go of the old hipGraphs (and their private pool) before capturing new ones
+            self.g_main, self.g_opt, self.g_front, self._pool = None, None, None, None
+            torch.cuda.synchronize()
         self.g_main = []
         if self.pipelined:
             self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
@@ -1400,9 +1405,16 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         codes = [_split_activation(l.activation)[0] for l in layers]
         if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
             return False
-        if not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
+        from .nn_modules import NodeEmbeddingPrep
+        if isinstance(model.prep, NodeEmbeddingPrep):
+            # BASELINE config 4: no features, trainable node embeddings (+ affine) are the level-0 rows
+            if feats is not None or model.prep.input_dim or model.prep.embedding_dim % 8 != 0:
+                return False
+            if not model.prep.embedding.weight.is_cuda:
+                return False
+        elif not isinstance(model.prep, IdentityPrep) or not isinstance(feats, FeatureStore):
             return False
-        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda or feats.ld % 8 != 0:
+        elif feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda or feats.ld % 8 != 0:
             return False
         if not isinstance(model.train_sampler, SparseUniformNeighborSampler) or model.train_sampler.rng != "philox":
             return False
@@ -1414,12 +1426,20 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
 
     # ---- construction ------------------------------------------------------------------------------
     def _init_levels(self, example_ids, example_targets):
+        from .nn_modules import NodeEmbeddingPrep
         feats, dev, L = self.store, self.dev, self.L
         T, f32 = self.tdt, torch.float32
         self.Ha = 32
         self.h = [l.output_dim_ for l in self.layers]
-        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
-        self.ldin = [feats.ld] + [2 * h for h in self.h[:-1]]
+        self.emb = isinstance(self.model.prep, NodeEmbeddingPrep)
+        if self.emb:
+            assert self.ddp is None, "the embedding-prep engine is single-GPU (data-parallel runs use the module path)"
+            E = int(self.model.prep.embedding_dim)
+            d0, ld0 = E, _r64(E) if T == torch.bfloat16 else E
+        else:
+            d0, ld0 = feats.dim, feats.ld
+        self.din = [d0] + [2 * h for h in self.h[:-1]]
+        self.ldin = [ld0] + [2 * h for h in self.h[:-1]]
         self.rows = [self.off[L - l] for l in range(L)]              # x rows of level l
         self.rall = [self.off[L - l + 1] for l in range(L)]          # all input rows of level l
         assert all(d % 8 == 0 for d in self.ldin)
@@ -1434,16 +1454,31 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             return w, wt
         self.w0, self.w0T, self.w2, self.w2T, self.wx, self.wxT, self.wn, self.wnT = ([] for _ in range(8))
         for l, layer in enumerate(self.layers):
-            a, b = copies(layer.att[0].weight, l > 0); self.w0.append(a); self.w0T.append(b)
+            ing = l > 0 or self.emb                  # does this level's input need a gradient?
+            a, b = copies(layer.att[0].weight, ing); self.w0.append(a); self.w0T.append(b)
             a, b = copies(layer.att[2].weight, True); self.w2.append(a); self.w2T.append(b)
-            a, b = copies(layer.fc_x.weight, l > 0); self.wx.append(a); self.wxT.append(b)
+            a, b = copies(layer.fc_x.weight, ing); self.wx.append(a); self.wxT.append(b)
             a, b = copies(layer.fc_neib.weight, True); self.wn.append(a); self.wnT.append(b)
+        if self.emb:
+            self.wp, self.wpT = copies(self.model.prep.fc.weight, True)
         self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
         self.max_elems = max(d.rows * d.cols for d in descs)
 
         # level-0 rows of every hop, gathered once per step (one set per batch in flight)
-        self.g0_set = [torch.zeros(self.rall[0], feats.ld, dtype=T, device=dev) for _ in range(self.nset)]
+        self.g0_set = [torch.zeros(self.rall[0], self.ldin[0], dtype=T, device=dev) for _ in range(self.nset)]
+        if self.emb:
+            prep, RA0, E = self.model.prep, self.rall[0], self.din[0]
+            self.table = prep.embedding.weight                 # a view of the flat parameter bucket
+            assert self.pidx[id(self.table)] == 0 and self.table.shape[1] == E and self.table.numel() % 4 == 0
+            self.seed_rows = torch.full((self.B,), int(prep.n_nodes), dtype=torch.int64, device=dev)
+            self.eraw32 = torch.zeros(RA0, E, dtype=f32, device=dev)            # embedding rows as gathered
+            self.eraw = self.eraw32 if T == f32 else torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)
+            self.din0f = torch.zeros(RA0, E, dtype=f32, device=dev)             # d prep output
+            self.din0 = self.din0f if T == f32 else torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)
+            self.deraw = torch.zeros(RA0, E, dtype=f32, device=dev)             # d embedding rows
+            self.bpart = torch.zeros(256, E, dtype=f32, device=dev)             # prep.fc.bias gradient partials
+            self._cur_ids = self.ids_set[0]
         Ha, HL = self.Ha, self.HA_LD
         z = lambda *shape, dt=f32: torch.zeros(*shape, dtype=dt, device=dev)
         self.hid, self.a, self.agg, self.aggc, self.ws, self.hout, self.dc = ([] for _ in range(7))
@@ -1456,7 +1491,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             self.hout.append(z(R, 2 * h, dt=f32 if last else T)); self.dc.append(z(R, 2 * h, dt=T))
             self.dagg.append(z(R, ld)); self.dan.append(z(RA, Ha)); self.dax.append(z(RA, Ha))
             self.da.append(z(RA, HL, dt=T)); self.dhg.append(z(RA, Ha)); self.dhid.append(z(RA, HL, dt=T))
-            self.datt.append(z(RA, ld) if l > 0 else None); self.dx.append(z(R, ld) if l > 0 else None)
+            ing = l > 0 or self.emb
+            self.datt.append(z(RA, ld) if ing else None); self.dx.append(z(R, ld) if ing else None)
         self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
         self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
 
@@ -1472,10 +1508,13 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         """(dC, A, lda, M, Ntot, K, parameter) of the four weight gradients of level l"""
         inp, ld = self._in(l, s)
         h, Ha, D, layer = self.h[l], self.Ha, self.din[l], self.layers[l]
-        return [(self.dc[l][:, :h], inp, ld, self.rows[l], h, D, layer.fc_x.weight),
-                (self.dc[l][:, h:], self.aggc[l], ld, self.rows[l], h, D, layer.fc_neib.weight),
-                (self.da[l], self.hid[l], self.HA_LD, self.rall[l], Ha, Ha, layer.att[2].weight),
-                (self.dhid[l], inp, ld, self.rall[l], Ha, D, layer.att[0].weight)]
+        probs = [(self.dc[l][:, :h], inp, ld, self.rows[l], h, D, layer.fc_x.weight),
+                 (self.dc[l][:, h:], self.aggc[l], ld, self.rows[l], h, D, layer.fc_neib.weight),
+                 (self.da[l], self.hid[l], self.HA_LD, self.rall[l], Ha, Ha, layer.att[2].weight),
+                 (self.dhid[l], inp, ld, self.rall[l], Ha, D, layer.att[0].weight)]
+        if l == 0 and self.emb:      # the prep's affine: d out^T x embedding rows
+            probs.append((self.din0, self.eraw, self.eraw.stride(0), self.rall[0], D, D, self.model.prep.fc.weight))
+        return probs
 
     def _init_reduce(self):
         dev, f32 = self.dev, torch.float32
@@ -1488,15 +1527,115 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
                 bufs.append(buf)
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
             self.slabs.append(bufs)
+        if self.emb:
+            E = self.din[0]
+            ib = self.pidx[id(self.model.prep.fc.bias)]
+            rdesc.append(_ReduceDesc(self.bpart.data_ptr(), E, self.poff[ib], self.bpart.shape[0], 1, E, E))
         self._install_reduce(rdesc)
+        if self.emb:
+            # the table's gradient comes from scatter-adds, its squared norm from a pass of its own whose
+            # partials sit behind the finalisation's in the same array
+            self.n_tab = int(self.table.numel())
+            self.n_tab_partial = nat.lib().gsage_adam_partials(self.n_tab)
+            self.partial = torch.zeros(self.n_partial + self.n_tab_partial, dtype=torch.float32, device=self.dev)
+
+    def _uncovered(self):
+        return int(self.table.numel()) if getattr(self, "emb", False) else 0
 
     # ---- stages ----------------------------------------------------------------------------------------
     def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
+        if self.emb:
+            return               # nothing to gather ahead: the embedding rows are weights (read after Adam)
         st = self.store
         if ids is None:
             ids = self.ids_set[s]
         segs = [(st.data, ids[:self.rall[0]], self.g0_set[s], self.rall[0], 1)]
         ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None, hops=hops)
+
+    # embedding prep: the level-0 rows are prep.fc(embedding[ids]) (nn_modules.py:144-155) -- computed at the start of
+    # the step from the CURRENT table, their gradient scattered back into the table's (dense) gradient at the end
+    def _prep_forward(self, s):
+        lib, stream, prep = nat.lib(), ops._stream(), self.model.prep
+        ids, B, RA0, E = self._cur_ids, self.B, self.rall[0], self.din[0]
+        tab = self.table
+        segs = [(tab, self.seed_rows, self.eraw32[:B], B, 1),                    # seeds read the spare row n_nodes
+                (tab, ids[B:RA0], self.eraw32[B:], RA0 - B, 1)]
+        ops.gather_mean_multi(segs, E, E, E)
+        if self.eraw is not self.eraw32:
+            nat.check(lib.gsage_add_cast(self.eraw32.data_ptr(), E, None, 0, self.eraw.data_ptr(), self.code,
+                                         self.eraw.stride(0), RA0, E, stream), "add_cast")
+        ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wp.data_ptr(), self.wp.shape[1],
+                           prep.fc.bias.data_ptr(), self.g0_set[s].data_ptr(), self.ldin[0], RA0, E, E, nat.ACT_NONE, 1,
+                           0, 0, 0, self.code, self.code)
+
+    def _prep_backward(self, s):
+        """level 0's input gradient -> prep.fc (weight: K5b problem of level 0; bias: column sums) -> table gradient."""
+        lib, stream = nat.lib(), ops._stream()
+        ids, B, RA0, E, L = self._cur_ids, self.B, self.rall[0], self.din[0], self.L
+        ld = self.ldin[0]
+        nat.check(lib.gsage_attn_merge_bwd(None, self.code, 0, self.datt[0].data_ptr(), ld, self.dx[0].data_ptr(), ld,
+                                           self.rows[0], self.dagg[0].data_ptr(), ld, self.ws[0].data_ptr(),
+                                           self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host,
+                                           self.fan_host, stream), "attn_merge_bwd")
+        if self.din0 is not self.din0f:
+            nat.check(lib.gsage_add_cast(self.din0f.data_ptr(), E, None, 0, self.din0.data_ptr(), self.code,
+                                         self.din0.stride(0), RA0, E, stream), "add_cast")
+        nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
+                                            self.bpart.shape[0], stream), "colsum_partials")
+        self._gemm(self.din0.data_ptr(), self.din0.stride(0), self.wpT, self.deraw.data_ptr(), nat.F32, E, RA0, E, E,
+                   nat.ACT_NONE)
+        g = self._grad_slice(self.table)
+        for rows, idv, M in ((self.deraw[:B], self.seed_rows, B), (self.deraw[B:], ids[B:RA0], RA0 - B)):
+            nat.check(lib.gsage_scatter_add_rows(rows.data_ptr(), E, idv.data_ptr(), M, 1, E, 1.0, g.data_ptr(), E,
+                                                 stream), "scatter_add_rows")
+
+    def _stage_opt(self):
+        if not self.emb:
+            return super(FusedAttnTrainStep, self)._stage_opt()
+        lib, stream = nat.lib(), ops._stream()
+        d = self._adam_desc()
+        nt, B, RA0, E = self.n_tab, self.B, self.rall[0], self.din[0]
+        g = self._grad_slice(self.table)
+        nat.check(lib.gsage_grad_sqnorm(g.data_ptr(), nt, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+                                        stream), "grad_sqnorm")
+        n_all = self.n_partial + self.n_tab_partial
+        # the table (16-byte lanes, no operand copies), then everything else (operand copies refreshed)
+        # (flag 2 on the table: its gradient is zeroed below, no need to write the clipped values back)
+        for (o, n, prep, n_prep, cur) in ((0, nt, None, 0, 3), (nt, self.flat_p.numel() - nt, d.prep_descs, d.n_prep, 1)):
+            nat.check(lib.gsage_clip_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
+                                               self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
+                                               self.partial.data_ptr(), d.lr, d.step, d.beta1, d.beta2, d.eps,
+                                               d.weight_decay, d.max_norm, d.norm_out, cur, n_all, prep, n_prep, None,
+                                               0, None, 0, stream), "clip_adam_step")
+        # the table's gradient goes back to zero by touching the rows this step wrote
+        ids = self._cur_ids
+        for idv, M in ((self.seed_rows[:1], 1), (ids[B:RA0], RA0 - B)):
+            nat.check(lib.gsage_zero_rows(g.data_ptr(), E, idv.data_ptr(), M, E, stream), "zero_rows")
+
+    # queue mode with an embedding prep: sampling runs ahead, nothing else can (the rows are weights)
+    def _queue_prime(self):
+        if not self.emb:
+            return super(FusedAttnTrainStep, self)._queue_prime()
+        self._stage_sample(0, ids=self.ids_q[0])
+        self._stage_sample(0, ids=self.ids_q[1], ahead=True)
+
+    def _queue_compute(self, par):
+        if self.emb:
+            self._cur_ids = self.ids_q[par]
+        return super(FusedAttnTrainStep, self)._queue_compute(par)
+
+    def _queue_front(self, par, with_adam):
+        if not self.emb:
+            return super(FusedAttnTrainStep, self)._queue_front(par, with_adam)
+        assert with_adam
+        self._cur_ids = self.ids_q[par]
+        self._stage_opt()                                  # Adam(i) + zeroing of the rows batch i touched
+        self._stage_sample(0, ids=self.ids_q[par], ahead=True)      # batch i+2 (batch i's frontier is done with)
+
+    def _run_sequential(self, s):
+        if self.emb:
+            self._cur_ids = self.ids_set[s]
+        return super(FusedAttnTrainStep, self)._run_sequential(s)
 
     def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
         ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
@@ -1505,6 +1644,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
     def _stage_compute(self, s):
         L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
         Ha, HL, esz = self.Ha, self.HA_LD, self.esz
+        if self.emb:
+            self._prep_forward(s)
         for l in range(L):
             R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
             inp, ld = self._in(l, s)
@@ -1561,10 +1702,13 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
                        nat.ACT_NONE)
             nat.check(lib.gsage_tanh_bwd(self.dhg[l].data_ptr(), Ha, self.hid[l].data_ptr(), self.code, HL,
                                          self.dhid[l].data_ptr(), HL, RA, Ha, stream), "tanh_bwd")
-            if l > 0:
+            if l > 0 or self.emb:
                 self._gemm(self.dhid[l].data_ptr(), HL, self.w0T[l], self.datt[l].data_ptr(), nat.F32, ld, RA, D, Ha,
                            nat.ACT_NONE)
                 self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dx[l].data_ptr(), nat.F32, ld, R, D, h, nat.ACT_NONE)
+            if l == 0 and self.emb:
+                self._prep_backward(s)
+            if l > 0:
                 below = self.hout[l - 1]
                 nat.check(lib.gsage_attn_merge_bwd(
                     below.data_ptr(), self.code, below.stride(0), self.datt[l].data_ptr(), ld, self.dx[l].data_ptr(), ld,

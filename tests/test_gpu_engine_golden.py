@@ -261,3 +261,40 @@ def test_bf16_attention_engine_matches_reference_and_queue_mode():
         for st in range(2):
             close(preds[st].cpu().numpy(), g[p + "s%d_preds" % st], (queued, st, "preds vs reference"), 4e-2, 4e-2)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("capture", [False, "graph"])
+def test_fp32_attention_embedding_engine_replays_reference_train_steps(capture):
+    """BASELINE config 4's model family through the native engine: attention aggregators over TRAINABLE node
+    embeddings (node_embedding prep, no features), regression_mae -- the reference's fixture (model_kat case 4),
+    two train steps in fp32 with the recorded draws.  The embedding table's dense-gradient semantics are checked
+    through the weights: every row of the table after each Adam step (touched rows moved like the reference's,
+    the others not at all)."""
+    g = load_golden("model_kat.npz")
+    p = "c4_"
+    assert [str(v) for v in g[p + "cfg"]][:3] == ["attention", "node_embedding", "regression_mae"]
+    ops.set_compute_dtype("fp32")
+    model, store, task = build_model(gs, g, p, device=DEV, feats_dtype="fp32")
+    assert store is None
+    fan = [int(v) for v in g[p + "fanouts"]]
+    ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+    tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cls = gs.engine.fused_engine_for(model, None)
+    assert cls is gs.engine.FusedAttnTrainStep
+    eng = cls(model, None, gs.ProblemLosses.regression_mae, ids, tg, capture=capture)
+    assert eng.emb and eng.tdt == torch.float32
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        eng.set_sel([g[p + "s%d_sel%d" % (step, h)] for h in range(len(fan))])
+        preds = eng(ids, tg).detach().cpu().numpy()
+        close(preds, g[p + "s%d_preds" % step], (step, "preds"), 2e-4, 2e-5)
+        gn = float(eng.gnorm.item())
+        assert abs(gn - float(g[p + "s%d_gradnorm" % step])) <= 2e-4 * max(1.0, float(g[p + "s%d_gradnorm" % step]))
+        for k, v in model.named_parameters():
+            if k != "prep.embedding.weight":             # the table's gradient is consumed (zeroed) by the step
+                close_rel(v.grad.cpu().numpy(), g[p + "s%d_cg_%s" % (step, k)], (step, "clipped grad", k), 2e-4)
+        for k, v in model.state_dict().items():
+            close_update(v.detach().cpu().numpy(), g[p + "w%d_%s" % (step + 1, k)], w0[k].numpy(), (step, "weights", k))
+        assert float(eng._grad_slice(eng.table).abs().max()) == 0.0
+    model.train_sampler.csr(DEV).check()

@@ -17,11 +17,12 @@ ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--papers-nodes", type=int, default=8_000_000)
 ap.add_argument("--precision", type=str, default=None)
+ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"])
 args = ap.parse_args()
 dev = torch.device("cuda")
 gs.ops.set_compute_dtype("bf16")
 gs.ops.warmup(dev)
 if args.config == "pokec":
-    print(json.dumps(bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup, precision=args.precision)))
+    print(json.dumps(bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup, precision=args.precision, engine=args.engine)))
 else:
     print(json.dumps(bench.extra_papers(gs, dev, steps=args.steps, warmup=args.warmup, n_nodes=args.papers_nodes)))
