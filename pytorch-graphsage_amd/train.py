@@ -200,7 +200,6 @@ def train_fused(args, problem, model, ddp, start_time):
     assert args.cuda and args.rng == 'philox', '--engine fused needs CUDA and --rng philox'
     cls = gs.engine.fused_engine_for(model, problem.feats)
     assert cls is not None, '--engine fused: no fused engine covers this model (use --engine eager)'
-    assert problem.task == 'classification', '--engine fused: classification problems only'
     world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
     B = args.batch_size // world                       # per-rank share of the global batch
     nodes = problem.nodes['train']
@@ -213,22 +212,31 @@ def train_fused(args, problem, model, ddp, start_time):
         order = np.random.permutation(np.arange(nodes.shape[0]))[:n_batches * B * world]     # problem.py:146
         mids = nodes[order].reshape(n_batches, world, B)[:, rank]
         ids = torch.from_numpy(np.ascontiguousarray(mids)).to(dev)
-        tgs = torch.from_numpy(np.asarray(problem.targets[mids.reshape(-1)]).reshape(n_batches, B)).long().to(dev)
+        tg = np.asarray(problem.targets[mids.reshape(-1)])
+        if problem.task == 'classification':
+            tgs = torch.from_numpy(tg.reshape(n_batches, B)).long().to(dev)
+        else:                                        # multilabel: [.., n_classes] floats; regression: [.., 1] floats
+            tgs = torch.from_numpy(tg.reshape(n_batches, B, -1).astype(np.float32)).to(dev)
         return ids, tgs
     ids, tgs = epoch_batches()
-    step = cls(model, problem.feats, problem.loss_fn, ids[0], tgs[0].view(B, 1), ddp=ddp)
+    first = tgs[0].view(B, 1) if problem.task == 'classification' else tgs[0]
+    step = cls(model, problem.feats, problem.loss_fn, ids[0], first, ddp=ddp)
+    # engines with the fused classification head walk a device-resident queue of the epoch's batches; the others
+    # (regression / multilabel heads run as stock torch ops inside the captured step) take one batch per call
+    queued = bool(getattr(step, "fused_head", False))
     val_metric = train_metric = None
     epoch = 0
     for epoch in range(args.epochs):
         model.train()
         if epoch > 0:
             ids, tgs = epoch_batches()
-        step.load_epoch(ids, tgs)
+        if queued:
+            step.load_epoch(ids, tgs)
         for b in range(n_batches):
             step.set_progress((epoch + b / n_batches) / args.epochs)
-            preds = step.step_queue()
+            preds = step.step_queue() if queued else step(ids[b], tgs[b])
             if (b % max(args.log_interval, 1) == 0 or b == n_batches - 1) and rank == 0:
-                train_metric = batch_metric(problem.task, tgs[b].view(B, 1), preds)
+                train_metric = batch_metric(problem.task, tgs[b].view(B, -1), preds)
                 print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
                              "val_metric": val_metric, "time": time() - start_time}))
                 sys.stdout.flush()

@@ -229,3 +229,97 @@ def test_stream_kat_with_the_stream_on_the_device():
     finally:
         hp.legacy_stream.drop()
         hp.legacy_stream.enabled = False
+
+
+def test_train_cli_pokec_style_with_the_native_attention_engine(tmp_path, capsys):
+    """The reference's Pokec command line (utils/pokec.sh: --prep-class node_embedding --aggregator-class
+    attention, no features, regression_mae) through train.py --engine fused: the native attention engine with
+    the trainable embedding table, one batch per call (its head runs as stock torch ops), MAE on the device.
+    The target is a function of the neighbourhood's ids that embeddings can pick up; the loss must fall."""
+    import importlib
+    rng = np.random.RandomState(0)
+    n = 600
+    degs = rng.randint(2, 10, size=n + 1)
+    degs[0] = 0
+    rows = np.repeat(np.arange(n + 1), degs)
+    cols = np.concatenate([np.arange(d) for d in degs])
+    vals = rng.randint(1, n + 1, size=rows.shape[0])
+    adj = sparse.csr_matrix((vals, (rows, cols)))
+    targets = (20.0 + 10.0 * (np.arange(n + 1) % 3)).astype(np.float32).reshape(-1, 1)
+    folds = np.array(["train"] * 450 + ["val"] * 100 + ["test"] * 51)
+    folds[0] = "dummy"
+    path = os.path.join(str(tmp_path), "problem.npz")
+    gs.problem.save_problem_npz(path, {"task": "regression_mae", "n_classes": 1, "folds": folds, "targets": targets,
+                                       "sparse": True, "adj": adj, "train_adj": adj})
+    train = importlib.import_module("pytorch-graphsage_amd.train")
+    before = gs._native.launch_count()
+    train.main(["--problem-path", path, "--engine", "fused", "--rng", "philox", "--batch-size", "64", "--epochs", "8",
+                "--lr-init", "0.05", "--sampler-class", "sparse_uniform_neighbor_sampler", "--aggregator-class",
+                "attention", "--prep-class", "node_embedding", "--n-train-samples", "4,3", "--n-val-samples", "4,3",
+                "--output-dims", "16,16", "--log-interval", "2"])
+    assert gs._native.launch_count() - before > 100      # recording + evaluation (hipGraph replays are not counted)
+    out = [json.loads(l) for l in capsys.readouterr().out.strip().split("\n") if l.startswith("{")]
+    logged = [o for o in out if "epoch_progress" in o]
+    assert len(logged) >= 8 and isinstance(logged[0]["train_metric"], float)
+    assert out[-1]["train_metric"] < 0.6 * logged[0]["train_metric"], (logged[0], out[-1])
+    assert isinstance(out[-1]["val_metric"], float)
+
+
+def test_attention_glue_kernels_against_torch():
+    """gsage_add_cast / gsage_tanh_bwd / gsage_attn_merge_bwd / gsage_colsum_partials / gsage_zero_rows /
+    gsage_grad_sqnorm, each against its one-line torch definition."""
+    import ctypes
+    nat = gs._native
+    L = nat.lib()
+    st = ops._stream()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    R, D = 777, 40
+    a = torch.randn(R, 48, device=DEV, generator=g)
+    b = torch.randn(R, 44, device=DEV, generator=g)
+    for dt, code in ((torch.bfloat16, nat.BF16), (torch.float32, nat.F32)):
+        out = torch.zeros(R, 64, dtype=dt, device=DEV)
+        nat.check(L.gsage_add_cast(a.data_ptr(), 48, b.data_ptr(), 44, out.data_ptr(), code, 64, R, D, st), "add_cast")
+        assert torch.equal(out[:, :D], (a[:, :D] + b[:, :D]).to(dt)) and float(out[:, D:].float().abs().max()) == 0
+        hid = torch.tanh(torch.randn(R, 64, device=DEV, generator=g)).to(dt)
+        o2 = torch.zeros(R, 64, dtype=dt, device=DEV)
+        nat.check(L.gsage_tanh_bwd(a.data_ptr(), 48, hid.data_ptr(), code, 64, o2.data_ptr(), 64, R, D, st), "tanh_bwd")
+        want = a[:, :D] * (1 - hid[:, :D].float() ** 2)      # (the kernel may contract 1 - h*h into an fma)
+        tol = 1e-2 if dt == torch.bfloat16 else 1e-6
+        assert torch.allclose(o2[:, :D].float(), want, rtol=tol, atol=tol)
+    # merged input gradient on a 3-hop frontier (B = 5, fan-outs 3 and 2): rows 5 | 15 | 30
+    B, f1, f2, Dm = 5, 3, 2, 8
+    off = [0, B, B + B * f1, B + B * f1 + B * f1 * f2]
+    RA, rx = off[3], off[2]
+    datt = torch.randn(RA, Dm, device=DEV, generator=g)
+    dx = torch.randn(rx, Dm, device=DEV, generator=g)
+    dagg = torch.randn(rx, Dm, device=DEV, generator=g)
+    ws = torch.rand(RA - B, device=DEV, generator=g)
+    H = torch.randn(RA, Dm, device=DEV, generator=g).bfloat16()
+    out = torch.zeros(RA, Dm, dtype=torch.bfloat16, device=DEV)
+    offh = (ctypes.c_int64 * 6)(*(off[:3] + [0, 0, 0]))
+    fanh = (ctypes.c_int32 * 6)(1, f1, f2, 1, 1, 1)
+    nat.check(L.gsage_attn_merge_bwd(H.data_ptr(), nat.BF16, Dm, datt.data_ptr(), Dm, dx.data_ptr(), Dm, rx,
+                                     dagg.data_ptr(), Dm, ws.data_ptr(), out.data_ptr(), nat.BF16, Dm, RA, Dm, 3, offh,
+                                     fanh, st), "attn_merge_bwd")
+    want = datt.clone()
+    want[:rx] += dx
+    parent = torch.cat([torch.arange(B, device=DEV).repeat_interleave(f1),
+                        B + torch.arange(B * f1, device=DEV).repeat_interleave(f2)])
+    want[B:] += ws.unsqueeze(1) * dagg[parent]
+    want = torch.where(H.float() > 0, want, torch.zeros_like(want)).bfloat16()
+    assert torch.equal(out, want)
+    # column sums, zero rows, squared norm
+    src = torch.randn(5000, 64, device=DEV, generator=g)
+    part = torch.empty(256, 40, device=DEV)
+    nat.check(L.gsage_colsum_partials(src.data_ptr(), 64, 5000, 40, part.data_ptr(), 256, st), "colsum")
+    assert float((part.sum(0) - src[:, :40].sum(0)).abs().max()) < 1e-3
+    tab = torch.randn(100, 64, device=DEV, generator=g)
+    keep = tab.clone()
+    idz = torch.tensor([3, 3, 99, 0], device=DEV)
+    nat.check(L.gsage_zero_rows(tab.data_ptr(), 64, idz.data_ptr(), 4, 64, st), "zero_rows")
+    keep[idz] = 0
+    assert torch.equal(tab, keep)
+    v = torch.randn(1_000_003, device=DEV, generator=g)
+    ps = torch.empty(777, device=DEV)
+    nat.check(L.gsage_grad_sqnorm(v.data_ptr(), v.numel(), ps.data_ptr(), 777, st), "sqnorm")
+    assert abs(float(ps.double().sum()) - float((v.double() ** 2).sum())) < 1e-4 * v.numel()
