@@ -592,11 +592,13 @@ class FusedMeanTrainStep(object):
         d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
         return d
 
-    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0, part=None, adam=None):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
         launch; with_adam: the clip + Adam update of the batch just finished rides along; hops: so
         does the sampling of a later batch's frontier (a gsage_hops_desc writing ANOTHER buffer).
-        ids: frontier to gather from (default: the set's own)."""
+        ids: frontier to gather from (default: the set's own).  part: "means" = only the last hop's
+        neighbour means (the bulk: what runs while a gradient exchange is in flight), "rest" = the other
+        segments (what then shares a launch with Adam and the sampler); None = everything."""
         L, st = self.L, self.store
         if ids is None:
             ids = self.ids_set[s]
@@ -609,13 +611,18 @@ class FusedMeanTrainStep(object):
         segs = []
         for k in range(L):
             n, r0 = self.fan[k + 1], (skip_rows if k == L - 1 else 0)   # rows the seed-level launch gathered
-            if self.size[k] > r0:
+            if self.size[k] > r0 and (part is None or (part == "means") == (k == L - 1)):
                 segs.append((st.data, ids[self.off[k + 1] + r0 * n:self.off[k + 2]],
                              xa[1][self.off[k] + r0:self.off[k + 1]], self.size[k] - r0, n))
-        segs.append((st.data, ids[:R], xa[0], R, 1))
+        if part != "means":
+            segs.append((st.data, ids[:R], xa[0], R, 1))
+        if not segs:
+            return False
         # (D = the real width: the pad columns of the operand buffers were zeroed once and stay zero)
-        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None,
-                              hops=hops)
+        if adam is None and with_adam:
+            adam = self._adam_desc()
+        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=adam, hops=hops)
+        return True
 
     def _stage_compute(self, s):
         """Forward GEMMs, head, backward; everything that needs the current weights."""
@@ -898,8 +905,16 @@ class FusedMeanTrainStep(object):
                 # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
                 # gathers (see step_queue)
                 self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
-                self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
-                self.g_opt = self._record(self._stage_opt)
+                self._ddp_split = bool(type(self) is FusedMeanTrainStep and self.size[self.L - 1] > self._tail_rows
+                                       and os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
+                if self._ddp_split:
+                    # the bulk of the gathers runs while the exchange is in flight; what follows the exchange
+                    # is ONE norm pass and ONE launch: the remaining gathers with Adam(i) and K1(i+2) riding along
+                    self.g_qfront = [self._record(lambda par=par: self._queue_front_means(par)) for par in range(2)]
+                    self.g_opt = [self._record(lambda par=par: self._queue_front_rest(par)) for par in range(2)]
+                else:
+                    self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
+                    self.g_opt = self._record(self._stage_opt)
 
     def instrument(self, on=True):
         """Measurement only (bench.py's roofline object): re-record the queue-mode command lists with
@@ -963,6 +978,20 @@ class FusedMeanTrainStep(object):
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
                            hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
 
+    def _queue_front_means(self, par):
+        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._tail_rows, part="means")
+
+    def _queue_front_rest(self, par):
+        """after the exchange: squared norm of the averaged gradient, then the rest of the gathers || Adam || K1"""
+        n = self.flat_g.numel()
+        n_sq = nat.lib().gsage_adam_partials(n)
+        nat.check(nat.lib().gsage_grad_sqnorm(self.flat_g.data_ptr(), n, self.partial.data_ptr(), n_sq, ops._stream()),
+                  "grad_sqnorm")
+        d = self._adam_desc()
+        d.n_partial_ready = n_sq
+        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], part="rest", adam=d,
+                           hops=self._hops_desc(self.ids_q[par], True))
+
     def _queue_compute(self, par):
         if self._tail_rows:
             L, st, nxt = self.L, self.store, self.ids_q[1 - par]
@@ -1018,14 +1047,21 @@ class FusedMeanTrainStep(object):
         # side stream that only waits for the gradients, which would hide the ~25 us the collective
         # call costs the host) it did not start until the 8 320-workgroup gather launch had been
         # dispatched completely -- no overlap at all (tools/overlap_check.py).
+        # (Order and priority were measured on one rank, 0.1205 ms/step as written: the means submitted BEFORE
+        # the collective 0.137; RCCL's stream at high priority 0.46 -- its kernel then preempts the gathers.)
+        split = getattr(self, "_ddp_split", False)
         work = self._all_reduce(async_op=True)
         if rec:                                      # batch i+1's gathers overlap the exchange
             self.g_qfront[par].replay()
+        elif split:
+            self._queue_front_means(par)
         else:
             self._queue_front(par, False)
         work.wait()                                  # stream-level wait, the host does not block
         if rec:
-            self.g_opt.replay()
+            (self.g_opt[par] if isinstance(self.g_opt, list) else self.g_opt).replay()
+        elif getattr(self, "_ddp_split", False):
+            self._queue_front_rest(par)
         else:
             self._stage_opt()
         return self.preds
