@@ -91,15 +91,41 @@ class _GradRound(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
-def attention_aggregator(x, neibs, w, act):
-    def att(t):
-        return torch.tanh(t @ w["att.0.weight"].t()) @ w["att.2.weight"].t()
-    na = _segments(x, att(neibs))                       # [M, n, 32]
-    xa = att(x).unsqueeze(2)                            # [M, 32, 1]
-    scores = torch.bmm(na, xa).squeeze(2)               # [M, n]  (n>1, M>1: same as .squeeze())
+class _TanhStoredBF16(torch.autograd.Function):
+    """tanh whose OUTPUT is stored in bf16 and whose backward uses that stored value, the result again stored
+    in bf16 -- what engine.FusedAttnTrainStep does with the att MLP's hidden layer (K5 with fused tanh writes
+    bf16; gsage_tanh_bwd reads it back and writes the bf16 operand of K5 / K5b)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.tanh(x).to(torch.bfloat16).to(x.dtype)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return (g * (1 - y * y)).to(torch.bfloat16).to(g.dtype)
+
+
+def att_mlp(t, w, rounding=None):
+    """att(.) of nn_modules.py:293-297: Linear(D, 32, no bias) -> tanh -> Linear(32, 32, no bias)."""
+    if rounding == "bf16":
+        hid = _TanhStoredBF16.apply(t @ _rb(w["att.0.weight"], rounding).t())
+        return _GradRound.apply(hid @ _rb(w["att.2.weight"], rounding).t())      # d a is stored in bf16
+    return torch.tanh(t @ w["att.0.weight"].t()) @ w["att.2.weight"].t()
+
+
+def attention_weighting(x, neibs, xa, na, w, act, rounding=None):
+    """nn_modules.py:309-317 given att(x), att(neibs)."""
+    scores = torch.bmm(_segments(x, na), xa.unsqueeze(2)).squeeze(2)      # [M, n]  (n>1, M>1: same as .squeeze())
     ws = torch.softmax(scores, dim=1)
     agg = (_segments(x, neibs) * ws.unsqueeze(-1)).sum(dim=1)
-    return _combine(x, agg, w, act)
+    return _combine(x, _rb(agg, rounding), w, act, rounding)
+
+
+def attention_aggregator(x, neibs, w, act):
+    return attention_weighting(x, neibs, att_mlp(x, w), att_mlp(neibs, w), w, act)
 
 
 def aggregator(name, x, neibs, w, act, rounding=None):
@@ -109,8 +135,8 @@ def aggregator(name, x, neibs, w, act, rounding=None):
         return pool_aggregator(x, neibs, w, act, "max", rounding)
     if name == "mean_pool":
         return pool_aggregator(x, neibs, w, act, "mean", rounding)
-    assert rounding is None, "the bf16 rounding points are defined for the mean / pool engines"
     if name == "attention":
+        assert rounding is None, "with rounding points the attention levels go through forward() (att once per row)"
         return attention_aggregator(x, neibs, w, act)
     raise KeyError(name)
 
@@ -165,6 +191,17 @@ def forward(w, ids, feats, indptr, data, fanouts, sels, agg_name, prep_name, n_n
         cur = torch.from_numpy(nxt)
         hs.append(prep(prep_name, cur, take(cur), prep_w, n_nodes, hop + 1))
     for li, lw in enumerate(layers):
+        if agg_name == "attention" and rounding is not None:
+            # like the engine: att(.) ONCE per row of the level (the reference applies the same MLP to a row as
+            # "x" and as a neighbour: same values), so that a row's two gradient contributions to att(.) are
+            # summed in fp32 and rounded once
+            sizes = [h.shape[0] for h in hs]
+            a_all = torch.split(att_mlp(torch.cat(hs, dim=0), lw, rounding), sizes, dim=0)
+            hs = [attention_weighting(hs[k], hs[k + 1], a_all[k], a_all[k + 1], lw, acts[li], rounding)
+                  for k in range(len(hs) - 1)]
+            if li < len(layers) - 1:
+                hs = [_rb(h, rounding, round_grad=True) for h in hs]
+            continue
         hs = [aggregator(agg_name, hs[k], hs[k + 1], lw, acts[li], rounding) for k in range(len(hs) - 1)]
         if li < len(layers) - 1:
             # hidden levels are stored (and their gradients written) in bf16; the last level stays fp32
