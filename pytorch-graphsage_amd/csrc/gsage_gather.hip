@@ -13,6 +13,7 @@
 // needed by exactly one output row); L2 / Infinity Cache absorb the duplicates that sampling
 // with replacement produces.
 #include "gsage_common.h"
+#include <stdlib.h>
 #include "gsage_optim_dev.h"
 #include "gsage_sample_dev.h"
 
@@ -243,13 +244,12 @@ k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
 template <typename TI, typename TO, int VEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
-                    int n_adam, const AdamParams a, int n_smp, const HopsParams h)
+                    int n_adam, const AdamParams a, int n_smp, const HopsParams h, int first)
 {
     extern __shared__ int64_t frontier[];
     __shared__ float red[4];
     const int n_side = n_adam + n_smp;
     const int n_gather = (int)gridDim.x - n_side;
-    const int first = n_gather / 2;
     const int bx = (int)blockIdx.x;
     if (bx >= first && bx < first + n_adam)
         adam_workgroup(a, bx - first, n_adam, red);
@@ -452,12 +452,19 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
         if (rc != GSAGE_OK) return rc;
         n_smp = (int)ceil_div(hops->B, HOPS_SPW);
     }
+    // where the side roles sit in the grid (fraction of the gather workgroups dispatched before them).
+    // Measured in-step at config 2 (tools/role_sweep.sh): 0.0 -> 33.1 us, 0.5 -> 34.8 us, 1.0 -> 37.2 us:
+    // the Adam/sampler workgroups have a long serial latency, so they go first.
+    static const double side_pos = [] { const char *e = getenv("GSAGE_SIDE_ROLE_POS"); return e ? atof(e) : 0.0; }();
+    const int n_gather = grid_for(q.first[n_seg]);
+    int first = (int)(n_gather * side_pos);
+    first = first < 0 ? 0 : (first > n_gather ? n_gather : first);
     if (dtype == GSAGE_F32)
-        launch(k_gather_multi_adam<float, float, 4>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
-               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
+        launch(k_gather_multi_adam<float, float, 4>, dim3(n_gather + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
     else
-        launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(grid_for(q.first[n_seg]) + n_adam + n_smp),
-               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h);
+        launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(n_gather + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
     return check_launch("gather_mean_multi_adam");
 }
 
