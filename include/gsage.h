@@ -540,6 +540,43 @@ int gsage_zero_rows(float *table, int64_t ld, const int64_t *ids, int64_t M, int
 int gsage_colsum_partials(const float *src, int64_t ld, int64_t M, int32_t D, float *part, int32_t n_part, void *stream);
 int gsage_adam_partials(int64_t n);
 
+/* Deferred ("lazy") Adam over the rows of a trainable embedding table: the reference's dense update
+ * (torch.optim.Adam over nn.Embedding.weight, nn_modules.py:131-155 + models.py:44-46), applied row by row
+ * and bit-identical to gsage_clip_adam_step over the whole table.  The update of a row whose gradient is zero
+ * (m, v decay; p moves by -step_size * m / (sqrt(v) / sqrt(bc2) + eps); weight decay adds wd * p) depends on that
+ * row alone, so it is replayed when the row is next needed instead of streaming the table every step:
+ *   last[r]   number of the last update applied to row r (initialise to the optimizer's step count)
+ *   seen[r]   stamp used to count every row once in the norm (initialise to 0)
+ *   hist      2 * hist_cap floats: (step_size, 1/sqrt(bc2)) of update t at slot t % hist_cap, written by
+ *             gsage_rows_adam -- every row must be caught up at least once every hist_cap - 1 updates
+ * The update number of a call is *step + step_off (device counter, like gsage_clip_adam_step).
+ *   gsage_rows_catch_up      rows ids0[0:n0] ++ ids1[0:n1] (duplicates allowed) brought up to that update --
+ *                            BEFORE the forward reads them
+ *   gsage_rows_catch_up_all  every row -- before anything else reads the table, m or v
+ *   gsage_rows_sqnorm        partial[0:n_partial] = squared-norm partials of the listed gradient rows, each row
+ *                            once (to sit beside gsage_finalize_grads' partials)
+ *   gsage_rows_adam          clip (total norm from partial[0:n_partial_ready]) + update of the listed rows, each
+ *                            once, and their gradient rows zeroed; records the update's constants in hist.
+ *                            Must run for EVERY update (also with empty lists). */
+typedef struct gsage_row_adam {
+    float *p, *g, *m, *v;           /* [n_rows, E] fp32, dense rows, 16-byte aligned */
+    int32_t *last, *seen;           /* [n_rows] */
+    float *hist;
+    const float *lr;                /* device scalar */
+    const int64_t *step;            /* device counter */
+    int64_t n_rows;
+    int32_t E, hist_cap;            /* E % 4 == 0, E <= 256 */
+    float beta1, beta2, eps, weight_decay, max_norm;
+    int32_t reserved;
+} gsage_row_adam;
+int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                        int32_t step_off, void *stream);
+int gsage_rows_catch_up_all(const gsage_row_adam *d, int32_t step_off, void *stream);
+int gsage_rows_sqnorm(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                      int32_t step_off, float *partial, int32_t n_partial, void *stream);
+int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                    int32_t step_off, const float *partial, int32_t n_partial_ready, void *stream);
+
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
  * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy
  * dst_t[c, r] (leading dimension dst_t_ld), and/or the fragment-ordered copy dst_p (see

@@ -86,6 +86,10 @@ SIGNATURES = {
     "gsage_grad_sqnorm": (_int, [_vp, _i64, _vp, _i32, _vp]),
     "gsage_zero_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _vp]),
     "gsage_colsum_partials": (_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp]),
+    "gsage_rows_catch_up": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "gsage_rows_catch_up_all": (_int, [_vp, _i32, _vp]),
+    "gsage_rows_sqnorm": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "gsage_rows_adam": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gsage_adam_partials": (_int, [_i64]),
     "gsage_prep_weights": (_int, [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
     "gsage_bwd_merge": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp,
@@ -177,6 +181,12 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
                 ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
                 ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
                 ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64)]
+
+
+class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("last", _vp), ("seen", _vp), ("hist", _vp),
+                ("lr", _vp), ("step", _vp), ("n_rows", _i64), ("E", _i32), ("hist_cap", _i32), ("beta1", _f32),
+                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_norm", _f32), ("reserved", _i32)]
 
 
 class TailGatherDesc(ctypes.Structure):       # mirrors gsage_tail_gather_desc (include/gsage.h)

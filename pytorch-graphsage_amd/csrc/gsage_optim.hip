@@ -213,6 +213,150 @@ k_zero_rows(float *__restrict__ table, int64_t ld, const int64_t *__restrict__ i
     }
 }
 
+// ---- deferred ("lazy") Adam over the rows of a trainable embedding table ------------------------------------------
+// The reference's optimizer is dense: every row of the table moves every step, also rows whose gradient is
+// zero (m and v decay, p -= step_size * m / (sqrt(v)..)).  That update of a zero-gradient row depends on the row
+// alone, so it can be replayed later without changing a bit: `last[r]` holds the number of the last update applied
+// to row r, `hist` the per-step constants (step_size, 1/sqrt(bc2)) of every update since, and a row is brought
+// up to date (a) before the forward reads it (k_rows_catch_up on the step's frontier) and (b) when anything else
+// looks at the table (k_rows_catch_up<true>: every row).  A step then touches ~10 % of a Pokec-sized table
+// instead of streaming 2.9 GB.  Duplicate ids in a frontier are settled by atomicMax on the row's stamp.
+struct RowAdam {
+    float *p, *g, *m, *v;
+    int32_t *last, *seen;
+    float *hist;                 // [2 * hist_cap]
+    int32_t hist_cap, E, lpr;    // lanes per row: power of two >= E / 4
+    int64_t n_rows;
+    const float *lr;
+    const int64_t *step;
+    float beta1, beta2, eps, weight_decay, max_norm;
+};
+
+__device__ __forceinline__ void row_replay(const RowAdam &a, int32_t from, int32_t to, f32x4 &p, f32x4 &m, f32x4 &v)
+{
+    for (int32_t t = from; t <= to; ++t) {
+        const int32_t h = (t % a.hist_cap) * 2;
+        const float ss = a.hist[h], rb = a.hist[h + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float me = m[e], ve = v[e];
+            p[e] = adam_update(0.f, p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, ss, rb);
+            m[e] = me; v[e] = ve;
+        }
+    }
+}
+
+// rows ids0[0:n0] ++ ids1[0:n1] (ALL: every row) brought up to update number *step + step_off
+template <bool ALL>
+__global__ void __launch_bounds__(256)
+k_rows_catch_up(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
+                int64_t n1, int32_t step_off)
+{
+    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
+    const int sub = lane & (lpr - 1);
+    const int64_t total = ALL ? a.n_rows : n0 + n1;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    const int32_t target = (int32_t)(*a.step + step_off);
+    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
+        const int64_t e = base + lane / lpr;
+        const bool valid = e < total;
+        const int64_t r = !valid ? 0 : ALL ? e : (e < n0 ? ids0[e] : ids1[e - n0]);
+        int32_t old = target;
+        if (valid && sub == 0) {
+            if (ALL) { old = a.last[r]; if (old < target) a.last[r] = target; }
+            else old = atomicMax(&a.last[r], target);
+        }
+        old = __shfl(old, lane & ~(lpr - 1));
+        if (!valid || old >= target || sub * 4 >= a.E) continue;
+        const int64_t o = r * a.E + sub * 4;
+        f32x4 p = *reinterpret_cast<const f32x4 *>(a.p + o);
+        f32x4 m = *reinterpret_cast<const f32x4 *>(a.m + o);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(a.v + o);
+        row_replay(a, old + 1, target, p, m, v);
+        *reinterpret_cast<f32x4 *>(a.p + o) = p;
+        *reinterpret_cast<f32x4 *>(a.m + o) = m;
+        *reinterpret_cast<f32x4 *>(a.v + o) = v;
+    }
+}
+
+// partial[bx] = sum of squares of the gradient rows in the lists, every row once (stamp `seen`)
+__global__ void __launch_bounds__(256)
+k_rows_sqnorm(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
+              int64_t n1, int32_t step_off, float *__restrict__ partial)
+{
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
+    const int sub = lane & (lpr - 1);
+    const int64_t total = n0 + n1;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    const int32_t t = (int32_t)(*a.step + step_off);
+    float acc = 0.f;
+    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
+        const int64_t e = base + lane / lpr;
+        const bool valid = e < total;
+        const int64_t r = !valid ? 0 : (e < n0 ? ids0[e] : ids1[e - n0]);
+        int32_t old = t;
+        if (valid && sub == 0) old = atomicMax(&a.seen[r], t);
+        old = __shfl(old, lane & ~(lpr - 1));
+        if (!valid || old >= t || sub * 4 >= a.E) continue;
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(a.g + r * a.E + sub * 4);
+        acc += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// update number t = *step + step_off of the rows in the lists (every row once; rows behind t - 1 are caught up
+// first), their gradient rows zeroed; records the step's constants for later replays
+__global__ void __launch_bounds__(256)
+k_rows_adam(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
+            int64_t n1, int32_t step_off, const float *__restrict__ partial, int32_t n_partial)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+    const float total_norm = sqrtf(block_sum_256(s, red));
+    float coef = a.max_norm / (total_norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+    coef = coef < 1.f ? coef : 1.f;
+    const int64_t tl = *a.step + step_off;
+    const int32_t t = (int32_t)tl;
+    const AdamConsts ac = adam_consts(*a.lr, (float)tl, a.beta1, a.beta2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.hist[(t % a.hist_cap) * 2] = ac.step_size;
+        a.hist[(t % a.hist_cap) * 2 + 1] = ac.rsqrt_bc2;
+    }
+    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
+    const int sub = lane & (lpr - 1);
+    const int64_t total = n0 + n1;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
+        const int64_t e = base + lane / lpr;
+        const bool valid = e < total;
+        const int64_t r = !valid ? 0 : (e < n0 ? ids0[e] : ids1[e - n0]);
+        int32_t old = t;
+        if (valid && sub == 0) old = atomicMax(&a.last[r], t);
+        old = __shfl(old, lane & ~(lpr - 1));
+        if (!valid || old >= t || sub * 4 >= a.E) continue;
+        const int64_t o = r * a.E + sub * 4;
+        f32x4 p = *reinterpret_cast<const f32x4 *>(a.p + o);
+        f32x4 m = *reinterpret_cast<const f32x4 *>(a.m + o);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(a.v + o);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(a.g + o);
+        row_replay(a, old + 1, t - 1, p, m, v);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float me = m[e4], ve = v[e4];
+            p[e4] = adam_update(g[e4] * coef, p[e4], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, ac.step_size,
+                                ac.rsqrt_bc2);
+            m[e4] = me; v[e4] = ve;
+        }
+        *reinterpret_cast<f32x4 *>(a.p + o) = p;
+        *reinterpret_cast<f32x4 *>(a.m + o) = m;
+        *reinterpret_cast<f32x4 *>(a.v + o) = v;
+        *reinterpret_cast<f32x4 *>(a.g + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // part[b, c] = sum over rows i = b, b + n_part, ... of src[i, c]   (bias gradient of a Linear: column sums)
 // A workgroup = 256 / DW row lanes x DW columns (DW = D rounded up to a power of two <= 256): every thread
 // streams rows, four loads in flight, the row lanes meet in LDS in a fixed order.
@@ -581,6 +725,73 @@ int gsage_zero_rows(float *table, int64_t ld, const int64_t *ids, int64_t M, int
     launch(k_zero_rows, dim3(grid_for(M * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, table, ld, ids, M,
            (int32_t)(D / 4));
     return check_launch("zero_rows");
+}
+
+static int fill_rows(RowAdam &a, const gsage_row_adam *d, const char *who)
+{
+    GSAGE_REQUIRE(d && d->p && d->g && d->m && d->v && d->last && d->seen && d->hist && d->lr && d->step, who);
+    GSAGE_REQUIRE(d->n_rows > 0 && d->E > 0 && d->E % 4 == 0 && d->E <= 256 && d->hist_cap >= 2, who);
+    GSAGE_REQUIRE(((((uintptr_t)d->p | (uintptr_t)d->g | (uintptr_t)d->m | (uintptr_t)d->v)) & 15) == 0, who);
+    a.p = d->p; a.g = d->g; a.m = d->m; a.v = d->v; a.last = d->last; a.seen = d->seen; a.hist = d->hist;
+    a.hist_cap = d->hist_cap; a.E = d->E; a.n_rows = d->n_rows; a.lr = d->lr; a.step = d->step;
+    a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.weight_decay = d->weight_decay; a.max_norm = d->max_norm;
+    a.lpr = 1;
+    while (a.lpr * 4 < d->E) a.lpr <<= 1;
+    return GSAGE_OK;
+}
+
+static int rows_grid(const RowAdam &a, int64_t entries, int cap)
+{
+    return grid_for(ceil_div(entries, (int64_t)(64 / a.lpr)) * 64, cap);
+}
+
+int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                        int32_t step_off, void *stream)
+{
+    RowAdam a;
+    int rc = fill_rows(a, d, "rows_catch_up: bad descriptor");
+    if (rc != GSAGE_OK) return rc;
+    GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1), "rows_catch_up: bad id lists");
+    if (n0 + n1 == 0) return GSAGE_OK;
+    launch(k_rows_catch_up<false>, dim3(rows_grid(a, n0 + n1, 4096)), dim3(256), 0, (hipStream_t)stream, a, ids0, n0,
+           ids1, n1, step_off);
+    return check_launch("rows_catch_up");
+}
+
+int gsage_rows_catch_up_all(const gsage_row_adam *d, int32_t step_off, void *stream)
+{
+    RowAdam a;
+    int rc = fill_rows(a, d, "rows_catch_up_all: bad descriptor");
+    if (rc != GSAGE_OK) return rc;
+    launch(k_rows_catch_up<true>, dim3(rows_grid(a, a.n_rows, 8192)), dim3(256), 0, (hipStream_t)stream, a,
+           (const int64_t *)nullptr, (int64_t)0, (const int64_t *)nullptr, (int64_t)0, step_off);
+    return check_launch("rows_catch_up_all");
+}
+
+int gsage_rows_sqnorm(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                      int32_t step_off, float *partial, int32_t n_partial, void *stream)
+{
+    RowAdam a;
+    int rc = fill_rows(a, d, "rows_sqnorm: bad descriptor");
+    if (rc != GSAGE_OK) return rc;
+    GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial >= 1 &&
+                  n_partial <= 1024, "rows_sqnorm: bad arguments");
+    launch(k_rows_sqnorm, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, a, ids0, n0, ids1, n1, step_off, partial);
+    return check_launch("rows_sqnorm");
+}
+
+int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
+                    int32_t step_off, const float *partial, int32_t n_partial_ready, void *stream)
+{
+    RowAdam a;
+    int rc = fill_rows(a, d, "rows_adam: bad descriptor");
+    if (rc != GSAGE_OK) return rc;
+    GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial_ready >= 1,
+                  "rows_adam: bad arguments");
+    // (always launched, also for empty lists: the launch records the step's constants)
+    launch(k_rows_adam, dim3(rows_grid(a, n0 + n1 > 0 ? n0 + n1 : 1, 4096)), dim3(256), 0, (hipStream_t)stream, a, ids0,
+           n0, ids1, n1, step_off, partial, n_partial_ready);
+    return check_launch("rows_adam");
 }
 
 int gsage_colsum_partials(const float *src, int64_t ld, int64_t M, int32_t D, float *part, int32_t n_part, void *stream)

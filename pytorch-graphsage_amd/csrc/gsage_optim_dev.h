@@ -66,6 +66,35 @@ struct AdamParams {
     int32_t discard_clipped;       // != 0: the clipped gradient is not written back (the caller zeroes g next)
 };
 
+// The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
+// kernels and the deferred row updates of a trainable embedding table (gsage_rows_*): the latter replay the
+// dense update row by row and must produce the SAME bits, so nothing here may be contracted differently
+// from one call site to the next -- contraction is off and every rounding is the source's.
+struct AdamConsts { float step_size, rsqrt_bc2; };
+
+__device__ __forceinline__ AdamConsts adam_consts(float lr, float t, float beta1, float beta2)
+{
+#pragma clang fp contract(off)
+    const float bc1 = 1.f - powf(beta1, t);
+    const float bc2 = 1.f - powf(beta2, t);
+    AdamConsts c;
+    c.step_size = lr / bc1;
+    c.rsqrt_bc2 = 1.f / sqrtf(bc2);
+    return c;
+}
+
+// g: the (clipped) gradient; returns the new parameter, updates m and v in place
+__device__ __forceinline__ float adam_update(float g, float p, float &m, float &v, float beta1, float beta2,
+                                             float eps, float weight_decay, float step_size, float rsqrt_bc2)
+{
+#pragma clang fp contract(off)
+    if (weight_decay != 0.f) g = g + weight_decay * p;
+    m = beta1 * m + (1.f - beta1) * g;
+    v = beta2 * v + ((1.f - beta2) * g) * g;
+    const float denom = sqrtf(v) * rsqrt_bc2 + eps;
+    return p - step_size * (m / denom);
+}
+
 // one workgroup of the clip + Adam update: grid-stride slice bx of gx
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
@@ -75,11 +104,8 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
     const float total = sqrtf(sq);
     float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
     coef = coef < 1.f ? coef : 1.f;
-    const float t = (float)(*a.step + a.step_off);
-    const float bc1 = 1.f - powf(a.beta1, t);
-    const float bc2 = 1.f - powf(a.beta2, t);
-    const float step_size = *a.lr / bc1;
-    const float rsqrt_bc2 = 1.f / sqrtf(bc2);
+    const AdamConsts ac = adam_consts(*a.lr, (float)(*a.step + a.step_off), a.beta1, a.beta2);
+    const float step_size = ac.step_size, rsqrt_bc2 = ac.rsqrt_bc2;
     if (bx == 0 && threadIdx.x == 0) {
         if (a.norm_out) *a.norm_out = total;
         if (a.tick1) *a.tick1 += a.inc1;
@@ -99,12 +125,13 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             v4 m = reinterpret_cast<const v4 *>(a.m)[i];
             v4 v = reinterpret_cast<const v4 *>(a.v)[i];
             if (clipped) reinterpret_cast<v4 *>(a.g)[i] = g;
-            if (a.weight_decay != 0.f) g += a.weight_decay * p;
-            m = a.beta1 * m + (1.f - a.beta1) * g;
-            v = a.beta2 * v + (1.f - a.beta2) * g * g;
             v4 pn;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pn[e] = p[e] - step_size * (m[e] / (sqrtf(v[e]) * rsqrt_bc2 + a.eps));
+            for (int e = 0; e < 4; ++e) {
+                float me = m[e], ve = v[e];
+                pn[e] = adam_update(g[e], p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
+                m[e] = me; v[e] = ve;
+            }
             reinterpret_cast<v4 *>(a.m)[i] = m;
             reinterpret_cast<v4 *>(a.v)[i] = v;
             reinterpret_cast<v4 *>(a.p)[i] = pn;
@@ -127,14 +154,10 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             if (i >= a.n) continue;
             float g = gv[u] * coef;
             if (clipped) a.g[i] = g;                    // clipped gradient stays visible (p.grad)
-            const float p = pv[u];
-            if (a.weight_decay != 0.f) g += a.weight_decay * p;
-            const float m = a.beta1 * mv[u] + (1.f - a.beta1) * g;
-            const float v = a.beta2 * vv[u] + (1.f - a.beta2) * g * g;
+            float m = mv[u], v = vv[u];
+            const float pn = adam_update(g, pv[u], m, v, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
             a.m[i] = m;
             a.v[i] = v;
-            const float denom = sqrtf(v) * rsqrt_bc2 + a.eps;
-            const float pn = p - step_size * (m / denom);
             a.p[i] = pn;
             // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
             for (int d = 0; d < a.n_prep; ++d) {

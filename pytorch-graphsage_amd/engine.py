@@ -283,6 +283,9 @@ class FusedMeanTrainStep(object):
         self.csr = self.sampler.csr(dev)
 
         # ---- flat parameter / gradient / Adam buckets; Parameters become views ----------------
+        settle = getattr(model, "_settle_rows", None)
+        if settle is not None:                    # an earlier engine's deferred table rows (sync_rows)
+            settle()
         self.params = [p for p in model.parameters() if p.requires_grad]
         sizes = [p.numel() for p in self.params]
         self.poff = [0]
@@ -466,7 +469,7 @@ class FusedMeanTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.flat_p.copy_(saved)
-        for t in (self.flat_m, self.flat_v, self.step, self.counter):
+        for t in (self.flat_m, self.flat_v, self.step, self.counter) + tuple(getattr(self, "_warm_reset", ())):
             t.zero_()
         self.refresh_weights()
         torch.cuda.synchronize()
@@ -1429,7 +1432,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
     Level 0 reads its rows from ONE buffer gathered per step (all hops, next batch, beside Adam and K1): the att
     MLP, K4, the x projection and two of the four weight gradients all want plain row-major operands."""
 
-    HA_LD = 64            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
+    HA_LD = 64
+    ROW_HIST = 1 << 15   # updates whose constants are kept for deferred table rows (sync_rows() before it wraps)            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
     WG_TARGET = 120       # K5b workgroups per problem (eight problems share the launch)
 
     @staticmethod
@@ -1468,6 +1472,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         self.Ha = 32
         self.h = [l.output_dim_ for l in self.layers]
         self.emb = isinstance(self.model.prep, NodeEmbeddingPrep)
+        self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1"
         if self.emb:
             assert self.ddp is None, "the embedding-prep engine is single-GPU (data-parallel runs use the module path)"
             E = int(self.model.prep.embedding_dim)
@@ -1572,8 +1577,29 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             # the table's gradient comes from scatter-adds, its squared norm from a pass of its own whose
             # partials sit behind the finalisation's in the same array
             self.n_tab = int(self.table.numel())
-            self.n_tab_partial = nat.lib().gsage_adam_partials(self.n_tab)
+            self.n_tab_partial = 256 if self.lazy_rows else nat.lib().gsage_adam_partials(self.n_tab)
             self.partial = torch.zeros(self.n_partial + self.n_tab_partial, dtype=torch.float32, device=self.dev)
+        if self.emb and self.lazy_rows:
+            # deferred row updates (gsage_rows_*): a step touches its frontier's rows, everything else is
+            # replayed -- bit for bit -- when it is next read (sync_rows: module forward, state_dict, eval)
+            n_rows, E = int(self.table.shape[0]), self.din[0]
+            i32 = torch.int32
+            self.row_last = torch.zeros(n_rows, dtype=i32, device=dev)
+            self.row_seen = torch.zeros(n_rows, dtype=i32, device=dev)
+            self.row_hist = torch.zeros(2 * self.ROW_HIST, dtype=f32, device=dev)
+            d = self.row_desc = nat.RowAdamDesc()
+            o, n = 0, self.n_tab
+            d.p, d.g, d.m, d.v = (self.flat_p[o:o + n].data_ptr(), self.flat_g[o:o + n].data_ptr(),
+                                  self.flat_m[o:o + n].data_ptr(), self.flat_v[o:o + n].data_ptr())
+            d.last, d.seen, d.hist = self.row_last.data_ptr(), self.row_seen.data_ptr(), self.row_hist.data_ptr()
+            d.lr, d.step, d.n_rows, d.E, d.hist_cap = self.lr.data_ptr(), self.step.data_ptr(), n_rows, E, self.ROW_HIST
+            d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
+            self._rows_dirty, self._rows_since = False, 0
+            self._warm_reset = (self.row_last, self.row_seen)
+            self.model._settle_rows = self.sync_rows
+            emb_mod = self.model.prep.embedding
+            self._row_hooks = [emb_mod.register_forward_pre_hook(lambda *_: self.sync_rows()),
+                               emb_mod.register_state_dict_pre_hook(lambda *_: self.sync_rows())]
 
     def _uncovered(self):
         return int(self.table.numel()) if getattr(self, "emb", False) else 0
@@ -1594,6 +1620,9 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         lib, stream, prep = nat.lib(), ops._stream(), self.model.prep
         ids, B, RA0, E = self._cur_ids, self.B, self.rall[0], self.din[0]
         tab = self.table
+        if self.lazy_rows:       # the rows this step reads, brought up to the last update
+            nat.check(lib.gsage_rows_catch_up(ctypes.byref(self.row_desc), self.seed_rows.data_ptr(), 1,
+                                              ids[B:RA0].data_ptr(), RA0 - B, 0, stream), "rows_catch_up")
         segs = [(tab, self.seed_rows, self.eraw32[:B], B, 1),                    # seeds read the spare row n_nodes
                 (tab, ids[B:RA0], self.eraw32[B:], RA0 - B, 1)]
         ops.gather_mean_multi(segs, E, E, E)
@@ -1632,9 +1661,22 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         d = self._adam_desc()
         nt, B, RA0, E = self.n_tab, self.B, self.rall[0], self.din[0]
         g = self._grad_slice(self.table)
+        n_all = self.n_partial + self.n_tab_partial
+        if self.lazy_rows:
+            ids, rd = self._cur_ids, ctypes.byref(self.row_desc)
+            lists = (self.seed_rows.data_ptr(), 1, ids[B:RA0].data_ptr(), RA0 - B, 0)
+            nat.check(lib.gsage_rows_sqnorm(rd, *lists, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+                                            stream), "rows_sqnorm")
+            nat.check(lib.gsage_rows_adam(rd, *lists, self.partial.data_ptr(), n_all, stream), "rows_adam")
+            o, n = nt, self.flat_p.numel() - nt
+            nat.check(lib.gsage_clip_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
+                                               self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
+                                               self.partial.data_ptr(), d.lr, d.step, d.beta1, d.beta2, d.eps,
+                                               d.weight_decay, d.max_norm, d.norm_out, 1, n_all, d.prep_descs, d.n_prep,
+                                               None, 0, None, 0, stream), "clip_adam_step")
+            return
         nat.check(lib.gsage_grad_sqnorm(g.data_ptr(), nt, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
                                         stream), "grad_sqnorm")
-        n_all = self.n_partial + self.n_tab_partial
         # the table (16-byte lanes, no operand copies), then everything else (operand copies refreshed)
         # (flag 2 on the table: its gradient is zeroed below, no need to write the clipped values back)
         for (o, n, prep, n_prep, cur) in ((0, nt, None, 0, 3), (nt, self.flat_p.numel() - nt, d.prep_descs, d.n_prep, 1)):
@@ -1647,6 +1689,44 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         ids = self._cur_ids
         for idv, M in ((self.seed_rows[:1], 1), (ids[B:RA0], RA0 - B)):
             nat.check(lib.gsage_zero_rows(g.data_ptr(), E, idv.data_ptr(), M, E, stream), "zero_rows")
+
+    def sync_rows(self):
+        """Deferred table rows: apply every pending update to every row (table, exp_avg, exp_avg_sq all current
+        afterwards).  Runs by itself before the embedding module's forward and state_dict; call it before reading
+        `prep.embedding.weight` or the optimizer buckets directly."""
+        if not getattr(self, "lazy_rows", False) or not self._rows_dirty:
+            return
+        nat.check(nat.lib().gsage_rows_catch_up_all(ctypes.byref(self.row_desc), 0, ops._stream()), "rows_catch_up_all")
+        self._rows_dirty, self._rows_since = False, 0
+
+    def close(self):
+        """Settle the deferred rows and detach from the model (hooks on the embedding module, model._settle_rows):
+        call before pickling the model or when the engine is done with."""
+        if getattr(self, "lazy_rows", False):
+            self.sync_rows()
+            for h in self._row_hooks:
+                h.remove()
+            self._row_hooks = []
+            if getattr(self.model, "_settle_rows", None) == self.sync_rows:
+                del self.model._settle_rows
+            self._closed = True
+
+    def _rows_tick(self):
+        if getattr(self, "_closed", False):
+            raise RuntimeError("this engine was closed (deferred table rows settled, hooks removed): build a new one")
+        if getattr(self, "lazy_rows", False):
+            if self._rows_since >= self.ROW_HIST - 2:
+                self.sync_rows()
+            self._rows_dirty = True
+            self._rows_since += 1
+
+    def __call__(self, *args, **kwargs):
+        self._rows_tick()
+        return super(FusedAttnTrainStep, self).__call__(*args, **kwargs)
+
+    def step_queue(self):
+        self._rows_tick()
+        return super(FusedAttnTrainStep, self).step_queue()
 
     # queue mode with an embedding prep: sampling runs ahead, nothing else can (the rows are weights)
     def _queue_prime(self):

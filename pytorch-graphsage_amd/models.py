@@ -99,6 +99,9 @@ class GSSupervised(nn.Module):
         views of flat buckets, clip + Adam become two launches.  An optimizer assigned from outside,
         one that has state already, CPU parameters or GSAGE_TORCH_ADAM=1 keep the stock route."""
         opt = self.optimizer
+        settle = getattr(self, "_settle_rows", None)
+        if settle is not None:                    # a fused engine with deferred embedding-table rows
+            settle()
         if isinstance(opt, FlatAdam):
             if not opt.owns():                    # somebody re-pointed the Parameters (e.g. a fused engine):
                 opt._attach()                     # take them back WITH their current values

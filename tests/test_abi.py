@@ -122,7 +122,7 @@ def test_ctypes_structs_mirror_the_header(tmp_path):
     import subprocess
     gs = pkg()
     nat, eng = gs._native, gs.engine
-    mirrors = {"gsage_hops_desc": nat.HopsDesc, "gsage_adam_desc": nat.AdamDesc, "gsage_wgrad_desc": nat.WgradDesc,
+    mirrors = {"gsage_hops_desc": nat.HopsDesc, "gsage_adam_desc": nat.AdamDesc, "gsage_wgrad_desc": nat.WgradDesc, "gsage_row_adam": nat.RowAdamDesc,
                "gsage_tail_gather_desc": nat.TailGatherDesc, "gsage_reduce_desc": eng._ReduceDesc,
                "gsage_prep_desc": eng._PrepDesc}
     lines = []

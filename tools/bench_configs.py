@@ -6,7 +6,8 @@ no features, fan-out 20/15, regression_mae) and configs[4] (ogbn-papers100M: mea
     python tools/bench_configs.py pokec|papers [--steps K] [--papers-nodes N]
 """
 import argparse, importlib, json, sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 gs = importlib.import_module("pytorch-graphsage_amd")
