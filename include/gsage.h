@@ -548,7 +548,8 @@ int gsage_adam_partials(int64_t n);
  *   last[r]   number of the last update applied to row r (initialise to the optimizer's step count)
  *   seen[r]   stamp used to count every row once in the norm (initialise to 0)
  *   hist      2 * hist_cap floats: (step_size, 1/sqrt(bc2)) of update t at slot t % hist_cap, written by
- *             gsage_rows_adam -- every row must be caught up at least once every hist_cap - 1 updates
+ *             gsage_rows_adam (hist_cap: a power of two) -- every row must be caught up at least once every
+ *             hist_cap - 1 updates
  * The update number of a call is *step + step_off (device counter, like gsage_clip_adam_step).
  *   gsage_rows_catch_up      rows ids0[0:n0] ++ ids1[0:n1] (duplicates allowed) brought up to that update --
  *                            BEFORE the forward reads them

@@ -232,82 +232,187 @@ struct RowAdam {
     float beta1, beta2, eps, weight_decay, max_norm;
 };
 
-__device__ __forceinline__ void row_replay(const RowAdam &a, int32_t from, int32_t to, f32x4 &p, f32x4 &m, f32x4 &v)
+// VEC elements per lane (1: rows of <= 64 elements, a row per wave -- lanes of a wave never wait for another row's
+// longer replay; 4: wider rows).  Replays are ALU work (one adam_update per element and skipped step); the step
+// constants of the next iteration are fetched while this one computes.
+template <int VEC> struct RowVec { float x[VEC]; };
+
+template <int VEC>
+__device__ __forceinline__ RowVec<VEC> row_load(const float *base)
 {
-    for (int32_t t = from; t <= to; ++t) {
-        const int32_t h = (t % a.hist_cap) * 2;
-        const float ss = a.hist[h], rb = a.hist[h + 1];
+    RowVec<VEC> r;
+    if (VEC == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(base);
+        r.x[0] = t[0]; r.x[1 % VEC] = t[1]; r.x[2 % VEC] = t[2]; r.x[3 % VEC] = t[3];
+    } else {
+        r.x[0] = *base;
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void row_store(float *base, const RowVec<VEC> &r)
+{
+    if (VEC == 4) *reinterpret_cast<f32x4 *>(base) = f32x4{r.x[0], r.x[1 % VEC], r.x[2 % VEC], r.x[3 % VEC]};
+    else *base = r.x[0];
+}
+
+typedef const __attribute__((address_space(4))) float *const_f32_ptr;     // scalar (SMEM) loads
+
+// group g of the ring: the constants of 8 consecutive updates, 16 floats, one scalar load
+struct HistGroup { float c[16]; };
+__device__ __forceinline__ HistGroup hist_group(const RowAdam &a, int32_t t)
+{
+    const_f32_ptr hp = (const_f32_ptr)(uintptr_t)(a.hist + 2 * (int64_t)((t & (a.hist_cap - 1)) & ~7));
+    HistGroup h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float me = m[e], ve = v[e];
-            p[e] = adam_update(0.f, p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, ss, rb);
-            m[e] = me; v[e] = ve;
+    for (int k = 0; k < 16; ++k) h.c[k] = hp[k];
+    return h;
+}
+
+// updates from .. to with a zero gradient (the constants come from `hist`)
+template <int VEC, bool UNI>
+__device__ __forceinline__ void row_replay(const RowAdam &a, int32_t from, int32_t to, RowVec<VEC> &p, RowVec<VEC> &m,
+                                           RowVec<VEC> &v)
+{
+    if (from > to) return;
+    if (UNI) {
+        // a row per wave: the trip count is wave-uniform.  Eight updates per trip (aligned groups of the ring: never
+        // wrap), the next group's constants requested before this group is worked through.
+        int32_t t = __builtin_amdgcn_readfirstlane(from);
+        const int32_t last = __builtin_amdgcn_readfirstlane(to);
+        HistGroup cur = hist_group(a, t);
+        while (t <= last) {
+            const int32_t k0 = t & 7;
+            const int32_t k1 = (last - t + k0) < 7 ? (last - t + k0) : 7;      // slots k0 .. k1 of this group
+            const HistGroup nxt = hist_group(a, t + 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < k0 || k > k1) continue;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    p.x[e] = adam_update(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay,
+                                         cur.c[2 * k], cur.c[2 * k + 1]);
+            }
+            t += k1 - k0 + 1;
+            cur = nxt;
         }
+        return;
+    }
+    const float2 *hist = reinterpret_cast<const float2 *>(a.hist);
+    const int32_t mask = a.hist_cap - 1;                        // (a power of two)
+    for (int32_t t = from; t <= to; ++t) {
+        const float2 h = hist[t & mask];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            p.x[e] = adam_update(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay, h.x, h.y);
     }
 }
 
+// A wave takes RB * (64 / lpr) list entries at a time: one atomicMax per entry (all in flight together) settles
+// which occurrence of a row does the work, then the rows' loads are issued together (RB row groups in flight per
+// wave), the replays run, the stores follow.
+enum { ROWS_CATCH_UP = 0, ROWS_CATCH_UP_ALL = 1, ROWS_SQNORM = 2, ROWS_ADAM = 3, ROWS_RB = 4 };
+
+template <int MODE, int VEC, int RB, bool UNI>
+__device__ __forceinline__ float rows_pass(const RowAdam &a, const int64_t *__restrict__ ids0, int64_t n0,
+                                           const int64_t *__restrict__ ids1, int64_t n1, int32_t target, float coef,
+                                           const AdamConsts ac)
+{
+    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
+    const int sub = lane & (lpr - 1), grp = lane / lpr;
+    const int ch = RB * rpw;                                  // entries per wave and trip (<= 64: RB <= lpr)
+    const int64_t total = MODE == ROWS_CATCH_UP_ALL ? a.n_rows : n0 + n1;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    float acc = 0.f;
+    for (int64_t base = wave * ch; base < total; base += n_waves * ch) {
+        const int64_t e = base + lane;
+        const bool valid = lane < ch && e < total;
+        const int32_t r_l = !valid ? 0 : MODE == ROWS_CATCH_UP_ALL ? (int32_t)e : (int32_t)(e < n0 ? ids0[e] : ids1[e - n0]);
+        int32_t old_l = target;
+        if (valid) {
+            if (MODE == ROWS_CATCH_UP_ALL) { old_l = a.last[r_l]; if (old_l < target) a.last[r_l] = target; }
+            else old_l = atomicMax(MODE == ROWS_SQNORM ? &a.seen[r_l] : &a.last[r_l], target);
+        }
+        if (!__any(old_l < target)) continue;
+        RowVec<VEC> p[RB], m[RB], v[RB], g[RB];
+        int32_t old[RB];
+        int64_t o[RB];
+        bool act[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int src = j * rpw + grp;
+            const int32_t r = __shfl(r_l, src);
+            old[j] = __shfl(old_l, src);
+            act[j] = old[j] < target && sub * VEC < a.E;
+            o[j] = (int64_t)r * a.E + sub * VEC;
+            if (act[j]) {
+                if (MODE == ROWS_SQNORM || MODE == ROWS_ADAM) g[j] = row_load<VEC>(a.g + o[j]);
+                if (MODE != ROWS_SQNORM) {
+                    p[j] = row_load<VEC>(a.p + o[j]); m[j] = row_load<VEC>(a.m + o[j]); v[j] = row_load<VEC>(a.v + o[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (!act[j]) continue;
+            if (MODE == ROWS_SQNORM) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc += g[j].x[k] * g[j].x[k];
+            } else if (MODE == ROWS_ADAM) {
+                row_replay<VEC, UNI>(a, old[j] + 1, target - 1, p[j], m[j], v[j]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    p[j].x[k] = adam_update(g[j].x[k] * coef, p[j].x[k], m[j].x[k], v[j].x[k], a.beta1, a.beta2, a.eps,
+                                            a.weight_decay, ac.step_size, ac.rsqrt_bc2);
+            } else {
+                row_replay<VEC, UNI>(a, old[j] + 1, target, p[j], m[j], v[j]);
+            }
+        }
+        if (MODE == ROWS_SQNORM) continue;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (!act[j]) continue;
+            row_store<VEC>(a.p + o[j], p[j]);
+            row_store<VEC>(a.m + o[j], m[j]);
+            row_store<VEC>(a.v + o[j], v[j]);
+            if (MODE == ROWS_ADAM) {
+                RowVec<VEC> zero;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) zero.x[k] = 0.f;
+                row_store<VEC>(a.g + o[j], zero);
+            }
+        }
+    }
+    return acc;
+}
+
 // rows ids0[0:n0] ++ ids1[0:n1] (ALL: every row) brought up to update number *step + step_off
-template <bool ALL>
+template <bool ALL, int VEC, bool UNI>
 __global__ void __launch_bounds__(256)
 k_rows_catch_up(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
                 int64_t n1, int32_t step_off)
 {
-    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
-    const int sub = lane & (lpr - 1);
-    const int64_t total = ALL ? a.n_rows : n0 + n1;
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
-    const int32_t target = (int32_t)(*a.step + step_off);
-    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
-        const int64_t e = base + lane / lpr;
-        const bool valid = e < total;
-        const int64_t r = !valid ? 0 : ALL ? e : (e < n0 ? ids0[e] : ids1[e - n0]);
-        int32_t old = target;
-        if (valid && sub == 0) {
-            if (ALL) { old = a.last[r]; if (old < target) a.last[r] = target; }
-            else old = atomicMax(&a.last[r], target);
-        }
-        old = __shfl(old, lane & ~(lpr - 1));
-        if (!valid || old >= target || sub * 4 >= a.E) continue;
-        const int64_t o = r * a.E + sub * 4;
-        f32x4 p = *reinterpret_cast<const f32x4 *>(a.p + o);
-        f32x4 m = *reinterpret_cast<const f32x4 *>(a.m + o);
-        f32x4 v = *reinterpret_cast<const f32x4 *>(a.v + o);
-        row_replay(a, old + 1, target, p, m, v);
-        *reinterpret_cast<f32x4 *>(a.p + o) = p;
-        *reinterpret_cast<f32x4 *>(a.m + o) = m;
-        *reinterpret_cast<f32x4 *>(a.v + o) = v;
-    }
+    rows_pass<ALL ? ROWS_CATCH_UP_ALL : ROWS_CATCH_UP, VEC, ROWS_RB, UNI>(a, ids0, n0, ids1, n1, (int32_t)(*a.step + step_off),
+                                                                     1.f, AdamConsts{0.f, 0.f});
 }
 
 // partial[bx] = sum of squares of the gradient rows in the lists, every row once (stamp `seen`)
+template <int VEC>
 __global__ void __launch_bounds__(256)
 k_rows_sqnorm(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
               int64_t n1, int32_t step_off, float *__restrict__ partial)
 {
     __shared__ float red[4];
-    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
-    const int sub = lane & (lpr - 1);
-    const int64_t total = n0 + n1;
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
-    const int32_t t = (int32_t)(*a.step + step_off);
-    float acc = 0.f;
-    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
-        const int64_t e = base + lane / lpr;
-        const bool valid = e < total;
-        const int64_t r = !valid ? 0 : (e < n0 ? ids0[e] : ids1[e - n0]);
-        int32_t old = t;
-        if (valid && sub == 0) old = atomicMax(&a.seen[r], t);
-        old = __shfl(old, lane & ~(lpr - 1));
-        if (!valid || old >= t || sub * 4 >= a.E) continue;
-        const f32x4 g = *reinterpret_cast<const f32x4 *>(a.g + r * a.E + sub * 4);
-        acc += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
-    }
+    const float acc = rows_pass<ROWS_SQNORM, VEC, 2 * ROWS_RB, false>(a, ids0, n0, ids1, n1, (int32_t)(*a.step + step_off), 1.f,
+                                                               AdamConsts{0.f, 0.f});
     const float s = block_sum_256(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 // update number t = *step + step_off of the rows in the lists (every row once; rows behind t - 1 are caught up
 // first), their gradient rows zeroed; records the step's constants for later replays
+template <int VEC, bool UNI>
 __global__ void __launch_bounds__(256)
 k_rows_adam(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1,
             int64_t n1, int32_t step_off, const float *__restrict__ partial, int32_t n_partial)
@@ -322,39 +427,10 @@ k_rows_adam(const RowAdam a, const int64_t *__restrict__ ids0, int64_t n0, const
     const int32_t t = (int32_t)tl;
     const AdamConsts ac = adam_consts(*a.lr, (float)tl, a.beta1, a.beta2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.hist[(t % a.hist_cap) * 2] = ac.step_size;
-        a.hist[(t % a.hist_cap) * 2 + 1] = ac.rsqrt_bc2;
+        a.hist[(t & (a.hist_cap - 1)) * 2] = ac.step_size;
+        a.hist[(t & (a.hist_cap - 1)) * 2 + 1] = ac.rsqrt_bc2;
     }
-    const int lane = threadIdx.x & 63, lpr = a.lpr, rpw = 64 / lpr;
-    const int sub = lane & (lpr - 1);
-    const int64_t total = n0 + n1;
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t base = wave * rpw; base < total; base += n_waves * rpw) {
-        const int64_t e = base + lane / lpr;
-        const bool valid = e < total;
-        const int64_t r = !valid ? 0 : (e < n0 ? ids0[e] : ids1[e - n0]);
-        int32_t old = t;
-        if (valid && sub == 0) old = atomicMax(&a.last[r], t);
-        old = __shfl(old, lane & ~(lpr - 1));
-        if (!valid || old >= t || sub * 4 >= a.E) continue;
-        const int64_t o = r * a.E + sub * 4;
-        f32x4 p = *reinterpret_cast<const f32x4 *>(a.p + o);
-        f32x4 m = *reinterpret_cast<const f32x4 *>(a.m + o);
-        f32x4 v = *reinterpret_cast<const f32x4 *>(a.v + o);
-        const f32x4 g = *reinterpret_cast<const f32x4 *>(a.g + o);
-        row_replay(a, old + 1, t - 1, p, m, v);
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-            float me = m[e4], ve = v[e4];
-            p[e4] = adam_update(g[e4] * coef, p[e4], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, ac.step_size,
-                                ac.rsqrt_bc2);
-            m[e4] = me; v[e4] = ve;
-        }
-        *reinterpret_cast<f32x4 *>(a.p + o) = p;
-        *reinterpret_cast<f32x4 *>(a.m + o) = m;
-        *reinterpret_cast<f32x4 *>(a.v + o) = v;
-        *reinterpret_cast<f32x4 *>(a.g + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    rows_pass<ROWS_ADAM, VEC, ROWS_RB, UNI>(a, ids0, n0, ids1, n1, t, coef, ac);
 }
 
 // part[b, c] = sum over rows i = b, b + n_part, ... of src[i, c]   (bias gradient of a Linear: column sums)
@@ -730,19 +806,24 @@ int gsage_zero_rows(float *table, int64_t ld, const int64_t *ids, int64_t M, int
 static int fill_rows(RowAdam &a, const gsage_row_adam *d, const char *who)
 {
     GSAGE_REQUIRE(d && d->p && d->g && d->m && d->v && d->last && d->seen && d->hist && d->lr && d->step, who);
-    GSAGE_REQUIRE(d->n_rows > 0 && d->E > 0 && d->E % 4 == 0 && d->E <= 256 && d->hist_cap >= 2, who);
+    GSAGE_REQUIRE(d->n_rows > 0 && d->E > 0 && d->E % 4 == 0 && d->E <= 256 && d->hist_cap >= 2 &&
+                  (d->hist_cap & (d->hist_cap - 1)) == 0, who);
     GSAGE_REQUIRE(((((uintptr_t)d->p | (uintptr_t)d->g | (uintptr_t)d->m | (uintptr_t)d->v)) & 15) == 0, who);
     a.p = d->p; a.g = d->g; a.m = d->m; a.v = d->v; a.last = d->last; a.seen = d->seen; a.hist = d->hist;
     a.hist_cap = d->hist_cap; a.E = d->E; a.n_rows = d->n_rows; a.lr = d->lr; a.step = d->step;
     a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.weight_decay = d->weight_decay; a.max_norm = d->max_norm;
+    GSAGE_REQUIRE(d->n_rows < ((int64_t)1 << 31), who);
+    const int per = d->E <= 64 ? 1 : 4;          // elements per lane (rows_vec)
     a.lpr = 1;
-    while (a.lpr * 4 < d->E) a.lpr <<= 1;
+    while (a.lpr * per < d->E || a.lpr < 2 * ROWS_RB) a.lpr <<= 1;     // (a wave's trip: <= 64 entries)
     return GSAGE_OK;
 }
 
+static inline bool rows_vec4(const RowAdam &a) { return a.E > 64; }
+
 static int rows_grid(const RowAdam &a, int64_t entries, int cap)
 {
-    return grid_for(ceil_div(entries, (int64_t)(64 / a.lpr)) * 64, cap);
+    return grid_for(ceil_div(entries, (int64_t)(ROWS_RB * (64 / a.lpr))) * 64, cap);      // a wave per RB row groups
 }
 
 int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
@@ -753,8 +834,12 @@ int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1), "rows_catch_up: bad id lists");
     if (n0 + n1 == 0) return GSAGE_OK;
-    launch(k_rows_catch_up<false>, dim3(rows_grid(a, n0 + n1, 4096)), dim3(256), 0, (hipStream_t)stream, a, ids0, n0,
-           ids1, n1, step_off);
+    const dim3 grid(rows_grid(a, n0 + n1, 4096));
+    hipStream_t s = (hipStream_t)stream;
+    if (rows_vec4(a) && a.lpr == 64) launch(k_rows_catch_up<false, 4, true>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off);
+    else if (rows_vec4(a)) launch(k_rows_catch_up<false, 4, false>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off);
+    else if (a.lpr == 64) launch(k_rows_catch_up<false, 1, true>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off);
+    else launch(k_rows_catch_up<false, 1, false>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off);
     return check_launch("rows_catch_up");
 }
 
@@ -763,8 +848,14 @@ int gsage_rows_catch_up_all(const gsage_row_adam *d, int32_t step_off, void *str
     RowAdam a;
     int rc = fill_rows(a, d, "rows_catch_up_all: bad descriptor");
     if (rc != GSAGE_OK) return rc;
-    launch(k_rows_catch_up<true>, dim3(rows_grid(a, a.n_rows, 8192)), dim3(256), 0, (hipStream_t)stream, a,
-           (const int64_t *)nullptr, (int64_t)0, (const int64_t *)nullptr, (int64_t)0, step_off);
+    const dim3 grid(rows_grid(a, a.n_rows, 8192));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t *none = nullptr;
+    const int64_t zero = 0;
+    if (rows_vec4(a) && a.lpr == 64) launch(k_rows_catch_up<true, 4, true>, grid, dim3(256), 0, s, a, none, zero, none, zero, step_off);
+    else if (rows_vec4(a)) launch(k_rows_catch_up<true, 4, false>, grid, dim3(256), 0, s, a, none, zero, none, zero, step_off);
+    else if (a.lpr == 64) launch(k_rows_catch_up<true, 1, true>, grid, dim3(256), 0, s, a, none, zero, none, zero, step_off);
+    else launch(k_rows_catch_up<true, 1, false>, grid, dim3(256), 0, s, a, none, zero, none, zero, step_off);
     return check_launch("rows_catch_up_all");
 }
 
@@ -776,7 +867,10 @@ int gsage_rows_sqnorm(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, 
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial >= 1 &&
                   n_partial <= 1024, "rows_sqnorm: bad arguments");
-    launch(k_rows_sqnorm, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, a, ids0, n0, ids1, n1, step_off, partial);
+    if (rows_vec4(a))
+        launch(k_rows_sqnorm<4>, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, a, ids0, n0, ids1, n1, step_off, partial);
+    else
+        launch(k_rows_sqnorm<1>, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, a, ids0, n0, ids1, n1, step_off, partial);
     return check_launch("rows_sqnorm");
 }
 
@@ -789,8 +883,11 @@ int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, co
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial_ready >= 1,
                   "rows_adam: bad arguments");
     // (always launched, also for empty lists: the launch records the step's constants)
-    launch(k_rows_adam, dim3(rows_grid(a, n0 + n1 > 0 ? n0 + n1 : 1, 4096)), dim3(256), 0, (hipStream_t)stream, a, ids0,
-           n0, ids1, n1, step_off, partial, n_partial_ready);
+    const dim3 grid(rows_grid(a, n0 + n1 > 0 ? n0 + n1 : 1, 4096));
+    hipStream_t s = (hipStream_t)stream;
+    // (its replays -- rows that skipped their catch-up -- read the ring it writes: vector loads, UNI = false)
+    if (rows_vec4(a)) launch(k_rows_adam<4, false>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off, partial, n_partial_ready);
+    else launch(k_rows_adam<1, false>, grid, dim3(256), 0, s, a, ids0, n0, ids1, n1, step_off, partial, n_partial_ready);
     return check_launch("rows_adam");
 }
 

@@ -1577,7 +1577,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             # the table's gradient comes from scatter-adds, its squared norm from a pass of its own whose
             # partials sit behind the finalisation's in the same array
             self.n_tab = int(self.table.numel())
-            self.n_tab_partial = 256 if self.lazy_rows else nat.lib().gsage_adam_partials(self.n_tab)
+            self.n_tab_partial = 1024 if self.lazy_rows else nat.lib().gsage_adam_partials(self.n_tab)
             self.partial = torch.zeros(self.n_partial + self.n_tab_partial, dtype=torch.float32, device=self.dev)
         if self.emb and self.lazy_rows:
             # deferred row updates (gsage_rows_*): a step touches its frontier's rows, everything else is
