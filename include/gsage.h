@@ -299,6 +299,8 @@ typedef struct gsage_wgrad_desc {
     float *slabs;
     int64_t ldc, lda, a_gstride;
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
+    const int64_t *a_rows;      /* optional (NULL = A's own rows): reduction index m reads row a_rows[m] of A -- a
+                                 * frontier's table rows in place, no gathered copy; 16-byte aligned, ids < 2^32 */
 } gsage_wgrad_desc;
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
 /* dtype (both entry points) = type of dC and A: GSAGE_BF16 (the MFMA kernel described above) or

@@ -197,7 +197,7 @@ class TailGatherDesc(ctypes.Structure):       # mirrors gsage_tail_gather_desc (
 class WgradDesc(ctypes.Structure):            # mirrors gsage_wgrad_desc (include/gsage.h)
     _fields_ = [("dC", _vp), ("A", _vp), ("slabs", _vp), ("ldc", _i64), ("lda", _i64),
                 ("a_gstride", _i64), ("M", _i64), ("Ntot", _i64), ("K", _i64), ("n_per_group", _i64),
-                ("ldk", _i64), ("rows_per_split", _i64)]
+                ("ldk", _i64), ("rows_per_split", _i64), ("a_rows", _vp)]
 
 
 class CommandList(object):

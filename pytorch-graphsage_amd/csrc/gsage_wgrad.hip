@@ -37,6 +37,7 @@ struct WgradParams {
     float *slabs;
     int64_t ldc, lda, a_gstride;
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
+    const int64_t *a_rows;      // optional: row m of the A operand is A[a_rows[m]] (a frontier read in place)
 };
 
 // operand for column residue E (0..7) out of eight 16-byte row segments: element E of rows 0..7
@@ -152,6 +153,96 @@ __device__ __forceinline__ void wgrad_mainloop(const WgradParams &p, const uint1
     }
 }
 
+// Same pipeline with the A operand read IN PLACE through a row list (a_rows[m] = table row of reduction index m:
+// the frontier's level-0 rows, no gathered copy).  A lane needs the eight ids of its row group per step: 64
+// contiguous bytes, four more 16-byte loads per step and lane, issued TWO steps ahead of the data they address so
+// that they have landed when the addresses are formed.  In-order completion makes the waits countable:
+//     ... ids(s+1) | data(s) | ids(s+2) | data(s+1) ...
+//   addresses of data(s+1) need ids(s+1):  younger = data(s) [16] + ids(s+2) [4]      -> vmcnt(20)
+//   MFMAs of step s need data(s):          younger = ids(s+2) [4] + data(s+1) [16]    -> vmcnt(20)
+// (16 / 4 / 0 where the younger loads were not issued: the last two steps).
+__device__ __forceinline__ void wgrad_mainloop_rows(const WgradParams &p, const uint16_t *A, int64_t m_begin,
+                                                    int64_t m_end, int64_t n_off, int64_t k_off, int rg,
+                                                    f32x4 (&acc)[8][8])
+{
+    u32x4 cb[2][8], ab[2][8], ib[2][4];
+    const int64_t nfull = (m_end - m_begin) / 32;
+    const uint16_t *c_base = p.dC + (m_begin + 8 * rg) * p.ldc + n_off;
+    const int64_t *i_base = p.a_rows + m_begin + 8 * rg;
+    const uint16_t *a_col = A + k_off;
+    auto load_ids = [&](u32x4 (&dst)[4], int64_t step) {
+        const uint16_t *ip = reinterpret_cast<const uint16_t *>(i_base + step * 32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load16_async(dst[q], ip + 8 * q);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait = [&](int n) {      // simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+        if (n == 20) __builtin_amdgcn_s_waitcnt(0x4F74);
+        else if (n == 16) __builtin_amdgcn_s_waitcnt(0x4F70);
+        else if (n == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_data = [&](u32x4 (&cdst)[8], u32x4 (&adst)[8], const u32x4 (&ids)[4], int64_t step) {
+        const uint16_t *cp = c_base + step * 32 * p.ldc;
+        const uint16_t *ap[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)          // (row ids are < 2^32: the low dword)
+            ap[r] = a_col + (int64_t)ids[r >> 1][(r & 1) * 2] * p.lda;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            load16_async(cdst[r], cp + r * p.ldc);
+            load16_async(adst[r], ap[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto consume = [&](u32x4 (&c)[8], u32x4 (&a)[8], int younger) {
+        wait(younger);
+        mma_step(c, a, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nfull > 0) {
+        load_ids(ib[0], 0);
+        if (nfull > 1) load_ids(ib[1], 1);
+        wait(nfull > 1 ? 4 : 0);
+        load_data(cb[0], ab[0], ib[0], 0);
+    }
+    for (int64_t s0 = 0; s0 < nfull; s0 += 2) {
+        const bool more1 = s0 + 1 < nfull, more2 = s0 + 2 < nfull, more3 = s0 + 3 < nfull;   // wave-uniform
+        if (more2) load_ids(ib[0], s0 + 2);
+        if (more1) {
+            wait(more2 ? 20 : 16);
+            load_data(cb[1], ab[1], ib[1], s0 + 1);
+        }
+        consume(cb[0], ab[0], (more2 ? 4 : 0) + (more1 ? 16 : 0));
+        if (more1) {
+            if (more3) load_ids(ib[1], s0 + 3);
+            if (more2) {
+                wait(more3 ? 20 : 16);
+                load_data(cb[0], ab[0], ib[0], s0 + 2);
+            }
+            consume(cb[1], ab[1], (more3 ? 4 : 0) + (more2 ? 16 : 0));
+        }
+    }
+    const int64_t m_tail = m_begin + nfull * 32;
+    if (m_tail < m_end) {
+        u32x4 ct[8], at[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t m = m_tail + 8 * rg + r;
+            const bool ok = m < m_end;
+            const int64_t mm = ok ? m : m_begin;
+            u32x4 c = *reinterpret_cast<const u32x4 *>(p.dC + mm * p.ldc + n_off);
+            u32x4 a = *reinterpret_cast<const u32x4 *>(A + p.a_rows[mm] * p.lda + k_off);
+            ct[r] = ok ? c : u32x4{0u, 0u, 0u, 0u};
+            at[r] = ok ? a : u32x4{0u, 0u, 0u, 0u};
+        }
+        mma_step(ct, at, acc);
+    }
+}
+
 // ---- in-workgroup reduction of the four waves' partial tiles ---------------------------------------
 // D[i][j] of MFMA (E, f) is dW[n_base + 8i + E][k_base + 8j + f]; lane l holds j = l & 15 and
 // i = 4 (l >> 4) + reg, so (f = 0..7) of one reg are eight consecutive floats of one output row.
@@ -235,7 +326,8 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, rg, acc);
+    if (p.a_rows) wgrad_mainloop_rows(p, A, w_begin, w_end, n_off, k_off, rg, acc);
+    else wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, rg, acc);
 
     // two rounds of four residue blocks (16 x 8 KiB of LDS)
     float *slab = p.slabs + bx * p.Ntot * p.ldk;
@@ -315,7 +407,7 @@ __device__ __forceinline__ void wgrad_workgroup_f32(const WgradParams &p, int64_
         for (int e = 0; e < 4; ++e) {
             const int64_t n = n_base + lc + e, k = k_base + lc + e;
             cs[lr * 128 + lc + e] = (m < m_end && n < p.Ntot) ? dC[m * p.ldc + n] : 0.f;
-            as[lr * 128 + lc + e] = (m < m_end && k < p.lda) ? A[m * p.lda + k] : 0.f;
+            as[lr * 128 + lc + e] = (m < m_end && k < p.lda) ? A[(p.a_rows ? p.a_rows[m] : m) * p.lda + k] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -416,8 +508,10 @@ static int wgrad_raise_lds(K kernel, bool &done)
 
 static int wgrad_fill(WgradParams &p, int dtype, const void *dC, int64_t ldc, const void *A, int64_t lda,
                       int64_t a_gstride, int64_t M, int64_t Ntot, int64_t K, int64_t n_per_group,
-                      int64_t rows_per_split, float *slabs, int64_t ldk)
+                      int64_t rows_per_split, float *slabs, int64_t ldk, const int64_t *a_rows = nullptr)
 {
+    GSAGE_REQUIRE(((uintptr_t)a_rows % 16) == 0, "wgrad: a_rows must be 16-byte aligned");
+    p.a_rows = a_rows;
     GSAGE_REQUIRE(dC && A && slabs, "wgrad: null pointer");
     GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "wgrad: bad dtype");
     GSAGE_REQUIRE(M > 0 && Ntot > 0 && K > 0, "wgrad: bad sizes");
@@ -450,7 +544,7 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, 
         if (s < n_prob) {
             const gsage_wgrad_desc &d = probs[s];
             int rc = wgrad_fill(q.p[s], dtype, d.dC, d.ldc, d.A, d.lda, d.a_gstride, d.M, d.Ntot, d.K,
-                                d.n_per_group, d.rows_per_split, d.slabs, d.ldk);
+                                d.n_per_group, d.rows_per_split, d.slabs, d.ldk, d.a_rows);
             if (rc != GSAGE_OK) return rc;
             q.S[s] = (int32_t)ceil_div(d.M, d.rows_per_split);
             q.ny[s] = (int32_t)ceil_div(d.Ntot, 128);

@@ -1249,9 +1249,14 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         self.n_desc = len(descs)
         self.max_elems = max(d.rows * d.cols for d in descs)
 
-        # level-0 operands, gathered once per step: x rows (hops 0..L-1) and neighbour rows (hops 1..L)
+        # level-0 operands: x rows (hops 0..L-1) gathered once per step; the neighbour rows (hops 1..L: 141 k rows,
+        # 180 MB at Reddit's shape) are read IN PLACE through the frontier's row list by K3 and by K5b
+        # (gsage_wgrad_desc.a_rows) -- GSAGE_POOL_COPY_ROWS=1 brings back the gathered copy
+        self.inplace0 = os.environ.get("GSAGE_POOL_COPY_ROWS", "0") != "1" and self.B % 2 == 0
         self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
-        self.xn0_set = [torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+        self.xn0_set = [None if self.inplace0 else torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev)
+                        for _ in range(self.nset)]
+        self._q_ids = None
         self.pooled, self.pooled_b, self.argmax, self.hout, self.dc = [], [], [], [], []
         self.dpool, self.ghc, self.dxb, self.dnb, self.bpart = [], [], [], [], []
         for l in range(L):
@@ -1281,10 +1286,14 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         return (self.x0_set[s], self.store.ld) if l == 0 else (self.hout[l - 1], self.din[l])
 
     def _nb_operand(self, l, s):
-        """neighbour rows of level l as one contiguous row block + its leading dimension"""
+        """neighbour rows of level l: (row block, leading dimension, row list or None).  With a row list, neighbour
+        row i is block[list[i]] (level 0 read in place from the feature table)."""
         if l == 0:
-            return self.xn0_set[s], self.store.ld
-        return self.hout[l - 1][self.off[1]:], self.din[l]
+            if self.inplace0:       # the frontier of the batch being computed: the queue's, else the set's own
+                ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
+                return self.store.data, self.store.ld, ids[self.off[1]:]
+            return self.xn0_set[s], self.store.ld, None
+        return self.hout[l - 1][self.off[1]:], self.din[l], None
 
     def _init_reduce(self):
         dev, L, f32 = self.dev, self.L, torch.float32
@@ -1308,11 +1317,19 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         L, st = self.L, self.store
         if ids is None:
             ids = self.ids_set[s]
-        segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1),
-                (st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1)]
+        segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1)]
+        if not self.inplace0:
+            segs.append((st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1))
         # (D = the real width: the pad columns of the operand buffers were zeroed once and stay zero)
         ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None,
                               hops=hops)
+
+    def _queue_compute(self, par):
+        self._q_ids = self.ids_q[par]
+        try:
+            return super(FusedPoolTrainStep, self)._queue_compute(par)
+        finally:
+            self._q_ids = None
 
     def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act, Wp=None):
         if Wp is not None and lda % 64 == 0 and lda >= -(-K // 64) * 64:
@@ -1325,10 +1342,12 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
         for l, layer in enumerate(self.layers):
             R, Hm, h, din = self.rows[l], self.Hm[l], self.h[l], self.din[l]
-            nb, ldnb = self._nb_operand(l, s)
+            nb, ldnb, nrows = self._nb_operand(l, s)
             for k in range(L - l):                       # one K3 launch per hop: its fan-out is the segment
                 r0, r1 = self.off[k], self.off[k + 1]
                 a0 = self.off[k + 1] - self.off[1]
+                a_ptr = nb.data_ptr() if nrows is not None else nb[a0:].data_ptr()
+                r_ptr = nrows[a0:].data_ptr() if nrows is not None else None
                 is_max = self.pool_mode == nat.POOL_MAX
                 is_bf = self.code == nat.BF16
                 tail = (self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
@@ -1336,11 +1355,11 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
                         None if is_max else self.argmax[l][a0:].data_ptr(), stream)
                 if self.wm_p[l] is not None and ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
                     nat.check(lib.gsage_pool_mlp_packed(
-                        nb[a0:].data_ptr(), ldnb, None, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
+                        a_ptr, ldnb, r_ptr, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
                         self.size[k], self.fan[k + 1], Hm, din, self.pool_mode, *tail), "pool_mlp_packed")
                 else:
                     nat.check(lib.gsage_pool_mlp(
-                        nb[a0:].data_ptr(), self.code, ldnb, None, self.wm[l].data_ptr(), self.wm[l].shape[1],
+                        a_ptr, self.code, ldnb, r_ptr, self.wm[l].data_ptr(), self.wm[l].shape[1],
                         layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
                         *tail), "pool_mlp")
             x, ldx = self._x_operand(l, s)
@@ -1402,13 +1421,13 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
         for l in range(L - 1, -1, -1):
             R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
             x, ldx = self._x_operand(l, s)
-            nb, ldnb = self._nb_operand(l, s)
+            nb, ldnb, nrows = self._nb_operand(l, s)
             dc = self.dc[l]
             T = self.WG_TARGET
             probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"], T["x"]))
             probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"],
                           T["n"]))
-            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"]))
+            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"], nrows))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)
@@ -1432,8 +1451,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
     Level 0 reads its rows from ONE buffer gathered per step (all hops, next batch, beside Adam and K1): the att
     MLP, K4, the x projection and two of the four weight gradients all want plain row-major operands."""
 
-    HA_LD = 64
-    ROW_HIST = 1 << 15   # updates whose constants are kept for deferred table rows (sync_rows() before it wraps)            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
+    HA_LD = 64            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
+    ROW_HIST = 1 << 15    # updates whose constants are kept for deferred table rows (sync_rows() before it wraps)
     WG_TARGET = 120       # K5b workgroups per problem (eight problems share the launch)
 
     @staticmethod

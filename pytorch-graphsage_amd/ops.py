@@ -386,12 +386,16 @@ def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None, slabs=None, 
 def wgrad_multi(problems):
     """Several K5b problems in one launch; partial tiles stay in each problem's slabs
     (gsage_finalize_grads sums them).  problems: list of (dC, A, lda, a_gstride, M, Ntot, K,
-    n_per_group, slabs) with the meaning of wgrad()."""
+    n_per_group, slabs[, workgroup target[, a_rows]]) with the meaning of wgrad(); a_rows (int64 [M], 16-byte
+    aligned): reduction index m reads row a_rows[m] of A -- a frontier's table rows in place."""
     descs = (nat.WgradDesc * len(problems))()
     for d, prob in zip(descs, problems):
         dC, A, lda, a_gs, M, Ntot, K, npg, slabs = prob[:9]
-        rps, S, ldk = wgrad_plan(M, Ntot, K, *prob[9:])       # optional 10th entry: workgroup target
+        rps, S, ldk = wgrad_plan(M, Ntot, K, *[v for v in prob[9:10] if v is not None])
         assert tuple(slabs.shape) == (S, Ntot, ldk) and slabs.is_contiguous()
+        rows = prob[10] if len(prob) > 10 else None
+        assert rows is None or (rows.dtype == torch.int64 and rows.is_contiguous() and rows.numel() >= M)
+        d.a_rows = _ptr(rows) if rows is not None else None
         d.dC, d.A, d.slabs = _ptr(dC), _ptr(A), _ptr(slabs)
         d.ldc, d.lda, d.a_gstride = dC.stride(0), lda, a_gs
         d.M, d.Ntot, d.K, d.n_per_group, d.ldk, d.rows_per_split = M, Ntot, K, npg, ldk, rps

@@ -586,6 +586,38 @@ def test_wgrad_multi_equals_single_launches():
         assert torch.equal(got[:, :, :K], ref[:, :, :K]), (M, Ntot, K)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_wgrad_reads_its_operand_rows_in_place_through_a_row_list(dtype):
+    """gsage_wgrad_desc.a_rows: the A operand is a table read through a frontier's row list (duplicates, any
+    order) -- bit-identical to the same launch over a gathered copy of those rows, for slices of 1, 2, 3 and many
+    32-row steps per wave and ragged tails (every vmcnt path of the pipelined loop)."""
+    T = torch.bfloat16 if dtype == "bf16" else torch.float32
+    rng = np.random.RandomState(5)
+    table_rows = 5000
+    shapes = [(16384, 256, 602, 128), (1300, 256, 602, 128), (640, 128, 256, 128), (257, 32, 64, 32), (96, 16, 40, 16),
+              (33, 8, 24, 8)]
+    for wg_target in (None, 8, 64):
+        probs, refs = [], []
+        for (M, Ntot, K, npg) in shapes:
+            lda = gs.store._round_up(K, 8)
+            dC = torch.from_numpy(rng.normal(size=(M, Ntot)).astype(np.float32)).to(DEV).to(T)
+            table = torch.zeros(table_rows, lda, dtype=T, device=DEV)
+            table[:, :K] = torch.from_numpy(rng.normal(size=(table_rows, K)).astype(np.float32)).to(DEV).to(T)
+            rows = torch.from_numpy(rng.randint(0, table_rows, size=M + 3)).to(DEV)[:M + 2]
+            copy = table[rows[:M]].contiguous()
+            rps, S, ldk = ops.wgrad_plan(M, Ntot, K, *([wg_target] if wg_target else []))
+            ref = torch.full((S, Ntot, ldk), float("nan"), dtype=torch.float32, device=DEV)
+            got = torch.full((S, Ntot, ldk), float("nan"), dtype=torch.float32, device=DEV)
+            refs.append((copy, (dC, copy, lda, 0, M, Ntot, K, Ntot, ref, wg_target)))
+            probs.append((dC, table, lda, 0, M, Ntot, K, Ntot, got, wg_target, rows))
+        ops.wgrad_multi([r[1] for r in refs])
+        ops.wgrad_multi(probs)
+        torch.cuda.synchronize()
+        for (M, Ntot, K, npg), pr, rf in zip(shapes, probs, refs):
+            assert torch.equal(pr[8][:, :, :K], rf[1][8][:, :, :K]), (dtype, wg_target, M, Ntot, K)
+            assert not torch.isnan(pr[8][:, :, :K]).any()
+
+
 @pytest.mark.parametrize("B,n,C", [(512, 25, 41), (13, 7, 5), (6, 32, 64), (4, 1, 2), (33, 16, 41), (35, 17, 3)])
 def test_seed_level_kernel_vs_fp64(B, n, C):
     """gsage_mean_tail_ce = segment mean + both projections + normalize/fc/CE + every gradient down to
