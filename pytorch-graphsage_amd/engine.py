@@ -1525,8 +1525,13 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         self.n_desc = len(descs)
         self.max_elems = max(d.rows * d.cols for d in descs)
 
-        # level-0 rows of every hop, gathered once per step (one set per batch in flight)
-        self.g0_set = [torch.zeros(self.rall[0], self.ldin[0], dtype=T, device=dev) for _ in range(self.nset)]
+        # level-0 rows of every hop.  Feature rows are read IN PLACE through the frontier's row list (K5 / K4 / K4' /
+        # K5b all take one; GSAGE_ATTN_COPY_ROWS=1: gathered once per step into one buffer per batch in flight, as
+        # the embedding prep needs anyway for its output rows); the gather launch then only carries the seeds' rows
+        self.inplace0 = (not self.emb) and os.environ.get("GSAGE_ATTN_COPY_ROWS", "0") != "1" and self.B % 2 == 0
+        self._q_ids, self._cur_ids = None, self.ids_set[0]
+        self.g0_set = [torch.zeros(self.B if self.inplace0 else self.rall[0], self.ldin[0], dtype=T, device=dev)
+                       for _ in range(self.nset)]
         if self.emb:
             prep, RA0, E = self.model.prep, self.rall[0], self.din[0]
             self.table = prep.embedding.weight                 # a view of the flat parameter bucket
@@ -1561,19 +1566,24 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         self.fused_tail = False
 
     def _in(self, l, s):
-        """input rows of level l (all hops it reads) and their leading dimension"""
-        return (self.g0_set[s], self.ldin[0]) if l == 0 else (self.hout[l - 1], self.ldin[l])
+        """input rows of level l (all hops it reads): (row block, leading dimension, row list or None) -- with a
+        row list, input row i is block[list[i]] (level 0 read in place from the feature table)"""
+        if l > 0:
+            return self.hout[l - 1], self.ldin[l], None
+        if self.inplace0:
+            return self.store.data, self.ldin[0], self._cur_ids
+        return self.g0_set[s], self.ldin[0], None
 
     def _wg_problems(self, l, s):
         """(dC, A, lda, M, Ntot, K, parameter) of the four weight gradients of level l"""
-        inp, ld = self._in(l, s)
+        inp, ld, rows = self._in(l, s)
         h, Ha, D, layer = self.h[l], self.Ha, self.din[l], self.layers[l]
-        probs = [(self.dc[l][:, :h], inp, ld, self.rows[l], h, D, layer.fc_x.weight),
-                 (self.dc[l][:, h:], self.aggc[l], ld, self.rows[l], h, D, layer.fc_neib.weight),
-                 (self.da[l], self.hid[l], self.HA_LD, self.rall[l], Ha, Ha, layer.att[2].weight),
-                 (self.dhid[l], inp, ld, self.rall[l], Ha, D, layer.att[0].weight)]
+        probs = [(self.dc[l][:, :h], inp, ld, self.rows[l], h, D, layer.fc_x.weight, rows),
+                 (self.dc[l][:, h:], self.aggc[l], ld, self.rows[l], h, D, layer.fc_neib.weight, None),
+                 (self.da[l], self.hid[l], self.HA_LD, self.rall[l], Ha, Ha, layer.att[2].weight, None),
+                 (self.dhid[l], inp, ld, self.rall[l], Ha, D, layer.att[0].weight, rows)]
         if l == 0 and self.emb:      # the prep's affine: d out^T x embedding rows
-            probs.append((self.din0, self.eraw, self.eraw.stride(0), self.rall[0], D, D, self.model.prep.fc.weight))
+            probs.append((self.din0, self.eraw, self.eraw.stride(0), self.rall[0], D, D, self.model.prep.fc.weight, None))
         return probs
 
     def _init_reduce(self):
@@ -1581,7 +1591,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         rdesc, self.slabs = [], []
         for l in range(self.L):
             bufs = []
-            for (dC, A, lda, M, ntot, K, prm) in self._wg_problems(l, 0):
+            for (dC, A, lda, M, ntot, K, prm, _rows) in self._wg_problems(l, 0):
                 rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET)
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs.append(buf)
@@ -1630,7 +1640,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         st = self.store
         if ids is None:
             ids = self.ids_set[s]
-        segs = [(st.data, ids[:self.rall[0]], self.g0_set[s], self.rall[0], 1)]
+        n0 = self.B if self.inplace0 else self.rall[0]        # (in place: a token segment carries Adam and K1)
+        segs = [(st.data, ids[:n0], self.g0_set[s], n0, 1)]
         ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None, hops=hops)
 
     # embedding prep: the level-0 rows are prep.fc(embedding[ids]) (nn_modules.py:144-155) -- computed at the start of
@@ -1755,9 +1766,11 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         self._stage_sample(0, ids=self.ids_q[1], ahead=True)
 
     def _queue_compute(self, par):
-        if self.emb:
-            self._cur_ids = self.ids_q[par]
-        return super(FusedAttnTrainStep, self)._queue_compute(par)
+        self._q_ids = self.ids_q[par]
+        try:
+            return super(FusedAttnTrainStep, self)._queue_compute(par)
+        finally:
+            self._q_ids = None
 
     def _queue_front(self, par, with_adam):
         if not self.emb:
@@ -1772,32 +1785,41 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             self._cur_ids = self.ids_set[s]
         return super(FusedAttnTrainStep, self)._run_sequential(s)
 
-    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act):
-        ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
-                           self.code, c_code)
+    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act, rows=None):
+        ops._linear_launch(A, lda, rows.data_ptr() if rows is not None else None, 0, W.data_ptr(), W.shape[1], None, C,
+                           ldc, M, N, K, act, 1, 0, 0, 0, self.code, c_code)
+
+    @staticmethod
+    def _child_rows(inp, rows, c0):
+        """(table pointer, id pointer) of the rows from position c0 on, for K4 / K4'"""
+        if rows is None:
+            return inp[c0:].data_ptr(), None
+        return inp.data_ptr(), rows[c0:].data_ptr()
 
     def _stage_compute(self, s):
         L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
         Ha, HL, esz = self.Ha, self.HA_LD, self.esz
+        self._cur_ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
         if self.emb:
             self._prep_forward(s)
         for l in range(L):
             R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
-            inp, ld = self._in(l, s)
-            self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RA, Ha, D, nat.ACT_TANH)
+            inp, ld, rows = self._in(l, s)
+            self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RA, Ha, D, nat.ACT_TANH, rows)
             self._gemm(self.hid[l].data_ptr(), HL, self.w2[l], self.a[l].data_ptr(), nat.F32, Ha, RA, Ha, Ha, nat.ACT_NONE)
             for k in range(L - l):
                 r0, c0 = self.off[k], self.off[k + 1]
+                tab, idp = self._child_rows(inp, rows, c0)
                 nat.check(lib.gsage_attn_aggregate(
-                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, inp[c0:].data_ptr(), self.code, ld,
-                    None, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
+                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
+                    idp, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
                     self.ws[l][c0 - self.off[1]:].data_ptr(), stream), "attn_aggregate")
             nat.check(lib.gsage_add_cast(self.agg[l].data_ptr(), ld, None, 0, self.aggc[l].data_ptr(), self.code, ld, R, D,
                                          stream), "add_cast")
             last = l == L - 1
             out, code = self.hout[l], (nat.F32 if last else self.code)
             act = nat.ACT_NONE if last else nat.ACT_RELU
-            self._gemm(inp.data_ptr(), ld, self.wx[l], out.data_ptr(), code, 2 * h, R, h, D, act)
+            self._gemm(inp.data_ptr(), ld, self.wx[l], out.data_ptr(), code, 2 * h, R, h, D, act, rows)
             self._gemm(self.aggc[l].data_ptr(), ld, self.wn[l], out.data_ptr() + h * out.element_size(), code, 2 * h,
                        R, h, D, act)
         if self.fused_head:
@@ -1818,17 +1840,18 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         Ha, HL, esz = self.Ha, self.HA_LD, self.esz
         for l in range(L - 1, -1, -1):
             R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
-            inp, ld = self._in(l, s)
+            inp, ld, rows = self._in(l, s)
             dc = self.dc[l]
             # d agg = dC[:, h:] Wn
             self._gemm(dc.data_ptr() + h * esz, 2 * h, self.wnT[l], self.dagg[l].data_ptr(), nat.F32, ld, R, D, h,
                        nat.ACT_NONE)
             for k in range(L - l):
                 r0, c0 = self.off[k], self.off[k + 1]
+                tab, idp = self._child_rows(inp, rows, c0)
                 nat.check(lib.gsage_attn_bwd(
                     self.dagg[l][r0:].data_ptr(), ld, self.ws[l][c0 - self.off[1]:].data_ptr(),
-                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, inp[c0:].data_ptr(), self.code, ld,
-                    None, self.size[k], self.fan[k + 1], Ha, D, self.dan[l][c0:].data_ptr(), Ha,
+                    self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
+                    idp, self.size[k], self.fan[k + 1], Ha, D, self.dan[l][c0:].data_ptr(), Ha,
                     self.dax[l][r0:].data_ptr(), Ha, stream), "attn_bwd")
             # d a = (as a child) + (as a parent); hop 0 is never a child, the last hop never a parent (zeros)
             nat.check(lib.gsage_add_cast(self.dan[l].data_ptr(), Ha, self.dax[l].data_ptr(), Ha, self.da[l].data_ptr(),
@@ -1851,8 +1874,8 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
                     self.dc[l - 1].stride(0), RA, D, L - l + 1, self.off_host, self.fan_host, stream), "attn_merge_bwd")
         probs = []
         for l in range(L - 1, -1, -1):
-            for (dC, A, lda, M, ntot, K, prm), slab in zip(self._wg_problems(l, s), self.slabs[l]):
-                probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.WG_TARGET))
+            for (dC, A, lda, M, ntot, K, prm, rows), slab in zip(self._wg_problems(l, s), self.slabs[l]):
+                probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.WG_TARGET, rows))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)
