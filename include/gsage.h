@@ -300,7 +300,9 @@ typedef struct gsage_wgrad_desc {
     int64_t ldc, lda, a_gstride;
     int64_t M, Ntot, K, n_per_group, ldk, rows_per_split;
     const int64_t *a_rows;      /* optional (NULL = A's own rows): reduction index m reads row a_rows[m] of A -- a
-                                 * frontier's table rows in place, no gathered copy; 16-byte aligned, ids < 2^32 */
+                                 * frontier's table rows in place, no gathered copy; 16-byte aligned, ids < 2^32.
+                                 * With several groups the list belongs to group 0's operand only (the other groups
+                                 * read A + g * a_gstride row by row, like gsage_linear_nt's a_rows_group0_only) */
 } gsage_wgrad_desc;
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
 /* dtype (both entry points) = type of dC and A: GSAGE_BF16 (the MFMA kernel described above) or

@@ -303,6 +303,7 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
     const int64_t k_base = bz * 128;
     const int g = (int)(n_base / p.n_per_group);
     const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
+    const bool by_rows = p.a_rows != nullptr && g == 0;     // (the row list belongs to group 0's operand)
 
     const int64_t m_begin = bx * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
@@ -326,7 +327,7 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (p.a_rows) wgrad_mainloop_rows(p, A, w_begin, w_end, n_off, k_off, rg, acc);
+    if (by_rows) wgrad_mainloop_rows(p, A, w_begin, w_end, n_off, k_off, rg, acc);
     else wgrad_mainloop(p, A, w_begin, w_end, n_off, k_off, rg, acc);
 
     // two rounds of four residue blocks (16 x 8 KiB of LDS)
@@ -407,7 +408,7 @@ __device__ __forceinline__ void wgrad_workgroup_f32(const WgradParams &p, int64_
         for (int e = 0; e < 4; ++e) {
             const int64_t n = n_base + lc + e, k = k_base + lc + e;
             cs[lr * 128 + lc + e] = (m < m_end && n < p.Ntot) ? dC[m * p.ldc + n] : 0.f;
-            as[lr * 128 + lc + e] = (m < m_end && k < p.lda) ? A[(p.a_rows ? p.a_rows[m] : m) * p.lda + k] : 0.f;
+            as[lr * 128 + lc + e] = (m < m_end && k < p.lda) ? A[(p.a_rows && g == 0 ? p.a_rows[m] : m) * p.lda + k] : 0.f;
         }
         __syncthreads();
 #pragma unroll

@@ -311,6 +311,7 @@ class FusedMeanTrainStep(object):
         self.n_calls = 0
         # optional device-resident batch queue (load_epoch): the graph then needs no per-step copies
         self.queue = None
+        self._q_ids = None                            # frontier of the batch a queue-mode compute stage works on
         self.batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         self.ids_set = [torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev) for _ in range(self.nset)]
         self.tg_set = [example_targets.clone() for _ in range(self.nset)]
@@ -361,6 +362,11 @@ class FusedMeanTrainStep(object):
         #   xa0   level-0 operands [x rows | neighbour means], gathered ONCE per step so the forward
         #         GEMM and the weight-gradient kernel both read plain row-major operands
         self.xa0_set = [torch.zeros(2, self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+        # K5 and K5b read the x rows of level 0 in place through the frontier's row list (gsage_linear_nt_packed
+        # a_rows / gsage_wgrad_desc.a_rows) instead of from xa0[0]: no row copies in the gather launch (28.5 vs
+        # 32.9 us in-step, 0.092 vs 0.095 ms/step at config 2; GSAGE_MEAN_INPLACE_X=0 brings the copies back)
+        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.B % 2 == 0 and
+                          not getattr(self, "gather_cus", 0))         # (split mode keeps frontier rings of its own)
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
         for l in range(L):
             R = self.rows[l]
@@ -617,7 +623,7 @@ class FusedMeanTrainStep(object):
             if self.size[k] > r0 and (part is None or (part == "means") == (k == L - 1)):
                 segs.append((st.data, ids[self.off[k + 1] + r0 * n:self.off[k + 2]],
                              xa[1][self.off[k] + r0:self.off[k + 1]], self.size[k] - r0, n))
-        if part != "means":
+        if part != "means" and not self.inplace_x:
             segs.append((st.data, ids[:R], xa[0], R, 1))
         if not segs:
             return False
@@ -634,7 +640,11 @@ class FusedMeanTrainStep(object):
         esz = self.esz
         for l in range(L - 1 if self.fused_tail else L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
-            if l == 0:
+            rows = None
+            if l == 0 and self.inplace_x:      # the x rows of every hop, read in place through the frontier
+                xbuf, agg, lda = st.data, self.xa0_set[s][1], st.ld
+                rows = (self._q_ids if self._q_ids is not None else self.ids_set[s]).data_ptr()
+            elif l == 0:
                 xbuf, agg, lda = self.xa0_set[s][0], self.xa0_set[s][1], st.ld
             else:
                 xbuf, agg, lda = self.hout[l - 1], self.agg[l], din
@@ -645,12 +655,12 @@ class FusedMeanTrainStep(object):
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
             if self.wp[l] is not None:
-                ops._linear_packed_launch(xbuf.data_ptr(), lda, None, 0, self.wp[l].data_ptr(), None,
+                ops._linear_packed_launch(xbuf.data_ptr(), lda, rows, int(rows is not None), self.wp[l].data_ptr(), None,
                                           self.hout[l].data_ptr(), 2 * h, R, h, din,
                                           nat.ACT_NONE if last else nat.ACT_RELU, 2, delta // esz, h,
                                           nat.F32 if last else nat.BF16)
                 continue
-            self._linear(xbuf.data_ptr(), lda, None, 0, self.w2[l].data_ptr(), self.w2[l].shape[2],
+            self._linear(xbuf.data_ptr(), lda, rows, int(rows is not None), self.w2[l].data_ptr(), self.w2[l].shape[2],
                          self.hout[l].data_ptr(), nat.F32 if last else self.code, 2 * h, R, h, din,
                          nat.ACT_NONE if last else nat.ACT_RELU, delta // esz,
                          h * self.w2[l].shape[2], h)
@@ -725,14 +735,17 @@ class FusedMeanTrainStep(object):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             dc = self.dc[l]
             xbuf, lda = (self.xa0_set[s][0], st.ld) if l == 0 else (self.hout[l - 1], din)
+            rows = None
+            if l == 0 and self.inplace_x:
+                xbuf, rows = st.data, (self._q_ids if self._q_ids is not None else self.ids_set[s])
             aggl = self.xa0_set[s][1] if l == 0 else self.agg[l]
             delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
             if h % 128 == 0:
-                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0], self._wg_target()))
+                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0], self._wg_target(), rows))
             else:
                 for g in range(2):
                     probs.append((dc[:, g * h:], xbuf if g == 0 else aggl, lda, 0, R, h, din, h,
-                                  self.slabs[l][g], self._wg_target()))
+                                  self.slabs[l][g], self._wg_target(), rows if g == 0 else None))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)
@@ -947,6 +960,8 @@ class FusedMeanTrainStep(object):
         step: every sampled frontier row is read exactly once, by one of the two."""
         total = self.off[self.L + 1]
         tail = self._tail_rows * self.fan[self.L]
+        if getattr(self, "inplace_x", False):          # K5 / K5b read the x rows themselves
+            total -= self.rows[0]
         return total - tail, tail
 
     def _tail_gather_rows(self):
@@ -996,6 +1011,13 @@ class FusedMeanTrainStep(object):
                            hops=self._hops_desc(self.ids_q[par], True))
 
     def _queue_compute(self, par):
+        self._q_ids = self.ids_q[par]
+        try:
+            return self._queue_compute_body(par)
+        finally:
+            self._q_ids = None
+
+    def _queue_compute_body(self, par):
         if self._tail_rows:
             L, st, nxt = self.L, self.store, self.ids_q[1 - par]
             d = nat.TailGatherDesc()
