@@ -239,6 +239,154 @@ k_attn_bwd_wide(const float *__restrict__ g, int64_t g_ld, const float *__restri
     }
 }
 
+// ---- grouped variants: lanes in groups of `lpc`, one child row per group ---------------------------------
+// The wide kernels give every lane one 16-byte chunk of EVERY child row: with 76 chunks (Reddit, bf16) the second
+// pass has 12 of 64 lanes busy, with 8 chunks (64-d embeddings) one lane in eight ever works, and the unrolled
+// batches of 8 rows load padding rows (n = 10: 16 loads for 10 rows).  Here a group of lpc lanes (8 / 16 / 32:
+// the power of two that covers the row in <= TMAX strided chunks per lane) takes ONE child at a time and the
+// 64 / lpc groups take different children; two children per group are in flight.  Forward: per-lane partial sums
+// over the group's children, added across groups at the end; backward: per-child dot products reduced inside the
+// group, parked in LDS for the softmax lanes.
+template <typename T, int VEC, int TMAX>
+__global__ void __launch_bounds__(256)
+k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
+                     const T *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M, int32_t n,
+                     int32_t Ha, int32_t D, float *__restrict__ agg, int64_t agg_ld, float *__restrict__ ws, int32_t lpc)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;                                                 // wave-uniform exit
+    const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
+    if (lane < n) ws[i * n + lane] = w;
+    const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
+    const int chunks = (D + VEC - 1) / VEC;
+    const int Tn = (chunks + lpc - 1) / lpc;                            // <= TMAX (host)
+    int cc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int c = sub + lpc * t;
+        cc[t] = c < chunks ? c : chunks - 1;                            // clamped: loads stay unconditional
+    }
+    float acc[TMAX][VEC];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 2 * G) {                             // wave-uniform trip count
+        vec16 raw[2][TMAX];
+        float wj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = j0 + u * G + grp;
+            const int jj = j < n ? j : n - 1;
+            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
+            const float wv = __shfl(w, jj, 64);
+            wj[u] = j < n ? wv : 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Tn) {
+                    float f[VEC];
+                    chunk_to_f32<T, VEC>(raw[u][t], f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[t][e] += wj[u] * f[e];
+                }
+    }
+    for (int off = lpc; off < 64; off <<= 1)                            // add the groups' partial sums
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < Tn)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] += __shfl_xor(acc[t][e], off, 64);
+    if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            const int c = sub + lpc * t;
+            if (t < Tn && c < chunks) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (c * VEC + e < D) agg[i * agg_ld + c * VEC + e] = acc[t][e];
+            }
+        }
+    }
+}
+
+template <typename T, int VEC, int TMAX>
+__global__ void __launch_bounds__(256)
+k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restrict__ ws, const float *__restrict__ na,
+               int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld, const T *__restrict__ table, int64_t ld,
+               const int64_t *__restrict__ ids, int64_t M, int32_t n, int32_t Ha, int32_t D, float *__restrict__ dna,
+               int64_t dna_ld, float *__restrict__ dxa, int64_t dxa_ld, int32_t lpc)
+{
+    __shared__ float dws_s[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= M) return;
+    const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
+    const int chunks = (D + VEC - 1) / VEC;
+    const int Tn = (chunks + lpc - 1) / lpc;
+    int cc[TMAX];
+    float gv[TMAX][VEC];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int c = sub + lpc * t;
+        const bool live = t < Tn && c < chunks;
+        cc[t] = c < chunks ? c : chunks - 1;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gv[t][e] = (live && c * VEC + e < D) ? g[i * g_ld + c * VEC + e] : 0.f;
+    }
+    volatile float *mine = dws_s[wave];
+    for (int j0 = 0; j0 < n; j0 += 2 * G) {
+        vec16 raw[2][TMAX];
+        int jv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = j0 + u * G + grp;
+            jv[u] = j;
+            const int jj = j < n ? j : n - 1;
+            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Tn) {
+                    float f[VEC];
+                    chunk_to_f32<T, VEC>(raw[u][t], f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) d += f[e] * gv[t][e];       // (clamped chunks meet gv = 0)
+                }
+            for (int off = lpc >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+            if (sub == 0 && jv[u] < n) mine[jv[u]] = d;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane j keeps dws[j]; softmax backward
+    const float dws = lane < n ? mine[lane] : 0.f;
+    const float w = lane < n ? ws[i * n + lane] : 0.f;
+    const float dot = wave_sum(dws * w);
+    const float ds = w * (dws - dot);
+    for (int h = lane; h < Ha; h += 64) {
+        const float xh = xa[i * xa_ld + h];
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float dsj = __shfl(ds, j, 64);
+            acc += dsj * na[(i * n + j) * na_ld + h];
+            dna[(i * n + j) * dna_ld + h] = dsj * xh;
+        }
+        dxa[i * dxa_ld + h] = acc;
+    }
+}
+
 // ---- glue of the native attention train step (engine.FusedAttnTrainStep) ------------------------------
 // Element-wise kernels between K4 / K5 / K5b: what autograd ran as a cast, an add, a tanh backward and
 // four scatter / expand kernels per level (52 casts and 34 adds per Pokec-shaped step).
@@ -387,6 +535,15 @@ extern "C" int gsage_attn_merge_bwd(const void *H, int h_dtype, int64_t ldh, con
 }
 
 
+// lanes per child row of the grouped K4 kernels (0: the row is too wide for TMAX chunks per lane -> wide kernels)
+constexpr int ATTN_TMAX = 3;
+static int attn_group_lanes(int64_t D, int vec)
+{
+    const int64_t chunks = ceil_div(D, (int64_t)vec);
+    if (chunks > 32 * ATTN_TMAX) return 0;
+    return chunks <= 8 ? 8 : chunks <= 16 ? 16 : 32;
+}
+
 template <typename T, int VEC>
 static bool attn_wide_ok(const void *table, int64_t ld, int64_t D)
 {
@@ -406,7 +563,14 @@ extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, con
     GSAGE_REQUIRE(g && ws && na && xa && table && dna && dxa, "attn_bwd: null pointer");
     dim3 grid((unsigned)ceil_div(M, 4));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
+    const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b)
+        launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
+    else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
+        launch(k_attn_bwd_grp<float, 4, ATTN_TMAX>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_f);
+    else if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
         launch(k_attn_bwd_wide<uint16_t, 8, 32>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
                (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld);
     else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D))
@@ -432,6 +596,17 @@ extern "C" int gsage_attn_aggregate(const float *na, int64_t na_ld, const float 
     if (M == 0) return GSAGE_OK;
     GSAGE_REQUIRE(na && xa && table && agg && ws, "attn_aggregate: null pointer");
     dim3 grid((unsigned)ceil_div(M, 4));
+    const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b && n <= 64) {
+        launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
+               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b);
+        return check_launch("attn_aggregate");
+    }
+    if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f && n <= 64) {
+        launch(k_attn_aggregate_grp<float, 4, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
+               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_f);
+        return check_launch("attn_aggregate");
+    }
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D)) {
         launch(k_attn_aggregate_wide<uint16_t, 8>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
                (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws);

@@ -366,6 +366,55 @@ def test_attn_aggregate_forward_backward():
         close(nb.grad.cpu().numpy(), nb_c.grad.numpy(), "dnb", 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("D,n", [(64, 20), (64, 15), (100, 10), (256, 15), (256, 32), (602, 10), (602, 25), (760, 5),
+                                 (800, 10), (24, 1), (602, 3)])
+def test_attn_kernels_all_lane_groupings_vs_fp64(dtype, D, n):
+    """K4 / K4' through the C ABI on table rows read through ids: every lane grouping of the grouped kernels
+    (8 / 16 / 32 lanes per child row, 1..3 chunks per lane), ragged last passes (n not a multiple of the children
+    in flight), and the wide fallback (rows too wide for the grouped kernels: 800 bf16 columns, fp32 beyond 384).
+    Reference: fp64 torch on the same (bf16-rounded) rows."""
+    T = torch.bfloat16 if dtype == "bf16" else torch.float32
+    code = nat.BF16 if dtype == "bf16" else nat.F32
+    vec = 8 if dtype == "bf16" else 4
+    rng = np.random.RandomState(D * 7 + n)
+    M, Ha, rows_in_table = 37, 32, 900
+    ld = -(-D // vec) * vec
+    table = torch.zeros(rows_in_table, ld, dtype=T, device=DEV)
+    table[:, :D] = torch.from_numpy(rng.normal(size=(rows_in_table, D)).astype(np.float32)).to(DEV).to(T)
+    ids = torch.from_numpy(rng.randint(0, rows_in_table, size=M * n)).to(DEV)
+    na = torch.from_numpy(rng.normal(size=(M * n, Ha)).astype(np.float32)).to(DEV)
+    xa = torch.from_numpy(rng.normal(size=(M, Ha)).astype(np.float32)).to(DEV)
+    g = torch.from_numpy(rng.normal(size=(M, ld)).astype(np.float32)).to(DEV)
+    agg = torch.full((M, ld), float("nan"), device=DEV)
+    ws = torch.zeros(M * n, device=DEV)
+    dna = torch.full((M * n, Ha), float("nan"), device=DEV)
+    dxa = torch.full((M, Ha), float("nan"), device=DEV)
+    lib, st = nat.lib(), ops._stream()
+    nat.check(lib.gsage_attn_aggregate(na.data_ptr(), Ha, xa.data_ptr(), Ha, table.data_ptr(), code, ld, ids.data_ptr(),
+                                       M, n, Ha, D, agg.data_ptr(), ld, ws.data_ptr(), st), "fwd")
+    nat.check(lib.gsage_attn_bwd(g.data_ptr(), ld, ws.data_ptr(), na.data_ptr(), Ha, xa.data_ptr(), Ha, table.data_ptr(),
+                                 code, ld, ids.data_ptr(), M, n, Ha, D, dna.data_ptr(), Ha, dxa.data_ptr(), Ha, st), "bwd")
+    torch.cuda.synchronize()
+    rows = table[ids][:, :D].double().cpu().view(M, n, D)
+    na_c = na.double().cpu().requires_grad_(True)
+    xa_c = xa.double().cpu().requires_grad_(True)
+    w = torch.softmax(torch.bmm(na_c.view(M, n, Ha), xa_c.view(M, Ha, 1)).squeeze(2), dim=1)
+    ref = (rows * w.unsqueeze(-1)).sum(1)
+    close(agg[:, :D].cpu().numpy(), ref.detach().numpy(), ("K4 forward", dtype, D, n), 1e-5, 1e-5)
+    close(ws.cpu().numpy(), w.detach().reshape(-1).numpy(), "softmax weights", 1e-5, 1e-6)
+    (ref * g[:, :D].double().cpu()).sum().backward()
+    close(dna.cpu().numpy(), na_c.grad.numpy(), ("d att(neibs)", dtype, D, n), 1e-4, 1e-4)
+    close(dxa.cpu().numpy(), xa_c.grad.numpy(), ("d att(x)", dtype, D, n), 1e-4, 1e-4)
+    # no row list: children are consecutive rows of the table
+    seq = table[ids].contiguous()
+    agg2 = torch.full((M, ld), float("nan"), device=DEV)
+    nat.check(lib.gsage_attn_aggregate(na.data_ptr(), Ha, xa.data_ptr(), Ha, seq.data_ptr(), code, ld, None,
+                                       M, n, Ha, D, agg2.data_ptr(), ld, ws.data_ptr(), st), "fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(agg2[:, :D], agg[:, :D])
+
+
 @pytest.mark.parametrize("M,N,K,groups", [(16, 128, 8, 1), (100, 128, 602, 2), (513, 128, 256, 2),
                                           (1300, 8, 70, 1), (3000, 128, 1433, 2), (64, 128, 128, 1), (37, 24, 200, 1)])
 def test_wgrad_mfma_vs_fp64(M, N, K, groups):
