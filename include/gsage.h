@@ -381,6 +381,20 @@ int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_
                          const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
                          int32_t n, int64_t Ha, int64_t D, float *agg, int64_t agg_ld, float *ws,
                          void *stream);
+/* Same, plus (agg_lp != NULL) the result rounded to the table's type, [M, agg_lp_ld] with zero pad columns -- the
+ * operand copy the fc_neib projection and its weight gradient read (no cast launch); agg may then be NULL. */
+int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld, const void *table,
+                            int dtype, int64_t ld, const int64_t *ids, int64_t M, int32_t n, int64_t Ha, int64_t D,
+                            float *agg, int64_t agg_ld, float *ws, void *agg_lp, int64_t agg_lp_ld, void *stream);
+/* Second layer of the att MLP (nn_modules.py:292-296: Linear(32, 32, bias=False) after the tanh), Ha == 32:
+ *   gsage_attn_mlp2_fwd   a[m, :] = hid[m, :] W2^T                       hid, W2: `dtype` (operand copies), a: fp32
+ *   gsage_attn_mlp2_bwd   da = T(dan + dax);  dhid = T((da W2) * (1 - hid^2))   -- the cast, the product and the
+ *                         tanh backward of the chain d a -> d hid in one pass; W2T = the transposed operand copy */
+int gsage_attn_mlp2_fwd(const void *hid, int dtype, int64_t ldh, const void *W2, int64_t ldw, float *a, int64_t lda,
+                        int64_t M, int32_t Ha, void *stream);
+int gsage_attn_mlp2_bwd(const float *dan, int64_t ldn, const float *dax, int64_t ldx, const void *hid, int dtype,
+                        int64_t ldh, const void *W2T, int64_t ldw, void *da, int64_t ldda, void *dhid, int64_t lddh,
+                        int64_t M, int32_t Ha, void *stream);
 /* Backward of the weighting w.r.t. att(neibs) and att(x), one launch (autograd of the three lines
  * above):  dws[i,r] = <neibs[i*n+r,:], g[i,:]>;  ds = ws * (dws - sum_r dws*ws);
  *          dxa[i,:] = sum_r ds[i,r] * na[i*n+r,:];   dna[i*n+r,:] = ds[i,r] * xa[i,:].

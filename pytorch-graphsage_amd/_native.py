@@ -103,6 +103,11 @@ SIGNATURES = {
     "gsage_pool_merge_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_aggregate": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
                                     _i64, _vp, _i64, _vp, _vp]),
+    "gsage_attn_aggregate_lp": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
+                                       _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "gsage_attn_mlp2_fwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "gsage_attn_mlp2_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32,
+                                   _vp]),
     "gsage_add_cast": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _i64, _i64, _vp]),
     "gsage_tanh_bwd": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _i64, _i64, _i64, _vp]),
     "gsage_attn_merge_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _i64,

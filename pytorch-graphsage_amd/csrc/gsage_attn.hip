@@ -239,6 +239,11 @@ k_attn_bwd_wide(const float *__restrict__ g, int64_t g_ld, const float *__restri
     }
 }
 
+__device__ __forceinline__ void store_as(uint16_t *p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void store_as(float *p, float v) { *p = v; }
+__device__ __forceinline__ float load_as(const uint16_t *p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float load_as(const float *p) { return *p; }
+
 // ---- grouped variants: lanes in groups of `lpc`, one child row per group ---------------------------------
 // The wide kernels give every lane one 16-byte chunk of EVERY child row: with 76 chunks (Reddit, bf16) the second
 // pass has 12 of 64 lanes busy, with 8 chunks (64-d embeddings) one lane in eight ever works, and the unrolled
@@ -251,7 +256,8 @@ template <typename T, int VEC, int TMAX>
 __global__ void __launch_bounds__(256)
 k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
                      const T *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M, int32_t n,
-                     int32_t Ha, int32_t D, float *__restrict__ agg, int64_t agg_ld, float *__restrict__ ws, int32_t lpc)
+                     int32_t Ha, int32_t D, float *__restrict__ agg, int64_t agg_ld, float *__restrict__ ws, int32_t lpc,
+                     T *__restrict__ agg_lp, int64_t lp_ld)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -308,9 +314,16 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
         for (int t = 0; t < TMAX; ++t) {
             const int c = sub + lpc * t;
             if (t < Tn && c < chunks) {
+                if (agg) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    if (c * VEC + e < D) agg[i * agg_ld + c * VEC + e] = acc[t][e];
+                    for (int e = 0; e < VEC; ++e)
+                        if (c * VEC + e < D) agg[i * agg_ld + c * VEC + e] = acc[t][e];
+                }
+                if (agg_lp) {            // the operand copy the fc_neib projection and its weight gradient read
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (c * VEC + e < lp_ld) store_as(agg_lp + i * lp_ld + c * VEC + e, c * VEC + e < D ? acc[t][e] : 0.f);
+                }
             }
         }
     }
@@ -387,13 +400,96 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
     }
 }
 
+// ---- second layer of the att MLP (32 -> 32, nn_modules.py:292-296), forward and backward --------------------
+// A [M x 32] x [32 x 32] product is 145 MFLOP at Reddit's frontier: as a GEMM launch it cost 25 us (and its
+// backward needed a cast, a GEMM and a tanh-backward launch, 50 us); here lane j of a half-wave owns output
+// column j (its weight column in registers), a row's 32 inputs reach every lane through LDS, and the element-wise
+// neighbours of the product are fused in.  The roundings are the engine's: operands in T, fp32 sums.
+constexpr int MLP2_ROWS = 8;      // row pairs per wave and trip: 16 rows in flight
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_attn_mlp2_fwd(const T *__restrict__ hid, int64_t ldh, const T *__restrict__ W2, int64_t ldw, float *__restrict__ a,
+                int64_t lda, int64_t M)
+{
+    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_ROWS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, half = lane >> 5;
+    float w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = load_as(W2 + j * ldw + k);          // a[m, j] = sum_k hid[m, k] W2[j, k]
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wv = (int64_t)blockIdx.x * 4 + wave;
+    for (int64_t m0 = wv * 2 * MLP2_ROWS; m0 < M; m0 += n_waves * 2 * MLP2_ROWS) {
+        float x[MLP2_ROWS];
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) {
+            const int64_t m = m0 + 2 * r + half;
+            x[r] = m < M ? load_as(hid + m * ldh + j) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) xs[wave][r][lane] = x[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) {
+            const int64_t m = m0 + 2 * r + half;
+            float acc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&xs[wave][r][half * 32 + 4 * k4]);
+                acc += v.x * w[4 * k4] + v.y * w[4 * k4 + 1] + v.z * w[4 * k4 + 2] + v.w * w[4 * k4 + 3];
+            }
+            if (m < M) a[m * lda + j] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// da = T(dan + dax);   dhid = T( (da W2) * (1 - hid^2) )
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_attn_mlp2_bwd(const float *__restrict__ dan, int64_t ldn, const float *__restrict__ dax, int64_t ldx,
+                const T *__restrict__ hid, int64_t ldh, const T *__restrict__ W2T, int64_t ldw, T *__restrict__ da,
+                int64_t ldda, T *__restrict__ dhid, int64_t lddh, int64_t M)
+{
+    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_ROWS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 31, half = lane >> 5;
+    float w[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) w[jj] = load_as(W2T + k * ldw + jj);    // dhg[m, k] = sum_j da[m, j] W2[j, k]
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wv = (int64_t)blockIdx.x * 4 + wave;
+    for (int64_t m0 = wv * 2 * MLP2_ROWS; m0 < M; m0 += n_waves * 2 * MLP2_ROWS) {
+        float x[MLP2_ROWS], h[MLP2_ROWS];
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) {
+            const int64_t m = m0 + 2 * r + half;
+            const bool ok = m < M;
+            const float sum = ok ? dan[m * ldn + k] + dax[m * ldx + k] : 0.f;
+            h[r] = ok ? load_as(hid + m * ldh + k) : 0.f;
+            T rounded;
+            store_as(&rounded, sum);                        // d a as the next GEMMs see it (K5b operand, this product)
+            x[r] = load_as(&rounded);
+            if (ok) da[m * ldda + k] = rounded;
+        }
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) xs[wave][r][lane] = x[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < MLP2_ROWS; ++r) {
+            const int64_t m = m0 + 2 * r + half;
+            float acc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&xs[wave][r][half * 32 + 4 * k4]);
+                acc += v.x * w[4 * k4] + v.y * w[4 * k4 + 1] + v.z * w[4 * k4 + 2] + v.w * w[4 * k4 + 3];
+            }
+            if (m < M) store_as(dhid + m * lddh + k, acc * (1.f - h[r] * h[r]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- glue of the native attention train step (engine.FusedAttnTrainStep) ------------------------------
 // Element-wise kernels between K4 / K5 / K5b: what autograd ran as a cast, an add, a tanh backward and
 // four scatter / expand kernels per level (52 casts and 34 adds per Pokec-shaped step).
-__device__ __forceinline__ void store_as(uint16_t *p, float v) { *p = f32_to_bf16(v); }
-__device__ __forceinline__ void store_as(float *p, float v) { *p = v; }
-__device__ __forceinline__ float load_as(const uint16_t *p) { return bf16_to_f32(*p); }
-__device__ __forceinline__ float load_as(const float *p) { return *p; }
 
 // dst[m, c] = T(a[m, c] (+ b[m, c]))
 template <typename T>
@@ -584,28 +680,90 @@ extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, con
     return check_launch("attn_bwd");
 }
 
+extern "C" int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld, const void *table,
+                                       int dtype, int64_t ld, const int64_t *ids, int64_t M, int32_t n, int64_t Ha,
+                                       int64_t D, float *agg, int64_t agg_ld, float *ws, void *agg_lp, int64_t agg_lp_ld,
+                                       void *stream);
+
 extern "C" int gsage_attn_aggregate(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld,
                                     const void *table, int dtype, int64_t ld, const int64_t *ids,
                                     int64_t M, int32_t n, int64_t Ha, int64_t D, float *agg,
                                     int64_t agg_ld, float *ws, void *stream)
 {
+    return gsage_attn_aggregate_lp(na, na_ld, xa, xa_ld, table, dtype, ld, ids, M, n, Ha, D, agg, agg_ld, ws, nullptr, 0,
+                                   stream);
+}
+
+extern "C" int gsage_attn_mlp2_fwd(const void *hid, int dtype, int64_t ldh, const void *W2, int64_t ldw, float *a,
+                                   int64_t lda, int64_t M, int32_t Ha, void *stream)
+{
+    GSAGE_REQUIRE(hid && W2 && a && M >= 0 && Ha == 32 && ldh >= 32 && ldw >= 32 && lda >= 32,
+                  "attn_mlp2_fwd: needs the reference's 32-wide att MLP");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "attn_mlp2_fwd: bad dtype");
+    if (M == 0) return GSAGE_OK;
+    const dim3 grid(ew_grid(ceil_div(M, (int64_t)(2 * MLP2_ROWS)) * 64));
+    if (dtype == GSAGE_BF16)
+        launch(k_attn_mlp2_fwd<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)hid, ldh,
+               (const uint16_t *)W2, ldw, a, lda, M);
+    else
+        launch(k_attn_mlp2_fwd<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)hid, ldh, (const float *)W2,
+               ldw, a, lda, M);
+    return check_launch("attn_mlp2_fwd");
+}
+
+extern "C" int gsage_attn_mlp2_bwd(const float *dan, int64_t ldn, const float *dax, int64_t ldx, const void *hid, int dtype,
+                                   int64_t ldh, const void *W2T, int64_t ldw, void *da, int64_t ldda, void *dhid,
+                                   int64_t lddh, int64_t M, int32_t Ha, void *stream)
+{
+    GSAGE_REQUIRE(dan && dax && hid && W2T && da && dhid && M >= 0 && Ha == 32 && ldn >= 32 && ldx >= 32 && ldh >= 32 &&
+                  ldw >= 32 && ldda >= 32 && lddh >= 32, "attn_mlp2_bwd: needs the reference's 32-wide att MLP");
+    GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "attn_mlp2_bwd: bad dtype");
+    if (M == 0) return GSAGE_OK;
+    const dim3 grid(ew_grid(ceil_div(M, (int64_t)(2 * MLP2_ROWS)) * 64));
+    if (dtype == GSAGE_BF16)
+        launch(k_attn_mlp2_bwd<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, dan, ldn, dax, ldx, (const uint16_t *)hid,
+               ldh, (const uint16_t *)W2T, ldw, (uint16_t *)da, ldda, (uint16_t *)dhid, lddh, M);
+    else
+        launch(k_attn_mlp2_bwd<float>, grid, dim3(256), 0, (hipStream_t)stream, dan, ldn, dax, ldx, (const float *)hid, ldh,
+               (const float *)W2T, ldw, (float *)da, ldda, (float *)dhid, lddh, M);
+    return check_launch("attn_mlp2_bwd");
+}
+
+extern "C" int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const float *xa, int64_t xa_ld, const void *table,
+                                       int dtype, int64_t ld, const int64_t *ids, int64_t M, int32_t n, int64_t Ha,
+                                       int64_t D, float *agg, int64_t agg_ld, float *ws, void *agg_lp, int64_t agg_lp_ld,
+                                       void *stream)
+{
+    GSAGE_REQUIRE(agg || agg_lp, "attn_aggregate: no output");
+    GSAGE_REQUIRE(!agg_lp || agg_lp_ld >= D, "attn_aggregate: leading dimension too small");
+    if (!agg) agg_ld = D;
     GSAGE_REQUIRE(n >= 1 && n <= 64, "attn_aggregate: fanout must be in [1, 64]");
     GSAGE_REQUIRE(M >= 0 && Ha > 0 && D > 0, "attn_aggregate: bad sizes");
     GSAGE_REQUIRE(na_ld >= Ha && xa_ld >= Ha && ld >= D && agg_ld >= D,
                   "attn_aggregate: leading dimension too small");
     if (M == 0) return GSAGE_OK;
-    GSAGE_REQUIRE(na && xa && table && agg && ws, "attn_aggregate: null pointer");
+    GSAGE_REQUIRE(na && xa && table && ws, "attn_aggregate: null pointer");
     dim3 grid((unsigned)ceil_div(M, 4));
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b && n <= 64) {
         launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
-               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b);
+               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
+               (uint16_t *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");
     }
     if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f && n <= 64) {
         launch(k_attn_aggregate_grp<float, 4, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
-               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_f);
+               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_f, (float *)agg_lp,
+               agg_lp_ld);
         return check_launch("attn_aggregate");
+    }
+    // the kernels below write fp32 only: the copy in the table's type follows as a cast launch
+    GSAGE_REQUIRE(agg, "attn_aggregate: rows this wide need the fp32 output (the low-precision copy is derived from it)");
+    if (agg_lp) {
+        int rc = gsage_attn_aggregate_lp(na, na_ld, xa, xa_ld, table, dtype, ld, ids, M, n, Ha, D, agg, agg_ld, ws, nullptr,
+                                         0, stream);
+        if (rc != GSAGE_OK) return rc;
+        return gsage_add_cast(agg, agg_ld, nullptr, 0, agg_lp, dtype, agg_lp_ld, M, (int32_t)D, stream);
     }
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D)) {
         launch(k_attn_aggregate_wide<uint16_t, 8>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,

@@ -1828,16 +1828,15 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
             inp, ld, rows = self._in(l, s)
             self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RA, Ha, D, nat.ACT_TANH, rows)
-            self._gemm(self.hid[l].data_ptr(), HL, self.w2[l], self.a[l].data_ptr(), nat.F32, Ha, RA, Ha, Ha, nat.ACT_NONE)
-            for k in range(L - l):
+            nat.check(lib.gsage_attn_mlp2_fwd(self.hid[l].data_ptr(), self.code, HL, self.w2[l].data_ptr(),
+                                              self.w2[l].shape[1], self.a[l].data_ptr(), Ha, RA, Ha, stream), "attn_mlp2_fwd")
+            for k in range(L - l):                   # K4 writes the aggregate as fp32 and as the next GEMMs' operand
                 r0, c0 = self.off[k], self.off[k + 1]
                 tab, idp = self._child_rows(inp, rows, c0)
-                nat.check(lib.gsage_attn_aggregate(
+                nat.check(lib.gsage_attn_aggregate_lp(
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
                     idp, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
-                    self.ws[l][c0 - self.off[1]:].data_ptr(), stream), "attn_aggregate")
-            nat.check(lib.gsage_add_cast(self.agg[l].data_ptr(), ld, None, 0, self.aggc[l].data_ptr(), self.code, ld, R, D,
-                                         stream), "add_cast")
+                    self.ws[l][c0 - self.off[1]:].data_ptr(), self.aggc[l][r0:].data_ptr(), ld, stream), "attn_aggregate")
             last = l == L - 1
             out, code = self.hout[l], (nat.F32 if last else self.code)
             act = nat.ACT_NONE if last else nat.ACT_RELU
@@ -1875,13 +1874,12 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
                     idp, self.size[k], self.fan[k + 1], Ha, D, self.dan[l][c0:].data_ptr(), Ha,
                     self.dax[l][r0:].data_ptr(), Ha, stream), "attn_bwd")
-            # d a = (as a child) + (as a parent); hop 0 is never a child, the last hop never a parent (zeros)
-            nat.check(lib.gsage_add_cast(self.dan[l].data_ptr(), Ha, self.dax[l].data_ptr(), Ha, self.da[l].data_ptr(),
-                                         self.code, HL, RA, Ha, stream), "add_cast")
-            self._gemm(self.da[l].data_ptr(), HL, self.w2T[l], self.dhg[l].data_ptr(), nat.F32, Ha, RA, Ha, Ha,
-                       nat.ACT_NONE)
-            nat.check(lib.gsage_tanh_bwd(self.dhg[l].data_ptr(), Ha, self.hid[l].data_ptr(), self.code, HL,
-                                         self.dhid[l].data_ptr(), HL, RA, Ha, stream), "tanh_bwd")
+            # d a = (as a child) + (as a parent); hop 0 is never a child, the last hop never a parent (zeros);
+            # d hid = (d a W2) * tanh' -- one pass
+            nat.check(lib.gsage_attn_mlp2_bwd(self.dan[l].data_ptr(), Ha, self.dax[l].data_ptr(), Ha,
+                                              self.hid[l].data_ptr(), self.code, HL, self.w2T[l].data_ptr(),
+                                              self.w2T[l].shape[1], self.da[l].data_ptr(), HL, self.dhid[l].data_ptr(), HL,
+                                              RA, Ha, stream), "attn_mlp2_bwd")
             if l > 0 or self.emb:
                 self._gemm(self.dhid[l].data_ptr(), HL, self.w0T[l], self.datt[l].data_ptr(), nat.F32, ld, RA, D, Ha,
                            nat.ACT_NONE)

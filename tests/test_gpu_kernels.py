@@ -777,3 +777,36 @@ def test_flat_adam_equals_torch_clip_plus_adam(wd):
             close(q.detach().cpu().numpy(), p.detach().cpu().numpy(), ("weights", step), 2e-6, 2e-7)
             close(q.grad.cpu().numpy(), p.grad.cpu().numpy(), ("clipped grad", step), 2e-6, 1e-7)
     assert int(opt_m.step_count) == 6
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 1000, 70001])
+def test_attn_mlp_second_layer_kernels(dtype, M):
+    """gsage_attn_mlp2_fwd / _bwd (the 32 -> 32 layer of the att MLP with its element-wise neighbours fused in)
+    against torch on the same rounded operands: a = hid W2^T;  da = T(dan + dax), dhid = T((da W2) (1 - hid^2))."""
+    T = torch.bfloat16 if dtype == "bf16" else torch.float32
+    code = nat.BF16 if dtype == "bf16" else nat.F32
+    gen = torch.Generator(device="cpu").manual_seed(M)
+    lib, st = nat.lib(), ops._stream()
+    hid = torch.zeros(M, 64, dtype=T, device=DEV)
+    hid[:, :32] = torch.tanh(torch.randn(M, 32, generator=gen)).to(DEV).to(T)
+    W2 = torch.zeros(32, 64, dtype=T, device=DEV)
+    W2[:, :32] = (torch.randn(32, 32, generator=gen) * 0.3).to(DEV).to(T)
+    W2T = torch.zeros(32, 64, dtype=T, device=DEV)
+    W2T[:, :32] = W2[:, :32].t()
+    a = torch.full((M, 32), float("nan"), device=DEV)
+    nat.check(lib.gsage_attn_mlp2_fwd(hid.data_ptr(), code, 64, W2.data_ptr(), 64, a.data_ptr(), 32, M, 32, st), "fwd")
+    ref = hid[:, :32].double() @ W2[:, :32].double().t()
+    assert torch.allclose(a.double(), ref, rtol=1e-5, atol=1e-5)
+    dan = torch.randn(M, 32, generator=gen).to(DEV)
+    dax = torch.randn(M, 32, generator=gen).to(DEV)
+    da = torch.zeros(M, 64, dtype=T, device=DEV)
+    dhid = torch.zeros(M, 64, dtype=T, device=DEV)
+    nat.check(lib.gsage_attn_mlp2_bwd(dan.data_ptr(), 32, dax.data_ptr(), 32, hid.data_ptr(), code, 64, W2T.data_ptr(), 64,
+                                      da.data_ptr(), 64, dhid.data_ptr(), 64, M, 32, st), "bwd")
+    torch.cuda.synchronize()
+    da_ref = (dan + dax).to(T)
+    assert torch.equal(da[:, :32], da_ref) and float(da[:, 32:].abs().max()) == 0.0
+    dh_ref = (da_ref.double() @ W2[:, :32].double()) * (1 - hid[:, :32].double() ** 2)
+    tol = 1e-2 if dtype == "bf16" else 1e-5
+    assert torch.allclose(dhid[:, :32].double(), dh_ref, rtol=tol, atol=tol)
