@@ -423,6 +423,24 @@ int gsage_attn_merge_bwd(const void *H, int h_dtype, int64_t ldh, const float *D
                          int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg, const float *ws, void *out,
                          int out_dtype, int64_t ldo, int64_t R, int32_t D, int32_t n_hops, const int64_t *off,
                          const int32_t *fan, void *stream);
+/* gsage_attn_merge_bwd2: the same, plus (out2_bf16 != NULL) a second, bf16 copy of the result [R, ldo2] -- the operand
+ * the following GEMMs read when `out` has to stay fp32 (a bias gradient's column sums). */
+int gsage_attn_merge_bwd2(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt, const float *DX,
+                         int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg, const float *ws, void *out,
+                         int out_dtype, int64_t ldo, int64_t R, int32_t D, int32_t n_hops, const int64_t *off,
+                         const int32_t *fan, void *out2_bf16, int64_t ldo2,
+                          void *stream);
+
+/* L1 head of the reference's regression problems, forward + backward (Pokec: problem.py:39-42 behind models.py:90-91,100):
+ *     z = E / max(||E||_2, 1e-12);  preds[i] = <z_i, W> + bias;  loss = F.l1_loss(preds [B,1], targets [B])
+ * The reference passes targets.squeeze(), so [B,1] against [B] broadcasts to [B,B]: loss = mean_ij |p_i - t_j| and
+ * d loss / d p_i = (1/B^2) sum_j sign(p_i - t_j) -- reproduced as is.  One output column (n_classes == 1), B <= 2048.
+ * scratch: fp32, gsage_head_l1_scratch(B, D) elements; its first ceil(B / 16) rows of D + 2 floats are per-workgroup
+ * partials [d fc.weight (D) | d fc.bias | loss] whose sum is the result (gsage_finalize_grads: S = ceil(B / 16),
+ * stride D + 2); dE: [B, ldd] in dE_dtype. */
+int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t B,
+                  int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch, void *stream);
+int gsage_head_l1_scratch(int64_t B, int64_t D);
 
 /* ------------------------------------------------------------------------------------------
  * Classification head, forward + backward   replaces F.normalize(dim=1) -> fc -> F.cross_entropy

@@ -112,6 +112,10 @@ SIGNATURES = {
     "gsage_tanh_bwd": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _i64, _i64, _i64, _vp]),
     "gsage_attn_merge_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _i64,
                                     _i64, _i32, _i32, _vp, _vp, _vp]),
+    "gsage_attn_merge_bwd2": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _i64,
+                                     _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "gsage_head_l1": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _i64, _vp, _vp]),
+    "gsage_head_l1_scratch": (_int, [_i64, _i64]),
     "gsage_metric_f1": (_int, [_vp, _i64, _vp, _int, _int, _i64, _i64, _i32, _vp, _vp, _vp]),
     "gsage_metric_mae": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "gsage_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64, _i64,

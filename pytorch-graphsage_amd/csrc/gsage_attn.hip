@@ -532,6 +532,8 @@ struct AttnMergeParams {
     const void *H;
     const float *DATT, *DX, *DAGG, *ws;
     void *out;
+    uint16_t *out2;              // optional second copy of the result, bf16 (the operand the next GEMMs read)
+    int64_t ldo2;
     int64_t ldh, ldatt, ldx, ldagg, ldo;
     int64_t R, r_x;
     int32_t D, n_hops;
@@ -559,6 +561,7 @@ k_attn_merge_bwd(const AttnMergeParams q)
         }
         if (q.H && !(load_as((const TH *)q.H + m * q.ldh + c) > 0.f)) v = 0.f;
         store_as((TO *)q.out + m * q.ldo + c, v);
+        if (q.out2) store_as(q.out2 + m * q.ldo2 + c, v);
     }
 }
 
@@ -602,18 +605,35 @@ extern "C" int gsage_tanh_bwd(const float *g, int64_t ldg, const void *hid, int 
     return check_launch("tanh_bwd");
 }
 
+extern "C" int gsage_attn_merge_bwd2(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt,
+                                     const float *DX, int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg,
+                                     const float *ws, void *out, int out_dtype, int64_t ldo, int64_t R, int32_t D,
+                                     int32_t n_hops, const int64_t *off, const int32_t *fan, void *out2_bf16,
+                                     int64_t ldo2, void *stream);
+
 extern "C" int gsage_attn_merge_bwd(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt,
                                     const float *DX, int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg,
                                     const float *ws, void *out, int out_dtype, int64_t ldo, int64_t R, int32_t D,
                                     int32_t n_hops, const int64_t *off, const int32_t *fan, void *stream)
 {
+    return gsage_attn_merge_bwd2(H, h_dtype, ldh, DATT, ldatt, DX, ldx, r_x, DAGG, ldagg, ws, out, out_dtype, ldo, R, D,
+                                 n_hops, off, fan, nullptr, 0, stream);
+}
+
+extern "C" int gsage_attn_merge_bwd2(const void *H, int h_dtype, int64_t ldh, const float *DATT, int64_t ldatt,
+                                     const float *DX, int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg,
+                                     const float *ws, void *out, int out_dtype, int64_t ldo, int64_t R, int32_t D,
+                                     int32_t n_hops, const int64_t *off, const int32_t *fan, void *out2_bf16,
+                                     int64_t ldo2, void *stream)
+{
+    GSAGE_REQUIRE(!out2_bf16 || ldo2 >= D, "attn_merge_bwd: leading dimension too small");
     GSAGE_REQUIRE(DATT && DAGG && ws && out && off && fan, "attn_merge_bwd: null pointer");
     GSAGE_REQUIRE(n_hops >= 2 && n_hops <= 6 && R >= 0 && r_x >= 0 && r_x <= R && D > 0, "attn_merge_bwd: bad sizes");
     GSAGE_REQUIRE((out_dtype == GSAGE_BF16 || out_dtype == GSAGE_F32) && (!H || h_dtype == GSAGE_BF16 || h_dtype == GSAGE_F32),
                   "attn_merge_bwd: bad dtype");
     if (R == 0) return GSAGE_OK;
     AttnMergeParams q;
-    q.H = H; q.DATT = DATT; q.DX = DX; q.DAGG = DAGG; q.ws = ws; q.out = out;
+    q.H = H; q.DATT = DATT; q.DX = DX; q.DAGG = DAGG; q.ws = ws; q.out = out; q.out2 = (uint16_t *)out2_bf16; q.ldo2 = ldo2;
     q.ldh = ldh; q.ldatt = ldatt; q.ldx = ldx; q.ldagg = ldagg; q.ldo = ldo; q.R = R; q.r_x = r_x; q.D = D;
     q.n_hops = n_hops;
     for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }

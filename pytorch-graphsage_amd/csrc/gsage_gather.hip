@@ -374,8 +374,9 @@ static int fill_multi(MultiSeg &q, int32_t &chunks, int32_t n_seg, const void *c
 {
     GSAGE_REQUIRE(n_seg >= 1 && n_seg <= 8, "gather_mean_multi: 1..8 segments");
     GSAGE_REQUIRE(tables && ids && outs && M && n, "gather_mean_multi: null pointer");
-    GSAGE_REQUIRE((dtype == GSAGE_BF16 || dtype == GSAGE_F32) && out_dtype == dtype,
-                  "gather_mean_multi: bf16 -> bf16 or fp32 -> fp32 (the exact-arithmetic parity mode)");
+    GSAGE_REQUIRE((dtype == GSAGE_BF16 || dtype == GSAGE_F32) && (out_dtype == dtype || out_dtype == GSAGE_BF16),
+                  "gather_mean_multi: bf16 -> bf16, fp32 -> fp32 (the exact-arithmetic parity mode) or fp32 -> bf16 "
+                  "(fp32 embedding rows as a bf16 operand)");
     const int vec = dtype == GSAGE_BF16 ? 8 : 4;
     GSAGE_REQUIRE(D > 0 && ld % vec == 0 && out_ld % vec == 0 && ceil_div(D, vec) * vec <= ld &&
                   ceil_div(D, vec) * vec <= out_ld, "gather_mean_multi: needs 16-byte row chunks");
@@ -414,7 +415,10 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
     int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
     if (rc != GSAGE_OK) return rc;
     if (q.first[n_seg] == 0) return GSAGE_OK;
-    if (dtype == GSAGE_F32)
+    if (dtype == GSAGE_F32 && out_dtype == GSAGE_BF16)
+        launch(k_gather_mean_multi<float, uint16_t, 4>, dim3(grid_for(q.first[n_seg])),
+               dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
+    else if (dtype == GSAGE_F32)
         launch(k_gather_mean_multi<float, float, 4>, dim3(grid_for(q.first[n_seg])),
                dim3(256), 0, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld);
     else
@@ -432,6 +436,7 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
     int32_t chunks = 0;
     int rc = fill_multi(q, chunks, n_seg, tables, ids, outs, M, n, dtype, ld, D, out_dtype, out_ld);
     if (rc != GSAGE_OK) return rc;
+    GSAGE_REQUIRE(out_dtype == dtype, "gather_mean_multi_adam: table and output share a type");
     GSAGE_REQUIRE((adam || hops) && q.first[n_seg] > 0,
                   "gather_mean_multi_adam: needs an Adam or a sampler descriptor and a non-empty gather");
     GSAGE_REQUIRE(!adam || adam->step_is_current, "gather_mean_multi_adam: Adam descriptor needs step_is_current");

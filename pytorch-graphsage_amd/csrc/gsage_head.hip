@@ -284,6 +284,101 @@ k_head_reduce(const float *__restrict__ partial, int32_t n_wg, int64_t width, in
     }
 }
 
+
+// ---- L1 head of the reference's regression problems (Pokec: problem.py:39-42 behind models.py:100) -------------------
+//     z = E / max(||E||_2, 1e-12);  preds[i] = <z_i, w> + b;  loss = F.l1_loss(preds [B,1], targets [B])
+// The reference calls the loss with targets.squeeze(): [B,1] against [B] BROADCASTS to [B,B], i.e.
+//     loss = mean_{i,j} |p_i - t_j|,   d loss / d p_i = (1/B^2) sum_j sign(p_i - t_j)        (sign(0) = 0, as torch's)
+// kept as is (it is what the recorded Pokec result was trained with).  Two launches (every d p_i needs every
+// prediction): (a) a wave per row: norm, prediction; (b) 16 rows per workgroup: d p, d E, and one partial row
+// [d W | d b | loss] per workgroup for gsage_finalize_grads.  As stock torch ops the head was ~15 launches per step.
+constexpr int L1_BMAX = 2048;
+constexpr int L1_ROWS = 16;
+__device__ __forceinline__ void store_out(uint16_t *p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
+
+__global__ void __launch_bounds__(256)
+k_head_l1_pred(const float *__restrict__ E, int64_t lde, const float *__restrict__ W, const float *__restrict__ bias,
+               int32_t B, int32_t D, float *__restrict__ preds, float *__restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float e = E[(int64_t)i * lde + c];
+        ss += e * e;
+        dot += e * W[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); dot += __shfl_xor(dot, o, 64); }
+    if (lane == 0) {
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);          // F.normalize's eps
+        inv[i] = 1.f / nrm;
+        preds[i] = dot / nrm + bias[0];
+    }
+}
+
+template <typename TD>
+__global__ void __launch_bounds__(256)
+k_head_l1_bwd(const float *__restrict__ E, int64_t lde, const float *__restrict__ W, const float *__restrict__ targets,
+              const float *__restrict__ preds, const float *__restrict__ inv, int32_t B, int32_t D,
+              TD *__restrict__ dE, int64_t ldd, float *__restrict__ partial)
+{
+    __shared__ float ts[L1_BMAX], dps[L1_ROWS], ivs[L1_ROWS], lss[L1_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * L1_ROWS;
+    for (int j = tid; j < B; j += 256) ts[j] = targets[j];
+    __syncthreads();
+    const float scale = 1.f / ((float)B * (float)B);
+    // d p of the workgroup's rows: a wave per row, lanes over the targets
+    for (int r = wave; r < L1_ROWS; r += 4) {
+        const int i = r0 + r;
+        float cnt = 0.f, l = 0.f;
+        if (i < B) {
+            const float pv = preds[i];
+            for (int j = lane; j < B; j += 64) {
+                const float d = pv - ts[j];
+                cnt += (float)((d > 0.f) - (d < 0.f));
+                l += fabsf(d);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); l += __shfl_xor(l, o, 64); }
+        if (lane == 0) { dps[r] = scale * cnt; lss[r] = scale * l; ivs[r] = i < B ? inv[i] : 0.f; }
+    }
+    __syncthreads();
+    // d E_i = (dz_i - z_i <z_i, dz_i>) / ||E_i||, dz_i = dp_i w
+    for (int r = wave; r < L1_ROWS; r += 4) {
+        const int i = r0 + r;
+        if (i >= B) continue;
+        const float iv = ivs[r], dp = dps[r];
+        float zdz = 0.f;
+        for (int c = lane; c < D; c += 64) zdz += (E[(int64_t)i * lde + c] * iv) * (dp * W[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) zdz += __shfl_xor(zdz, o, 64);
+        for (int c = lane; c < D; c += 64) {
+            const float z = E[(int64_t)i * lde + c] * iv;
+            store_out(dE + (int64_t)i * ldd + c, (dp * W[c] - z * zdz) * iv);
+        }
+    }
+    // the workgroup's partial row: dW[c] = sum_i dp_i z_i[c] | db = sum_i dp_i | loss
+    float *row = partial + (int64_t)blockIdx.x * (D + 2);
+    for (int c = tid; c < D; c += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < L1_ROWS; ++r)
+            if (r0 + r < B) acc += dps[r] * (E[(int64_t)(r0 + r) * lde + c] * ivs[r]);
+        row[c] = acc;
+    }
+    if (tid == 0) {
+        float dbv = 0.f, lv = 0.f;
+        for (int r = 0; r < L1_ROWS; ++r) { dbv += dps[r]; lv += lss[r]; }      // (rows past B hold zeros)
+        row[D] = dbv;
+        row[D + 1] = lv;
+    }
+}
+
 }  // namespace gsage
 
 using namespace gsage;
@@ -328,6 +423,33 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
                        (hipStream_t)stream, (const float *)scratch, n_wg, width, (int64_t)C * D, C, dW,
                        db, loss, 1.f / (float)B);
     return check_launch("head_reduce");
+}
+
+int gsage_head_l1_scratch(int64_t B, int64_t D)
+{
+    return (int)(ceil_div(B, (int64_t)L1_ROWS) * (D + 2) + B);
+}
+
+int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t B,
+                  int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch, void *stream)
+{
+    GSAGE_REQUIRE(E && W && bias && targets && preds && dE && scratch, "head_l1: null pointer");
+    GSAGE_REQUIRE(B > 0 && B <= L1_BMAX && D > 0 && lde >= D && ldd >= D, "head_l1: needs 1 <= B <= %d", L1_BMAX);
+    GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_l1: bad dE dtype");
+    const int n_wg = (int)ceil_div(B, (int64_t)L1_ROWS);
+    float *inv = scratch + (int64_t)n_wg * (D + 2);
+    hipStream_t s = (hipStream_t)stream;
+    launch(k_head_l1_pred, dim3((unsigned)ceil_div(B, (int64_t)4)), dim3(256), 0, s, E, lde, W, bias, (int32_t)B, (int32_t)D,
+           preds, inv);
+    int rc = check_launch("head_l1_pred");
+    if (rc != GSAGE_OK) return rc;
+    if (dE_dtype == GSAGE_BF16)
+        launch(k_head_l1_bwd<uint16_t>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
+               (const float *)inv, (int32_t)B, (int32_t)D, (uint16_t *)dE, ldd, scratch);
+    else
+        launch(k_head_l1_bwd<float>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
+               (const float *)inv, (int32_t)B, (int32_t)D, (float *)dE, ldd, scratch);
+    return check_launch("head_l1_bwd");
 }
 
 }  // extern "C"

@@ -448,6 +448,10 @@ class FusedMeanTrainStep(object):
             width = Cc * D2c + Cc + 1
             rdesc.append(_ReduceDesc(self.head_scratch.data_ptr(), width, self.poff[ifc],
                                      self.head_scratch.numel() // width, 1, Cc * D2c + Cc, width))
+        elif getattr(self, "fused_l1", False):           # gsage_head_l1: one partial row [dW | db | loss] per 16 seeds
+            width, n_wg = D2c + 2, (self.B + 15) // 16
+            self.l1_scratch = torch.zeros(nat.lib().gsage_head_l1_scratch(self.B, D2c), dtype=f32, device=dev)
+            rdesc.append(_ReduceDesc(self.l1_scratch.data_ptr(), width, self.poff[ifc], n_wg, 1, D2c + 1, width))
         else:
             self.head_stage = torch.zeros(Cc * D2c + Cc, dtype=f32, device=dev)
             rdesc.append(_ReduceDesc(self.head_stage.data_ptr(), 0, self.poff[ifc], 1, 1, Cc * D2c + Cc,
@@ -1586,6 +1590,16 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
     def _init_head(self, loss_fn, example_targets):
         super(FusedAttnTrainStep, self)._init_head(loss_fn, example_targets)
         self.fused_tail = False
+        # the regression head of the Pokec problem (F.l1_loss with the reference's [B,1]-vs-[B] broadcast) as one kernel
+        from .problem import ProblemLosses
+        C, D2 = self.model.fc.weight.shape
+        probe = torch.randn(3, 4, device=self.dev)
+        ident = self.post is None or torch.equal(self.post(probe), probe)
+        self.fused_l1 = bool(self.loss_fn is ProblemLosses.regression_mae and C == 1 and ident and self.B <= 2048 and
+                             example_targets.dtype == torch.float32 and example_targets.numel() == self.B and
+                             self.B > 1 and os.environ.get("GSAGE_TORCH_HEAD", "0") != "1")
+        if self.fused_l1:
+            self.preds = torch.zeros(self.B, 1, dtype=torch.float32, device=self.dev)
 
     def _in(self, l, s):
         """input rows of level l (all hops it reads): (row block, leading dimension, row list or None) -- with a
@@ -1675,12 +1689,9 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         if self.lazy_rows:       # the rows this step reads, brought up to the last update
             nat.check(lib.gsage_rows_catch_up(ctypes.byref(self.row_desc), self.seed_rows.data_ptr(), 1,
                                               ids[B:RA0].data_ptr(), RA0 - B, 0, stream), "rows_catch_up")
-        segs = [(tab, self.seed_rows, self.eraw32[:B], B, 1),                    # seeds read the spare row n_nodes
-                (tab, ids[B:RA0], self.eraw32[B:], RA0 - B, 1)]
-        ops.gather_mean_multi(segs, E, E, E)
-        if self.eraw is not self.eraw32:
-            nat.check(lib.gsage_add_cast(self.eraw32.data_ptr(), E, None, 0, self.eraw.data_ptr(), self.code,
-                                         self.eraw.stride(0), RA0, E, stream), "add_cast")
+        # fp32 table rows -> the operand type in the gather itself (seeds read the spare row n_nodes)
+        segs = [(tab, self.seed_rows, self.eraw[:B], B, 1), (tab, ids[B:RA0], self.eraw[B:], RA0 - B, 1)]
+        ops.gather_mean_multi(segs, E, E, self.eraw.stride(0))
         ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wp.data_ptr(), self.wp.shape[1],
                            prep.fc.bias.data_ptr(), self.g0_set[s].data_ptr(), self.ldin[0], RA0, E, E, nat.ACT_NONE, 1,
                            0, 0, 0, self.code, self.code)
@@ -1690,13 +1701,12 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         lib, stream = nat.lib(), ops._stream()
         ids, B, RA0, E, L = self._cur_ids, self.B, self.rall[0], self.din[0], self.L
         ld = self.ldin[0]
-        nat.check(lib.gsage_attn_merge_bwd(None, self.code, 0, self.datt[0].data_ptr(), ld, self.dx[0].data_ptr(), ld,
-                                           self.rows[0], self.dagg[0].data_ptr(), ld, self.ws[0].data_ptr(),
-                                           self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host,
-                                           self.fan_host, stream), "attn_merge_bwd")
-        if self.din0 is not self.din0f:
-            nat.check(lib.gsage_add_cast(self.din0f.data_ptr(), E, None, 0, self.din0.data_ptr(), self.code,
-                                         self.din0.stride(0), RA0, E, stream), "add_cast")
+        lp = self.din0 is not self.din0f          # fp32 for the bias gradient's column sums + the GEMMs' operand copy
+        nat.check(lib.gsage_attn_merge_bwd2(None, self.code, 0, self.datt[0].data_ptr(), ld, self.dx[0].data_ptr(), ld,
+                                            self.rows[0], self.dagg[0].data_ptr(), ld, self.ws[0].data_ptr(),
+                                            self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host,
+                                            self.fan_host, self.din0.data_ptr() if lp else None,
+                                            self.din0.stride(0) if lp else 0, stream), "attn_merge_bwd")
         nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
                                             self.bpart.shape[0], stream), "colsum_partials")
         self._gemm(self.din0.data_ptr(), self.din0.stride(0), self.wpT, self.deraw.data_ptr(), nat.F32, E, RA0, E, E,
@@ -1852,6 +1862,12 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
                                         self.head_scratch.data_ptr(),
                                         self.batch_idx.data_ptr() if self.queue else None,
                                         self.queue[2] if self.queue else 0, stream), "head_ce")
+        elif self.fused_l1:
+            out = self.hout[L - 1]
+            nat.check(lib.gsage_head_l1(out.data_ptr(), out.stride(0), m.fc.weight.data_ptr(), m.fc.bias.data_ptr(),
+                                        self.tg_set[s].data_ptr(), B, out.shape[1], self.preds.data_ptr(),
+                                        self.dc[L - 1].data_ptr(), self.code, self.dc[L - 1].stride(0),
+                                        self.l1_scratch.data_ptr(), stream), "head_l1")
         else:
             self._torch_head(s)
         self._backward_levels(s)

@@ -340,15 +340,15 @@ def gather_mean_multi(segments, ld, D, out_ld, adam=None, hops=None):
     O = (ctypes.c_void_p * k)(*[s[2].data_ptr() for s in segments])
     Ms = (ctypes.c_int64 * k)(*[int(s[3]) for s in segments])
     ns = (ctypes.c_int32 * k)(*[int(s[4]) for s in segments])
-    code = _code(segments[0][0].dtype)
-    assert all(s[0].dtype == s[2].dtype == segments[0][0].dtype for s in segments)
+    code, ocode = _code(segments[0][0].dtype), _code(segments[0][2].dtype)
+    assert all(s[0].dtype == segments[0][0].dtype and s[2].dtype == segments[0][2].dtype for s in segments)
     if adam is not None or hops is not None:
         nat.check(nat.lib().gsage_gather_mean_multi_adam(
             k, T, I, O, Ms, ns, code, ld, D, code, out_ld,
             ctypes.addressof(adam) if adam is not None else None,
             ctypes.addressof(hops) if hops is not None else None, _stream()), "gather_mean_multi_adam")
         return
-    nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, code, ld, D, code, out_ld,
+    nat.check(nat.lib().gsage_gather_mean_multi(k, T, I, O, Ms, ns, code, ld, D, ocode, out_ld,
                                                 _stream()), "gather_mean_multi")
 
 

@@ -810,3 +810,38 @@ def test_attn_mlp_second_layer_kernels(dtype, M):
     dh_ref = (da_ref.double() @ W2[:, :32].double()) * (1 - hid[:, :32].double() ** 2)
     tol = 1e-2 if dtype == "bf16" else 1e-5
     assert torch.allclose(dhid[:, :32].double(), dh_ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("B,D", [(512, 256), (48, 256), (7, 40), (2048, 128)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_l1_head_with_the_reference_broadcast(B, D, dtype):
+    """gsage_head_l1 against torch autograd of the reference's own expression: F.l1_loss(fc(F.normalize(E)),
+    targets.squeeze()) -- [B,1] against [B], which broadcasts to [B,B] (problem.py:39-42 behind models.py:100)."""
+    import warnings
+    T = torch.bfloat16 if dtype == "bf16" else torch.float32
+    gen = torch.Generator(device="cpu").manual_seed(B + D)
+    E = torch.randn(B, D, generator=gen).to(DEV)
+    W = (torch.randn(1, D, generator=gen) * 0.5).to(DEV)
+    b = torch.randn(1, generator=gen).to(DEV)
+    t = torch.randn(B, 1, generator=gen).to(DEV)
+    preds = torch.full((B, 1), float("nan"), device=DEV)
+    dE = torch.zeros(B, D, dtype=T, device=DEV)
+    scratch = torch.full((nat.lib().gsage_head_l1_scratch(B, D),), float("nan"), device=DEV)
+    nat.check(nat.lib().gsage_head_l1(E.data_ptr(), D, W.data_ptr(), b.data_ptr(), t.data_ptr(), B, D, preds.data_ptr(),
+                                      dE.data_ptr(), nat.BF16 if dtype == "bf16" else nat.F32, D, scratch.data_ptr(),
+                                      ops._stream()), "head_l1")
+    n_wg = (B + 15) // 16
+    part = scratch[:n_wg * (D + 2)].view(n_wg, D + 2).sum(0)            # what gsage_finalize_grads sums
+    dwb, loss = part[:D + 1], part[D + 1]
+    Ec, Wc, bc = [x.detach().double().cpu().requires_grad_(True) for x in (E, W, b)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p_ref = torch.nn.functional.linear(torch.nn.functional.normalize(Ec, dim=1), Wc, bc)
+        l_ref = torch.nn.functional.l1_loss(p_ref, t.double().cpu().squeeze())
+    l_ref.backward()
+    close(preds.cpu().numpy(), p_ref.detach().numpy(), "preds", 1e-5, 1e-5)
+    assert abs(float(loss) - float(l_ref)) <= 1e-5 * max(1.0, float(l_ref))
+    close(dwb[:D].cpu().numpy(), Wc.grad.numpy().reshape(-1), "d fc.weight", 1e-4, 1e-6)
+    close(dwb[D:].cpu().numpy(), bc.grad.numpy(), "d fc.bias", 1e-4, 1e-6)
+    tol = (2e-2, 1e-6) if dtype == "bf16" else (1e-4, 1e-7)
+    close(dE.float().cpu().numpy(), Ec.grad.numpy(), "dE", *tol)
