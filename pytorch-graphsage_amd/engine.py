@@ -365,8 +365,10 @@ class FusedMeanTrainStep(object):
         # K5 and K5b read the x rows of level 0 in place through the frontier's row list (gsage_linear_nt_packed
         # a_rows / gsage_wgrad_desc.a_rows) instead of from xa0[0]: no row copies in the gather launch (28.5 vs
         # 32.9 us in-step, 0.092 vs 0.095 ms/step at config 2; GSAGE_MEAN_INPLACE_X=0 brings the copies back)
-        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.B % 2 == 0 and
-                          not getattr(self, "gather_cus", 0))         # (split mode keeps frontier rings of its own)
+        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.B % 2 == 0 and self.L >= 2 and
+                          not getattr(self, "gather_cus", 0))         # (split mode keeps frontier rings of its own;
+        #                                                                one level: the copies ARE the "rest" launch
+        #                                                                that carries Adam in data-parallel runs)
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
         for l in range(L):
             R = self.rows[l]
