@@ -68,8 +68,10 @@ __device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t
     const int esz = p.c_dtype == GSAGE_BF16 ? 2 : 4;
     const int epc = 16 / esz;                                    // output elements per 16-byte chunk
     const int64_t cbase = (int64_t)g * p.c_gstride + n0;         // first output column of the tile
-    const bool wide = n0 + BN <= p.N && p.ldc % epc == 0 && cbase % epc == 0 &&
-                      ((uintptr_t)p.C % 16) == 0;
+    // columns of this tile that exist: whole 16-byte chunks of them leave through LDS as 16-byte lane stores
+    // (also the narrow outputs of the att MLP / embedding prep: N = 32, 64)
+    const int ncols = (int)(p.N - n0 < BN ? p.N - n0 : BN);
+    const bool wide = ncols % epc == 0 && p.ldc % epc == 0 && cbase % epc == 0 && ((uintptr_t)p.C % 16) == 0;
     if (wide) {
         __syncthreads();                                         // operand buffers are free now
         const int ldt = BN + epc;                                // padded row, still 16-byte aligned
@@ -77,6 +79,7 @@ __device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t
         for (int t = 0; t < 2; ++t) {
             const f32x16_t &acc = t ? acc1 : acc0;
             const int jl = wn * 64 + t * 32 + (lane & 31);
+            if (jl >= ncols) continue;
             const float bj = bias ? bias[n0 + jl] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -89,7 +92,7 @@ __device__ __forceinline__ void store_tile(const LinearParams &p, const f32x16_t
             }
         }
         __syncthreads();
-        const int cpr = BN / epc;                                // chunks per tile row
+        const int cpr = ncols / epc;                             // chunks per tile row
         for (int q = tid; q < BM * cpr; q += 256) {
             const int row = q / cpr, ch = q - row * cpr;
             const int64_t m = m0 + row;
@@ -308,13 +311,18 @@ k_linear_nt(const LinearParams p)
 // operands' zero padding, which is why rows must be whole lines (lda, ldw % (8*EPC) == 0).
 // -------------------------------------------------------------------------------------------------
 
-template <typename T, int ACT>
+// NBUF: operand buffers.  3 = the ring described above (72 KiB: two workgroups per CU).  1 = reductions of ONE k-tile
+// (K <= 64 bf16: the 64-d embedding prep and the 32-wide att MLP over a 164 k-row frontier): nothing to pipeline inside
+// a workgroup, so the overlap has to come from more workgroups per CU -- 34 KiB (one operand buffer, or the output
+// staging tile) lets four of them share a CU instead of two.
+template <typename T, int ACT, int NBUF>
 __global__ void __launch_bounds__(256)
 k_linear_nt_dma(const LinearParams p)
 {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int TILE = (BM + BN) * CH;                 // vec16 slots per buffer (24 KiB)
-    __shared__ vec16 smem[3 * TILE];                     // single LDS object: 72 KiB
+    constexpr int STAGE = (BM * (BN + 4) * 4) / 16;      // output staging tile of store_tile
+    __shared__ vec16 smem[NBUF * TILE > STAGE ? NBUF * TILE : STAGE];   // single LDS object: 72 KiB (NBUF = 3)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -485,20 +493,24 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
     const int64_t epc = dtype == GSAGE_BF16 ? 8 : 4;
     const int64_t kpad = ceil_div(K, 8 * epc) * 8 * epc;
     const bool dma = lda % (8 * epc) == 0 && ldw % (8 * epc) == 0 && kpad <= lda && kpad <= ldw;
-#define GSAGE_LAUNCH_DMA(T)                                                                       \
+#define GSAGE_LAUNCH_DMA(T, NB)                                                                   \
     do {                                                                                          \
         if (act == ACT_RELU)                                                                      \
-            launch(k_linear_nt_dma<T, ACT_RELU>, grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_RELU, NB>, grid, dim3(256), 0, s, p);     \
         else if (act == ACT_TANH)                                                                 \
-            launch(k_linear_nt_dma<T, ACT_TANH>, grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_TANH, NB>, grid, dim3(256), 0, s, p);     \
         else                                                                                      \
-            launch(k_linear_nt_dma<T, ACT_NONE>, grid, dim3(256), 0, s, p);         \
+            launch(k_linear_nt_dma<T, ACT_NONE, NB>, grid, dim3(256), 0, s, p);     \
     } while (0)
     if (dma) {
-        if (dtype == GSAGE_BF16)
-            GSAGE_LAUNCH_DMA(uint16_t);
-        else
-            GSAGE_LAUNCH_DMA(float);
+        const bool one_tile = kpad <= 8 * epc;            // a single k-tile: see NBUF
+        if (dtype == GSAGE_BF16) {
+            if (one_tile) GSAGE_LAUNCH_DMA(uint16_t, 1);
+            else GSAGE_LAUNCH_DMA(uint16_t, 3);
+        } else {
+            if (one_tile) GSAGE_LAUNCH_DMA(float, 1);
+            else GSAGE_LAUNCH_DMA(float, 3);
+        }
         return check_launch("linear_nt_dma");
     }
 #undef GSAGE_LAUNCH_DMA
