@@ -1571,6 +1571,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             self.din0 = self.din0f if T == f32 else torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)
             self.deraw = torch.zeros(RA0, E, dtype=f32, device=dev)             # d embedding rows
             self.bpart = torch.zeros(256, E, dtype=f32, device=dev)             # prep.fc.bias gradient partials
+            self.seed_grad = torch.zeros(1, E, dtype=f32, device=dev)           # gradient of the spare row the seeds read
             self._cur_ids = self.ids_set[0]
         Ha, HL = self.Ha, self.HA_LD
         z = lambda *shape, dt=f32: torch.zeros(*shape, dtype=dt, device=dev)
@@ -1714,7 +1715,10 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         self._gemm(self.din0.data_ptr(), self.din0.stride(0), self.wpT, self.deraw.data_ptr(), nat.F32, E, RA0, E, E,
                    nat.ACT_NONE)
         g = self._grad_slice(self.table)
-        for rows, idv, M in ((self.deraw[:B], self.seed_rows, B), (self.deraw[B:], ids[B:RA0], RA0 - B)):
+        # every seed reads the SAME spare row: its B gradient rows are summed first (B atomics onto one row took 15 us)
+        nat.check(lib.gsage_colsum_partials(self.deraw.data_ptr(), E, B, E, self.seed_grad.data_ptr(), 1, stream),
+                  "colsum_partials")
+        for rows, idv, M in ((self.seed_grad, self.seed_rows, 1), (self.deraw[B:], ids[B:RA0], RA0 - B)):
             nat.check(lib.gsage_scatter_add_rows(rows.data_ptr(), E, idv.data_ptr(), M, 1, E, 1.0, g.data_ptr(), E,
                                                  stream), "scatter_add_rows")
 
