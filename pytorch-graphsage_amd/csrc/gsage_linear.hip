@@ -311,10 +311,10 @@ k_linear_nt(const LinearParams p)
 // operands' zero padding, which is why rows must be whole lines (lda, ldw % (8*EPC) == 0).
 // -------------------------------------------------------------------------------------------------
 
-// NBUF: operand buffers.  3 = the ring described above (72 KiB: two workgroups per CU).  1 = reductions of ONE k-tile
-// (K <= 64 bf16: the 64-d embedding prep and the 32-wide att MLP over a 164 k-row frontier): nothing to pipeline inside
-// a workgroup, so the overlap has to come from more workgroups per CU -- 34 KiB (one operand buffer, or the output
-// staging tile) lets four of them share a CU instead of two.
+// NBUF: operand buffers.  3 = the ring described above (72 KiB: two workgroups per CU).  1 / 2 = reductions of one / two
+// k-tiles (K <= 64 / 128 bf16: the 64-d embedding prep, the 32-wide att MLP, 128-wide hidden layers over a 164 k-row
+// frontier): little or nothing to pipeline inside a workgroup, so the overlap has to come from more workgroups per
+// CU -- 34 KiB (one operand buffer, or the output staging tile) lets four of them share a CU, 48 KiB three.
 template <typename T, int ACT, int NBUF>
 __global__ void __launch_bounds__(256)
 k_linear_nt_dma(const LinearParams p)
@@ -503,12 +503,14 @@ int gsage_linear_nt(const void *A, int dtype, int64_t lda, const int64_t *a_rows
             launch(k_linear_nt_dma<T, ACT_NONE, NB>, grid, dim3(256), 0, s, p);     \
     } while (0)
     if (dma) {
-        const bool one_tile = kpad <= 8 * epc;            // a single k-tile: see NBUF
+        const int64_t n_tiles = kpad / (8 * epc);         // one or two k-tiles: see NBUF
         if (dtype == GSAGE_BF16) {
-            if (one_tile) GSAGE_LAUNCH_DMA(uint16_t, 1);
+            if (n_tiles <= 1) GSAGE_LAUNCH_DMA(uint16_t, 1);
+            else if (n_tiles == 2) GSAGE_LAUNCH_DMA(uint16_t, 2);
             else GSAGE_LAUNCH_DMA(uint16_t, 3);
         } else {
-            if (one_tile) GSAGE_LAUNCH_DMA(float, 1);
+            if (n_tiles <= 1) GSAGE_LAUNCH_DMA(float, 1);
+            else if (n_tiles == 2) GSAGE_LAUNCH_DMA(float, 2);
             else GSAGE_LAUNCH_DMA(float, 3);
         }
         return check_launch("linear_nt_dma");
