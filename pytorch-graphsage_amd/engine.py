@@ -365,7 +365,7 @@ class FusedMeanTrainStep(object):
         # K5 and K5b read the x rows of level 0 in place through the frontier's row list (gsage_linear_nt_packed
         # a_rows / gsage_wgrad_desc.a_rows) instead of from xa0[0]: no row copies in the gather launch (28.5 vs
         # 32.9 us in-step, 0.092 vs 0.095 ms/step at config 2; GSAGE_MEAN_INPLACE_X=0 brings the copies back)
-        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.B % 2 == 0 and self.L >= 2 and
+        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.L >= 2 and
                           not getattr(self, "gather_cus", 0))         # (split mode keeps frontier rings of its own;
         #                                                                one level: the copies ARE the "rest" launch
         #                                                                that carries Adam in data-parallel runs)
@@ -1279,7 +1279,8 @@ class FusedPoolTrainStep(FusedMeanTrainStep):
 
         # level-0 operands: x rows (hops 0..L-1) gathered once per step; the neighbour rows (hops 1..L: 141 k rows,
         # 180 MB at Reddit's shape) are read IN PLACE through the frontier's row list by K3 and by K5b
-        # (gsage_wgrad_desc.a_rows) -- GSAGE_POOL_COPY_ROWS=1 brings back the gathered copy
+        # (gsage_wgrad_desc.a_rows; its list starts at entry B of the frontier and must be 16-byte aligned: even B) --
+        # GSAGE_POOL_COPY_ROWS=1 brings back the gathered copy
         self.inplace0 = os.environ.get("GSAGE_POOL_COPY_ROWS", "0") != "1" and self.B % 2 == 0
         self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
         self.xn0_set = [None if self.inplace0 else torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev)
@@ -1556,7 +1557,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         # level-0 rows of every hop.  Feature rows are read IN PLACE through the frontier's row list (K5 / K4 / K4' /
         # K5b all take one; GSAGE_ATTN_COPY_ROWS=1: gathered once per step into one buffer per batch in flight, as
         # the embedding prep needs anyway for its output rows); the gather launch then only carries the seeds' rows
-        self.inplace0 = (not self.emb) and os.environ.get("GSAGE_ATTN_COPY_ROWS", "0") != "1" and self.B % 2 == 0
+        self.inplace0 = (not self.emb) and os.environ.get("GSAGE_ATTN_COPY_ROWS", "0") != "1"
         self._q_ids, self._cur_ids = None, self.ids_set[0]
         self.g0_set = [torch.zeros(self.B if self.inplace0 else self.rall[0], self.ldin[0], dtype=T, device=dev)
                        for _ in range(self.nset)]

@@ -338,3 +338,73 @@ def test_bf16_attention_engine_against_rounding_aware_oracle():
         worst = max(worst, float(np.linalg.norm(d_eng - d_ref) / max(np.linalg.norm(d_ref), 1e-12)))
         close_fro(d_eng, d_ref, ("weight update", k), 1e-2)
     _note("bf16attn/w2", upd_fro=worst)
+
+
+@pytest.mark.parametrize("c,flag", [(0, "GSAGE_MEAN_INPLACE_X"), (3, "GSAGE_MEAN_INPLACE_X"), (4, "GSAGE_POOL_COPY_ROWS"),
+                                    (5, "GSAGE_POOL_COPY_ROWS")])
+@pytest.mark.parametrize("mode", ["call", "queue"])
+def test_operands_read_in_place_equal_the_gathered_copies_bit_for_bit(c, flag, mode):
+    """Level-0 operands read in place through the frontier's row list (default) against the gathered-copy paths
+    (GSAGE_MEAN_INPLACE_X=0 / GSAGE_POOL_COPY_ROWS=1): same rows, same arithmetic, same summation order -> the same
+    predictions and the same weights after two steps, bit for bit."""
+    g = load_golden("engine_kat.npz")
+    res = []
+    for copy in (False, True):
+        if copy:
+            os.environ[flag] = "0" if flag == "GSAGE_MEAN_INPLACE_X" else "1"
+        try:
+            p, model, store, fan, ids, tg, sels = _case(g, c, "bf16")
+            eng = _engine(model, store, ids, tg, "cmdlist")
+            in_place = getattr(eng, "inplace_x", False) or getattr(eng, "inplace0", False)
+            assert in_place == (not copy)
+            if mode == "queue":
+                sel_q = torch.stack([torch.cat([torch.from_numpy(np.asarray(x)).reshape(-1) for x in sels[st]])
+                                     for st in range(2)])
+                eng.load_epoch(torch.stack([ids, ids]), torch.stack([tg, tg]), sel_epoch=sel_q)
+            preds = []
+            for step in range(2):
+                eng.set_progress(0.25 * step)
+                if mode == "queue":
+                    preds.append(eng.step_queue().detach().clone())
+                else:
+                    eng.set_sel(sels[step])
+                    preds.append(eng(ids, tg).detach().clone())
+            torch.cuda.synchronize()
+            res.append((preds, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        finally:
+            os.environ.pop(flag, None)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_attention_rows_in_place_equal_the_gathered_copy():
+    """FusedAttnTrainStep on the reference's attention fixture: level-0 rows read in place (default) against
+    GSAGE_ATTN_COPY_ROWS=1 -- identical predictions and weights (K4's float atomics are not involved: no embeddings)."""
+    g = load_golden("model_kat.npz")
+    p = "c6_"
+    res = []
+    for copy in (False, True):
+        if copy:
+            os.environ["GSAGE_ATTN_COPY_ROWS"] = "1"
+        try:
+            model, store, task = build_model(gs, g, p, device=DEV, feats_dtype="bf16")
+            fan = [int(v) for v in g[p + "fanouts"]]
+            ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+            tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+            eng = gs.engine.FusedAttnTrainStep(model, store, gs.ProblemLosses.classification, ids, tg, capture="cmdlist")
+            assert eng.inplace0 == (not copy)
+            preds = []
+            for step in range(2):
+                eng.set_progress(0.25 * step)
+                eng.set_sel([g[p + "s%d_sel%d" % (step, h)] for h in range(len(fan))])
+                preds.append(eng(ids, tg).detach().clone())
+            torch.cuda.synchronize()
+            res.append((preds, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        finally:
+            os.environ.pop("GSAGE_ATTN_COPY_ROWS", None)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
