@@ -204,3 +204,30 @@ def test_close_settles_rows_and_detaches_and_a_second_engine_starts_from_current
     b(ids[5], tg[5])
     b.close()
     assert not hasattr(model, "_settle_rows") and len(model.prep.embedding._forward_pre_hooks) == 0
+
+
+def test_ring_of_step_constants_wraps_safely(monkeypatch):
+    """The constants of past updates live in a ring (ROW_HIST slots); the engine settles every row before a slot a
+    deferred row still needs is overwritten.  With an 8-slot ring and 20 steps the table must still equal the dense
+    run's."""
+    outs = []
+    for mode in ("dense", "deferred"):
+        if mode == "dense":
+            os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
+        else:
+            os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
+            monkeypatch.setattr(gs.engine.FusedAttnTrainStep, "ROW_HIST", 8)
+        ops.set_compute_dtype("fp32")
+        model, ids, tg = _emb_model(seed=6)
+        eng = gs.engine.FusedAttnTrainStep(model, None, gs.ProblemLosses.regression_mae, ids[0], tg[0], capture="cmdlist")
+        settles = 0
+        for s in range(20):
+            before = eng._rows_since if mode == "deferred" else 0
+            eng(ids[s % 10], tg[s % 10])
+            if mode == "deferred" and eng._rows_since <= before:
+                settles += 1
+        if mode == "deferred":
+            assert settles >= 2 and eng.row_hist.numel() == 16
+        outs.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k in outs[0]:
+        assert torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=2e-5), (k, float((outs[0][k] - outs[1][k]).abs().max()))
