@@ -405,40 +405,75 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
 // backward needed a cast, a GEMM and a tanh-backward launch, 50 us); here lane j of a half-wave owns output
 // column j (its weight column in registers), a row's 32 inputs reach every lane through LDS, and the element-wise
 // neighbours of the product are fused in.  The roundings are the engine's: operands in T, fp32 sums.
-constexpr int MLP2_ROWS = 8;      // row pairs per wave and trip: 16 rows in flight
+constexpr int MLP2_RT = 16;       // rows per wave and trip
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// 16 rows x 32 elements of T (ld elements apart) -> LDS as floats; 16-byte lane loads
+template <typename T>
+__device__ __forceinline__ void mlp2_stage_rows(const T *__restrict__ src, int64_t ld, int64_t m0, int64_t M, int lane,
+                                                float (*dst)[32])
+{
+    constexpr int EPC = 16 / (int)sizeof(T);                 // 8 (bf16) / 4 (fp32) elements per chunk
+    constexpr int CPR = 32 / EPC;                            // chunks per row
+    for (int q = lane; q < MLP2_RT * CPR; q += 64) {
+        const int r = q / CPR, c = q - r * CPR;
+        vec16 raw = {0u, 0u, 0u, 0u};
+        if (m0 + r < M) raw = *reinterpret_cast<const vec16 *>(src + (m0 + r) * ld + c * EPC);
+        float f[EPC];
+        chunk_to_f32<T, EPC>(raw, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[r][c * EPC + e] = f[e];
+    }
+}
+
+// 16 rows x 32 floats in LDS -> global rows of T; 16-byte lane stores
+template <typename T>
+__device__ __forceinline__ void mlp2_store_rows(T *__restrict__ dstp, int64_t ld, int64_t m0, int64_t M, int lane,
+                                                const float (*srcs)[32])
+{
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int CPR = 32 / EPC;
+    for (int q = lane; q < MLP2_RT * CPR; q += 64) {
+        const int r = q / CPR, c = q - r * CPR;
+        if (m0 + r >= M) continue;
+        T out[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) store_as(&out[e], srcs[r][c * EPC + e]);
+        *reinterpret_cast<vec16 *>(dstp + (m0 + r) * ld + c * EPC) = *reinterpret_cast<const vec16 *>(out);
+    }
+}
+
+// lane (half, j): out[r][j] = sum_k x[r][k] w[k] for the rows r = half, half + 2, ... of the staged tile
+#define MLP2_DOT(xs, r, acc)                                                                            \
+    do {                                                                                                \
+        _Pragma("unroll") for (int k4 = 0; k4 < 8; ++k4) {                                              \
+            const float4 v = *reinterpret_cast<const float4 *>(&(xs)[r][4 * k4]);                       \
+            acc += v.x * w[4 * k4] + v.y * w[4 * k4 + 1] + v.z * w[4 * k4 + 2] + v.w * w[4 * k4 + 3];   \
+        }                                                                                               \
+    } while (0)
 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_attn_mlp2_fwd(const T *__restrict__ hid, int64_t ldh, const T *__restrict__ W2, int64_t ldw, float *__restrict__ a,
                 int64_t lda, int64_t M)
 {
-    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_ROWS][64];
+    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_RT][32], os[4][MLP2_RT][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, half = lane >> 5;
     float w[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) w[k] = load_as(W2 + j * ldw + k);          // a[m, j] = sum_k hid[m, k] W2[j, k]
     const int64_t n_waves = (int64_t)gridDim.x * 4, wv = (int64_t)blockIdx.x * 4 + wave;
-    for (int64_t m0 = wv * 2 * MLP2_ROWS; m0 < M; m0 += n_waves * 2 * MLP2_ROWS) {
-        float x[MLP2_ROWS];
-#pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) {
-            const int64_t m = m0 + 2 * r + half;
-            x[r] = m < M ? load_as(hid + m * ldh + j) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) xs[wave][r][lane] = x[r];
+    for (int64_t m0 = wv * MLP2_RT; m0 < M; m0 += n_waves * MLP2_RT) {
+        mlp2_stage_rows<T>(hid, ldh, m0, M, lane, xs[wave]);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) {
-            const int64_t m = m0 + 2 * r + half;
+        for (int r = 0; r < MLP2_RT; r += 2) {
             float acc = 0.f;
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                const float4 v = *reinterpret_cast<const float4 *>(&xs[wave][r][half * 32 + 4 * k4]);
-                acc += v.x * w[4 * k4] + v.y * w[4 * k4 + 1] + v.z * w[4 * k4 + 2] + v.w * w[4 * k4 + 3];
-            }
-            if (m < M) a[m * lda + j] = acc;
+            MLP2_DOT(xs[wave], r + half, acc);
+            os[wave][r + half][j] = acc;
         }
+        __builtin_amdgcn_wave_barrier();
+        mlp2_store_rows<float>(a, lda, m0, M, lane, os[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -450,39 +485,41 @@ k_attn_mlp2_bwd(const float *__restrict__ dan, int64_t ldn, const float *__restr
                 const T *__restrict__ hid, int64_t ldh, const T *__restrict__ W2T, int64_t ldw, T *__restrict__ da,
                 int64_t ldda, T *__restrict__ dhid, int64_t lddh, int64_t M)
 {
-    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_ROWS][64];
+    __shared__ __attribute__((aligned(16))) float xs[4][MLP2_RT][32], hs[4][MLP2_RT][32], os[4][MLP2_RT][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 31, half = lane >> 5;
     float w[32];
 #pragma unroll
     for (int jj = 0; jj < 32; ++jj) w[jj] = load_as(W2T + k * ldw + jj);    // dhg[m, k] = sum_j da[m, j] W2[j, k]
     const int64_t n_waves = (int64_t)gridDim.x * 4, wv = (int64_t)blockIdx.x * 4 + wave;
-    for (int64_t m0 = wv * 2 * MLP2_ROWS; m0 < M; m0 += n_waves * 2 * MLP2_ROWS) {
-        float x[MLP2_ROWS], h[MLP2_ROWS];
-#pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) {
-            const int64_t m = m0 + 2 * r + half;
-            const bool ok = m < M;
-            const float sum = ok ? dan[m * ldn + k] + dax[m * ldx + k] : 0.f;
-            h[r] = ok ? load_as(hid + m * ldh + k) : 0.f;
-            T rounded;
-            store_as(&rounded, sum);                        // d a as the next GEMMs see it (K5b operand, this product)
-            x[r] = load_as(&rounded);
-            if (ok) da[m * ldda + k] = rounded;
-        }
-#pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) xs[wave][r][lane] = x[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < MLP2_ROWS; ++r) {
-            const int64_t m = m0 + 2 * r + half;
-            float acc = 0.f;
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                const float4 v = *reinterpret_cast<const float4 *>(&xs[wave][r][half * 32 + 4 * k4]);
-                acc += v.x * w[4 * k4] + v.y * w[4 * k4 + 1] + v.z * w[4 * k4 + 2] + v.w * w[4 * k4 + 3];
+    for (int64_t m0 = wv * MLP2_RT; m0 < M; m0 += n_waves * MLP2_RT) {
+        // d a = dan + dax, rounded to T as the next GEMMs see it: 16 rows x 8 chunks of four floats
+        for (int q = lane; q < MLP2_RT * 8; q += 64) {
+            const int r = q >> 3, c = q & 7;
+            f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + r < M) {
+                const f32x4_t u = *reinterpret_cast<const f32x4_t *>(dan + (m0 + r) * ldn + 4 * c);
+                const f32x4_t v = *reinterpret_cast<const f32x4_t *>(dax + (m0 + r) * ldx + 4 * c);
+                s4 = u + v;
             }
-            if (m < M) store_as(dhid + m * lddh + k, acc * (1.f - h[r] * h[r]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                T rounded;
+                store_as(&rounded, s4[e]);
+                xs[wave][r][4 * c + e] = load_as(&rounded);
+            }
         }
+        mlp2_stage_rows<T>(hid, ldh, m0, M, lane, hs[wave]);
+        __builtin_amdgcn_wave_barrier();
+        mlp2_store_rows<T>(da, ldda, m0, M, lane, xs[wave]);                 // (exact: the values are T already)
+#pragma unroll
+        for (int r = 0; r < MLP2_RT; r += 2) {
+            float acc = 0.f;
+            MLP2_DOT(xs[wave], r + half, acc);
+            const float h = hs[wave][r + half][k];
+            os[wave][r + half][k] = acc * (1.f - h * h);
+        }
+        __builtin_amdgcn_wave_barrier();
+        mlp2_store_rows<T>(dhid, lddh, m0, M, lane, os[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -721,7 +758,7 @@ extern "C" int gsage_attn_mlp2_fwd(const void *hid, int dtype, int64_t ldh, cons
                   "attn_mlp2_fwd: needs the reference's 32-wide att MLP");
     GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "attn_mlp2_fwd: bad dtype");
     if (M == 0) return GSAGE_OK;
-    const dim3 grid(ew_grid(ceil_div(M, (int64_t)(2 * MLP2_ROWS)) * 64));
+    const dim3 grid(ew_grid(ceil_div(M, (int64_t)MLP2_RT) * 64));
     if (dtype == GSAGE_BF16)
         launch(k_attn_mlp2_fwd<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)hid, ldh,
                (const uint16_t *)W2, ldw, a, lda, M);
@@ -739,7 +776,7 @@ extern "C" int gsage_attn_mlp2_bwd(const float *dan, int64_t ldn, const float *d
                   ldw >= 32 && ldda >= 32 && lddh >= 32, "attn_mlp2_bwd: needs the reference's 32-wide att MLP");
     GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "attn_mlp2_bwd: bad dtype");
     if (M == 0) return GSAGE_OK;
-    const dim3 grid(ew_grid(ceil_div(M, (int64_t)(2 * MLP2_ROWS)) * 64));
+    const dim3 grid(ew_grid(ceil_div(M, (int64_t)MLP2_RT) * 64));
     if (dtype == GSAGE_BF16)
         launch(k_attn_mlp2_bwd<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, dan, ldn, dax, ldx, (const uint16_t *)hid,
                ldh, (const uint16_t *)W2T, ldw, (uint16_t *)da, ldda, (uint16_t *)dhid, lddh, M);
