@@ -183,6 +183,10 @@ int gsage_sample_hops(const gsage_hops_desc *hops, void *stream);
 
 /* *ctr += inc on the stream (advances the Philox call counter inside a captured graph). */
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream);
+/* Two small device-to-device copies in one launch (4-byte granularity): a step's seed ids and targets into the
+ * static buffers a recorded / captured step reads (train.py:141-148 hands over fresh tensors per batch). */
+int gsage_copy_pair(void *dst0, const void *src0, int64_t bytes0, void *dst1, const void *src1, int64_t bytes1,
+                    void *stream);
 
 /* [host] the numpy legacy MT19937 stream the reference draws from (helpers.py:15,
  * nn_modules.py:88, problem.py:146), for compat mode.  All pointers here are HOST pointers. */

@@ -50,6 +50,7 @@ SIGNATURES = {
                                         _vp, _vp, _i64, _vp, _vp]),
     "gsage_sample_hops": (_int, [_vp, _vp]),
     "gsage_counter_add": (_int, [_vp, _u64, _vp]),
+    "gsage_copy_pair": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "gsage_mt_create": (_vp, [_u32]),
     "gsage_mt_destroy": (None, [_vp]),
     "gsage_mt_seed": (None, [_vp, _u32]),

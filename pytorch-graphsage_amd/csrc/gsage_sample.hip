@@ -57,6 +57,19 @@ k_sample_philox(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ 
     }
 }
 
+// two small device-to-device copies in ONE launch (a step's seed ids and targets into the buffers a captured step
+// reads): as hipMemcpyAsync each was a ~7 us blit on the step's stream
+__global__ void __launch_bounds__(256)
+k_copy_pair(uint32_t *__restrict__ d0, const uint32_t *__restrict__ s0, int64_t n0, uint32_t *__restrict__ d1,
+            const uint32_t *__restrict__ s1, int64_t n1)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n0 + n1; t += stride) {
+        if (t < n0) d0[t] = s0[t];
+        else d1[t - n0] = s1[t - n0];
+    }
+}
+
 __global__ void k_counter_add(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
 __global__ void __launch_bounds__(256)
@@ -302,6 +315,23 @@ int gsage_sample_hops(const gsage_hops_desc *hops, void *stream)
     if (rc != GSAGE_OK || hops->B == 0) return rc;
     launch(k_sample_hops, dim3((unsigned)ceil_div(hops->B, HOPS_SPW)), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("sample_hops");
+}
+
+int gsage_copy_pair(void *dst0, const void *src0, int64_t bytes0, void *dst1, const void *src1, int64_t bytes1,
+                    void *stream)
+{
+    GSAGE_REQUIRE(bytes0 >= 0 && bytes1 >= 0 && (bytes0 == 0 || (dst0 && src0)) && (bytes1 == 0 || (dst1 && src1)),
+                  "copy_pair: bad arguments");
+    GSAGE_REQUIRE(bytes0 % 4 == 0 && bytes1 % 4 == 0 &&
+                  ((((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) & 3) == 0),
+                  "copy_pair: 4-byte granularity");
+    const int64_t words = (bytes0 + bytes1) / 4;
+    if (words == 0) return GSAGE_OK;
+    int64_t blocks = ceil_div(words, (int64_t)256);
+    if (blocks > 1024) blocks = 1024;
+    launch(k_copy_pair, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t *)dst0,
+           (const uint32_t *)src0, bytes0 / 4, (uint32_t *)dst1, (const uint32_t *)src1, bytes1 / 4);
+    return check_launch("copy_pair");
 }
 
 int gsage_counter_add(uint64_t *ctr, uint64_t inc, void *stream)
