@@ -363,6 +363,10 @@ k_linear_nt_dma(const LinearParams p)
     const int a_dst0 = (8 * wave) * CH, a_dst1 = (32 + 8 * wave) * CH;
     const int w_dst0 = BM * CH + (8 * wave) * CH;
 
+    // one-k-tile instantiation with <= 64 output columns: the upper half of the W tile would be 64 copies of the last
+    // row -- not fetched, and the two waves that own those columns sit the MFMAs out (the waits of this instantiation
+    // are all vmcnt(0), so the shorter tile needs no other count)
+    const bool half_w = NBUF == 1 && p.N - n0 <= 64;
     auto issue_tile = [&](int kt, int buf) {
         vec16 *base = smem + buf * TILE;
         const int64_t ko = (int64_t)kt * CH * EPC;
@@ -370,8 +374,9 @@ k_linear_nt_dma(const LinearParams p)
         __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[1] + ko), (lds_void_t *)(base + a_dst1), 16, 0, 0);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
-            __builtin_amdgcn_global_load_lds((global_void_t *)(w_src[s4] + ko),
-                                             (lds_void_t *)(base + w_dst0 + 32 * s4 * CH), 16, 0, 0);
+            if (s4 < 2 || !half_w)
+                __builtin_amdgcn_global_load_lds((global_void_t *)(w_src[s4] + ko),
+                                                 (lds_void_t *)(base + w_dst0 + 32 * s4 * CH), 16, 0, 0);
     };
 
     const int wm = wave & 1;
@@ -402,6 +407,7 @@ k_linear_nt_dma(const LinearParams p)
         }
     };
     auto mma_tile = [&](const vec16 (&fa)[4], const vec16 (&fb0)[4], const vec16 (&fb1)[4]) {
+        if (half_w && wn == 1) return;                   // (wave-uniform)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             mma_chunk<T>::run(fa[kk], fb0[kk], acc0);
