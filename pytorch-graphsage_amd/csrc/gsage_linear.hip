@@ -363,10 +363,10 @@ k_linear_nt_dma(const LinearParams p)
     const int a_dst0 = (8 * wave) * CH, a_dst1 = (32 + 8 * wave) * CH;
     const int w_dst0 = BM * CH + (8 * wave) * CH;
 
-    // one-k-tile instantiation with <= 64 output columns: the upper half of the W tile would be 64 copies of the last
-    // row -- not fetched, and the two waves that own those columns sit the MFMAs out (the waits of this instantiation
-    // are all vmcnt(0), so the shorter tile needs no other count)
-    const bool half_w = NBUF == 1 && p.N - n0 <= 64;
+    // <= 64 output columns: the upper half of the W tile would be 64 copies of the last row -- not fetched (a tile is
+    // then 4 DMA instructions per wave instead of 6: the counted waits below follow), and the two waves that own those
+    // columns sit the MFMAs out
+    const bool half_w = p.N - n0 <= 64;
     auto issue_tile = [&](int kt, int buf) {
         vec16 *base = smem + buf * TILE;
         const int64_t ko = (int64_t)kt * CH * EPC;
@@ -422,8 +422,10 @@ k_linear_nt_dma(const LinearParams p)
         // the reads issued below before the MFMAs)
         __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
         if (kt + 1 < nk) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 2 < nk) {                                    // one later tile may stay in flight
+                if (half_w) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (kt + 3 < nk) issue_tile(kt + 3, b);               // tile kt's own buffer
             read_frags(b == 2 ? 0 : b + 1, na, nb0, nb1);
@@ -434,9 +436,13 @@ k_linear_nt_dma(const LinearParams p)
     issue_tile(0, 0);
     if (nk > 1) issue_tile(1, 1);
     if (nk > 2) issue_tile(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 2) {
+        if (half_w) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else if (nk > 1) {
+        if (half_w) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(0, xa, xb0, xb1);
     int buf = 0;
