@@ -1575,8 +1575,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             self.table = prep.embedding.weight                 # a view of the flat parameter bucket
             assert self.pidx[id(self.table)] == 0 and self.table.shape[1] == E and self.table.numel() % 4 == 0
             self.seed_rows = torch.full((self.B,), int(prep.n_nodes), dtype=torch.int64, device=dev)
-            self.eraw32 = torch.zeros(RA0, E, dtype=f32, device=dev)            # embedding rows as gathered
-            self.eraw = self.eraw32 if T == f32 else torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)
+            self.eraw = torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)     # embedding rows as gathered (operand type)
             self.din0f = torch.zeros(RA0, E, dtype=f32, device=dev)             # d prep output
             self.din0 = self.din0f if T == f32 else torch.zeros(RA0, self.ldin[0], dtype=T, device=dev)
             self.deraw = torch.zeros(RA0, E, dtype=f32, device=dev)             # d embedding rows
@@ -1587,7 +1586,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
         Ha, HL = self.Ha, self.HA_LD
         z = lambda *shape, dt=f32: torch.zeros(*shape, dtype=dt, device=dev)
         self.hid, self.a, self.agg, self.aggc, self.ws, self.hout, self.dc = ([] for _ in range(7))
-        self.dagg, self.dan, self.dax, self.da, self.dhg, self.dhid, self.datt, self.dx = ([] for _ in range(8))
+        self.dagg, self.dan, self.dax, self.da, self.dhid, self.datt, self.dx = ([] for _ in range(7))
         for l in range(L):
             R, RA, ld, h = self.rows[l], self.rall[l], self.ldin[l], self.h[l]
             last = l == L - 1
@@ -1595,7 +1594,7 @@ class FusedAttnTrainStep(FusedMeanTrainStep):
             self.agg.append(z(R, ld)); self.aggc.append(z(R, ld, dt=T)); self.ws.append(z(RA - self.off[1]))
             self.hout.append(z(R, 2 * h, dt=f32 if last else T)); self.dc.append(z(R, 2 * h, dt=T))
             self.dagg.append(z(R, ld)); self.dan.append(z(RA, Ha)); self.dax.append(z(RA, Ha))
-            self.da.append(z(RA, HL, dt=T)); self.dhg.append(z(RA, Ha)); self.dhid.append(z(RA, HL, dt=T))
+            self.da.append(z(RA, HL, dt=T)); self.dhid.append(z(RA, HL, dt=T))
             ing = l > 0 or self.emb
             self.datt.append(z(RA, ld) if ing else None); self.dx.append(z(R, ld) if ing else None)
         self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
