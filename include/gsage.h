@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSAGE_ABI_VERSION 2
+#define GSAGE_ABI_VERSION 3
 
 enum { GSAGE_F32 = 0, GSAGE_BF16 = 1 };
 enum {
@@ -125,6 +125,15 @@ int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_ro
                          const int64_t *ids, int64_t M, int32_t n, const int32_t *sel,
                          int64_t *out, int32_t *err_flag, void *stream);
 
+/* UniformNeighborSampler.__call__ (reference nn_modules.py:43-49): `adj[ids][:, perm][:, :n]` over the dense
+ * int64 [n_rows, ld] adjacency (every row pre-sampled to exactly ld neighbours by the converter), in one launch:
+ *     out[i*n + j] = adj[ids[i]*ld + keep[j]]
+ * keep: DEVICE int64 [n] = the first n entries of the torch.randperm(ld) the caller drew from torch's global
+ * CPU generator (one permutation per call, shared by the whole batch).  An id outside
+ * [0, n_rows) or a column outside [0, ld) yields 0 and raises *err_flag (the reference: IndexError). */
+int gsage_sample_dense(const int64_t *adj, int64_t ld, int64_t n_rows, const int64_t *ids, int64_t M,
+                       const int64_t *keep, int32_t n, int64_t *out, int32_t *err_flag, void *stream);
+
 /* Counter mode (throughput): sel is generated in-kernel by Philox4x32-10,
  *     g    = g0 + i*n + j                      global sample index of the whole job
  *     call = call_base + (call_ctr ? *call_ctr : 0)        (call_ctr: device word, may be NULL;
@@ -177,6 +186,15 @@ typedef struct gsage_hops_desc {
      * drew at nn_modules.py:88).  With a seed queue the draws of batch b start at sel + b*sel_stride. */
     const int32_t *sel;
     int64_t sel_stride;
+    /* dense_adj (may be NULL; ABI 3): the frontier of the reference's DENSE sampler (UniformNeighborSampler,
+     * nn_modules.py:19-49) instead of the CSR walk -- int64 [n_rows, dense_ld], every row pre-sampled to exactly
+     * dense_ld neighbours.  `sel` is then mandatory and holds, per batch, the columns the sampler keeps:
+     * [fan[0] columns for hop 1 | fan[1] columns for hop 2 | ...] (sel_stride = their sum), i.e. the head of the
+     * torch.randperm(K) the reference draws ONCE per sampler call and shares between all parents:
+     *     ids[hop k][i*fan + j] = dense_adj[ids[hop k-1][i], keep_k[j]].
+     * rowptr / col / max_deg / seed / call_* are ignored. */
+    const int64_t *dense_adj;
+    int64_t dense_ld;
 } gsage_hops_desc;
 /* gsage_sample_hops_philox from a descriptor (the only way to pass batch_base). */
 int gsage_sample_hops(const gsage_hops_desc *hops, void *stream);
@@ -202,6 +220,15 @@ int64_t gsage_mt_choice_i32(void *mt, int64_t high, int64_t count, int32_t *out)
  * rejection are parallel inside it).  Not recordable into a graph-free command list restriction: it IS an
  * ordinary kernel launch and can be recorded like any other. */
 int gsage_mt_choice_device(uint32_t *state, int64_t high, int64_t count, int32_t *out, void *stream);
+/* n_seg requests served back to back from the same device-resident stream in ONE launch: request q writes
+ * seg_cnt[q] values to out + seg_off[q] (seg_off / seg_cnt: DEVICE int64 arrays).  Consecutive
+ * np.random.choice(high, .) calls consume numpy's stream exactly like this, so a whole training epoch's sampler
+ * draws (per batch: hop 1's M * n_1 values, hop 2's M * n_1 * n_2, ... -- nn_modules.py:88 called from
+ * models.py:78-80 batch after batch) are produced up front and the fused engines' device-side batch queue replays
+ * them (gsage_hops_desc.sel): samples bit-identical to the reference's for the same seed.  high >= 2 (numpy draws
+ * nothing for a range of one value). */
+int gsage_mt_choice_segments(uint32_t *state, int64_t high, int64_t n_seg, const int64_t *seg_off,
+                             const int64_t *seg_cnt, int32_t *out, void *stream);
 /* np.random.permutation(n) -> int64 out[n]. */
 void gsage_mt_permutation(void *mt, int64_t n, int64_t *out);
 
@@ -418,7 +445,8 @@ int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *n
  *       dIn[m] = mask(m) * ( DATT[m] + (m < r_x ? DX[m] : 0) + (hop(m) >= 1 ? ws[m - off[1]] * DAGG[parent(m)] : 0) )
  *       DATT: through att(.), every row; DX: through fc_x; ws: the softmax weights of every (parent, child) pair
  *       in hop order (the ws outputs of gsage_attn_aggregate, back to back); mask = (H[m, c] > 0) when H is given
- *       (the ReLU of the level below), else 1. */
+ *       (the ReLU of the level below), else 1.  DATT may be NULL (no such path: a MEAN aggregator level over an
+ *       embedding prep), ws may be NULL (uniform weights 1 / fan[hop]: the mean, nn_modules.py:197-198). */
 int gsage_add_cast(const float *a, int64_t lda, const float *b, int64_t ldb, void *dst, int dst_dtype, int64_t ldd,
                    int64_t M, int64_t D, void *stream);
 int gsage_tanh_bwd(const float *g, int64_t ldg, const void *hid, int dtype, int64_t ldh, void *out, int64_t ldo,
@@ -505,7 +533,10 @@ int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
  * gsage_prep_weights' / gsage_finalize_grads' tick) and is left alone.  partial: fp32 scratch of
  * gsage_adam_partials(n) elements.  norm_out (may be NULL) receives the pre-clip gradient norm.
  * (step_is_current & 2: the caller consumes g in this call and zeroes it next -- a scatter-added
- * embedding-table gradient --, so the clipped values are not written back.)
+ * embedding-table gradient --, so the clipped values are not written back.  step_is_current & 4: use the
+ * arithmetic of the deferred row updates (gsage_rows_*: 1-ulp sqrt and reciprocal) instead of
+ * torch.optim.Adam's correctly rounded sqrt and division, so that a table updated densely here and row by
+ * row there gets the same bits; every other caller leaves the bit clear and gets torch's roundings.)
  * n_partial_ready > 0: `partial` already holds that many squared-norm partials (written by
  * gsage_finalize_grads) and the norm pass is skipped.  prep_descs (DEVICE array of n_prep
  * gsage_prep_desc whose src point into p; may be NULL): the bf16 operand copies of the updated
@@ -535,6 +566,15 @@ typedef struct gsage_adam_desc {
 } gsage_adam_desc;
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
  * Philox call index and batch-queue index, when nothing in the same launch reads them). */
+/* Live rows for the NEXT head launch of the calling thread (gsage_head_ce, gsage_mean_tail_ce, gsage_head_l1),
+ * consumed by it -- also while a command list is being recorded, the pointer then belongs to the recorded
+ * launch.  n_valid: DEVICE int32, one word (or [n_batches], indexed like the target queue when the head is given
+ * a batch_idx).  Rows past n_valid are padding: they get predictions, but no loss term and a zero gradient,
+ * and the loss / gradient means run over n_valid rows.  Why: the reference's `iterate` (problem.py:141-153) cuts
+ * an epoch into near-equal chunks that are never all of one size, while a recorded step has one geometry -- short
+ * chunks are padded to it.  NULL (the default): every row is live. */
+int gsage_head_n_valid_next(const int32_t *n_valid);
+
 /* gsage_gather_mean_multi (the NEXT batch's level-0 gathers: they read features and ids only) with up
  * to two short latency-bound jobs riding in the same launch, each a few hundred workgroups that are
  * free next to the HBM-bound gather:
@@ -659,12 +699,15 @@ int gsage_bwd_merge(const void *H, int dtype, int64_t ldh, const float *DG, int6
  *                      mean runs over the classes that occur in targets or predictions (sklearn's label set)
  *       multilabel     (multilabel != 0): logits[i, c] > 0 against targets [B, ldy] (float32 when
  *                      targets_f32, else int64; non-zero = positive); macro over all C labels
- *     counts: int32 scratch [3 * C] (tp | fp | fn per class, integer atomics: exact).
- *   gsage_metric_mae: out[0] = mean |y_true[i] - y_pred[i]| over n elements (problem.py:62-64).
+ *     counts: int32 scratch [3 * C + 1] (tp | fp | fn per class, integer atomics: exact; + the number of
+ *     classification targets outside [0, C)).  out: DOUBLE [3] -- micro, macro, that number: sklearn would
+ *     add such a label to its label set, so a caller that sees out[2] != 0 must score the batch on the host
+ *     (problem.DeviceMetrics does).  argmax: first maximum wins and a NaN logit wins over numbers (np.argmax).
+ *   gsage_metric_mae: out[0] (DOUBLE) = mean |y_true[i] - y_pred[i]| over n elements (problem.py:62-64).
  * ---------------------------------------------------------------------------------------- */
 int gsage_metric_f1(const float *logits, int64_t ld, const void *targets, int multilabel, int targets_f32,
-                    int64_t ldy, int64_t B, int32_t C, int32_t *counts, float *out, void *stream);
-int gsage_metric_mae(const float *y_true, const float *y_pred, int64_t n, float *out, void *stream);
+                    int64_t ldy, int64_t B, int32_t C, int32_t *counts, double *out, void *stream);
+int gsage_metric_mae(const float *y_true, const float *y_pred, int64_t n, double *out, void *stream);
 
 #ifdef __cplusplus
 }

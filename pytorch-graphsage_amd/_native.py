@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
 F32, BF16 = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -44,6 +44,7 @@ SIGNATURES = {
     "gsage_cmdlist_replay": (_int, [_vp, _vp]),
     "gsage_cmdlist_destroy": (None, [_vp]),
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "gsage_sample_dense": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
                                        _vp, _vp, _vp, _vp]),
     "gsage_sample_hops_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _u32, _u64, _vp, _u64, _u64,
@@ -57,6 +58,8 @@ SIGNATURES = {
     "gsage_mt_choice_i32": (_i64, [_vp, _i64, _i64, _vp]),
     "gsage_mt_permutation": (None, [_vp, _i64, _vp]),
     "gsage_mt_choice_device": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gsage_mt_choice_segments": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gsage_head_n_valid_next": (_int, [_vp]),
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
     "gsage_gather_mean_multi": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64, _vp]),
     "gsage_gather_mean_multi_adam": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64,
@@ -182,7 +185,7 @@ class HopsDesc(ctypes.Structure):             # mirrors gsage_hops_desc (include
                 ("n_hops", _i32), ("fan", _i32 * 5), ("max_deg", _u32), ("seed", _u64),
                 ("call_ctr", _vp), ("call_base", _u64), ("rank", _u64), ("seed_queue", _vp),
                 ("batch_idx", _vp), ("batch_base", _i64), ("n_batches", _i64), ("err_flag", _vp),
-                ("sel", _vp), ("sel_stride", _i64)]
+                ("sel", _vp), ("sel_stride", _i64), ("dense_adj", _vp), ("dense_ld", _i64)]
 
 
 class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include/gsage.h)

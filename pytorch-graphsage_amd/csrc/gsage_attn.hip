@@ -586,7 +586,7 @@ k_attn_merge_bwd(const AttnMergeParams q)
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
         const int64_t m = t / q.D;
         const int c = (int)(t - m * q.D);
-        float v = q.DATT[m * q.ldatt + c];
+        float v = q.DATT ? q.DATT[m * q.ldatt + c] : 0.f;
         if (m < q.r_x && q.DX) v += q.DX[m * q.ldx + c];
         int k = 0;
 #pragma unroll
@@ -594,7 +594,7 @@ k_attn_merge_bwd(const AttnMergeParams q)
             if (j < q.n_hops && m >= q.off[j]) k = j;
         if (k >= 1) {
             const int64_t parent = q.off[k - 1] + (m - q.off[k]) / q.fan[k];
-            v += q.ws[m - q.off[1]] * q.DAGG[parent * q.ldagg + c];
+            v += (q.ws ? q.ws[m - q.off[1]] : 1.f / (float)q.fan[k]) * q.DAGG[parent * q.ldagg + c];
         }
         if (q.H && !(load_as((const TH *)q.H + m * q.ldh + c) > 0.f)) v = 0.f;
         store_as((TO *)q.out + m * q.ldo + c, v);
@@ -613,7 +613,8 @@ k_attn_merge_bwd_v4(const AttnMergeParams q)
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
         const int64_t m = t / D4;
         const int c = (int)(t - m * D4) * 4;
-        f32x4_t v = *reinterpret_cast<const f32x4_t *>(q.DATT + m * q.ldatt + c);
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (q.DATT) v = *reinterpret_cast<const f32x4_t *>(q.DATT + m * q.ldatt + c);
         if (m < q.r_x && q.DX) v += *reinterpret_cast<const f32x4_t *>(q.DX + m * q.ldx + c);
         int k = 0;
 #pragma unroll
@@ -621,7 +622,8 @@ k_attn_merge_bwd_v4(const AttnMergeParams q)
             if (j < q.n_hops && m >= q.off[j]) k = j;
         if (k >= 1) {
             const int64_t parent = q.off[k - 1] + (m - q.off[k]) / q.fan[k];
-            v += q.ws[m - q.off[1]] * *reinterpret_cast<const f32x4_t *>(q.DAGG + parent * q.ldagg + c);
+            v += (q.ws ? q.ws[m - q.off[1]] : 1.f / (float)q.fan[k]) *
+                 *reinterpret_cast<const f32x4_t *>(q.DAGG + parent * q.ldagg + c);
         }
         if (q.H) {
 #pragma unroll
@@ -704,7 +706,7 @@ extern "C" int gsage_attn_merge_bwd2(const void *H, int h_dtype, int64_t ldh, co
                                      int64_t ldo2, void *stream)
 {
     GSAGE_REQUIRE(!out2_bf16 || ldo2 >= D, "attn_merge_bwd: leading dimension too small");
-    GSAGE_REQUIRE(DATT && DAGG && ws && out && off && fan, "attn_merge_bwd: null pointer");
+    GSAGE_REQUIRE(DAGG && out && off && fan, "attn_merge_bwd: null pointer");
     GSAGE_REQUIRE(n_hops >= 2 && n_hops <= 6 && R >= 0 && r_x >= 0 && r_x <= R && D > 0, "attn_merge_bwd: bad sizes");
     GSAGE_REQUIRE((out_dtype == GSAGE_BF16 || out_dtype == GSAGE_F32) && (!H || h_dtype == GSAGE_BF16 || h_dtype == GSAGE_F32),
                   "attn_merge_bwd: bad dtype");

@@ -61,6 +61,14 @@ struct CmdList {
     }
 };
 extern thread_local CmdList *t_recording;
+// gsage_head_n_valid_next(): live-row count(s) for the NEXT head launch of this thread (consumed by it)
+extern thread_local const int32_t *t_head_n_valid;
+inline const int32_t *take_head_n_valid()
+{
+    const int32_t *p = t_head_n_valid;
+    t_head_n_valid = nullptr;
+    return p;
+}
 
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,

@@ -252,9 +252,9 @@ k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
     const int n_gather = (int)gridDim.x - n_side;
     const int bx = (int)blockIdx.x;
     if (bx >= first && bx < first + n_adam)
-        adam_workgroup(a, bx - first, n_adam, red);
+        adam_workgroup<false>(a, bx - first, n_adam, red);
     else if (bx >= first + n_adam && bx < first + n_side)
-        sample_hops_workgroup(h, bx - first - n_adam, frontier);
+        sample_hops_workgroup<false>(h, bx - first - n_adam, frontier);
     else
         gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_side, n_gather);
 }
@@ -453,6 +453,8 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
     HopsParams h = {};
     size_t lds = 0;
     if (hops) {
+        GSAGE_REQUIRE(!hops->dense_adj, "gather_mean_multi_adam: the sampler role walks a CSR; a dense adjacency is sampled "
+                                        "by gsage_sample_hops (a launch of its own)");
         rc = fill_hops(h, lds, *hops);
         if (rc != GSAGE_OK) return rc;
         n_smp = (int)ceil_div(hops->B, HOPS_SPW);

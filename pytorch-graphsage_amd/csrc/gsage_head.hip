@@ -24,6 +24,7 @@ struct HeadParams {
     const int64_t *targets;  // [B] class ids (or [n_batches, B] with batch_idx)
     const int64_t *batch_idx;
     int64_t n_batches;
+    const int32_t *n_valid;  // optional: live rows of the batch (one word, or [n_batches] with batch_idx)
     float *preds;            // [B, C] logits
     void *dE;                // [B, ldd] gradient w.r.t. E (bf16 or fp32)
     float *partial;          // [grid, C*D + C + 1] per-workgroup dW | db | loss
@@ -75,7 +76,10 @@ k_head_ce(const HeadParams p)
     // every global input is requested up front (one memory round trip on the critical path, not
     // one per phase): this wave's row target, the bias, the R embedding rows, then fc.weight
     const int row0 = blockIdx.x * R;
-    const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * p.B : 0);
+    const int64_t bq = p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) : 0;
+    const int64_t *tgt = p.targets + bq * p.B;
+    // rows past Bv are padding (the reference's chunks are not all of one size): no loss, no gradient
+    const int Bv = p.n_valid ? min(max(p.n_valid[bq], 1), p.B) : p.B;
     int64_t my_target[(R + 3) / 4];
 #pragma unroll
     for (int q = 0; q < (R + 3) / 4; ++q) {
@@ -116,7 +120,7 @@ k_head_ce(const HeadParams p)
         for (int r = 0; r < R; ++r) v[r] = (red[r] + red[R + r]) + (red[2 * R + r] + red[3 * R + r]);
     };
 
-    const float invB = 1.f / (float)p.B;
+    const float invB = 1.f / (float)Bv;
     // 1. L2 normalise (F.normalize: x / max(||x||, 1e-12)); rows past B behave as zero rows
     float ss[R], nrm[R];
 #pragma unroll
@@ -159,7 +163,7 @@ k_head_ce(const HeadParams p)
     float acc_db = 0.f, acc_loss = 0.f;
     for (int r = wave; r < R; r += 4) {
         const int i = row0 + r;
-        const bool ok = lane < C && i < p.B;
+        const bool ok = lane < C && i < Bv;
         float logit = -INFINITY;
         if (lane < C)
             logit = part[(0 * R + r) * HEAD_CMAX + lane] + part[(1 * R + r) * HEAD_CMAX + lane] +
@@ -170,8 +174,8 @@ k_head_ce(const HeadParams p)
         const int64_t t = my_target[(r - wave) / 4];
         const float dl = ok ? (ex / den - ((int64_t)lane == t ? 1.f : 0.f)) * invB : 0.f;
         dls[r * HEAD_CMAX + lane] = dl;
-        if (ok) p.preds[(int64_t)i * C + lane] = logit;
-        if (i < p.B && (int64_t)lane == t) acc_loss += -(logit - mx - logf(den));
+        if (lane < C && i < p.B) p.preds[(int64_t)i * C + lane] = logit;
+        if (i < Bv && (int64_t)lane == t) acc_loss += -(logit - mx - logf(den));
         acc_db += dl;                                   // lane c accumulates db[c] over its rows
     }
     __syncthreads();
@@ -322,12 +326,14 @@ k_head_l1_pred(const float *__restrict__ E, int64_t lde, const float *__restrict
 template <typename TD>
 __global__ void __launch_bounds__(256)
 k_head_l1_bwd(const float *__restrict__ E, int64_t lde, const float *__restrict__ W, const float *__restrict__ targets,
-              const float *__restrict__ preds, const float *__restrict__ inv, int32_t B, int32_t D,
-              TD *__restrict__ dE, int64_t ldd, float *__restrict__ partial)
+              const float *__restrict__ preds, const float *__restrict__ inv, int32_t Ball, int32_t D,
+              TD *__restrict__ dE, int64_t ldd, float *__restrict__ partial, const int32_t *__restrict__ n_valid)
 {
     __shared__ float ts[L1_BMAX], dps[L1_ROWS], ivs[L1_ROWS], lss[L1_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * L1_ROWS;
+    // rows past B are padding (n_valid): they enter neither the B x B pairs nor the gradient
+    const int32_t B = n_valid ? min(max(n_valid[0], 1), Ball) : Ball;
     for (int j = tid; j < B; j += 256) ts[j] = targets[j];
     __syncthreads();
     const float scale = 1.f / ((float)B * (float)B);
@@ -351,7 +357,11 @@ k_head_l1_bwd(const float *__restrict__ E, int64_t lde, const float *__restrict_
     // d E_i = (dz_i - z_i <z_i, dz_i>) / ||E_i||, dz_i = dp_i w
     for (int r = wave; r < L1_ROWS; r += 4) {
         const int i = r0 + r;
-        if (i >= B) continue;
+        if (i >= B) {
+            if (i < Ball)                    // padding rows: an explicit zero gradient
+                for (int c = lane; c < D; c += 64) store_out(dE + (int64_t)i * ldd + c, 0.f);
+            continue;
+        }
         const float iv = ivs[r], dp = dps[r];
         float zdz = 0.f;
         for (int c = lane; c < D; c += 64) zdz += (E[(int64_t)i * lde + c] * iv) * (dp * W[c]);
@@ -404,6 +414,7 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
     HeadParams p;
     p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches; p.preds = preds; p.dE = dE;
+    p.n_valid = take_head_n_valid();
     p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = D <= 256 ? 4 : 1;
     p.dE_dtype = dE_dtype;
     const int n_wg = (B + p.rows_per_wg - 1) / p.rows_per_wg;
@@ -443,12 +454,13 @@ int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias
            preds, inv);
     int rc = check_launch("head_l1_pred");
     if (rc != GSAGE_OK) return rc;
+    const int32_t *nv = take_head_n_valid();
     if (dE_dtype == GSAGE_BF16)
         launch(k_head_l1_bwd<uint16_t>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
-               (const float *)inv, (int32_t)B, (int32_t)D, (uint16_t *)dE, ldd, scratch);
+               (const float *)inv, (int32_t)B, (int32_t)D, (uint16_t *)dE, ldd, scratch, nv);
     else
         launch(k_head_l1_bwd<float>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
-               (const float *)inv, (int32_t)B, (int32_t)D, (float *)dE, ldd, scratch);
+               (const float *)inv, (int32_t)B, (int32_t)D, (float *)dE, ldd, scratch, nv);
     return check_launch("head_l1_bwd");
 }
 

@@ -16,7 +16,8 @@
 
 namespace gsage {
 
-// counts: int32 [3][C] = tp | fp | fn
+// counts: int32 [3][C] = tp | fp | fn, then one more: targets outside [0, C) (sklearn would add such a label to
+// the label set; the caller gets the count back and falls back to the host metric instead of dropping it)
 __global__ void __launch_bounds__(256)
 k_metric_counts_cls(const float *__restrict__ logits, int64_t ld, const int64_t *__restrict__ y, int64_t B,
                     int32_t C, int32_t *__restrict__ counts)
@@ -26,16 +27,18 @@ k_metric_counts_cls(const float *__restrict__ logits, int64_t ld, const int64_t 
         const float *row = logits + i * ld;
         int best = 0;
         float bv = row[0];
-        for (int c = 1; c < C; ++c) {           // first maximum wins, like np.argmax
+        for (int c = 1; c < C; ++c) {           // first maximum wins, like np.argmax -- and so does the first NaN
             const float v = row[c];
-            if (v > bv) { bv = v; best = c; }
+            if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }
         }
         const int64_t t = y[i];
-        if (t == best) {
+        if (t < 0 || t >= C) {
+            atomicAdd(counts + 3 * C, 1);
+        } else if (t == best) {
             atomicAdd(counts + best, 1);
         } else {
             atomicAdd(counts + C + best, 1);
-            if (t >= 0 && t < C) atomicAdd(counts + 2 * C + (int)t, 1);
+            atomicAdd(counts + 2 * C + (int)t, 1);
         }
     }
 }
@@ -58,9 +61,10 @@ k_metric_counts_ml(const float *__restrict__ logits, int64_t ld, const TY *__res
     }
 }
 
-// out[0] = micro, out[1] = macro; one workgroup.  present_only: macro over classes with any count
+// out[0] = micro, out[1] = macro, out[2] = targets outside [0, C); one workgroup.  present_only: macro over
+// classes with any count.  Doubles: the reference rounds float64 results to 5 decimals (ujson double_precision).
 __global__ void __launch_bounds__(256)
-k_metric_f1(const int32_t *__restrict__ counts, int32_t C, int present_only, float *__restrict__ out)
+k_metric_f1(const int32_t *__restrict__ counts, int32_t C, int present_only, double *__restrict__ out)
 {
     __shared__ double s_tp[256], s_fp[256], s_fn[256], s_f1[256], s_n[256];
     double tp = 0, fp = 0, fn = 0, f1 = 0, n = 0;
@@ -84,14 +88,15 @@ k_metric_f1(const int32_t *__restrict__ counts, int32_t C, int present_only, flo
     }
     if (threadIdx.x == 0) {
         const double den = 2.0 * s_tp[0] + s_fp[0] + s_fn[0];
-        out[0] = den > 0 ? (float)(2.0 * s_tp[0] / den) : 0.f;
-        out[1] = s_n[0] > 0 ? (float)(s_f1[0] / s_n[0]) : 0.f;
+        out[0] = den > 0 ? 2.0 * s_tp[0] / den : 0.0;
+        out[1] = s_n[0] > 0 ? s_f1[0] / s_n[0] : 0.0;
+        out[2] = (double)counts[3 * C];
     }
 }
 
 // out[0] = mean |a - b| over n elements (one workgroup: the log line of a batch / a fold)
 __global__ void __launch_bounds__(256)
-k_metric_mae(const float *__restrict__ a, const float *__restrict__ b, int64_t n, float *__restrict__ out)
+k_metric_mae(const float *__restrict__ a, const float *__restrict__ b, int64_t n, double *__restrict__ out)
 {
     __shared__ double s[256];
     double acc = 0;
@@ -102,7 +107,7 @@ k_metric_mae(const float *__restrict__ a, const float *__restrict__ b, int64_t n
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = n > 0 ? (float)(s[0] / (double)n) : 0.f;
+    if (threadIdx.x == 0) out[0] = n > 0 ? s[0] / (double)n : 0.0;
 }
 
 __global__ void k_zero_i32(int32_t *p, int32_t n)
@@ -123,13 +128,13 @@ using namespace gsage;
 extern "C" {
 
 int gsage_metric_f1(const float *logits, int64_t ld, const void *targets, int multilabel, int targets_f32,
-                    int64_t ldy, int64_t B, int32_t C, int32_t *counts, float *out, void *stream)
+                    int64_t ldy, int64_t B, int32_t C, int32_t *counts, double *out, void *stream)
 {
     GSAGE_REQUIRE(logits && targets && counts && out, "metric_f1: null pointer");
     GSAGE_REQUIRE(B >= 0 && C >= 1 && ld >= C && (!multilabel || ldy >= C), "metric_f1: bad sizes");
     GSAGE_REQUIRE(multilabel || !targets_f32, "metric_f1: classification targets are int64 class ids");
     hipStream_t s = (hipStream_t)stream;
-    launch(k_zero_i32, dim3(1), dim3(256), 0, s, counts, 3 * C);
+    launch(k_zero_i32, dim3(1), dim3(256), 0, s, counts, 3 * C + 1);
     int rc = check_launch("metric_zero");
     if (rc != GSAGE_OK) return rc;
     if (B > 0) {
@@ -149,7 +154,7 @@ int gsage_metric_f1(const float *logits, int64_t ld, const void *targets, int mu
     return check_launch("metric_f1");
 }
 
-int gsage_metric_mae(const float *y_true, const float *y_pred, int64_t n, float *out, void *stream)
+int gsage_metric_mae(const float *y_true, const float *y_pred, int64_t n, double *out, void *stream)
 {
     GSAGE_REQUIRE(y_true && y_pred && out && n >= 0, "metric_mae: bad arguments");
     launch(k_metric_mae, dim3(1), dim3(256), 0, (hipStream_t)stream, y_true, y_pred, n, out);

@@ -291,7 +291,7 @@ __device__ __forceinline__ void row_replay(const RowAdam &a, int32_t from, int32
                 if (k < k0 || k > k1) continue;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    p.x[e] = adam_update(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay,
+                    p.x[e] = adam_update<true>(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay,
                                          cur.c[2 * k], cur.c[2 * k + 1]);
             }
             t += k1 - k0 + 1;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void row_replay(const RowAdam &a, int32_t from, int32
         const float2 h = hist[t & mask];
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            p.x[e] = adam_update(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay, h.x, h.y);
+            p.x[e] = adam_update<true>(0.f, p.x[e], m.x[e], v.x[e], a.beta1, a.beta2, a.eps, a.weight_decay, h.x, h.y);
     }
 }
 
@@ -363,7 +363,7 @@ __device__ __forceinline__ float rows_pass(const RowAdam &a, const int64_t *__re
                 row_replay<VEC, UNI>(a, old[j] + 1, target - 1, p[j], m[j], v[j]);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    p[j].x[k] = adam_update(g[j].x[k] * coef, p[j].x[k], m[j].x[k], v[j].x[k], a.beta1, a.beta2, a.eps,
+                    p[j].x[k] = adam_update<true>(g[j].x[k] * coef, p[j].x[k], m[j].x[k], v[j].x[k], a.beta1, a.beta2, a.eps,
                                             a.weight_decay, ac.step_size, ac.rsqrt_bc2);
             } else {
                 row_replay<VEC, UNI>(a, old[j] + 1, target, p[j], m[j], v[j]);
@@ -754,7 +754,10 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
 {
     // step_is_current & 2: the caller consumes the gradient here (it is about to be zeroed): do not write the
     // clipped values back (a trainable embedding table: 418 MB of stores per clipped step at Pokec's size)
+    // step_is_current & 4: the deferred-row arithmetic (1-ulp sqrt / reciprocal, gsage_optim_dev.h) instead of
+    // torch.optim.Adam's correctly rounded ones -- for a table whose rows gsage_rows_* may update as well
     const int discard = (step_is_current & 2) != 0;
+    const int replay = (step_is_current & 4) != 0;
     step_is_current &= 1;
     gsage_adam_desc d;
     d.p = p; d.g = g; d.m = m; d.v = v; d.n = n; d.partial = partial; d.lr = lr; d.step = step;
@@ -776,6 +779,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     rc = fill_adam(a, d);
     if (rc != GSAGE_OK) return rc;
     a.discard_clipped = discard;
+    a.replay_math = replay;
     launch(k_adam_clip, dim3(adam_grid(a.n_prep > 0 ? ceil_div(n, 4) : n, 2048)), dim3(256), 0, s, a);
     rc = check_launch("adam_clip");
     if (rc != GSAGE_OK) return rc;

@@ -64,6 +64,8 @@ struct AdamParams {
     int64_t *tick1, *tick2;        // optional counters advanced at kernel start (not read here)
     int64_t inc1, inc2;
     int32_t discard_clipped;       // != 0: the clipped gradient is not written back (the caller zeroes g next)
+    int32_t replay_math;           // != 0: the deferred-row arithmetic (adam_update<true>), for a table whose rows
+                                   // may also be updated by gsage_rows_*: both must produce the same bits
 };
 
 // The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
@@ -83,7 +85,13 @@ __device__ __forceinline__ AdamConsts adam_consts(float lr, float t, float beta1
     return c;
 }
 
-// g: the (clipped) gradient; returns the new parameter, updates m and v in place
+// g: the (clipped) gradient; returns the new parameter, updates m and v in place.
+// REPLAY = false (every dense optimizer path: FlatAdam, the engines' weight buckets): correctly rounded sqrtf and
+// division, i.e. torch.optim.Adam's roundings.  REPLAY = true (gsage_rows_* and the dense update of a table that
+// those kernels may also touch): v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences
+// (~25 instructions each) -- the deferred row updates replay this function once per row and skipped step, which
+// makes them ALU-bound, and the two sides only have to agree WITH EACH OTHER bit for bit.
+template <bool REPLAY>
 __device__ __forceinline__ float adam_update(float g, float p, float &m, float &v, float beta1, float beta2,
                                              float eps, float weight_decay, float step_size, float rsqrt_bc2)
 {
@@ -91,13 +99,17 @@ __device__ __forceinline__ float adam_update(float g, float p, float &m, float &
     if (weight_decay != 0.f) g = g + weight_decay * p;
     m = beta1 * m + (1.f - beta1) * g;
     v = beta2 * v + ((1.f - beta2) * g) * g;
-    // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sqrtf and division (~25 instructions each):
-    // the deferred row updates replay this function once per row and skipped step, which makes it ALU-bound
-    const float denom = __builtin_amdgcn_sqrtf(v) * rsqrt_bc2 + eps;
-    return p - step_size * (m * __builtin_amdgcn_rcpf(denom));
+    if (REPLAY) {
+        const float denom = __builtin_amdgcn_sqrtf(v) * rsqrt_bc2 + eps;
+        return p - step_size * (m * __builtin_amdgcn_rcpf(denom));
+    }
+    const float denom = sqrtf(v) * rsqrt_bc2 + eps;
+    return p - step_size * (m / denom);
 }
 
-// one workgroup of the clip + Adam update: grid-stride slice bx of gx
+// one workgroup of the clip + Adam update: grid-stride slice bx of gx.  REPLAY_OK = false: the caller never sets
+// a.replay_math (k_gather_multi_adam: only the exact arithmetic is compiled in, its registers are the gather role's)
+template <bool REPLAY_OK = true>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
@@ -131,7 +143,9 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float me = m[e], ve = v[e];
-                pn[e] = adam_update(g[e], p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
+                pn[e] = (REPLAY_OK && a.replay_math)
+                    ? adam_update<true>(g[e], p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2)
+                    : adam_update<false>(g[e], p[e], me, ve, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
                 m[e] = me; v[e] = ve;
             }
             reinterpret_cast<v4 *>(a.m)[i] = m;
@@ -157,7 +171,9 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             float g = gv[u] * coef;
             if (clipped) a.g[i] = g;                    // clipped gradient stays visible (p.grad)
             float m = mv[u], v = vv[u];
-            const float pn = adam_update(g, pv[u], m, v, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
+            const float pn = (REPLAY_OK && a.replay_math)
+                ? adam_update<true>(g, pv[u], m, v, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2)
+                : adam_update<false>(g, pv[u], m, v, a.beta1, a.beta2, a.eps, a.weight_decay, step_size, rsqrt_bc2);
             a.m[i] = m;
             a.v[i] = v;
             a.p[i] = pn;
@@ -196,6 +212,7 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.beta2 = d.beta2; a.eps = d.eps; a.weight_decay = d.weight_decay; a.max_norm = d.max_norm;
     a.step_off = d.step_is_current ? 0 : 1;
     a.discard_clipped = 0;
+    a.replay_math = 0;
     return GSAGE_OK;
 }
 

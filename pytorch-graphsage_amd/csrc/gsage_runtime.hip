@@ -14,6 +14,7 @@ namespace gsage {
 static thread_local char t_err[512] = "";
 std::atomic<uint64_t> g_launches{0};
 thread_local CmdList *t_recording = nullptr;
+thread_local const int32_t *t_head_n_valid = nullptr;
 
 void set_error(const char *fmt, ...)
 {
@@ -30,6 +31,12 @@ using namespace gsage;
 extern "C" {
 
 int gsage_abi_version(void) { return GSAGE_ABI_VERSION; }
+
+int gsage_head_n_valid_next(const int32_t *n_valid)
+{
+    t_head_n_valid = n_valid;
+    return GSAGE_OK;
+}
 const char *gsage_last_error(void) { return t_err; }
 uint64_t gsage_launch_count(void) { return g_launches.load(); }
 

@@ -57,6 +57,24 @@ k_sample_philox(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ 
     }
 }
 
+// Dense sampler (reference nn_modules.py:19-49): out[i, j] = adj[ids[i], keep[j]] -- `tmp = adj[ids]; tmp[:, perm]
+// [:, :n]` of the reference without the [M, K] intermediate (and its second gather).  A parent's n samples sit in
+// consecutive lanes: they read n scattered 8-byte words of ONE K * 8-byte row (1 KiB at K = 128, eight lines).
+__global__ void __launch_bounds__(256)
+k_sample_dense(const int64_t *__restrict__ adj, int64_t ld, int64_t n_rows, const int64_t *__restrict__ ids,
+               int64_t total, uint32_t n, const int64_t *__restrict__ keep, int64_t *__restrict__ out,
+               int32_t *err_flag)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        const int64_t i = (total <= 0xffffffffLL) ? (int64_t)((uint32_t)g / n) : g / (int64_t)n;
+        const int64_t j = g - i * (int64_t)n;
+        const int64_t c = keep[j];
+        out[g] = (c < 0 || c >= ld) ? pick_dense(adj, ld, n_rows, -1, 0u, err_flag)
+                                    : pick_dense(adj, ld, n_rows, ids[i], (uint32_t)c, err_flag);
+    }
+}
+
 // two small device-to-device copies in ONE launch (a step's seed ids and targets into the buffers a captured step
 // reads): as hipMemcpyAsync each was a ~7 us blit on the step's stream
 __global__ void __launch_bounds__(256)
@@ -125,16 +143,12 @@ __device__ __forceinline__ void mt_refill(uint32_t *s)
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
-k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t count, int32_t *__restrict__ out)
+// `count` accepted values, in stream order, into out; s = the 624 state words in LDS, idx = position.
+// wave_tot / cut: LDS scratch.  Returns the new position (uniform across the workgroup).
+__device__ __forceinline__ uint32_t mt_fill(uint32_t *s, uint32_t idx, uint32_t top, uint32_t mask, int64_t count,
+                                            int32_t *__restrict__ out, int *wave_tot, int *cut_p)
 {
-    __shared__ uint32_t s[MT_N];
-    __shared__ int wave_tot[4];
-    __shared__ int cut;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int k = t; k < (int)MT_N; k += 256) s[k] = st[k];
-    uint32_t idx = st[MT_N];
-    __syncthreads();
     int64_t produced = 0;
     while (produced < count) {
         if (idx >= MT_N) {
@@ -153,7 +167,7 @@ k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t coun
             if (lane >= o) incl += up;
         }
         if (lane == 63) wave_tot[wave] = incl;
-        if (t == 0) cut = -1;
+        if (t == 0) *cut_p = -1;
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
@@ -164,9 +178,9 @@ k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t coun
         incl += before;
         const int64_t need = count - produced;
         if (acc && (int64_t)incl <= need) out[produced + incl - 1] = (int32_t)v;
-        if (acc && (int64_t)incl == need) cut = t;                 // the word that completes the request
+        if (acc && (int64_t)incl == need) *cut_p = t;              // the word that completes the request
         __syncthreads();
-        const int c = cut;
+        const int c = *cut_p;
         const uint32_t n_here = MT_N - idx < 256u ? MT_N - idx : 256u;
         if ((int64_t)total >= need) {
             idx += (uint32_t)c + 1u;
@@ -176,6 +190,29 @@ k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t coun
             produced += total;
         }
         __syncthreads();                                           // wave_tot / cut are reused
+    }
+    return idx;
+}
+
+// n_seg requests served back to back from ONE stream (n_seg == 1, seg_* null: `count` values into out):
+// request q puts seg_cnt[q] values at out + seg_off[q].  A training epoch's sampler draws are one launch:
+// consecutive np.random.choice calls with the same range consume the stream exactly like this.
+__global__ void __launch_bounds__(256)
+k_mt_choice(uint32_t *__restrict__ st, uint32_t top, uint32_t mask, int64_t count, int32_t *__restrict__ out,
+            const int64_t *__restrict__ seg_off, const int64_t *__restrict__ seg_cnt, int64_t n_seg)
+{
+    __shared__ uint32_t s[MT_N];
+    __shared__ int wave_tot[4];
+    __shared__ int cut;
+    const int t = threadIdx.x;
+    for (int k = t; k < (int)MT_N; k += 256) s[k] = st[k];
+    uint32_t idx = st[MT_N];
+    __syncthreads();
+    if (!seg_off) {
+        idx = mt_fill(s, idx, top, mask, count, out, wave_tot, &cut);
+    } else {
+        for (int64_t q = 0; q < n_seg; ++q)
+            idx = mt_fill(s, idx, top, mask, seg_cnt[q], out + seg_off[q], wave_tot, &cut);
     }
     for (int k = t; k < (int)MT_N; k += 256) st[k] = s[k];
     if (t == 0) st[MT_N] = idx;
@@ -271,6 +308,19 @@ int gsage_sample_csr_sel(const int64_t *rowptr, const int32_t *col, int64_t n_ro
     return check_launch("sample_csr_sel");
 }
 
+int gsage_sample_dense(const int64_t *adj, int64_t ld, int64_t n_rows, const int64_t *ids, int64_t M,
+                       const int64_t *keep, int32_t n, int64_t *out, int32_t *err_flag, void *stream)
+{
+    GSAGE_REQUIRE(n >= 0 && M >= 0 && n_rows >= 0 && ld >= 0, "sample_dense: negative size");
+    if (M == 0 || n == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(adj && ids && keep && out, "sample_dense: null pointer");
+    GSAGE_REQUIRE(n <= ld, "sample_dense: more samples than columns (the reference samples without replacement)");
+    const int64_t total = M * (int64_t)n;
+    launch(k_sample_dense, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, adj, ld, n_rows, ids, total,
+           (uint32_t)n, keep, out, err_flag);
+    return check_launch("sample_dense");
+}
+
 int gsage_sample_csr_philox(const int64_t *rowptr, const int32_t *col, int64_t n_rows,
                             const int64_t *ids, int64_t M, int32_t n, uint32_t max_deg,
                             uint64_t seed, const uint64_t *call_ctr, uint64_t call_base,
@@ -302,7 +352,7 @@ int gsage_sample_hops_philox(const int64_t *rowptr, const int32_t *col, int64_t 
     GSAGE_REQUIRE(fan, "sample_hops_philox: null pointer");
     d.max_deg = max_deg; d.seed = seed; d.call_ctr = call_ctr; d.call_base = call_base; d.rank = rank;
     d.seed_queue = seed_queue; d.batch_idx = batch_idx; d.batch_base = 0; d.n_batches = n_batches;
-    d.err_flag = err_flag; d.sel = nullptr; d.sel_stride = 0;
+    d.err_flag = err_flag; d.sel = nullptr; d.sel_stride = 0; d.dense_adj = nullptr; d.dense_ld = 0;
     return gsage_sample_hops(&d, stream);
 }
 
@@ -371,8 +421,20 @@ int gsage_mt_choice_device(uint32_t *state, int64_t high, int64_t count, int32_t
     }
     const uint32_t top = (uint32_t)(high - 1);
     launch(k_mt_choice, dim3(1), dim3(256), 0, (hipStream_t)stream, state, top, LegacyStream::mask_for(top), count,
-           out);
+           out, (const int64_t *)nullptr, (const int64_t *)nullptr, (int64_t)0);
     return check_launch("mt_choice_device");
+}
+
+int gsage_mt_choice_segments(uint32_t *state, int64_t high, int64_t n_seg, const int64_t *seg_off,
+                             const int64_t *seg_cnt, int32_t *out, void *stream)
+{
+    GSAGE_REQUIRE(state && n_seg >= 0 && (n_seg == 0 || (seg_off && seg_cnt && out)), "mt_choice_segments: null pointer");
+    GSAGE_REQUIRE(high >= 2 && high <= 0x100000000LL, "mt_choice_segments: high must be in [2, 2^32]");
+    if (n_seg == 0) return GSAGE_OK;
+    const uint32_t top = (uint32_t)(high - 1);
+    launch(k_mt_choice, dim3(1), dim3(256), 0, (hipStream_t)stream, state, top, LegacyStream::mask_for(top), (int64_t)0,
+           out, seg_off, seg_cnt, n_seg);
+    return check_launch("mt_choice_segments");
 }
 
 void gsage_mt_permutation(void *mt, int64_t n, int64_t *out)

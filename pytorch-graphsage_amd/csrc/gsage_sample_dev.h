@@ -21,6 +21,35 @@ __device__ __forceinline__ int64_t pick_neighbor(const int64_t *__restrict__ row
     return (int64_t)col[beg + (int64_t)off];
 }
 
+// Dense adjacency (reference nn_modules.py:19-49: UniformNeighborSampler over an int64 [n_rows, K] table whose
+// rows were pre-sampled to exactly K neighbours): neighbour `column` of node id
+__device__ __forceinline__ int64_t pick_dense(const int64_t *__restrict__ adj, int64_t ld, int64_t n_rows,
+                                              int64_t id, uint32_t column, int32_t *err_flag)
+{
+    if ((uint64_t)id >= (uint64_t)n_rows || (int64_t)column >= ld) {     // torch indexing raises IndexError here
+        if (err_flag) *err_flag = 1;
+        return 0;
+    }
+    return adj[id * ld + (int64_t)column];
+}
+
+
+// Either of the two inside the fused multi-hop kernel: a dense row is a CSR row with beg = id * ld, deg = ld
+// (one code path, two selects: the kernel shares its registers with the HBM-bound gather role, gsage_gather.hip)
+__device__ __forceinline__ int64_t pick_any(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                            const int64_t *__restrict__ dense, int64_t dense_ld, int64_t n_rows,
+                                            int64_t id, uint32_t s, int32_t *err_flag)
+{
+    if ((uint64_t)id >= (uint64_t)n_rows) {
+        if (err_flag) *err_flag = 1;
+        return 0;
+    }
+    const int64_t beg = dense ? id * dense_ld : rowptr[id];
+    const int64_t deg = dense ? dense_ld : rowptr[id + 1] - beg;
+    if (deg <= 0) return 0;
+    const uint64_t off = (deg <= 0xffffffffLL) ? (uint64_t)(s % (uint32_t)deg) : (uint64_t)s;
+    return dense ? dense[beg + (int64_t)off] : (int64_t)col[beg + (int64_t)off];
+}
 
 // All hops of a frontier in ONE launch.  A workgroup owns SPW consecutive seeds and walks their
 // whole sub-tree: the children of hop k are produced by the same workgroup that consumes them at
@@ -39,6 +68,8 @@ struct HopsParams {
     int64_t batch_base;           // added to *batch_idx (sampling AHEAD of the counters, see k_gather_multi_adam)
     const int32_t *sel;           // optional: caller-supplied sel [hop 1 | hop 2 | ...] instead of Philox
     int64_t sel_stride;           // with a seed queue: sel of batch b starts at sel + b * sel_stride
+    const int64_t *dense_adj;     // optional: dense [n_rows, dense_ld] adjacency instead of the CSR; sel then holds the
+    int64_t dense_ld;             // columns every parent of a hop keeps: [fan[1] of hop 1 | fan[2] of hop 2 | ...]
     int64_t n_rows;
     int64_t off[6];               // first element of hop k in ids
     uint64_t g0[6];               // global sample index of this rank's first sample of hop k
@@ -52,7 +83,10 @@ constexpr int HOPS_SPW = 1;       // seeds per workgroup: hop 2 of a 25x10 front
                                   // 250 lanes, so a seed's whole sub-tree costs two dependent
                                   // (rowptr -> col) round trips
 
-// frontier: two ping-pong LDS buffers of the widest hop; wg: which group of HOPS_SPW seeds
+// frontier: two ping-pong LDS buffers of the widest hop; wg: which group of HOPS_SPW seeds.
+// DENSE_OK = false compiles the dense-adjacency mode out: k_gather_multi_adam (gsage_gather.hip) runs this body
+// beside the HBM-bound gather role under a 72-VGPR cap it already sits on -- two more live values spill.
+template <bool DENSE_OK = true>
 __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int wg, int64_t *frontier)
 {
     const int seed0 = wg * HOPS_SPW;
@@ -83,10 +117,16 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
         const int64_t count = per_seed * nseed;
         const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
         const int64_t local0 = (int64_t)seed0 * per_seed;             // first sample of this WG in hop k
+        // dense sampler: ONE column permutation per sampler call, shared by every parent of the hop
+        // (nn_modules.py:44-48): sample j of a parent reads column keep_k[j], keep_k = sel[kbase ..]
+        int64_t kbase = 0;
+        if (DENSE_OK)
+            for (int q = 1; q < k; ++q) kbase += p.fan[q];
+        const bool dense = DENSE_OK && p.dense_adj != nullptr;
         for (int64_t t = threadIdx.x; t < count; t += 256) {
             uint32_t s;
             if (sel) {               // parity level 1: the reference's own draws (nn_modules.py:88), replayed
-                s = (uint32_t)sel[p.off[k] - p.off[1] + local0 + t];
+                s = (uint32_t)sel[dense ? kbase + (int64_t)((uint32_t)t % n) : p.off[k] - p.off[1] + local0 + t];
             } else {
                 const uint64_t g = p.g0[k] + (uint64_t)(local0 + t);
                 const uint64_t blk = g >> 2;
@@ -97,7 +137,9 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
                 s = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
             }
             const int64_t parent = cur[(uint32_t)t / n];
-            const int64_t v = pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
+            const int64_t v = DENSE_OK
+                ? pick_any(p.rowptr, p.col, p.dense_adj, p.dense_ld, p.n_rows, parent, s, p.err_flag)
+                : pick_neighbor(p.rowptr, p.col, p.n_rows, parent, s, p.err_flag);
             nxt[t] = v;
             p.ids[p.off[k] + local0 + t] = v;
         }
@@ -111,7 +153,9 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
 // [host] validate a gsage_hops_desc and turn it into kernel parameters + dynamic LDS bytes
 inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
 {
-    GSAGE_REQUIRE(d.rowptr && d.col && d.ids, "sample_hops_philox: null pointer");
+    GSAGE_REQUIRE(d.ids && ((d.rowptr && d.col) || d.dense_adj), "sample_hops_philox: null pointer");
+    GSAGE_REQUIRE(!d.dense_adj || (d.sel && d.dense_ld > 0),
+                  "sample_hops: a dense adjacency needs the kept columns in `sel` and its leading dimension");
     GSAGE_REQUIRE(!d.seed_queue || (d.batch_idx && d.n_batches > 0), "sample_hops_philox: bad seed queue");
     GSAGE_REQUIRE(d.n_hops >= 1 && d.n_hops <= 5, "sample_hops_philox: 1..5 hops");
     GSAGE_REQUIRE(d.B >= 0 && d.B < (1LL << 31) && d.max_deg > 0, "sample_hops_philox: bad sizes");
@@ -119,6 +163,7 @@ inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
     p.seed_queue = d.seed_queue; p.batch_idx = d.batch_idx; p.n_batches = d.n_batches;
     p.batch_base = d.batch_base;
     p.sel = d.sel; p.sel_stride = d.sel ? d.sel_stride : 0;
+    p.dense_adj = d.dense_adj; p.dense_ld = d.dense_adj ? d.dense_ld : 0;
     GSAGE_REQUIRE(!d.sel || d.sel_stride >= 0, "sample_hops: bad sel stride");
     p.n_rows = d.n_rows; p.call_base = d.call_base; p.n_hops = d.n_hops; p.B = (int32_t)d.B;
     p.max_deg = d.max_deg;

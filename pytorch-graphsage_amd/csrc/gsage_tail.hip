@@ -43,6 +43,7 @@ struct TailParams {
     const int64_t *targets;
     const int64_t *batch_idx;
     int64_t n_batches;
+    const int32_t *n_valid;  // optional: live seeds of the batch (one word, or [n_batches] with batch_idx)
     void *agg;               // out: T [B, 256] neighbour means (A operand of this level's K5b)
     void *dE;                // out: T [B, 256] d loss / d emb   (dC operand of this level's K5b)
     float *preds;            // out: [B, C] logits
@@ -226,7 +227,10 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     const int64_t B = p.B;
 
     // ---- 0. every request that depends on nothing, all in flight together -------------------------
-    const int64_t *tgt = p.targets + (p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) * B : 0);
+    const int64_t bq = p.batch_idx ? (int64_t)((uint64_t)*p.batch_idx % (uint64_t)p.n_batches) : 0;
+    const int64_t *tgt = p.targets + bq * B;
+    // seeds past Bv are padding (the reference's chunks are not all of one size): no loss, no gradient
+    const int64_t Bv = p.n_valid ? (int64_t)min(max(p.n_valid[bq], 1), (int32_t)B) : B;
     const int64_t iw = row0 + wave;               // this wave's seed
     const bool live = iw < B;
     const int64_t iwc = live ? iw : B - 1;        // clamped: loads stay unconditional
@@ -377,7 +381,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     };
 
     // ---- 3. head: normalise, fc, softmax cross-entropy, gradients (k_head_ce body, KPT = 1) --------
-    const float invB = 1.f / (float)B;
+    const float invB = 1.f / (float)Bv;
     float z[R], ss[R], nrm[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) ss[r] = e[r] * e[r];
@@ -419,7 +423,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     {
         const int r = wave;                                   // R == 4 waves: wave r <-> row r
         const int64_t i = row0 + r;
-        const bool ok = lane < C && i < B;
+        const bool ok = lane < C && i < Bv;
         float logit = -INFINITY;
         if (lane < C)
             logit = part[(0 * R + r) * TAIL_CMAX + lane] + part[(1 * R + r) * TAIL_CMAX + lane] +
@@ -429,10 +433,10 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
         const float den = tail_wave_sum(ex);
         const float dl = ok ? (ex / den - ((int64_t)lane == my_target ? 1.f : 0.f)) * invB : 0.f;
         dls[r * TAIL_CMAX + lane] = dl;
-        if (ok) p.preds[i * C + lane] = logit;
+        if (lane < C && i < B) p.preds[i * C + lane] = logit;
         const int tl = (my_target >= 0 && my_target < C) ? (int)my_target : 0;
         const float lt = __shfl(logit, tl, 64);                   // the target's logit (wave-uniform index)
-        if (lane == 0) lss[r] = (i < B && my_target >= 0 && my_target < C) ? -(lt - mx - logf(den)) : 0.f;
+        if (lane == 0) lss[r] = (i < Bv && my_target >= 0 && my_target < C) ? -(lt - mx - logf(den)) : 0.f;
     }
     lds_barrier();
     float dz[R], zdz[R];
@@ -623,6 +627,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     TailParams p;
     p.H = H; p.w2 = w2; p.w2t = w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
+    p.n_valid = take_head_n_valid();
     p.agg = agg; p.dE = dE; p.preds = preds; p.dH = dH;
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
     TailGather tg = {};

@@ -1,0 +1,1124 @@
+"""
+engine/common.py -- what the three fused train-step engines share: flat parameter / gradient / Adam buckets
+(the model's Parameters become views), frontier geometry, the fused multi-hop sampler's descriptor, the
+classification head, gradient finalisation + clip + Adam, recording into native command lists or hipGraphs,
+the device-resident batch queue with its one-batch-ahead software pipeline, the data-parallel order around
+the ONE gradient all-reduce, and the Adam-state hand-back to `GSSupervised.train_step`.
+
+The aggregator-specific parts (per-level operands, forward / backward launches, which rows are gathered
+ahead) live in mean.py / pool.py / attn.py: subclasses implement `why_not`, `_init_levels`, `_init_reduce`,
+`_stage_gather`, `_stage_compute` and `_backward_levels`.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import ops
+from ..nn_modules import IdentityPrep, NodeEmbeddingPrep, SparseUniformNeighborSampler, UniformNeighborSampler, \
+    _split_activation, concat_combine
+from ..store import FeatureStore
+
+
+class _ReduceDesc(ctypes.Structure):         # mirrors gsage_reduce_desc (include/gsage.h)
+    _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("out_off", ctypes.c_int64),
+                ("S", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("ld", ctypes.c_int32)]
+
+
+class _PrepDesc(ctypes.Structure):           # mirrors gsage_prep_desc (include/gsage.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_ld", ctypes.c_int32),
+                ("dst_t_ld", ctypes.c_int32), ("dst_p", ctypes.c_void_p), ("kc_p", ctypes.c_int64),
+                ("dst_f32", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def _r8(v):
+    return (v + 63) // 64 * 64          # whole 128-byte bf16 lines: enables the LDS-DMA GEMM path
+
+
+class _ListRunner(object):
+    """hipGraph-like handle over a native command list: replay() issues it on the current stream."""
+
+    def __init__(self, cl):
+        self.cl = cl
+
+    def replay(self):
+        self.cl.replay(ops._stream())
+
+
+def _r64(v):
+    return (int(v) + 63) // 64 * 64
+
+
+class FusedTrainStep(object):
+    """train_step (reference models.py:97-104) without autograd below the loss and without framework glue
+    kernels: the machinery common to the mean / pool / attention engines (see the module docstring).
+
+    The arithmetic is that of GSSupervised.train_step.  Parameters and gradients live in flat fp32
+    buckets; the model's Parameters become views of them, so `model.state_dict()`, evaluation and
+    checkpointing keep working.  `__call__(ids, targets)` has the contract of train_step;
+    `load_epoch()` + `step_queue()` walk a device-resident queue of seed batches with no host copies."""
+
+    MEAN_ENGINE = False       # FusedMeanTrainStep only: seed-level kernel, split mode, gathers split around the exchange
+    ROW_HIST = 1 << 15        # updates whose constants are kept for deferred table rows (sync_rows() before it wraps)
+
+    # ---- which (model, feature store) pairs an engine covers ----------------------------------------
+    @classmethod
+    def why_not(cls, model, feats):
+        """None when this engine covers (model, feats), else one sentence saying what it does not cover."""
+        raise NotImplementedError
+
+    @classmethod
+    def supports(cls, model, feats):
+        return cls.why_not(model, feats) is None
+
+    @staticmethod
+    def _why_not_common(model, feats, agg_types, what):
+        """The checks every engine shares: one aggregator family with the stock concat, ReLU on all but the last
+        layer, a sampler whose frontier the fused K1 can produce."""
+        layers = list(model.agg_layers.children())
+        if not layers or {type(l) for l in layers} not in [{t} for t in agg_types]:
+            return "the layers are not all %s aggregators" % what
+        if not all(l.combine_fn is concat_combine for l in layers):
+            return "a combine_fn other than the concat"
+        codes = [_split_activation(l.activation)[0] for l in layers]
+        if codes[:-1] != [nat.ACT_RELU] * (len(layers) - 1) or codes[-1] != nat.ACT_NONE:
+            return "activations other than ReLU on the hidden layers and identity on the last (train.py:105-118)"
+        s = model.train_sampler
+        if isinstance(s, SparseUniformNeighborSampler):
+            if s.rng not in ("philox", "compat"):
+                return "an unknown sampler rng mode %r" % (s.rng,)
+        elif isinstance(s, UniformNeighborSampler):
+            if not (torch.is_tensor(s.adj) and s.adj.is_cuda):
+                return "a dense adjacency that is not on the GPU"
+        else:
+            return "a sampler class the fused K1 does not know (%s)" % type(s).__name__
+        return None
+
+    @staticmethod
+    def _why_not_input(model, feats):
+        """Level-0 rows: an identity prep over a FeatureStore in HBM, or the trainable node-embedding prep without
+        features (BASELINE configs[3] / utils/pokec.sh: nn_modules.py:126-155)."""
+        if isinstance(model.prep, NodeEmbeddingPrep):
+            if feats is not None or model.prep.input_dim:
+                return "a node-embedding prep concatenated with features"
+            if model.prep.embedding_dim % 8 != 0 or not model.prep.embedding.weight.is_cuda:
+                return "an embedding width that is not a multiple of 8, or a table that is not in HBM"
+            return None
+        if not isinstance(model.prep, IdentityPrep):
+            return "a prep class other than identity / node_embedding (%s)" % type(model.prep).__name__
+        if not isinstance(feats, FeatureStore):
+            return "features that are not a FeatureStore"
+        if feats.dtype not in (torch.bfloat16, torch.float32) or not feats.is_cuda:
+            return "a feature table that is not bf16 / fp32 in HBM"
+        return None
+
+    def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
+                 warmup=2, pipelined=False, gather_cus=None):
+        """gather_cus (queue mode, single GPU, command lists): run the weight-independent half of the step
+        -- sampling of batch i+2 and the level-0 gathers of batch i+1 -- on a stream restricted to that many
+        compute units while the forward / backward / update chain of batch i runs on a stream restricted
+        to the others (see _split_* below).  None: GSAGE_GATHER_CUS from the environment, else off."""
+        if not type(self).supports(model, feats):
+            raise ValueError("%s does not cover this (model, feature store): %s"
+                             % (type(self).__name__, type(self).why_not(model, feats)))
+        if not (torch.is_tensor(example_ids) and example_ids.is_cuda and example_ids.dtype == torch.int64
+                and example_ids.dim() == 1):
+            raise ValueError("example_ids must be a CUDA int64 vector of seed ids (one batch)")
+        if not (torch.is_tensor(example_targets) and example_targets.is_cuda
+                and int(example_targets.shape[0]) == int(example_ids.shape[0])):
+            raise ValueError("example_targets must be a CUDA tensor with one row per seed")
+        if gather_cus is None:
+            gather_cus = int(os.environ.get("GSAGE_GATHER_CUS", "0"))
+        self.gather_cus = int(gather_cus) if (ddp is None and not pipelined and self.MEAN_ENGINE) else 0
+        self._init_common(model, feats, loss_fn, example_ids, example_targets, ddp, pipelined)
+        self._init_levels(example_ids, example_targets)
+        self._init_head(loss_fn, example_targets)
+        self._init_reduce()
+        self._finish_init(capture, warmup)
+
+    # ---- construction, in five steps (subclasses override the aggregator-specific ones) -----------
+    def _init_common(self, model, feats, loss_fn, example_ids, example_targets, ddp, pipelined):
+        """Everything that does not depend on the aggregator: exchange op, frontier geometry, flat
+        parameter / gradient / Adam buckets (Parameters become views), device counters."""
+        self.model, self.store, self.loss_fn, self.ddp = model, feats, loss_fn, ddp
+        # pipelined: batch k+1's sampling + gathers (which do not depend on the weights) run on a
+        # second graph branch WHILE batch k's GEMMs / backward / Adam run; results are identical
+        # to the sequential order, `__call__` then returns the predictions of the previous batch.
+        self.pipelined = bool(pipelined)
+        self.nset = 2 if self.pipelined else 1
+        # trainable node-embedding prep: the level-0 rows are weights (computed per step from the current table)
+        self.emb = isinstance(model.prep, NodeEmbeddingPrep)
+        self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1"
+        assert not (self.emb and ddp is not None), \
+            "the embedding-prep engines are single-GPU (data-parallel runs use the module path)"
+        self._front_ready, self._qstep = False, 0
+        self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        self._tail_gather, self._tail_rows = None, 0
+        self._reduce_op = None
+        if ddp is not None:
+            # averaging inside the collective saves a launch; fall back to divide-then-sum where
+            # the backend has no AVG
+            self._reduce_op = torch.distributed.ReduceOp.AVG
+            try:
+                probe = torch.ones(8, device=next(model.parameters()).device)
+                torch.distributed.all_reduce(probe, op=self._reduce_op)
+                if abs(float(probe[0]) - 1.0) > 1e-6:
+                    raise RuntimeError("AVG returned %r" % float(probe[0]))
+            except Exception:
+                self._reduce_op = torch.distributed.ReduceOp.SUM
+        dev = feats.device if feats is not None else next(model.parameters()).device
+        self.dev = dev
+        # storage type of features, activations and weight operand copies
+        self.tdt = feats.dtype if feats is not None else ops.torch_dtype()
+        self.code = nat.BF16 if self.tdt == torch.bfloat16 else nat.F32
+        self.esz = 2 if self.tdt == torch.bfloat16 else 4
+        self.sel, self.sel_queue = None, None     # caller-supplied sampler draws (set_sel / load_epoch)
+        self.layers = list(model.agg_layers.children())
+        L = self.L = len(self.layers)
+        self.post = _split_activation(self.layers[-1].activation)[1]
+        self.fan = [1] + [fn.keywords["n_samples"] for fn in model.train_sample_fns]
+        B = self.B = int(example_ids.shape[0])
+        self.size = [B]
+        for k in range(1, L + 1):
+            self.size.append(self.size[-1] * self.fan[k])
+        self.off = [0]
+        for k in range(L + 1):
+            self.off.append(self.off[-1] + self.size[k])          # off[k] = first row of hop k
+        self.sampler = model.train_sampler
+        self.csr = self.sampler.csr(dev)          # store.DeviceCSR, or store.DenseAdj for the dense sampler
+        # where the sampler's draws come from:
+        #   philox  in-kernel counter RNG (throughput runs)
+        #   compat  numpy's legacy MT19937 stream, consumed ON THE DEVICE in the reference's order: the frontier is
+        #           bit-identical to the eager compat run and to the reference (queue mode: load_epoch fills the
+        #           epoch's draws with gsage_mt_choice_device; per call: one k_mt_choice launch per hop)
+        #   dense   the reference's default sampler: one torch.randperm per sampler call, its head = the columns
+        #           every parent keeps (nn_modules.py:43-49)
+        self.dense = isinstance(self.sampler, UniformNeighborSampler)
+        self.draws = "dense" if self.dense else self.sampler.rng
+        assert not (self.pipelined and self.draws != "philox"), \
+            "pipelined=True keeps two batches in flight: only the counter-based sampler can run ahead of the host"
+        # number of int32 draws one batch's frontier consumes
+        self.n_sel = sum(self.fan[1:]) if self.dense else self.off[L + 1] - self.off[1]
+        if self.draws != "philox":
+            self.sel = torch.zeros(self.n_sel, dtype=torch.int32, device=dev)
+        self._sel_user = False                    # set_sel(): the caller's draws win over the engine's own
+        # live seeds of the batch (<= B): the reference's `iterate` yields near-equal chunks, never exactly
+        # batch_size (problem.py:141-153), so a batch may be one seed short of the recorded geometry.  Padded seeds
+        # run through the forward like any other; the head gives them no loss and no gradient (n_valid).
+        self.n_valid = torch.full((1,), B, dtype=torch.int32, device=dev)
+        self._nv_host, self.nv_queue = B, None
+        self.off_host = (ctypes.c_int64 * 6)(*([int(v) for v in self.off[:L + 1]] + [0] * (5 - L)))
+        self.fan_host = (ctypes.c_int32 * 6)(*([int(v) for v in self.fan[:L + 1]] + [1] * (5 - L)))
+
+        # ---- flat parameter / gradient / Adam buckets; Parameters become views ----------------
+        settle = getattr(model, "_settle_rows", None)
+        if settle is not None:                    # an earlier engine's deferred table rows (sync_rows)
+            settle()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        sizes = [p.numel() for p in self.params]
+        self.poff = [0]
+        for n in sizes:
+            self.poff.append(self.poff[-1] + n)
+        total = self.poff[-1]
+        self.flat_p = torch.cat([p.detach().reshape(-1).float() for p in self.params]).contiguous()
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros_like(self.flat_g)
+        self.flat_v = torch.zeros_like(self.flat_g)
+        for p, o, n in zip(self.params, self.poff, sizes):
+            p.data = self.flat_p[o:o + n].view_as(p)
+            p.grad = self.flat_g[o:o + n].view_as(p)
+        self.pidx = {id(p): i for i, p in enumerate(self.params)}
+        import weakref
+        model._engine = weakref.ref(self)          # models.py hands the Adam state back through this
+        self.step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr = torch.tensor([float(model.lr)], dtype=torch.float32, device=dev)
+        self.wd = float(model.optimizer.param_groups[0].get("weight_decay", 0.0))
+        self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.preds = None
+        self.n_calls = 0
+        # optional device-resident batch queue (load_epoch): the graph then needs no per-step copies
+        self.queue = None
+        self._q_ids = None                            # frontier of the batch a queue-mode compute stage works on
+        self.batch_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.ids_set = [torch.zeros(self.off[L + 1], dtype=torch.int64, device=dev) for _ in range(self.nset)]
+        self.tg_set = [example_targets.clone() for _ in range(self.nset)]
+        self.ids_set[0][:B].copy_(example_ids)
+
+
+    def _will_fuse_head(self, example_targets):
+        from ..problem import ProblemLosses
+        C, D2 = self.model.fc.weight.shape
+        probe = torch.randn(3, 4, device=self.dev)
+        ident = self.post is None or torch.equal(self.post(probe), probe)
+        return bool(self.loss_fn is ProblemLosses.classification and ident and C <= 64 and D2 <= 1024 and
+                    example_targets.dtype == torch.int64)
+
+    def _init_head(self, loss_fn, example_targets):
+        """Classification head as one fused kernel pair when it applies (else stock torch autograd)."""
+        model, dev, L, B = self.model, self.dev, self.L, self.B
+        C, D2 = model.fc.weight.shape
+        self.fused_head = self._will_fuse_head(example_targets)
+        self.fused_tail = bool(self._will_fuse_tail(example_targets))
+        if self.fused_head:
+            assert nat.lib().gsage_head_ce_scratch(B, C, D2) == nat.lib().gsage_mean_tail_ce_scratch(B, C) \
+                or not self.fused_tail
+            self.head_scratch = torch.zeros(nat.lib().gsage_head_ce_scratch(B, C, D2),
+                                            dtype=torch.float32, device=dev)
+            self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.preds = torch.zeros(B, C, dtype=torch.float32, device=dev)
+        # the regression head of the Pokec problem (F.l1_loss with the reference's [B,1]-vs-[B] broadcast) as one kernel
+        from ..problem import ProblemLosses
+        probe = torch.randn(3, 4, device=self.dev)
+        ident = self.post is None or torch.equal(self.post(probe), probe)
+        self.fused_l1 = bool(self.loss_fn is ProblemLosses.regression_mae and C == 1 and ident and self.B <= 2048 and
+                             example_targets.dtype == torch.float32 and example_targets.numel() == self.B and
+                             self.B > 1 and os.environ.get("GSAGE_TORCH_HEAD", "0") != "1")
+        if self.fused_l1:
+            self.preds = torch.zeros(self.B, 1, dtype=torch.float32, device=self.dev)
+
+    def _install_reduce(self, rdesc):
+        """Append the head's gradient source, check that every parameter is covered, upload."""
+        model, dev = self.model, self.dev
+        f32 = torch.float32
+        Cc, D2c = model.fc.weight.shape
+        ifc = self.pidx[id(model.fc.weight)]
+        assert self.pidx[id(model.fc.bias)] == ifc + 1
+        if self.fused_head:
+            width = Cc * D2c + Cc + 1
+            rdesc.append(_ReduceDesc(self.head_scratch.data_ptr(), width, self.poff[ifc],
+                                     self.head_scratch.numel() // width, 1, Cc * D2c + Cc, width))
+        elif self.fused_l1:                               # gsage_head_l1: one partial row [dW | db | loss] per 16 seeds
+            width, n_wg = D2c + 2, (self.B + 15) // 16
+            self.l1_scratch = torch.zeros(nat.lib().gsage_head_l1_scratch(self.B, D2c), dtype=f32, device=dev)
+            rdesc.append(_ReduceDesc(self.l1_scratch.data_ptr(), width, self.poff[ifc], n_wg, 1, D2c + 1, width))
+        else:
+            self.head_stage = torch.zeros(Cc * D2c + Cc, dtype=f32, device=dev)
+            rdesc.append(_ReduceDesc(self.head_stage.data_ptr(), 0, self.poff[ifc], 1, 1, Cc * D2c + Cc,
+                                     Cc * D2c + Cc))
+        covered = sum(d.rows * d.cols for d in rdesc)
+        uncovered = int(self.table.numel()) if self.emb else 0     # the scatter-added embedding table
+        assert covered + uncovered == self.flat_p.numel(), "every parameter must be covered by a gradient source"
+        self.rdescs = torch.frombuffer(bytearray(bytes((_ReduceDesc * len(rdesc))(*rdesc))),
+                                       dtype=torch.uint8).to(dev)
+        self.n_rdesc = len(rdesc)
+        self.r_max = max(d.rows * d.cols for d in rdesc)
+        self.n_partial = nat.lib().gsage_finalize_partials(self.n_rdesc, self.r_max)
+        self.partial = torch.zeros(max(self.n_partial, self.partial.numel()), dtype=f32, device=dev)
+        self.refresh_weights()
+
+    def _finish_init(self, capture, warmup):
+        ddp = self.ddp
+        # warm-up (library handles, allocator) with state restored afterwards, then capture
+        saved = self.flat_p.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._run_sequential(0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.flat_p.copy_(saved)
+        for t in (self.flat_m, self.flat_v, self.step, self.counter) + tuple(getattr(self, "_warm_reset", ())):
+            t.zero_()
+        self.refresh_weights()
+        torch.cuda.synchronize()
+        self.g_main, self.g_opt, self.g_front = None, None, None
+        # pipelined mode runs the two stages on two streams (two hardware queues): parallel
+        # branches inside ONE hipGraph were measured to be serialised by the runtime.
+        self.s_front = torch.cuda.Stream() if self.pipelined else None
+        self.s_back = torch.cuda.Stream() if self.pipelined else None
+        self.ev_front = [torch.cuda.Event() for _ in range(self.nset)]
+        self.ev_back = [torch.cuda.Event() for _ in range(self.nset)]
+        # capture: False = eager launches from Python; "cmdlist" (or True) = native command lists
+        # (include/gsage.h: recorded launches replayed by one C call, no device-side start-up gap);
+        # "graph" = hipGraphs.
+        self.capture_mode = {True: "cmdlist", False: None, None: None}.get(capture, capture)
+        assert self.capture_mode in (None, "cmdlist", "graph")
+        if self.capture_mode == "cmdlist" and not self.fused_head:
+            self.capture_mode = "graph"              # the stock-torch head cannot be recorded
+        self._pool = None
+        if self.capture_mode:
+            self._record_main()
+        torch.cuda.synchronize()
+
+    def _record_main(self):
+        """(Re-)record the per-call command lists / graphs of __call__."""
+        ddp = self.ddp
+        if self.capture_mode == "graph":
+            # re-recording: let go of the old hipGraphs (and their private pool) before capturing new ones
+            self.g_main, self.g_opt, self.g_front, self._pool = None, None, None, None
+            torch.cuda.synchronize()
+        self.g_main = []
+        if self.pipelined:
+            self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
+                            for st_ in range(2)]
+
+        def main(st_):
+            if not self.pipelined:
+                self._stage_sample_gather(0)
+            self._stage_compute(st_)
+            if ddp is None:
+                self._stage_opt()
+        for st_ in range(self.nset):
+            self.g_main.append(self._record(lambda st_=st_: main(st_),
+                                            self.s_back if self.pipelined else None))
+        if ddp is not None:
+            self.g_opt = self._record(self._stage_opt, self.s_back if self.pipelined else None)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _record(self, fn, stream=None):
+        """Record the launches of fn() once; returns an object whose replay() re-issues them on the
+        current stream (command list) or on the capture stream (hipGraph)."""
+        if self.capture_mode == "cmdlist":
+            with nat.CommandList.record() as cl:
+                fn()
+            return _ListRunner(cl)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool, stream=stream):
+            fn()
+        self._pool = g.pool()
+        return g
+
+    def refresh_weights(self):
+        """Rebuild the bf16 operand copies from the fp32 Parameters.  Adam keeps them current;
+        call this after changing the weights from outside (load_state_dict, manual edits)."""
+        nat.check(nat.lib().gsage_prep_weights(self.descs.data_ptr(), self.n_desc, self.max_elems,
+                                               None, 0, None, 0, ops._stream()), "prep_weights")
+
+    # ---- optimizer state for whoever trains next / writes a checkpoint -----------------------------
+    def holds_parameters(self):
+        """True while the model's Parameters still are views of this engine's flat bucket."""
+        base, es = self.flat_p.data_ptr(), 4
+        return all(p.data_ptr() == base + o * es for p, o in zip(self.params, self.poff))
+
+    def _settled(self):
+        self.sync_rows()
+
+    def optimizer_state_dict(self):
+        """torch.optim.Adam's format (as optim.FlatAdam.state_dict): the engine's exp_avg / exp_avg_sq / step."""
+        self._settled()
+        state, n = {}, int(self.step.item())
+        if n > 0:
+            step = torch.tensor(float(n))
+            for i, (p, o) in enumerate(zip(self.params, self.poff)):
+                k = p.numel()
+                state[i] = {"step": step.clone(), "exp_avg": self.flat_m[o:o + k].view_as(p).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + k].view_as(p).clone()}
+        g = self.model.optimizer.param_groups[0]
+        group = {k: v for k, v in g.items() if k != "params"}
+        group.update({"lr": float(self.lr.item()), "weight_decay": self.wd, "params": list(range(len(self.params)))})
+        return {"state": state, "param_groups": [group]}
+
+    def export_optimizer_state(self, flat_adam):
+        """Copy exp_avg / exp_avg_sq / the step count into an optim.FlatAdam over the same Parameters (models.py
+        calls this when GSSupervised.train_step takes over from the engine: Adam's bias correction and moments
+        continue instead of restarting)."""
+        assert [p.numel() for p in flat_adam.params] == [p.numel() for p in self.params], \
+            "export_optimizer_state: different parameter lists"
+        self._settled()
+        flat_adam.flat_m.copy_(self.flat_m)
+        flat_adam.flat_v.copy_(self.flat_v)
+        flat_adam.step_count.copy_(self.step)
+
+    def _grad_slice(self, prm):
+        i = self.pidx[id(prm)]
+        return self.flat_g[self.poff[i]:self.poff[i + 1]]
+
+    def _linear(self, A, lda, a_rows, a_g0, W, ldw, C, c_dtype, ldc, M, N, K, act, a_gs, w_gs, c_gs):
+        ops._linear_launch(A, lda, a_rows, a_g0, W, ldw, None, C, ldc, M, N, K, act, 2, a_gs, w_gs,
+                           c_gs, self.code, c_dtype)
+
+    # ---- stages (each is a sequence of kernel launches on the current stream) ---------------
+    def _hops_desc(self, ids, ahead, counters=None):
+        """gsage_hops_desc that samples a whole frontier into `ids`; ahead=True: the batch AFTER the
+        one the device counters point at (call_base / batch_base offsets, the counters themselves
+        are not touched).  counters: (philox call counter, batch index) to read instead of the step's own."""
+        L = self.L
+        ctr, bidx = counters if counters is not None else (self.counter, self.batch_idx)
+        d = nat.HopsDesc()
+        if self.dense:
+            d.dense_adj, d.dense_ld, d.n_rows = self.csr.adj.data_ptr(), self.csr.K, self.csr.n_rows
+        else:
+            d.rowptr, d.col, d.n_rows = self.csr.rowptr.data_ptr(), self.csr.col.data_ptr(), self.csr.n_rows
+        d.ids, d.B, d.n_hops = ids.data_ptr(), self.B, L
+        for k in range(5):
+            d.fan[k] = int(self.fan[k + 1]) if k < L else 1
+        d.max_deg, d.seed = self.csr.max_deg, int(getattr(self.sampler, "seed", 0))
+        d.call_ctr, d.call_base = ctr.data_ptr(), (L if ahead else 0)
+        d.rank = getattr(self.sampler, "shard", (0, 1))[0]
+        d.seed_queue = self.queue[0].data_ptr() if self.queue else None
+        d.batch_idx = bidx.data_ptr() if self.queue else None
+        d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
+        d.err_flag = self.csr.err_flag.data_ptr()
+        if self.queue and self.sel_queue is not None:
+            d.sel, d.sel_stride = self.sel_queue.data_ptr(), int(self.sel_queue.shape[1])
+        elif self.sel is not None:
+            d.sel, d.sel_stride = self.sel.data_ptr(), 0
+        return d
+
+    def _hop_draw_counts(self, b):
+        """[(offset into a batch's draws, number of draws)] per hop for a batch of b live seeds: the reference's
+        sampler call of hop k draws b * fan_1 ... fan_k values (sparse, nn_modules.py:88) -- padded seeds draw none."""
+        out, live = [], b
+        for k in range(1, self.L + 1):
+            live *= self.fan[k]
+            out.append((self.off[k] - self.off[1], live))
+        return out
+
+    def _draw_batch(self, b):
+        """compat / dense draws of ONE batch into self.sel, consumed from the same generators, in the same order,
+        as the reference's sampler calls of that batch (nn_modules.py:88 / :44)."""
+        if self.draws == "dense":
+            keep = torch.cat([UniformNeighborSampler.draw_keep(self.csr.K, n) for n in self.fan[1:]])
+            self.sel.copy_(keep.to(torch.int32), non_blocking=True)
+        elif self.draws == "compat":
+            from ..helpers import legacy_stream
+            st = legacy_stream.acquire(self.dev)
+            segs = [(o, c) for o, c in self._hop_draw_counts(b)]
+            ops.mt_choice_segments(st, self.csr.max_deg, segs, self.sel)
+
+    def _draw_epoch(self, n_valid):
+        """The draws of a whole epoch queue, batch after batch (the order the reference's training loop consumes
+        its generators in): -> int32 [n_batches, n_sel] on the device."""
+        nb = len(n_valid)
+        if self.draws == "dense":
+            keep = torch.stack([torch.cat([UniformNeighborSampler.draw_keep(self.csr.K, n) for n in self.fan[1:]])
+                                for _ in range(nb)])
+            return keep.to(device=self.dev, dtype=torch.int32).contiguous()
+        from ..helpers import legacy_stream
+        st = legacy_stream.acquire(self.dev)
+        out = torch.zeros(nb, self.n_sel, dtype=torch.int32, device=self.dev)
+        segs = [(i * self.n_sel + o, c) for i, b in enumerate(n_valid) for o, c in self._hop_draw_counts(int(b))]
+        ops.mt_choice_segments(st, self.csr.max_deg, segs, out)
+        return out
+
+    def _stage_sample(self, s, ids=None, ahead=False, counters=None):
+        """K1: every hop in one launch, frontier written in place into the concatenated ids."""
+        d = self._hops_desc(self.ids_set[s] if ids is None else ids, ahead, counters)
+        nat.check(nat.lib().gsage_sample_hops(ctypes.addressof(d), ops._stream()), "sample_hops")
+
+    def _stage_sample_gather(self, s):
+        """K1 for every hop + the level-0 gathers of batch set `s`; independent of the weights."""
+        self._stage_sample(s)
+        self._stage_gather(s)
+        # the next batch's samples use the next L Philox call indices (sequential mode: ticked by
+        # gsage_finalize_grads instead of a launch of its own)
+        if self.pipelined:
+            nat.check(nat.lib().gsage_counter_add(self.counter.data_ptr(), self.L, ops._stream()), "counter_add")
+
+    def _adam_desc(self):
+        d = nat.AdamDesc()
+        d.p, d.g, d.m, d.v = (self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                              self.flat_v.data_ptr())
+        d.n, d.partial, d.lr, d.step = (self.flat_p.numel(), self.partial.data_ptr(), self.lr.data_ptr(),
+                                        self.step.data_ptr())
+        d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
+        d.norm_out, d.step_is_current = self.gnorm.data_ptr(), 1
+        d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
+        d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
+        d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
+        return d
+
+    def _head_live_rows(self):
+        """tell the next head launch how many seeds of the batch are live (padded chunks, see _pad_batch)"""
+        nat.check(nat.lib().gsage_head_n_valid_next(self._nv_ptr()), "head_n_valid_next")
+
+    def _stage_head_ce(self, s):
+        """normalize + fc + softmax cross-entropy + their gradients (models.py:90-91,100) in one launch: predictions,
+        d loss / d embedding into dc[L-1], one partial row [dW | db | loss] per workgroup for the finalisation."""
+        m, L, B = self.model, self.L, self.B
+        C, D2 = m.fc.weight.shape
+        E = self.hout[L - 1]
+        tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+        self._head_live_rows()
+        nat.check(nat.lib().gsage_head_ce(E.data_ptr(), E.stride(0), m.fc.weight.data_ptr(), m.fc.bias.data_ptr(),
+                                          tg.data_ptr(), B, C, D2, self.preds.data_ptr(), self.dc[L - 1].data_ptr(),
+                                          self.code, self.dc[L - 1].stride(0), None, None, None,
+                                          self.head_scratch.data_ptr(),
+                                          self.batch_idx.data_ptr() if self.queue else None,
+                                          self.queue[2] if self.queue else 0, ops._stream()), "head_ce")
+
+    def _stage_head_l1(self, s):
+        """normalize + fc + F.l1_loss with the reference's [B,1]-vs-[B] broadcast (problem.py:39-42) + gradients"""
+        m, L = self.model, self.L
+        out = self.hout[L - 1]
+        self._head_live_rows()
+        nat.check(nat.lib().gsage_head_l1(out.data_ptr(), out.stride(0), m.fc.weight.data_ptr(), m.fc.bias.data_ptr(),
+                                          self.tg_set[s].data_ptr(), self.B, out.shape[1], self.preds.data_ptr(),
+                                          self.dc[L - 1].data_ptr(), self.code, self.dc[L - 1].stride(0),
+                                          self.l1_scratch.data_ptr(), ops._stream()), "head_l1")
+
+    def _stage_head(self, s):
+        """the head this model gets: fused cross-entropy, fused L1, or stock torch autograd over three ops"""
+        if self.fused_head:
+            self._stage_head_ce(s)
+        elif self.fused_l1:
+            self._stage_head_l1(s)
+        else:
+            self._torch_head(s)
+
+    def _will_fuse_tail(self, example_targets):
+        return False
+
+    def _wg_target(self):
+        return 240
+
+    def _tail_gather_rows(self):
+        return 0
+
+    def _queue_compute_body(self, par):
+        self._stage_compute(self._qset(par))
+
+    def _torch_head(self, s):
+        # head: normalize + fc + loss (stock torch, autograd confined to these few ops)
+        m, L = self.model, self.L
+        emb = self.hout[L - 1].detach().requires_grad_(True)
+        z = self.post(emb) if self.post is not None else emb
+        preds = m.fc(torch.nn.functional.normalize(z, dim=1))
+        loss = self.loss_fn(preds, self.tg_set[s].squeeze())
+        d_emb, d_w, d_b = torch.autograd.grad(loss, [emb, m.fc.weight, m.fc.bias])
+        nw = d_w.numel()
+        self.head_stage[:nw].copy_(d_w.reshape(-1))
+        self.head_stage[nw:].copy_(d_b.reshape(-1))
+        self.dc[L - 1].copy_(d_emb)
+        if self.preds is None:
+            self.preds = torch.empty_like(preds)
+        self.preds.copy_(preds.detach())
+
+    def _stage_finalize(self, s):
+        """Every partial buffer -> flat gradient bucket, + squared-norm partials, + the step's ticks:
+        Adam step, Philox call counter, batch-queue index (nothing else in this launch reads them)."""
+        L, lib, stream = self.L, nat.lib(), ops._stream()
+        nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
+                                           self.flat_g.data_ptr(), self.partial.data_ptr(),
+                                           self.step.data_ptr(),
+                                           None if self.pipelined else self.counter.data_ptr(), L,
+                                           self.batch_idx.data_ptr() if self.queue else None, 1,
+                                           stream), "finalize_grads")
+
+    def _all_reduce(self, async_op=False):
+        """The step's ONE exchange: average the flat fp32 gradient bucket over the ranks (RCCL)."""
+        if self._reduce_op == torch.distributed.ReduceOp.SUM:
+            self.flat_g.div_(self.ddp.world)
+        return torch.distributed.all_reduce(self.flat_g, op=self._reduce_op, async_op=async_op)
+
+    def _stage_opt(self):
+        """clip_grad_norm(5) + Adam over the flat bucket."""
+        if self.emb:
+            return self._stage_opt_emb()
+        d = self._adam_desc()
+        nat.check(nat.lib().gsage_clip_adam_step(d.p, d.g, d.m, d.v, d.n, d.partial, d.lr, d.step, d.beta1,
+                                                 d.beta2, d.eps, d.weight_decay, d.max_norm, d.norm_out,
+                                                 d.step_is_current, d.n_partial_ready, d.prep_descs,
+                                                 d.n_prep, d.tick1, d.inc1, d.tick2, d.inc2, ops._stream()),
+                  "clip_adam_step")
+
+    def _run_sequential(self, s):
+        if self.emb:
+            self._cur_ids = self.ids_set[s]
+        self._stage_sample_gather(s)
+        self._stage_compute(s)
+        if self.ddp is not None:
+            self._all_reduce()
+        self._stage_opt()
+
+
+    # =================================================================================================
+    # Trainable node-embedding prep (reference nn_modules.py:126-155; BASELINE configs[3], utils/pokec.sh).
+    # The level-0 rows are prep.fc(embedding[ids]) -- computed at the start of the step from the CURRENT table,
+    # their gradient scattered back into the table's (dense) gradient at the end.  Shared by the mean and the
+    # attention engines; a subclass calls _init_emb() from _init_levels, adds _emb_wgrad_problem() to its K5b
+    # problems of level 0, forms the level-0 input gradient (din0f / din0) and hands over to _prep_backward().
+    # =================================================================================================
+    def _init_emb(self, copies):
+        """copies(parameter, need_transposed) -> (operand copy, transposed copy): the subclass's operand-copy factory
+        (it also records the refresh descriptor).  Allocates the prep's work buffers; ld0 = self.ldin[0]."""
+        prep, dev, T, f32 = self.model.prep, self.dev, self.tdt, torch.float32
+        RA0, E, ld0 = self.off[self.L + 1], int(prep.embedding_dim), self.ldin[0]
+        self.wp, self.wpT = copies(prep.fc.weight, True)
+        self.table = prep.embedding.weight                 # a view of the flat parameter bucket
+        assert self.pidx[id(self.table)] == 0 and self.table.shape[1] == E and self.table.numel() % 4 == 0
+        self.seed_rows = torch.full((self.B,), int(prep.n_nodes), dtype=torch.int64, device=dev)
+        self.eraw = torch.zeros(RA0, ld0, dtype=T, device=dev)              # embedding rows as gathered (operand type)
+        self.din0f = torch.zeros(RA0, E, dtype=f32, device=dev)             # d prep output
+        self.din0 = self.din0f if T == f32 else torch.zeros(RA0, ld0, dtype=T, device=dev)
+        self.deraw = torch.zeros(RA0, E, dtype=f32, device=dev)             # d embedding rows
+        self.bpart = torch.zeros(256, E, dtype=f32, device=dev)             # prep.fc.bias gradient partials
+        self.seed_grad = torch.zeros(min(16, self.B), E, dtype=f32, device=dev)   # partial sums of the gradient of
+        #                                                                             the spare row the seeds read
+        self._cur_ids = self.ids_set[0]
+
+    def _emb_wgrad_problem(self):
+        """(dC, A, lda, M, Ntot, K, parameter, row list) of the prep's affine: d out^T x embedding rows"""
+        E = self.din[0]
+        return (self.din0, self.eraw, self.eraw.stride(0), self.off[self.L + 1], E, E, self.model.prep.fc.weight, None)
+
+    def _emb_reduce_desc(self):
+        """finalisation source of prep.fc.bias (column sums of the level-0 input gradient)"""
+        E = self.din[0]
+        ib = self.pidx[id(self.model.prep.fc.bias)]
+        return _ReduceDesc(self.bpart.data_ptr(), E, self.poff[ib], self.bpart.shape[0], 1, E, E)
+
+    def _init_emb_optimizer(self):
+        """after _install_reduce: the table's gradient comes from scatter-adds, its squared norm from a pass of its
+        own whose partials sit behind the finalisation's in the same array; deferred row updates (gsage_rows_*)."""
+        dev, f32 = self.dev, torch.float32
+        self.n_tab = int(self.table.numel())
+        self.n_tab_partial = 1024 if self.lazy_rows else nat.lib().gsage_adam_partials(self.n_tab)
+        self.partial = torch.zeros(self.n_partial + self.n_tab_partial, dtype=f32, device=dev)
+        if not self.lazy_rows:
+            return
+        # a step touches its frontier's rows, everything else is replayed -- bit for bit -- when it is next read
+        # (sync_rows: GSSupervised.forward, state_dict, another optimizer / engine taking the Parameters)
+        n_rows, E = int(self.table.shape[0]), self.din[0]
+        i32 = torch.int32
+        self.row_last = torch.zeros(n_rows, dtype=i32, device=dev)
+        self.row_seen = torch.zeros(n_rows, dtype=i32, device=dev)
+        self.row_hist = torch.zeros(2 * self.ROW_HIST, dtype=f32, device=dev)
+        d = self.row_desc = nat.RowAdamDesc()
+        o, n = 0, self.n_tab
+        d.p, d.g, d.m, d.v = (self.flat_p[o:o + n].data_ptr(), self.flat_g[o:o + n].data_ptr(),
+                              self.flat_m[o:o + n].data_ptr(), self.flat_v[o:o + n].data_ptr())
+        d.last, d.seen, d.hist = self.row_last.data_ptr(), self.row_seen.data_ptr(), self.row_hist.data_ptr()
+        d.lr, d.step, d.n_rows, d.E, d.hist_cap = self.lr.data_ptr(), self.step.data_ptr(), n_rows, E, self.ROW_HIST
+        d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
+        self._rows_dirty, self._rows_since = False, 0
+        self._warm_reset = (self.row_last, self.row_seen)
+        self.model._settle_rows = self.sync_rows
+        emb_mod = self.model.prep.embedding
+        self._row_hooks = [emb_mod.register_forward_pre_hook(lambda *_: self.sync_rows()),
+                           emb_mod.register_state_dict_pre_hook(lambda *_: self.sync_rows())]
+
+    def _prep_forward(self, s):
+        lib, stream, prep = nat.lib(), ops._stream(), self.model.prep
+        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.din[0]
+        tab = self.table
+        if self.lazy_rows:       # the rows this step reads, brought up to the last update
+            nat.check(lib.gsage_rows_catch_up(ctypes.byref(self.row_desc), self.seed_rows.data_ptr(), 1,
+                                              ids[B:RA0].data_ptr(), RA0 - B, 0, stream), "rows_catch_up")
+        # fp32 table rows -> the operand type in the gather itself (seeds read the spare row n_nodes)
+        segs = [(tab, self.seed_rows, self.eraw[:B], B, 1), (tab, ids[B:RA0], self.eraw[B:], RA0 - B, 1)]
+        ops.gather_mean_multi(segs, E, E, self.eraw.stride(0))
+        ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wp.data_ptr(), self.wp.shape[1],
+                           prep.fc.bias.data_ptr(), self.g0_set[s].data_ptr(), self.ldin[0], RA0, E, E, nat.ACT_NONE, 1,
+                           0, 0, 0, self.code, self.code)
+
+    def _prep_backward(self, s):
+        """level 0's input gradient (din0f fp32, din0 = its operand copy; formed by the subclass) -> prep.fc (weight:
+        a K5b problem of level 0; bias: column sums) -> the table's gradient."""
+        lib, stream = nat.lib(), ops._stream()
+        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.din[0]
+        nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
+                                            self.bpart.shape[0], stream), "colsum_partials")
+        ops._linear_launch(self.din0.data_ptr(), self.din0.stride(0), None, 0, self.wpT.data_ptr(), self.wpT.shape[1],
+                           None, self.deraw.data_ptr(), E, RA0, E, E, nat.ACT_NONE, 1, 0, 0, 0, self.code, nat.F32)
+        g = self._grad_slice(self.table)
+        # every seed reads the SAME spare row: its B gradient rows are summed first (B atomics onto one row took 15 us)
+        ns = self.seed_grad.shape[0]             # (partial sums: one workgroup summing B rows alone took 14 us)
+        nat.check(lib.gsage_colsum_partials(self.deraw.data_ptr(), E, B, E, self.seed_grad.data_ptr(), ns, stream),
+                  "colsum_partials")
+        for rows, idv, M in ((self.seed_grad, self.seed_rows, ns), (self.deraw[B:], ids[B:RA0], RA0 - B)):
+            nat.check(lib.gsage_scatter_add_rows(rows.data_ptr(), E, idv.data_ptr(), M, 1, E, 1.0, g.data_ptr(), E,
+                                                 stream), "scatter_add_rows")
+
+    def _stage_opt_emb(self):
+        lib, stream = nat.lib(), ops._stream()
+        d = self._adam_desc()
+        nt, B, RA0, E = self.n_tab, self.B, self.off[self.L + 1], self.din[0]
+        g = self._grad_slice(self.table)
+        n_all = self.n_partial + self.n_tab_partial
+        if self.lazy_rows:
+            ids, rd = self._cur_ids, ctypes.byref(self.row_desc)
+            lists = (self.seed_rows.data_ptr(), 1, ids[B:RA0].data_ptr(), RA0 - B, 0)
+            nat.check(lib.gsage_rows_sqnorm(rd, *lists, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+                                            stream), "rows_sqnorm")
+            nat.check(lib.gsage_rows_adam(rd, *lists, self.partial.data_ptr(), n_all, stream), "rows_adam")
+            o, n = nt, self.flat_p.numel() - nt
+            nat.check(lib.gsage_clip_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
+                                               self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
+                                               self.partial.data_ptr(), d.lr, d.step, d.beta1, d.beta2, d.eps,
+                                               d.weight_decay, d.max_norm, d.norm_out, 1, n_all, d.prep_descs, d.n_prep,
+                                               None, 0, None, 0, stream), "clip_adam_step")
+            return
+        nat.check(lib.gsage_grad_sqnorm(g.data_ptr(), nt, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+                                        stream), "grad_sqnorm")
+        # the table (16-byte lanes, no operand copies), then everything else (operand copies refreshed)
+        # (flag 2 on the table: its gradient is zeroed below, no need to write the clipped values back; flag 4: the
+        # arithmetic of the deferred row updates, so dense and deferred runs of the table stay bit-comparable)
+        for (o, n, prep, n_prep, cur) in ((0, nt, None, 0, 7), (nt, self.flat_p.numel() - nt, d.prep_descs, d.n_prep, 1)):
+            nat.check(lib.gsage_clip_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
+                                               self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
+                                               self.partial.data_ptr(), d.lr, d.step, d.beta1, d.beta2, d.eps,
+                                               d.weight_decay, d.max_norm, d.norm_out, cur, n_all, prep, n_prep, None,
+                                               0, None, 0, stream), "clip_adam_step")
+        # the table's gradient goes back to zero by touching the rows this step wrote
+        ids = self._cur_ids
+        for idv, M in ((self.seed_rows[:1], 1), (ids[B:RA0], RA0 - B)):
+            nat.check(lib.gsage_zero_rows(g.data_ptr(), E, idv.data_ptr(), M, E, stream), "zero_rows")
+
+    def sync_rows(self):
+        """Deferred table rows: apply every pending update to every row (table, exp_avg, exp_avg_sq all current
+        afterwards).  Runs by itself before GSSupervised.forward, the embedding module's forward and state_dict;
+        call it before reading `prep.embedding.weight` or the optimizer buckets directly."""
+        if not self.lazy_rows or not self._rows_dirty:
+            return
+        nat.check(nat.lib().gsage_rows_catch_up_all(ctypes.byref(self.row_desc), 0, ops._stream()), "rows_catch_up_all")
+        self._rows_dirty, self._rows_since = False, 0
+
+    def close(self):
+        """Settle the deferred rows and detach from the model (hooks on the embedding module, model._settle_rows):
+        call before pickling the model or when the engine is done with."""
+        if self.lazy_rows:
+            self.sync_rows()
+            for h in self._row_hooks:
+                h.remove()
+            self._row_hooks = []
+            if getattr(self.model, "_settle_rows", None) == self.sync_rows:
+                del self.model._settle_rows
+            self._closed = True
+
+    def _rows_tick(self):
+        if getattr(self, "_closed", False):
+            raise RuntimeError("this engine was closed (deferred table rows settled, hooks removed): build a new one")
+        if self.lazy_rows:
+            if self._rows_since >= self.ROW_HIST - 2:
+                self.sync_rows()
+            self._rows_dirty = True
+            self._rows_since += 1
+
+    # ---- per-batch entry --------------------------------------------------------------------------
+    def set_progress(self, progress):
+        self.model.lr = self.model.lr_scheduler(progress)
+        self.lr.fill_(float(self.model.lr))
+        self._user_dirty = True           # split mode: the chain stream must see this write
+
+    def set_sel(self, sels):
+        """Replace the Philox draws of the sampler by caller-supplied ones for the following steps
+        (None: back to Philox).  sels: one integer array per hop, [M_k, fan_k] or flat, each value in
+        [0, max_deg) -- exactly what the reference draws with np.random.choice at nn_modules.py:88, so a
+        recorded reference step can be replayed through the engine (parity level 1).  Re-records the
+        command lists / graphs (their kernels now read the sel buffer); later set_sel calls with
+        same-sized draws only overwrite the buffer."""
+        if sels is None:
+            assert self.draws == "philox", "only the counter-based sampler can do without caller-supplied draws"
+            changed, self.sel, self._sel_user = self.sel is not None, None, False
+        else:
+            flat = torch.cat([torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).reshape(-1)
+                              .to(device=self.dev, dtype=torch.int32) for x in sels])
+            assert flat.numel() == self.n_sel, "sel must cover every draw of the frontier"
+            changed = self.sel is None
+            self._sel_user = True
+            if changed:
+                self.sel = flat.clone()
+            else:
+                self.sel.copy_(flat)
+        if changed and self.g_main is not None:
+            torch.cuda.synchronize()
+            self._record_main()
+
+    def load_epoch(self, ids_epoch, targets_epoch, sel_epoch=None, n_valid=None):
+        """Device-resident batch queue: ids_epoch int64 [n_batches, B], targets_epoch int64
+        [n_batches, B(,1)] on the GPU.  Afterwards `step_queue()` runs one train_step on the next batch
+        of the queue (wrapping around) with no host->device or device->device copies at all.
+        Needs the fused classification head and the sequential (non-pipelined) mode; the graph is
+        re-captured because its kernels now read the queue.
+
+        n_valid (optional, one int per batch, <= B): the live seeds of each batch -- the reference's near-equal
+        `array_split` chunks padded to B (train.py pads with the chunk's first id; padded seeds get no loss and no
+        gradient).  sel_epoch: recorded sampler draws (see set_sel).  With a compat-mode or dense sampler and no
+        sel_epoch the engine draws the epoch's values itself, from the generator and in the order the reference's
+        training loop would consume them."""
+        if not self.fused_head:
+            raise ValueError("load_epoch needs the fused classification head (classification loss, <= 64 classes, "
+                             "int64 targets); this model runs per batch through __call__")
+        if self.pipelined:
+            raise ValueError("load_epoch is the sequential engine's queue mode; build the engine without pipelined=True")
+        if ids_epoch.dim() != 2 or int(ids_epoch.shape[1]) != self.B or ids_epoch.dtype != torch.int64:
+            raise ValueError("ids_epoch must be int64 [n_batches, %d], got %s %s"
+                             % (self.B, ids_epoch.dtype, tuple(ids_epoch.shape)))
+        n_batches = int(ids_epoch.shape[0])
+        if targets_epoch.dtype != torch.int64 or targets_epoch.numel() != n_batches * self.B:
+            raise ValueError("targets_epoch must be int64 class ids, one per seed: [n_batches, %d(, 1)], got %s %s"
+                             % (self.B, targets_epoch.dtype, tuple(targets_epoch.shape)))
+        if not (ids_epoch.is_cuda and targets_epoch.is_cuda):
+            raise ValueError("the epoch queue lives in HBM: pass CUDA tensors")
+        # the previous epoch's last launches (in split mode: on the CU-masked gather stream, which the caller's
+        # stream never waits for) still tick the sampler counters and write the frontier buffers zeroed below
+        torch.cuda.synchronize()
+        tq = targets_epoch.reshape(n_batches, self.B).contiguous()
+        self.queue = (ids_epoch.contiguous(), tq, n_batches)
+        nv = [self.B] * n_batches if n_valid is None else [int(v) for v in n_valid]
+        assert len(nv) == n_batches and all(2 <= v <= self.B for v in nv), "n_valid: one count in [2, B] per batch"
+        self.nv_queue = torch.tensor(nv, dtype=torch.int32, device=self.dev)
+        self.sel_queue = None
+        if sel_epoch is not None:               # [n_batches, draws per frontier] recorded draws (see set_sel)
+            self.sel_queue = sel_epoch.to(device=self.dev, dtype=torch.int32).reshape(n_batches, -1).contiguous()
+            assert self.sel_queue.shape[1] == self.n_sel
+        elif self.draws != "philox":
+            self.sel_queue = self._draw_epoch(nv)
+        self.batch_idx.zero_()
+        # From here on the step is software-pipelined (see step_queue): two frontier buffers, batch
+        # i+2 is sampled while batch i+1 is gathered and batch i is updated.
+        self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
+        # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
+        # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
+        # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
+        self.split = bool(self.gather_cus and self.capture_mode == "cmdlist" and self.ddp is None)
+        self._tail_rows = 0 if self.split else self._tail_gather_rows()
+        if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
+            self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
+        self._front_ready, self._qstep = False, 0
+        if self.split:
+            self._split_setup()
+        self._record_queue()
+        return self
+
+    def _record_queue(self):
+        self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        if getattr(self, "split", False):
+            torch.cuda.synchronize()
+            self.g_prime = self._record(self._split_prime)
+            self.g_qfront = [self._record(lambda par=par: self._split_front(par)) for par in range(2)]
+            self.g_queue = [self._record(lambda par=par: self._split_chain(par)) for par in range(2)]
+            return
+        if self.g_main is not None:
+            torch.cuda.synchronize()
+            self.g_prime = self._record(self._queue_prime)
+            if self.ddp is None:
+                self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(2)]
+            else:
+                # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
+                # gathers (see step_queue)
+                self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
+                self._ddp_split = bool(self.MEAN_ENGINE and self.size[self.L - 1] > self._tail_rows
+                                       and os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
+                if self._ddp_split:
+                    # the bulk of the gathers runs while the exchange is in flight; what follows the exchange
+                    # is ONE norm pass and ONE launch: the remaining gathers with Adam(i) and K1(i+2) riding along
+                    self.g_qfront = [self._record(lambda par=par: self._queue_front_means(par)) for par in range(2)]
+                    self.g_opt = [self._record(lambda par=par: self._queue_front_rest(par)) for par in range(2)]
+                else:
+                    self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
+                    self.g_opt = self._record(self._stage_opt)
+
+    def instrument(self, on=True):
+        """Measurement only (bench.py's roofline object): re-record the queue-mode command lists with
+        HIP start / stop events attached to the dispatch of the step's dominant launch -- the one that
+        gathers the next batch's level-0 rows (events 0/1) -- and of the seed-level launch that carries
+        the first part of those gathers (events 2/3).  `last_launch_ms()` then returns their durations
+        for the step just replayed: timed in place, on the stream the step runs on."""
+        assert self.queue is not None and self.capture_mode == "cmdlist" and self.ddp is None
+        self._marks = bool(on)
+        self._record_queue()
+
+    def last_launch_ms(self):
+        par = (self._qstep - 1) % 2
+        cl = self.g_queue[par].cl
+        out = {"gather": (self.g_qfront[par].cl if self.split else cl).elapsed_ms(0, 1)}
+        if self.fused_tail:
+            out["seed_level"] = cl.elapsed_ms(2, 3)
+        return out
+
+    def _time_next(self, a, b):
+        """While recording an instrumented list: attach start / stop events a, b to the next kernel."""
+        if getattr(self, "_marks", False) and self.capture_mode == "cmdlist":
+            nat.check(nat.lib().gsage_cmdlist_time_next(a, b), "cmdlist_time_next")
+
+    # the queue pipeline's pieces; par = parity of the step: batch i+1 is gathered from ids_q[1 - par]
+    # (into operand set 1 - par when the sets alternate) while batch i+2 is sampled into ids_q[par]
+    def _qset(self, par):
+        return par if self._tail_rows else 0
+
+    def _queue_prime(self):
+        self._stage_sample(0, ids=self.ids_q[0])
+        self._stage_sample(0, ids=self.ids_q[1], ahead=True)
+        if not self.emb:             # (embedding prep: sampling runs ahead, nothing else can -- the rows are weights)
+            self._stage_gather(0, ids=self.ids_q[0])
+
+    def _queue_front(self, par, with_adam):
+        if self.emb:
+            assert with_adam
+            self._cur_ids = self.ids_q[par]
+            self._stage_opt()                                  # Adam(i) + zeroing of the rows batch i touched
+            self._stage_sample(0, ids=self.ids_q[par], ahead=True)      # batch i+2 (batch i's frontier is done with)
+            return
+        self._time_next(0, 1)
+        if self.dense:           # (the gather launch's sampler role walks a CSR: the dense frontier is a launch of its own)
+            self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
+                               skip_rows=self._tail_rows)
+            self._stage_sample(0, ids=self.ids_q[par], ahead=True)
+            return
+        self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
+                           hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
+
+    def _queue_compute(self, par):
+        self._q_ids = self.ids_q[par]
+        try:
+            return self._queue_compute_body(par)
+        finally:
+            self._q_ids = None
+
+    def _queue_step(self, par):
+        self._queue_compute(par)
+        self._queue_front(par, True)              # Adam(i) || gathers(i+1) || sampling(i+2)
+
+    def step_queue(self):
+        """One train_step on the next batch of the loaded epoch queue -> preds (static buffer).
+
+        Software-pipelined, because sampling and the level-0 gathers do not depend on the weights:
+        the launch that gathers batch i+1 also carries Adam(i) and the frontier sampling of batch i+2
+        (two short latency-bound jobs that are free beside the HBM-bound gather); in data-parallel
+        runs the gathers + sampling run while batch i's gradient all-reduce is in flight on RCCL's
+        stream, Adam(i) following both.  Every call performs exactly one sampling, one gather, one
+        forward/backward, (one exchange) and one optimizer step, and the weights are up to date when
+        it returns; the first call after load_epoch() additionally samples batches 0 and 1 and
+        gathers batch 0."""
+        assert self.queue is not None, "call load_epoch() first"
+        self._rows_tick()
+        if getattr(self, "split", False):
+            return self._step_queue_split()
+        rec = self.g_queue is not None
+        if not self._front_ready:
+            if rec:
+                self.g_prime.replay()
+            else:
+                self._queue_prime()
+            self._front_ready = True
+        par = self._qstep % 2
+        self._qstep += 1
+        if self.ddp is None:
+            if rec:
+                self.g_queue[par].replay()
+            else:
+                self._queue_step(par)
+            return self.preds
+        if rec:
+            self.g_queue[par].replay()
+        else:
+            self._queue_compute(par)
+        # Order matters: the collective is submitted BEFORE the gathers.  Submitted after them (from a
+        # side stream that only waits for the gradients, which would hide the ~25 us the collective
+        # call costs the host) it did not start until the 8 320-workgroup gather launch had been
+        # dispatched completely -- no overlap at all (tools/overlap_check.py).
+        # (Order and priority were measured on one rank, 0.1205 ms/step as written: the means submitted BEFORE
+        # the collective 0.137; RCCL's stream at high priority 0.46 -- its kernel then preempts the gathers.)
+        split = getattr(self, "_ddp_split", False)
+        work = self._all_reduce(async_op=True)
+        if rec:                                      # batch i+1's gathers overlap the exchange
+            self.g_qfront[par].replay()
+        elif split:
+            self._queue_front_means(par)
+        else:
+            self._queue_front(par, False)
+        work.wait()                                  # stream-level wait, the host does not block
+        if rec:
+            (self.g_opt[par] if isinstance(self.g_opt, list) else self.g_opt).replay()
+        elif getattr(self, "_ddp_split", False):
+            self._queue_front_rest(par)
+        else:
+            self._stage_opt()
+        return self.preds
+
+    def _pad_batch(self, ids, targets):
+        """A batch one or a few seeds short of B (the reference's near-equal chunks): pad with its first seed."""
+        b = int(ids.shape[0])
+        if not (2 <= b < self.B) or not (self.fused_head or getattr(self, "fused_l1", False)):
+            raise ValueError("this engine was recorded for batches of %d seeds (got %d); shorter batches need one of "
+                             "the fused heads" % (self.B, b))
+        pad = self.B - b
+        ids = torch.cat([ids, ids[:1].expand(pad)])
+        targets = torch.cat([targets, targets[:1].expand(pad, *targets.shape[1:])])
+        return ids.contiguous(), targets.contiguous()
+
+    def _nv_ptr(self):
+        """device pointer to the live-seed count(s) the head reads: the epoch queue's array or the per-call word"""
+        return (self.nv_queue if self.queue else self.n_valid).data_ptr()
+
+    def _load(self, s, ids, targets):
+        dst_i, dst_t = self.ids_set[s][:self.B], self.tg_set[s]
+        if (ids.is_cuda and targets.is_cuda and ids.dtype == dst_i.dtype and targets.dtype == dst_t.dtype and
+                ids.is_contiguous() and targets.is_contiguous() and ids.numel() == dst_i.numel() and
+                targets.numel() == dst_t.numel() and targets.element_size() * targets.numel() % 4 == 0):
+            # one launch instead of two blits (hipMemcpyAsync: ~7 us each on the step's stream)
+            nat.check(nat.lib().gsage_copy_pair(dst_i.data_ptr(), ids.data_ptr(), ids.numel() * 8, dst_t.data_ptr(),
+                                                targets.data_ptr(), targets.numel() * targets.element_size(),
+                                                ops._stream()), "copy_pair")
+            return
+        dst_i.copy_(ids, non_blocking=True)
+        dst_t.copy_(targets, non_blocking=True)
+
+    def __call__(self, ids, targets):
+        """Sequential mode: same contract as GSSupervised.train_step -> preds of THIS batch.
+        Pipelined mode: submits this batch (its sampling/gathers start now), finishes the previous
+        one and returns ITS preds (None on the very first call); call flush() after the last batch."""
+        self._rows_tick()
+        k = self.n_calls
+        self.n_calls += 1
+        b = int(ids.shape[0])
+        if b != self.B:
+            ids, targets = self._pad_batch(ids, targets)
+        if b != self._nv_host:
+            self._nv_host = b
+            self.n_valid.fill_(b)
+        if self.draws != "philox" and not self._sel_user:
+            self._draw_batch(b)
+        if not self.pipelined:
+            self._load(0, ids, targets)
+            if self.g_main is None:
+                self._run_sequential(0)
+            else:
+                self.g_main[0].replay()
+                if self.g_opt is not None:
+                    self._all_reduce()
+                    self.g_opt.replay()
+            return self.preds
+        s = k % 2
+        cur = torch.cuda.current_stream()
+        # front stream: wait until the compute stage that last used buffer set s is done, load the
+        # batch, sample + gather
+        self.s_front.wait_stream(cur)
+        with torch.cuda.stream(self.s_front):
+            self.s_front.wait_event(self.ev_back[s])
+            self._load(s, ids, targets)
+            if self.g_front is None:
+                self._stage_sample_gather(s)
+            else:
+                self.g_front[s].replay()
+            self.ev_front[s].record(self.s_front)
+        if k == 0:
+            return None                              # pipeline primed
+        self._launch_back((k - 1) % 2)
+        cur.wait_event(self.ev_back[(k - 1) % 2])    # whoever reads preds on this stream sees them
+        return self.preds
+
+    def _launch_back(self, par):
+        with torch.cuda.stream(self.s_back):
+            self.s_back.wait_event(self.ev_front[par])
+            if self.g_main is None:
+                self._stage_compute(par)
+                if self.ddp is not None:
+                    self._all_reduce()
+                self._stage_opt()
+            else:
+                self.g_main[par].replay()
+                if self.g_opt is not None:
+                    self._all_reduce()
+                    self.g_opt.replay()
+            self.ev_back[par].record(self.s_back)
+
+    def flush(self):
+        """Pipelined mode: finish the last submitted batch; returns its preds."""
+        if not self.pipelined or self.n_calls == 0:
+            return self.preds
+        self._launch_back((self.n_calls - 1) % 2)
+        torch.cuda.current_stream().wait_stream(self.s_back)
+        torch.cuda.current_stream().wait_stream(self.s_front)
+        self.n_calls = 0                              # the next call primes a fresh pipeline
+        return self.preds

@@ -1,0 +1,267 @@
+"""
+engine/pool.py -- FusedPoolTrainStep: max-pool / mean-pool aggregators (reference nn_modules.py:207-256;
+BASELINE configs[2]).
+"""
+import os
+
+import torch
+
+from .. import _native as nat
+from .. import ops
+from ..nn_modules import IdentityPrep, MaxPoolAggregator, MeanPoolAggregator
+from .common import FusedTrainStep, _PrepDesc, _ReduceDesc, _r64
+
+
+class FusedPoolTrainStep(FusedTrainStep):
+    """train_step for max-pool / mean-pool aggregators (reference nn_modules.py:207-256; BASELINE config 3) with no
+    autograd and no framework glue, on the same machinery as FusedMeanTrainStep (flat buckets, fused
+    multi-hop sampler, head kernel, finalisation + Adam, command lists, batch queue, data-parallel
+    order).  Per level l, rows = hops 0 .. L-l-1 ("x"), neighbour rows = hops 1 .. L-l:
+
+      forward    K3   pooled = max_j relu(Wm nb_j + bm) per hop (hidden [M*n, Hm] never leaves the chip),
+                      fp32 + bf16 operand copy + argmax
+                 K5   out[:, :h] = act(x Wx^T);  K5  out[:, h:] = act(pooled Wn^T)
+      backward   K5   d pooled = dC[:, h:] Wn            (NT GEMM against the transposed operand copy)
+                 route d pooled through the max / ReLU -> bf16 d hidden [M*n, Hm]   (gsage_pool_route_bwd;
+                       mean pool: g / n where K3's sign mask is set, gsage_pool_route_mean_bwd)
+                 bias partials of the MLP                                           (gsage_pool_bias_partials)
+                 l > 0: K5 dX = dC[:, :h] Wx, K5 dN = d hidden Wm, merge + ReLU mask -> dC of level l-1
+                 K5b  all weight gradients of all levels in one grouped launch (fc_x, fc_neib, mlp)
+    Level 0 reads its operands from two row buffers gathered once per step (x rows, neighbour rows):
+    K3, K5 and K5b all want plain row-major operands, and the gathers run one batch ahead beside Adam.
+    """
+
+    NPART = 256          # partial rows per hop for the MLP bias gradient (summed by the finalisation)
+    # K5b workgroups per problem: the MLP's weight gradient is 20x the work of the two projections that
+    # share its launch, so those take few, long M-slices (fewer partial tiles to write and to sum)
+    WG_TARGET = {"m": 240, "x": 40, "n": 40}
+
+    @classmethod
+    def why_not(cls, model, feats):
+        why = cls._why_not_common(model, feats, (MaxPoolAggregator, MeanPoolAggregator), "max-pool / mean-pool")
+        if why:
+            return why
+        if not isinstance(model.prep, IdentityPrep):
+            return "a prep class other than identity (%s)" % type(model.prep).__name__
+        why = cls._why_not_input(model, feats)
+        if why:
+            return why
+        layers = list(model.agg_layers.children())
+        if feats.ld % (64 if feats.dtype == torch.bfloat16 else 4) != 0:      # whole lines for the LDS-DMA kernels
+            return "feature rows that are not whole 128-byte lines"
+        if any(fn.keywords["n_samples"] > 64 for fn in model.train_sample_fns) or len(layers) > 2:
+            return "a fan-out above 64 or more than two layers (K3 tiles hold whole segments up to 64 rows)"
+        if not all(l.output_dim_ % 64 == 0 and l.mlp[0].weight.shape[0] % 128 == 0 for l in layers):
+            return "output dims that are not multiples of 64, or a pooling MLP whose width is not a multiple of 128"
+        return None
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _init_levels(self, example_ids, example_targets):
+        feats, dev, L = self.store, self.dev, self.L
+        bf, f32, i32 = self.tdt, torch.float32, torch.int32
+        is_bf = self.code == nat.BF16
+        self.pool_mode = nat.POOL_MAX if type(self.layers[0]) is MaxPoolAggregator else nat.POOL_MEAN
+        self.h = [l.output_dim_ for l in self.layers]
+        self.Hm = [int(l.mlp[0].weight.shape[0]) for l in self.layers]
+        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
+        self.rows = [self.off[L - l] for l in range(L)]                     # x rows of level l
+        self.nrows = [self.off[L - l + 1] - self.off[1] for l in range(L)]  # neighbour rows of level l
+        assert all(d % 64 == 0 for d in self.din[1:]), "hidden widths must be multiples of 32"
+        descs = []
+
+        def copies(prm, need_t, packed=False):
+            r, c = prm.shape
+            w = torch.zeros(r, _r64(c), dtype=bf, device=dev)
+            wt = torch.zeros(c, _r64(r), dtype=bf, device=dev) if need_t else None
+            # forward operands of K3 / K5 also in MFMA fragment order (gsage_*_packed)
+            wp = (torch.zeros(nat.lib().gsage_packed_weight_elems(r, c, 1), dtype=bf, device=dev)
+                  if packed and is_bf else None)
+            descs.append(_PrepDesc(prm.data_ptr(), w.data_ptr(), wt.data_ptr() if need_t else None, r, c,
+                                   w.shape[1], wt.shape[1] if need_t else 0,
+                                   wp.data_ptr() if wp is not None else None, 4 * (-(-c // 64)),
+                                   int(not is_bf), 0))
+            return (w, wt, wp) if packed else (w, wt)
+        self.wm, self.wx, self.wn, self.wmT, self.wxT, self.wnT = [], [], [], [], [], []
+        self.wm_p, self.wx_p, self.wn_p = [], [], []
+        for l, layer in enumerate(self.layers):
+            order = [self.pidx[id(p)] for p in (layer.mlp[0].weight, layer.mlp[0].bias, layer.fc_x.weight,
+                                                layer.fc_neib.weight)]
+            assert order == list(range(order[0], order[0] + 4)), "unexpected parameter order"
+            wm, wmT, wm_p = copies(layer.mlp[0].weight, l > 0, True)
+            wx, wxT, wx_p = copies(layer.fc_x.weight, l > 0, True)
+            wn, wnT, wn_p = copies(layer.fc_neib.weight, True, True)
+            self.wm.append(wm); self.wmT.append(wmT); self.wx.append(wx); self.wxT.append(wxT)
+            self.wn.append(wn); self.wnT.append(wnT)
+            self.wm_p.append(wm_p); self.wx_p.append(wx_p); self.wn_p.append(wn_p)
+        self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
+        self.n_desc = len(descs)
+        self.max_elems = max(d.rows * d.cols for d in descs)
+
+        # level-0 operands: x rows (hops 0..L-1) gathered once per step; the neighbour rows (hops 1..L: 141 k rows,
+        # 180 MB at Reddit's shape) are read IN PLACE through the frontier's row list by K3 and by K5b
+        # (gsage_wgrad_desc.a_rows; its list starts at entry B of the frontier and must be 16-byte aligned: even B) --
+        # GSAGE_POOL_COPY_ROWS=1 brings back the gathered copy
+        self.inplace0 = os.environ.get("GSAGE_POOL_COPY_ROWS", "0") != "1" and self.B % 2 == 0
+        self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+        self.xn0_set = [None if self.inplace0 else torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev)
+                        for _ in range(self.nset)]
+        self._q_ids = None
+        self.pooled, self.pooled_b, self.argmax, self.hout, self.dc = [], [], [], [], []
+        self.dpool, self.ghc, self.dxb, self.dnb, self.bpart = [], [], [], [], []
+        for l in range(L):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            last = l == L - 1
+            self.pooled.append(torch.zeros(R, Hm, dtype=f32, device=dev))
+            # operand copy of `pooled` for the fc_neib projection and its weight gradient (parity mode:
+            # the fp32 result itself)
+            self.pooled_b.append(torch.zeros(R, _r64(Hm), dtype=bf, device=dev) if is_bf else self.pooled[l])
+            # what the backward needs of the hidden layer: the winning row (max) / the ReLU sign bits (mean)
+            self.argmax.append(torch.zeros(R, Hm, dtype=i32, device=dev) if self.pool_mode == nat.POOL_MAX
+                               else torch.zeros(NR, Hm // 32, dtype=i32, device=dev))
+            self.hout.append(torch.zeros(R, 2 * h, dtype=f32 if last else bf, device=dev))
+            self.dc.append(torch.zeros(R, 2 * h, dtype=bf, device=dev))
+            self.dpool.append(torch.zeros(R, Hm, dtype=f32, device=dev))
+            self.ghc.append(torch.zeros(NR, Hm, dtype=bf, device=dev))
+            self.dxb.append(torch.zeros(R, din, dtype=f32, device=dev) if l > 0 else None)
+            self.dnb.append(torch.zeros(NR, din, dtype=f32, device=dev) if l > 0 else None)
+            self.bpart.append(torch.zeros((L - l) * self.NPART, Hm, dtype=f32, device=dev))
+
+    def _init_head(self, loss_fn, example_targets):
+        super(FusedPoolTrainStep, self)._init_head(loss_fn, example_targets)
+        assert self.fused_head, "FusedPoolTrainStep needs the fused classification head"
+
+    def _x_operand(self, l, s):
+        return (self.x0_set[s], self.store.ld) if l == 0 else (self.hout[l - 1], self.din[l])
+
+    def _nb_operand(self, l, s):
+        """neighbour rows of level l: (row block, leading dimension, row list or None).  With a row list, neighbour
+        row i is block[list[i]] (level 0 read in place from the feature table)."""
+        if l == 0:
+            if self.inplace0:       # the frontier of the batch being computed: the queue's, else the set's own
+                ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
+                return self.store.data, self.store.ld, ids[self.off[1]:]
+            return self.xn0_set[s], self.store.ld, None
+        return self.hout[l - 1][self.off[1]:], self.din[l], None
+
+    def _init_reduce(self):
+        dev, L, f32 = self.dev, self.L, torch.float32
+        rdesc, self.slabs = [], []
+        for l, layer in enumerate(self.layers):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            bufs = {}
+            for key, prm, M, ntot, K in (("m", layer.mlp[0].weight, NR, Hm, din), ("x", layer.fc_x.weight, R, h, din),
+                                         ("n", layer.fc_neib.weight, R, h, Hm)):
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET[key])
+                buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
+                bufs[key] = buf
+                rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
+            ib = self.pidx[id(layer.mlp[0].bias)]
+            rdesc.append(_ReduceDesc(self.bpart[l].data_ptr(), Hm, self.poff[ib], self.bpart[l].shape[0], 1, Hm, Hm))
+            self.slabs.append(bufs)
+        self._install_reduce(rdesc)
+
+    # ---- stages ----------------------------------------------------------------------------------------
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
+        L, st = self.L, self.store
+        if ids is None:
+            ids = self.ids_set[s]
+        segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1)]
+        if not self.inplace0:
+            segs.append((st.data, ids[self.off[1]:self.off[L + 1]], self.xn0_set[s], self.nrows[0], 1))
+        # (D = the real width: the pad columns of the operand buffers were zeroed once and stay zero)
+        ops.gather_mean_multi(segs, st.ld, st.dim, st.ld, adam=self._adam_desc() if with_adam else None,
+                              hops=hops)
+
+    def _gemm(self, A, lda, W, C, c_code, ldc, M, N, K, act, Wp=None):
+        if Wp is not None and lda % 64 == 0 and lda >= -(-K // 64) * 64:
+            ops._linear_packed_launch(A, lda, None, 0, Wp.data_ptr(), None, C, ldc, M, N, K, act, 1, 0, 0, c_code)
+            return
+        ops._linear_launch(A, lda, None, 0, W.data_ptr(), W.shape[1], None, C, ldc, M, N, K, act, 1, 0, 0, 0,
+                           self.code, c_code)
+
+    def _stage_compute(self, s):
+        L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
+        for l, layer in enumerate(self.layers):
+            R, Hm, h, din = self.rows[l], self.Hm[l], self.h[l], self.din[l]
+            nb, ldnb, nrows = self._nb_operand(l, s)
+            for k in range(L - l):                       # one K3 launch per hop: its fan-out is the segment
+                r0, r1 = self.off[k], self.off[k + 1]
+                a0 = self.off[k + 1] - self.off[1]
+                a_ptr = nb.data_ptr() if nrows is not None else nb[a0:].data_ptr()
+                r_ptr = nrows[a0:].data_ptr() if nrows is not None else None
+                is_max = self.pool_mode == nat.POOL_MAX
+                is_bf = self.code == nat.BF16
+                tail = (self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
+                        self.pooled_b[l][r0:r1].data_ptr() if is_bf else None, self.pooled_b[l].shape[1],
+                        None if is_max else self.argmax[l][a0:].data_ptr(), stream)
+                if self.wm_p[l] is not None and ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
+                    nat.check(lib.gsage_pool_mlp_packed(
+                        a_ptr, ldnb, r_ptr, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
+                        self.size[k], self.fan[k + 1], Hm, din, self.pool_mode, *tail), "pool_mlp_packed")
+                else:
+                    nat.check(lib.gsage_pool_mlp(
+                        a_ptr, self.code, ldnb, r_ptr, self.wm[l].data_ptr(), self.wm[l].shape[1],
+                        layer.mlp[0].bias.data_ptr(), self.size[k], self.fan[k + 1], Hm, din, self.pool_mode,
+                        *tail), "pool_mlp")
+            x, ldx = self._x_operand(l, s)
+            last = l == L - 1
+            out, code = self.hout[l], (nat.F32 if last else self.code)
+            act = nat.ACT_NONE if last else nat.ACT_RELU
+            self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act, self.wx_p[l])
+            self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
+                       out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act, self.wn_p[l])
+        self._stage_head_ce(s)
+        self._backward_levels(s)
+
+    def _backward_levels(self, s):
+        L, lib, stream = self.L, nat.lib(), ops._stream()
+        for l in range(L - 1, -1, -1):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            dc = self.dc[l]
+            # d pooled = dC[:, h:] Wn
+            self._gemm(dc.data_ptr() + h * self.esz, 2 * h, self.wnT[l], self.dpool[l].data_ptr(), nat.F32, Hm, R, Hm,
+                       h, nat.ACT_NONE)
+            for k in range(L - l):
+                r0, r1 = self.off[k], self.off[k + 1]
+                a0 = self.off[k + 1] - self.off[1]
+                if self.pool_mode == nat.POOL_MEAN:
+                    nat.check(lib.gsage_pool_route_mean_bwd(self.dpool[l][r0:r1].data_ptr(), Hm,
+                                                            self.argmax[l][a0:].data_ptr(), self.size[k],
+                                                            self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), self.code,
+                                                            Hm, self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
+                                                            stream), "pool_route_mean_bwd")
+                    continue
+                nat.check(lib.gsage_pool_route_bwd(self.dpool[l][r0:r1].data_ptr(), Hm, self.pooled[l][r0:r1].data_ptr(),
+                                                   Hm, self.argmax[l][r0:r1].data_ptr(), Hm, self.size[k],
+                                                   self.fan[k + 1], Hm, self.ghc[l][a0:].data_ptr(), self.code, Hm,
+                                                   stream), "pool_route_bwd")
+                nat.check(lib.gsage_pool_bias_partials(self.dpool[l][r0:r1].data_ptr(), Hm,
+                                                       self.pooled[l][r0:r1].data_ptr(), Hm, self.size[k], Hm,
+                                                       self.bpart[l][k * self.NPART:].data_ptr(), self.NPART,
+                                                       stream),
+                          "pool_bias_partials")
+            if l > 0:
+                self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dxb[l].data_ptr(), nat.F32, din, R, din, h,
+                           nat.ACT_NONE)
+                self._gemm(self.ghc[l].data_ptr(), Hm, self.wmT[l], self.dnb[l].data_ptr(), nat.F32, din, NR, din,
+                           Hm, nat.ACT_NONE)
+                below = self.hout[l - 1]
+                nat.check(lib.gsage_pool_merge_bwd(below.data_ptr(), self.code, below.stride(0), self.dxb[l].data_ptr(),
+                                                   din, R,
+                                                   self.dnb[l].data_ptr(), din, self.off[1],
+                                                   self.dc[l - 1].data_ptr(), self.dc[l - 1].stride(0),
+                                                   self.rows[l - 1], din, stream), "pool_merge_bwd")
+        probs = []
+        for l in range(L - 1, -1, -1):
+            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            x, ldx = self._x_operand(l, s)
+            nb, ldnb, nrows = self._nb_operand(l, s)
+            dc = self.dc[l]
+            T = self.WG_TARGET
+            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"], T["x"]))
+            probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"],
+                          T["n"]))
+            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"], nrows))
+        for i in range(0, len(probs), 8):
+            ops.wgrad_multi(probs[i:i + 8])
+        self._stage_finalize(s)

@@ -69,6 +69,12 @@ class GSSupervised(nn.Module):
         return self._wrapped[key]
 
     def forward(self, ids, feats, train=True):
+        # a fused engine that defers the embedding table's zero-gradient Adam updates (engine.sync_rows)
+        # settles them HERE: the prep reads `embedding.weight` directly, not through the nn.Embedding
+        # module, so a hook on that module would never fire
+        settle = getattr(self, "_settle_rows", None)
+        if settle is not None:
+            settle()
         sample_fns = self.train_sample_fns if train else self.val_sample_fns
         table = self._rows_of(feats)
         rows = (lambda i: table[i]) if table is not None else (lambda i: None)
@@ -87,6 +93,13 @@ class GSSupervised(nn.Module):
         out = F.normalize(hops[0].float(), dim=1)
         return self.fc(out)
 
+    def __getstate__(self):
+        # per-process handles of a fused engine (a weakref and a bound method) do not pickle / deep-copy
+        state = dict(self.__dict__)
+        state.pop("_engine", None)
+        state.pop("_settle_rows", None)
+        return state
+
     def set_progress(self, progress):
         self.lr = self.lr_scheduler(progress)
         LRSchedule.set_lr(self.optimizer, self.lr)
@@ -102,9 +115,14 @@ class GSSupervised(nn.Module):
         settle = getattr(self, "_settle_rows", None)
         if settle is not None:                    # a fused engine with deferred embedding-table rows
             settle()
+        eng = getattr(self, "_engine", None)
+        eng = eng() if eng is not None else None
+        trained = eng is not None and eng.holds_parameters()     # a fused engine trained them last
         if isinstance(opt, FlatAdam):
             if not opt.owns():                    # somebody re-pointed the Parameters (e.g. a fused engine):
-                opt._attach()                     # take them back WITH their current values
+                opt._attach()                     # take them back WITH their current values ...
+                if trained:
+                    eng.export_optimizer_state(opt)   # ... and the engine's exp_avg / exp_avg_sq / step count
             return opt
         if opt is not self._init_optimizer or opt.state or os.environ.get("GSAGE_TORCH_ADAM", "0") == "1":
             return None
@@ -114,7 +132,19 @@ class GSSupervised(nn.Module):
         g = opt.param_groups[0]
         self.optimizer = FlatAdam(params, lr=g["lr"], weight_decay=g.get("weight_decay", 0.0),
                                   betas=g.get("betas", (0.9, 0.999)), eps=g.get("eps", 1e-8))
+        if trained:
+            eng.export_optimizer_state(self.optimizer)
         return self.optimizer
+
+    def optimizer_state_dict(self):
+        """torch.optim.Adam-format state of whoever trained last: the fused engine's buckets when one holds
+        the Parameters (`model.optimizer` is then still the never-stepped optimizer of __init__), else
+        `model.optimizer.state_dict()`.  Loads into the torch.optim.Adam the reference builds (models.py:69)."""
+        eng = getattr(self, "_engine", None)
+        eng = eng() if eng is not None else None
+        if eng is not None and eng.holds_parameters():
+            return eng.optimizer_state_dict()
+        return self.optimizer.state_dict()
 
     def train_step(self, ids, feats, targets, loss_fn):
         flat = self._flat_optimizer()

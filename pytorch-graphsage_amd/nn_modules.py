@@ -19,7 +19,7 @@ from torch.nn import functional as F
 
 from . import _native as nat
 from . import ops
-from .store import DeviceCSR, RowRef
+from .store import DenseAdj, DeviceCSR, RowRef
 
 
 # --------------------------------------------------------------------------------------------
@@ -28,17 +28,45 @@ from .store import DeviceCSR, RowRef
 class UniformNeighborSampler(object):
     """Dense `[n_nodes+1, K]` LongTensor adjacency (reference nn_modules.py:19-49): every row was
     pre-sampled to exactly K neighbours offline; a call picks the same n random columns for the
-    whole batch.  Stock torch indexing on whatever device `adj` lives on (SURVEY: 'next' row)."""
+    whole batch (ONE torch.randperm per call, from torch's global CPU generator -- SURVEY quirk 4).
+    On the GPU one launch of gsage_sample_dense computes `adj[ids][:, perm][:, :n]` without the
+    [M, K] intermediate; CPU tensors keep stock indexing (host mode)."""
 
     def __init__(self, adj):
         self.adj = adj
+        self._dev = {}                                    # device -> store.DenseAdj (train.check_samplers reads it)
+
+    def table(self, device=None):
+        """store.DenseAdj over the adjacency on `device` (default: where `adj` lives)."""
+        adj = self.adj if torch.is_tensor(self.adj) else torch.as_tensor(np.asarray(self.adj), dtype=torch.int64)
+        device = adj.device if device is None else torch.device(device)
+        key = (device.type, device.index if device.index is not None or device.type == "cpu"
+               else torch.cuda.current_device())
+        if key not in self._dev:
+            self._dev[key] = DenseAdj(adj.to(device))
+        return self._dev[key]
+
+    csr = table                                           # what the fused engines ask a sampler for
+
+    @staticmethod
+    def draw_keep(K, n_samples):
+        """The columns a call keeps: head of ONE permutation of the K columns, drawn exactly where the
+        reference draws it (nn_modules.py:44); n_samples = -1: all but the last (python slicing)."""
+        return torch.randperm(K)[:n_samples]
 
     def __call__(self, ids, n_samples=-1):
-        order = torch.randperm(self.adj.size(1))          # CPU generator, as the reference
-        keep = order[:n_samples]                          # n_samples=-1: all but the last column
-        if ids.is_cuda:
-            keep = keep.cuda()
-        return self.adj[ids][:, keep]
+        keep = self.draw_keep(self.adj.size(1), n_samples)
+        if not ids.is_cuda:
+            return self.adj[ids][:, keep]
+        tab = self.table(ids.device)
+        ids = ids.contiguous().view(-1)
+        M, n = int(ids.shape[0]), int(keep.shape[0])
+        out = torch.empty(M, n, dtype=torch.int64, device=ids.device)
+        keep = keep.to(ids.device, non_blocking=True)
+        nat.check(nat.lib().gsage_sample_dense(tab.adj.data_ptr(), tab.K, tab.n_rows, ids.data_ptr(), M,
+                                               keep.data_ptr(), n, out.data_ptr(), tab.err_flag.data_ptr(),
+                                               ops._stream()), "sample_dense")
+        return out
 
 
 class SparseUniformNeighborSampler(object):

@@ -128,6 +128,26 @@ def _philox_host(seed, call, g0, count, max_deg):
     return ((words * np.uint64(max_deg)) >> np.uint64(32)).astype(np.int64)
 
 
+def mt_choice_segments(state, high, segs, out):
+    """numpy's legacy stream on the device (`state`: helpers.legacy_stream.acquire), many np.random.choice(high, .)
+    requests in ONE launch: segs = [(offset into out, count)], served in order; out: int32 CUDA tensor (any shape,
+    offsets address its flat view)."""
+    segs = [(int(o), int(c)) for o, c in segs if c > 0]
+    if not segs:
+        return out
+    flat = out.view(-1)
+    assert flat.dtype == torch.int32 and flat.is_cuda and max(o + c for o, c in segs) <= flat.numel()
+    if high < 2:                                   # a range of one value: numpy draws nothing
+        for o, c in segs:
+            flat[o:o + c].zero_()
+        return out
+    host = torch.tensor([[o for o, _ in segs], [c for _, c in segs]], dtype=torch.int64)
+    dev = host.to(flat.device)
+    nat.check(nat.lib().gsage_mt_choice_segments(_ptr(state), int(high), len(segs), _ptr(dev[0]), _ptr(dev[1]),
+                                                 _ptr(flat), _stream()), "mt_choice_segments")
+    return out              # (`dev` may be freed: the caching allocator reuses it in stream order only)
+
+
 def sample_csr(csr, ids, n, sel=None, philox=None, out=None):
     """SparseUniformNeighborSampler.__call__ (nn_modules.py:80-101).
 

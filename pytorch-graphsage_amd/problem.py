@@ -80,12 +80,17 @@ class DeviceMetrics:
         y = y_true.detach().contiguous().float() if f32 else y_true.detach().contiguous().long()
         y = y.view(B, C) if multilabel else y.view(-1)
         assert y.shape[0] == B
-        counts = torch.empty(3 * C, dtype=torch.int32, device=preds.device)
-        out = torch.empty(2, dtype=torch.float32, device=preds.device)
+        counts = torch.empty(3 * C + 1, dtype=torch.int32, device=preds.device)
+        out = torch.empty(3, dtype=torch.float64, device=preds.device)
         nat.check(nat.lib().gsage_metric_f1(preds.data_ptr(), preds.stride(0), y.data_ptr(), int(multilabel),
                                             int(f32), C if multilabel else 0, B, C, counts.data_ptr(),
                                             out.data_ptr(), ops._stream()), "metric_f1")
-        micro, macro = out.tolist()
+        micro, macro, n_bad = out.tolist()
+        if n_bad:
+            # a class id outside [0, C): sklearn adds it to the label set (a false negative of a class that no
+            # logit column stands for) -- score this batch exactly as the reference does, on the host
+            fn = ProblemMetrics.multilabel_classification if multilabel else ProblemMetrics.classification
+            return fn(y_true.detach().cpu().numpy(), preds.cpu().numpy())
         return {"micro": float(micro), "macro": float(macro)}
 
     @staticmethod
@@ -102,7 +107,7 @@ class DeviceMetrics:
         a = y_true.detach().float().contiguous().view(-1)
         b = y_pred.detach().float().contiguous().view(-1)
         assert a.shape == b.shape, "regression_mae: y_true and y_pred must have the same number of elements"
-        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        out = torch.empty(1, dtype=torch.float64, device=a.device)
         nat.check(nat.lib().gsage_metric_mae(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
                                              ops._stream()), "metric_mae")
         return float(out.item())

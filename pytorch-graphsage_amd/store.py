@@ -80,6 +80,31 @@ class DeviceCSR(object):
             raise IndexError("sampler: node id out of range of the adjacency")
 
 
+class DenseAdj(object):
+    """The dense adjacency of the reference's default sampler (UniformNeighborSampler, nn_modules.py:19-49): an
+    int64 [n_rows, K] table in HBM, every row pre-sampled to exactly K neighbours by the converter
+    (utils/convert.py:71-98; ids 0-based, the dummy node is the LAST row).  Quacks like DeviceCSR where the fused
+    engines need it (n_rows, max_deg = K, err_flag, check())."""
+
+    def __init__(self, adj):
+        assert torch.is_tensor(adj) and adj.dim() == 2 and adj.dtype == torch.int64, \
+            "UniformNeighborSampler: adj must be a LongTensor [n_nodes + 1, K]"
+        self.adj = adj.contiguous()
+        self.n_rows, self.K = int(adj.shape[0]), int(adj.shape[1])
+        self.max_deg = self.K
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=adj.device)
+
+    @property
+    def device(self):
+        return self.adj.device
+
+    def check(self):
+        """Raise IndexError if a kernel saw an id outside the table (synchronises)."""
+        if self.adj.is_cuda and int(self.err_flag.item()) != 0:
+            self.err_flag.zero_()
+            raise IndexError("sampler: node id out of range of the adjacency")
+
+
 class FeatureStore(object):
     """Device-resident node-feature table.  Quacks enough like the reference's `problem.feats`
     tensor for models.py / train.py: `.shape`, `.size()`, `feats[ids]`, `.is_cuda`."""

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), "libgsage_hip.so does not export %s" % n
         assert n in gs._native.SIGNATURES, "ctypes binding lacks %s" % n
     assert set(gs._native.SIGNATURES) == set(names)
-    assert gs._native.lib().gsage_abi_version() == gs._native.ABI_VERSION == 2
+    assert gs._native.lib().gsage_abi_version() == gs._native.ABI_VERSION == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -99,6 +99,7 @@ def test_product_never_touches_the_oracle_or_the_reference():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prod = glob.glob(os.path.join(root, "pytorch-graphsage_amd", "*.py")) + \
+        glob.glob(os.path.join(root, "pytorch-graphsage_amd", "engine", "*.py")) + \
         glob.glob(os.path.join(root, "pytorch-graphsage_amd", "csrc", "*")) + \
         glob.glob(os.path.join(root, "include", "*.h"))
     prod = [f for f in prod if os.path.isfile(f) and not f.endswith((".o", ".so"))]

@@ -318,3 +318,38 @@ def test_split_mode_equals_single_stream(B, fans):
         res.append((torch.stack(preds), eng.flat_p.clone()))
         model.train_sampler.csr(DEV).check()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_engine_hands_its_adam_state_back_to_train_step_and_checkpoints():
+    """An engine trains three steps, then GSSupervised.train_step takes the Parameters back: FlatAdam must continue
+    from the engine's exp_avg / exp_avg_sq / step count (the moments used to restart from zero), and
+    `model.optimizer_state_dict()` while the engine holds the Parameters is torch.optim.Adam's format with that state."""
+    adj, feats, rng = _problem()
+    D, C, B = feats.shape[1], 5, 32
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    model = _model(adj, D, C, (16, 8), (5, 3))
+    loss_fn = gs.ProblemLosses.classification
+    batches = [(torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV),
+                torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)) for _ in range(4)]
+    eng = gs.engine.FusedMeanTrainStep(model, store, loss_fn, batches[0][0], batches[0][1], capture="cmdlist")
+    for ids, tg in batches[:3]:
+        eng(ids, tg)
+    torch.cuda.synchronize()
+    assert eng.holds_parameters()
+    sd = model.optimizer_state_dict()
+    assert int(sd["state"][0]["step"]) == 3 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in model.parameters()], lr=0.01)
+    ref.load_state_dict(sd)                                    # the reference's optimizer class accepts it
+    m3, v3 = eng.flat_m.clone(), eng.flat_v.clone()
+    assert float(m3.abs().max()) > 0
+    model.train_step(ids=batches[3][0], feats=store, targets=batches[3][1], loss_fn=loss_fn)
+    torch.cuda.synchronize()
+    opt = model.optimizer
+    assert isinstance(opt, gs.optim.FlatAdam) and not eng.holds_parameters()
+    assert int(opt.step_count.item()) == 4
+    g = opt.flat_g                                             # m4 = 0.9 m3 + 0.1 g4 (weight decay folded into g)
+    wd_g = g + 1e-4 * (opt.flat_p - 0)                         # p moved by <= lr; bound loosely below
+    assert torch.allclose(opt.flat_m, 0.9 * m3 + 0.1 * wd_g, rtol=0, atol=2e-4 * float(1 + wd_g.abs().max()))
+    assert float((opt.flat_v - 0.999 * v3).min()) >= -1e-12    # v4 = 0.999 v3 + 0.001 g^2 >= 0.999 v3
+    import pickle
+    pickle.dumps(model.state_dict())

@@ -129,8 +129,16 @@ def test_dense_sampler_golden_on_gpu():
     for c in range(int(g["n_cases"])):
         p = "c%d_" % c
         gs.helpers.set_seeds(int(g[p + "seed"]))
+        before = gs._native.launch_count()
         out = s(torch.from_numpy(g[p + "ids"]).to(DEV), n_samples=int(g[p + "n"]))
-        assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[p + "out"]), c
+        assert gs._native.launch_count() > before, "the dense sampler must run its HIP kernel on CUDA ids"
+        assert out.is_cuda and out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g[p + "out"]), c
+    s.table(DEV).check()
+    # an id outside the table: the reference's torch indexing raises IndexError; here a device flag, read by check()
+    bad = torch.tensor([0, adj.shape[0]], device=DEV)
+    s(bad, n_samples=3)
+    with pytest.raises(IndexError):
+        s.table(DEV).check()
 
 
 def test_bench_starts_its_own_ranks():
@@ -172,6 +180,19 @@ def test_device_metrics_match_the_reference_fixture():
     host = gs.batch_metric("classification", torch.from_numpy(g["cls_y"]), torch.from_numpy(g["cls_logits"]))
     dev = gs.batch_metric("classification", y, lg)
     assert abs(host["micro"] - dev["micro"]) < 1e-6 and abs(host["macro"] - dev["macro"]) < 1e-6
+    # a target outside [0, C) is a label of its own for sklearn: the device path must not drop it silently
+    y_bad = y.clone()
+    y_bad[0] = lg.shape[1] + 2
+    want = gs.ProblemMetrics.classification(y_bad.cpu().numpy(), lg.cpu().numpy())
+    got = gs.DeviceMetrics.classification(y_bad, lg)
+    assert abs(got["micro"] - want["micro"]) < 1e-9 and abs(got["macro"] - want["macro"]) < 1e-9
+    assert abs(got["macro"] - m["macro"]) > 1e-6               # (and it does change the macro mean)
+    # a NaN logit wins the argmax, like np.argmax
+    lg_nan = lg.clone()
+    lg_nan[1, 2] = float("nan")
+    want = gs.ProblemMetrics.classification(y.cpu().numpy(), lg_nan.cpu().numpy())
+    got = gs.DeviceMetrics.classification(y, lg_nan)
+    assert abs(got["micro"] - want["micro"]) < 1e-9 and abs(got["macro"] - want["macro"]) < 1e-9
 
 
 @pytest.mark.parametrize("seed", [0, 123, 15129])

@@ -92,7 +92,7 @@ def test_deferred_rows_equal_the_dense_update_bit_for_bit(E, wd, max_norm):
         # ---- dense side
         nat.check(lib.gsage_clip_adam_step(dn_p.data_ptr(), dn_g.data_ptr(), dn_m.data_ptr(), dn_v.data_ptr(), n_rows * E,
                                            dn_partial.data_ptr(), lz.lr.data_ptr(), dn_step.data_ptr(), 0.9, 0.999, 1e-8,
-                                           wd, max_norm, None, 2, 0, None, 0, None, 0, None, 0, st), "dense")
+                                           wd, max_norm, None, 2 | 4, 0, None, 0, None, 0, None, 0, st), "dense")
         dn_g.zero_()
     assert int(lz.last.min()) < 12                                        # some rows are still behind
     nat.check(lib.gsage_rows_catch_up_all(ctypes.byref(lz.d), 0, st), "all")
@@ -183,6 +183,35 @@ def test_module_forward_settles_deferred_rows():
         rows = torch.arange(1, 3000, device=DEV)
         outs.append(model.prep.embedding(rows).detach().clone())
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=2e-5)
+
+
+def test_model_forward_reads_settled_rows_after_deferred_engine_steps():
+    """The evaluation path of train.py (`model(ids, feats, train=False)`, reference train.py:29-36) never calls the
+    nn.Embedding module: NodeEmbeddingPrep reads `embedding.weight` itself.  After engine steps with deferred rows
+    the model's OWN forward must therefore settle them (GSSupervised.forward) -- compared with the dense-table run
+    on the same validation draws, over ids that include rows no training frontier touched."""
+    outs, behind = [], None
+    for mode in ("dense", "deferred"):
+        if mode == "dense":
+            os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
+        else:
+            os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
+        ops.set_compute_dtype("fp32")
+        model, ids, tg = _emb_model(seed=8)
+        eng = gs.engine.FusedAttnTrainStep(model, None, gs.ProblemLosses.regression_mae, ids[0], tg[0], capture="cmdlist")
+        for s in range(6):
+            eng(ids[s], tg[s])
+        if mode == "deferred":
+            behind = int((eng.row_last < 6).sum())
+            assert behind > 100                                  # most rows have pending zero-gradient updates
+        model.val_sampler.seed, model.val_sampler.calls = 77, 0
+        model.eval()
+        ev = torch.arange(1, 257, device=DEV)
+        with torch.no_grad():
+            outs.append(model(ev, None, train=False).detach().clone())
+        if mode == "deferred":
+            assert int(eng.row_last.min()) == 6                  # the forward settled every row
+    assert torch.allclose(outs[0], outs[1], rtol=1e-4, atol=1e-4), float((outs[0] - outs[1]).abs().max())
 
 
 def test_close_settles_rows_and_detaches_and_a_second_engine_starts_from_current_rows():
