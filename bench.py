@@ -21,13 +21,14 @@ has run for >= 0.5 s; `value` comes from the MEDIAN repeat (K = 20 steps is ~2 m
 noise), min / max are in config.timing.
 
 Extra objects on the line (tier contract, section 4 of the task):
-  roofline     the step's dominant launch, timed IN PLACE: the command list of the queue-mode step is
-               re-recorded with HIP-event marks around k_gather_multi_adam (the launch that gathers
-               the next batch's level-0 rows, with Adam and the sampler riding along) and around the
-               seed-level launch that carries the rest of those gathers; achieved = the frontier rows
-               that launch reads x D x 2 B / its mean duration over real steps (fresh frontier every
-               step, events on the stream the step runs on); peak = 8 TB/s HBM3E.  `step` adds the
-               whole-step figure (all 276 rows/seed / ms_per_step).
+  roofline     the step's dominant launch, timed IN PLACE (engine_roofline): the command list of the queue-mode
+               step is re-recorded with HIP-event marks on the dispatch of k_gather_multi_adam (the launch that
+               gathers the next batch's level-0 rows, with Adam and the sampler riding along) and of the
+               seed-level launch that carries the rest of those gathers; achieved = the frontier rows that launch
+               reads x D x 2 B / its mean duration over real steps; peak = 8 TB/s HBM3E.  `step` adds the
+               whole-step figure (all 276 rows/seed / ms_per_step).  Every `extra` entry carries the same object
+               for ITS dominant launch, timed the same way inside ITS step: K3 over the last hop (max-pool; MFMA),
+               K4 over the last hop (attention, Reddit and Pokec shapes; HBM), the gather launch (papers).
   cpu_baseline two CPU restatements of train_step on the host, bounded sample each: the OpenMP C one
                (oracle/gsage_train_omp.c, all cores, plain loops) and the plain-torch port of the reference's
                op sequence (oracle/torch_ref.py, MKL GEMMs, fixed thread count); `value` is the faster.
@@ -181,60 +182,116 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
             "which": names[0], "sample": best["sample"], names[1]: other}
 
 
-def dominant_kernel_roofline(eng, store, n_steps=64):
-    """Roofline object of the step's dominant launch, measured in place.
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_launches.json")
+TIMING_METHOD = ("HIP start/stop events attached to the launch's dispatch inside the step's command list "
+                 "(hipExtLaunchKernel), one read per step")
 
-    The queue-mode command lists are re-recorded with HIP start / stop events attached to the dispatch
-    (gsage_cmdlist_time_next) of k_gather_multi_adam -- the launch that gathers the next batch's level-0 rows (Adam of the current
-    batch and the sampler of the batch after ride along) -- and around the seed-level launch whose
-    spare workgroups gather the first part of the last hop.  n_steps real steps follow (every step a
-    fresh frontier, the events are recorded on the stream the step runs on, one host sync per step to
-    read them).  achieved = algorithmic bytes of the rows the launch reads (rows x D x sizeof) / mean
-    duration.  `traffic`: HBM bytes per launch of the same kernel from the rocprofv3 PMC passes
-    committed under profiles/ (FETCH_SIZE / WRITE_SIZE, guide's gfx950 corrections) when the workload is
-    the default one, else null."""
+
+def timed_launches(eng, run_step, n_steps=48):
+    """Mean duration (us) of the launches an engine can time IN PLACE (engine.TIMED): the command lists are
+    re-recorded with HIP start / stop events attached to the dispatch of those launches
+    (gsage_cmdlist_time_next), n_steps real steps follow (every step a fresh frontier, events on the stream the
+    step runs on, one host sync per step to read them), then the lists are recorded again without the events."""
     eng.instrument(True)
     torch.cuda.synchronize()
-    for _ in range(4):
-        eng.step_queue()
+    for k in range(4):
+        run_step(k)
     torch.cuda.synchronize()
-    g_ms, t_ms = [], []
-    for _ in range(n_steps):
-        eng.step_queue()
-        d = eng.last_launch_ms()
-        g_ms.append(d["gather"])
-        t_ms.append(d.get("seed_level", 0.0))
+    acc = {}
+    for k in range(n_steps):
+        run_step(4 + k)
+        for name, ms in eng.last_launch_ms().items():
+            acc.setdefault(name, []).append(ms)
     eng.instrument(False)
     torch.cuda.synchronize()
-    elem = store.data.element_size()
-    rows_g, rows_t = eng.gather_launch_rows()
-    g_us, t_us = float(np.mean(g_ms)) * 1e3, float(np.mean(t_ms)) * 1e3
-    alg = rows_g * store.dim * elem
-    achieved = alg / (g_us * 1e-6) / 1e9
-    traffic, twrite, src = None, None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_gather_launch.json")
-    if os.path.exists(pmc) and elem == 2 and (eng.B, tuple(eng.fan[1:]), store.dim) == (BATCH, FANOUT, FEAT_DIM):
-        with open(pmc) as f:
-            rec = json.load(f)
-        traffic, twrite, src = rec.get("hbm_read_bytes_per_launch"), rec.get("hbm_write_bytes_per_launch"), \
-            "profiles/r02_pmc_gather_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-    out = {"bound": "hbm", "kernel": "k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
-           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_write": twrite, "traffic_source": src,
-           "alg_bytes_per_launch": alg, "rows_per_launch": rows_g, "avg_launch_us": g_us,
-           "timed_steps": n_steps,
-           "method": "HIP start/stop events attached to the launch's dispatch inside the step's command list "
-                     "(hipExtLaunchKernel), one read per step"}
-    if rows_t:
-        out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
-                                    "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * store.dim * elem,
-                                    "avg_launch_us": t_us}
+    return {name: float(np.mean(v)) * 1e3 for name, v in acc.items()}
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of a timed kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
+    and WRITE_SIZE in separate passes, the guide's gfx950 corrections, a calibration copy per pass):
+    profiles/r03_pmc_launches.json, written by tools/refresh_profiles.py from the same bench command."""
+    if not os.path.exists(PMC_FILE):
+        return None, None, None
+    with open(PMC_FILE) as f:
+        rec = json.load(f).get(key)
+    if not rec:
+        return None, None, None
+    return rec.get("hbm_read_bytes_per_launch"), rec.get("hbm_write_bytes_per_launch"), \
+        "profiles/r03_pmc_launches.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" % key
+
+
+def hbm_roofline(kernel, alg_bytes, us, pmc_key, n_steps, **more):
+    achieved = alg_bytes / (us * 1e-6) / 1e9
+    rd, wr, src = pmc_traffic(pmc_key)
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": rd, "traffic_write": wr, "traffic_source": src,
+           "alg_bytes_per_launch": alg_bytes, "avg_launch_us": us, "timed_steps": n_steps, "method": TIMING_METHOD}
+    out.update(more)
+    return out
+
+
+def mfma_roofline(kernel, flops, us, pmc_key, n_steps, **more):
+    achieved = flops / (us * 1e-6) / 1e12
+    rd, wr, src = pmc_traffic(pmc_key)
+    out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": rd, "traffic_write": wr, "traffic_source": src,
+           "alg_flops_per_launch": flops, "avg_launch_us": us, "timed_steps": n_steps, "method": TIMING_METHOD}
+    out.update(more)
+    return out
+
+
+def engine_roofline(eng, run_step, pmc_key, n_steps=48):
+    """The roofline object of an engine's dominant launch, timed in place inside the real step.
+      FusedMeanTrainStep  k_gather_multi_adam: gathers of batch i+1 | Adam(i) | K1(i+2); HBM.  Algorithmic bytes =
+                          the frontier rows that launch reads x D x sizeof (every sampled row is read exactly once
+                          per step, by this launch or by the seed-level launch's gather role -- listed beside it).
+      FusedPoolTrainStep  K3 (k_pool_mlp_packed) over the last hop, reading the rows through the frontier's row
+                          list as the step does; MFMA.  FLOPs = 2 x rows x D x hidden (nn_modules.py:224).
+      FusedAttnTrainStep  K4 (k_attn_aggregate_grp) over the last hop: every child row read once; HBM."""
+    us = timed_launches(eng, run_step, n_steps)
+    kind = type(eng).__name__
+    L = eng.L
+    if kind == "FusedMeanTrainStep":
+        st = eng.store
+        elem = st.data.element_size()
+        rows_g, rows_t = eng.gather_launch_rows()
+        out = hbm_roofline("k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
+                           rows_g * st.dim * elem, us["gather"], pmc_key, n_steps, rows_per_launch=rows_g)
+        if rows_t and "seed_level" in us:
+            out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
+                                        "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * st.dim * elem,
+                                        "avg_launch_us": us["seed_level"]}
+        return out
+    rows = eng.size[L]                                    # rows of the last hop
+    if kind == "FusedPoolTrainStep":
+        D, Hm = eng.din[0], eng.Hm[0]
+        out = mfma_roofline("k_pool_mlp_packed (K3 in-step, last hop: %d rows x %d -> %d, rows read through the "
+                            "frontier's row list)" % (rows, D, Hm), 2.0 * rows * D * Hm, us["k3"], pmc_key, n_steps)
+        if "k5b" in us:
+            flops_b = sum(2.0 * eng.nrows[l] * eng.din[l] * eng.Hm[l] + 2.0 * eng.rows[l] * eng.h[l] *
+                          (eng.din[l] + eng.Hm[l]) for l in range(L))
+            out["k5b_launch"] = {"kernel": "k_wgrad_multi (every weight gradient of the step, one grouped launch)",
+                                 "alg_flops_per_launch": flops_b, "avg_launch_us": us["k5b"],
+                                 "achieved_tflops": flops_b / (us["k5b"] * 1e-6) / 1e12,
+                                 "frac": flops_b / (us["k5b"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS}
+        return out
+    D = eng.din[0]
+    elem = 2 if eng.tdt == torch.bfloat16 else 4
+    out = hbm_roofline("k_attn_aggregate_grp (K4 in-step, last hop: %d child rows x %d %s)"
+                       % (rows, D, "bf16" if elem == 2 else "fp32"), rows * D * elem, us["k4"], pmc_key, n_steps,
+                       rows_per_launch=rows)
+    if "k4_bwd" in us:
+        out["k4_bwd_launch"] = {"kernel": "k_attn_bwd_grp (K4' in-step, last hop: the same rows read once)",
+                                "alg_bytes_per_launch": rows * D * elem, "avg_launch_us": us["k4_bwd"],
+                                "achieved": rows * D * elem / (us["k4_bwd"] * 1e-6) / 1e9}
     return out
 
 
 def standalone_gather_probe(gs, model, store, data, dev, fanout, B, reps=40, n_frontiers=8):
-    """Fallback roofline object when the step is not the queue-mode fused mean engine (data-parallel
-    runs, other engines): the last hop's gather+mean as ONE stand-alone k_gather_mean launch on fresh
+    """Fallback roofline object when the step cannot be instrumented (data-parallel runs, eager / hipGraph
+    launching): the last hop's gather+mean as ONE stand-alone k_gather_mean launch on fresh
     frontiers, HIP events on the launch stream.  Labelled as a probe: it is not a kernel of the step."""
     ops = gs.ops
     rng = np.random.RandomState(7)
@@ -262,52 +319,6 @@ def standalone_gather_probe(gs, model, store, data, dev, fanout, B, reps=40, n_f
     return {"bound": "hbm", "kernel": "k_gather_mean (stand-alone probe of the last hop, NOT a launch of the step)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_us": dur_s * 1e6}
-
-
-MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
-
-
-def pool_kernel_roofline(gs, model, store, data, dev, reps=20, n_frontiers=4):
-    """BASELINE configs[2] (max-pool): the dominant kernel is K3 (pooling MLP + bias + ReLU + segment
-    max fused) on the hop-2 frontier -- MFMA-bound.  FLOPs = 2 * rows * D * hidden of the contraction
-    the reference runs as mlp(neibs) (nn_modules.py:224).  Timed exactly as engine.FusedPoolTrainStep
-    launches it: gsage_pool_mlp_packed over the frontier's rows gathered beforehand (not timed)."""
-    ops, nat = gs.ops, gs._native
-    layer = list(model.agg_layers.children())[0]
-    lin = layer.mlp[0]
-    rng = np.random.RandomState(7)
-    M, n = BATCH * FANOUT[0], FANOUT[1]
-    H = lin.weight.shape[0]
-    fronts = []
-    for _ in range(n_frontiers):
-        ids0 = torch.from_numpy(data["train_ids"][rng.randint(0, len(data["train_ids"]), size=BATCH)]).to(dev)
-        ids2 = model.train_sampler(model.train_sampler(ids0, n_samples=FANOUT[0]), n_samples=n)
-        fronts.append(ops.gather_mean(store, ids2, M * n, 1, out_dtype=torch.bfloat16, out_ld=store.ld))
-    wp = ops.pack_weight(lin.weight.detach().float().contiguous())
-    bias = lin.bias.detach().float().contiguous()
-    pooled = torch.empty(M, H, dtype=torch.float32, device=dev)
-    pooled_b = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
-    argmax = torch.empty(M, H, dtype=torch.int32, device=dev)
-
-    def run(rows):
-        nat.check(nat.lib().gsage_pool_mlp_packed(rows.data_ptr(), store.ld, None, wp.data_ptr(), bias.data_ptr(), M, n,
-                                                  H, FEAT_DIM, nat.POOL_MAX, pooled.data_ptr(), H, argmax.data_ptr(),
-                                                  pooled_b.data_ptr(), H, None, ops._stream()), "pool_mlp_packed")
-    for f in fronts:
-        run(f)
-    torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for r in range(reps):
-        run(fronts[r % n_frontiers])
-    stop.record()
-    torch.cuda.synchronize()
-    dur_s = start.elapsed_time(stop) / 1e3 / reps
-    flops = 2.0 * M * n * FEAT_DIM * H
-    achieved = flops / dur_s / 1e12
-    return {"bound": "mfma", "kernel": "k_pool_mlp_packed (K3, hop 2: 128 000 rows x 602 -> 512)",
-            "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-            "traffic": None, "alg_flops_per_launch": flops, "avg_launch_us": dur_s * 1e6}
 
 
 def _lognormal_graph(gs, n_nodes, mu, sigma, max_deg, seed=0):
@@ -339,39 +350,47 @@ def _timed_steps(step, n_warm, n_steps, finish=None):
     return (time.perf_counter() - t0) / n_steps
 
 
-def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=8_000_000, B=BATCH):
-    """BASELINE configs[4] at its SHAPE on one GPU: mean aggregator, three layers, fan-out 15/10/5, 128-d
-    bf16 features, synthetic graph of n_nodes nodes (~28 neighbours on average; the full 111 M-node table is
-    28 GB and would fit, building a 3.2e9-edge CSR on the host takes minutes).  Parity of this shape:
-    tests/test_gpu_large.py (8.4 M nodes, int64 row offsets) and the 3-layer golden fixtures."""
+def _placeholder_adj():
+    from scipy import sparse
+    return sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
+
+
+def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=111_059_956, B=BATCH):
+    """BASELINE configs[4] on one GPU at its REAL size: 111 059 956 nodes, ~3.2e9 edges (int64 row offsets, 13 GB of
+    int32 neighbour ids), 128-d bf16 features (28 GB), mean aggregator, three layers, fan-out 15/10/5 -- graph and
+    table generated on the device (store.DeviceCSR.synthetic / FeatureStore.synthetic; ~43 GB of the 288 GB).
+    Parity at this size: tests/test_gpu_large.py::test_three_layer_engine_step_at_papers_scale."""
     from torch.nn import functional as F
-    adj, rng = _lognormal_graph(gs, n_nodes, 2.6, 1.2, 30_000)
-    feats = torch.zeros(n_nodes + 1, 128, dtype=torch.bfloat16, device=dev)
-    feats[1:] = torch.randn(n_nodes, 128, device=dev).bfloat16()
-    store = gs.FeatureStore(feats, 128)
+    n_rows = n_nodes + 1
+    csr = gs.DeviceCSR.synthetic(n_rows, 14, 44, dev, max_deg=4096, seed=1, empty_every=1000)
+    store = gs.FeatureStore.synthetic(n_rows, 128, dev, dtype="bf16", seed=2)
     fan, dims = (15, 10, 5), (128, 128, 128)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
     specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
               "activation": (lambda x: x) if i == 2 else F.relu} for i, (f, h) in enumerate(zip(fan, dims))]
-    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
-                            prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup["mean"],
-                            input_dim=128, n_nodes=adj.shape[0], n_classes=N_CLASSES, layer_specs=specs,
-                            lr_init=0.01).to(dev)
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=_placeholder_adj(),
+                            train_adj=_placeholder_adj(), prep_class=gs.prep_lookup["identity"],
+                            aggregator_class=gs.aggregator_lookup["mean"], input_dim=128, n_nodes=n_rows,
+                            n_classes=N_CLASSES, layer_specs=specs, lr_init=0.01).to(dev)
     model.train_sampler.seed = 123
-    model.train_sampler.csr(dev)
+    model.train_sampler.use_device_csr(csr)
     total = steps + warmup
-    ids = torch.from_numpy(rng.integers(1, n_nodes + 1, size=(total, B))).to(dev)
+    rng = np.random.default_rng(0)
+    ids = torch.from_numpy(rng.integers(1, n_rows, size=(total, B))).to(dev)
     tg = torch.from_numpy(rng.integers(0, N_CLASSES, size=(total, B, 1))).to(dev)
     eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids[0], tg[0])
     eng.load_epoch(ids, tg)
     dt = _timed_steps(lambda k: eng.step_queue(), warmup, steps)
-    model.train_sampler.csr(dev).check()
+    csr.check()
     rows = 1 + 15 + 150 + 750
-    return {"config": "BASELINE configs[4] shape at %d nodes (nnz=%d): mean, 3 layers, fan-out 15/10/5, 128-d bf16 "
-                      "features, one GPU" % (n_nodes, adj.nnz),
-            "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec", "engine": "FusedMeanTrainStep",
-            "alg_bytes_per_seed": rows * 128 * 2,
-            "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2))}
+    rec = {"config": "BASELINE configs[4] at its real size (N=%d, nnz=%d): mean, 3 layers, fan-out 15/10/5, 128-d bf16 "
+                     "features (a %.1f GB table: the uncached reference point for the gather), one GPU"
+                     % (n_nodes, csr.nnz, store.data.numel() * 2 / 1e9),
+           "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec", "engine": "FusedMeanTrainStep",
+           "alg_bytes_per_seed": rows * 128 * 2,
+           "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2)),
+           "roofline": engine_roofline(eng, lambda k: eng.step_queue(), "papers_gather", n_steps=32)}
+    return rec
 
 
 def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fused"):
@@ -401,8 +420,9 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
     loss_fn = gs.ProblemLosses.regression_mae
     cls = gs.engine.fused_engine_for(model, None) if engine == "fused" else None
     if cls is not None:
-        step_fn = cls(model, None, loss_fn, ids[0], tg[0], capture="graph")
-        how = "%s (native attention step: K4 / K5 / K5b / K6, no autograd below the head), hipGraph" % cls.__name__
+        step_fn = cls(model, None, loss_fn, ids[0], tg[0], capture=os.environ.get("GSAGE_POKEC_LAUNCH", "cmdlist"))
+        how = "%s (native attention step: K4 / K5 / K5b / K6, no autograd below the head), %s" % (
+            cls.__name__, step_fn.capture_mode)
     else:
         step_fn = gs.engine.CapturedTrainStep(model, None, loss_fn, ids[0], tg[0])
         how = "CapturedTrainStep (native K4 / K5 / K5b / K6 kernels under autograd, hipGraph)"
@@ -415,10 +435,16 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
                "all rows settled inside the timed region"
     model.train_sampler.csr(dev).check()
     rows = 1 + 20 + 300
-    return {"config": "BASELINE configs[3] shape on one GPU: Pokec-sized graph (N=%d, nnz=%d), node_embedding(64) + "
-                      "attention(32), fan-out 20/15, regression_mae" % (N, adj.nnz),
-            "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec",
-            "engine": how, "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2)}
+    rec = {"config": "BASELINE configs[3] shape on one GPU: Pokec-sized graph (N=%d, nnz=%d), node_embedding(64) + "
+                     "attention(32), fan-out 20/15, regression_mae" % (N, adj.nnz),
+           "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec",
+           "engine": how, "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2),
+           "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 64 * 4))}
+    if cls is not None and step_fn.capture_mode == "cmdlist":
+        rec["roofline"] = engine_roofline(step_fn, lambda k: step_fn(ids[k % total], tg[k % total]), "pokec_k4",
+                                          n_steps=32)
+        step_fn.sync_rows()
+    return rec
 
 
 def _free_port():
@@ -527,9 +553,9 @@ def main():
         model.train_sampler.csr(dev)                       # upload the CSR before timing
         use_graph = args.launch != "eager"
         step_fn, engine = None, args.engine
-        fused_cls = gs.engine.fused_engine_for(model, store)
+        fused_cls = gs.engine.fused_engine_for(model, store, explain=(rank == 0))
         if engine == "fused" and fused_cls is None:
-            engine = "autograd"
+            engine = "autograd"                             # (fused_engine_for said on stderr what is not covered)
         if engine == "fused":
             step_fn = fused_cls(model, store, loss_fn, ids_all[0], tg_all[0], ddp=ddp,
                                 capture=args.launch if use_graph else False, pipelined=args.pipeline)
@@ -592,12 +618,11 @@ def main():
 
     if rank == 0:
         value = args.steps * B * world / elapsed
-        fused_mean_queue = (res["queued"] and ddp is None and type(step_fn) is gs.engine.FusedMeanTrainStep
-                            and getattr(step_fn, "capture_mode", None) == "cmdlist")
-        if args.aggregator in ("max_pool", "mean_pool") and fanout == FANOUT and B == BATCH:
-            roof = pool_kernel_roofline(gs, model, store, data, dev)
-        elif fused_mean_queue:
-            roof = dominant_kernel_roofline(step_fn, store)
+        instrumentable = (res["queued"] and ddp is None and getattr(step_fn, "capture_mode", None) == "cmdlist")
+        if instrumentable:
+            roof = engine_roofline(step_fn, lambda k: step_fn.step_queue(),
+                                   {"mean": "reddit_gather", "max_pool": "maxpool_k3",
+                                    "attention": "attention_k4"}.get(args.aggregator, args.aggregator))
         else:
             roof = standalone_gather_probe(gs, model, store, data, dev, fanout, B)
         step_alg = rows_per_seed(fanout) * FEAT_DIM * elem * B
@@ -644,8 +669,12 @@ def main():
                        "ms_per_step": e2 / args.steps * 1e3, "value": args.steps * B / e2,
                        "unit": "seed-nodes/sec", "engine": type(r2["step_fn"]).__name__,
                        "kernel_launches_per_step": r2["launches_per_step"], "repeats": len(r2["times"])}
-                if agg in ("max_pool", "mean_pool") and fanout == FANOUT and B == BATCH:
-                    rec["roofline"] = pool_kernel_roofline(gs, r2["model"], store, data, dev)
+                if r2["queued"] and getattr(r2["step_fn"], "capture_mode", None) == "cmdlist":
+                    rec["roofline"] = engine_roofline(r2["step_fn"], lambda k, e=r2["step_fn"]: e.step_queue(),
+                                                      {"max_pool": "maxpool_k3", "attention": "attention_k4"}.get(agg, agg),
+                                                      n_steps=32)
+                    rec["frac_of_hbm_gather_roofline"] = (args.steps * B / e2) / (HBM_PEAK_GBS * 1e9 / (
+                        rows_per_seed(fanout) * FEAT_DIM * elem))
                 extra[agg] = rec
                 del r2
                 torch.cuda.empty_cache()

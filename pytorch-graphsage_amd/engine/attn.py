@@ -34,6 +34,7 @@ class FusedAttnTrainStep(FusedTrainStep):
 
     HA_LD = 64            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
     WG_TARGET = 120       # K5b workgroups per problem (eight problems share the launch)
+    TIMED = {"gather": (0, 1), "k4": (4, 5), "k4_bwd": (6, 7)}   # K4 / K4' of level 0 over the LAST hop (the bulk)
 
     @classmethod
     def why_not(cls, model, feats):
@@ -198,6 +199,8 @@ class FusedAttnTrainStep(FusedTrainStep):
             for k in range(L - l):                   # K4 writes the aggregate as fp32 and as the next GEMMs' operand
                 r0, c0 = self.off[k], self.off[k + 1]
                 tab, idp = self._child_rows(inp, rows, c0)
+                if l == 0 and k == L - 1:
+                    self._time_next(4, 5)
                 nat.check(lib.gsage_attn_aggregate_lp(
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
                     idp, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
@@ -224,6 +227,8 @@ class FusedAttnTrainStep(FusedTrainStep):
             for k in range(L - l):
                 r0, c0 = self.off[k], self.off[k + 1]
                 tab, idp = self._child_rows(inp, rows, c0)
+                if l == 0 and k == L - 1:
+                    self._time_next(6, 7)
                 nat.check(lib.gsage_attn_bwd(
                     self.dagg[l][r0:].data_ptr(), ld, self.ws[l][c0 - self.off[1]:].data_ptr(),
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,

@@ -341,7 +341,7 @@ class FusedTrainStep(object):
         # "graph" = hipGraphs.
         self.capture_mode = {True: "cmdlist", False: None, None: None}.get(capture, capture)
         assert self.capture_mode in (None, "cmdlist", "graph")
-        if self.capture_mode == "cmdlist" and not self.fused_head:
+        if self.capture_mode == "cmdlist" and not (self.fused_head or self.fused_l1):
             self.capture_mode = "graph"              # the stock-torch head cannot be recorded
         self._pool = None
         if self.capture_mode:
@@ -908,22 +908,37 @@ class FusedTrainStep(object):
                     self.g_qfront = [self._record(lambda par=par: self._queue_front(par, False)) for par in range(2)]
                     self.g_opt = self._record(self._stage_opt)
 
+    # launches an engine can time in place: name -> (start mark, stop mark); subclasses add theirs
+    TIMED = {"gather": (0, 1)}
+
     def instrument(self, on=True):
-        """Measurement only (bench.py's roofline object): re-record the queue-mode command lists with
-        HIP start / stop events attached to the dispatch of the step's dominant launch -- the one that
-        gathers the next batch's level-0 rows (events 0/1) -- and of the seed-level launch that carries
-        the first part of those gathers (events 2/3).  `last_launch_ms()` then returns their durations
-        for the step just replayed: timed in place, on the stream the step runs on."""
-        assert self.queue is not None and self.capture_mode == "cmdlist" and self.ddp is None
+        """Measurement only (bench.py's roofline objects): re-record the command lists with HIP start / stop events
+        attached to the DISPATCH of the launches named in TIMED (gsage_cmdlist_time_next -> hipExtLaunchKernel):
+        `gather` = the launch that gathers the next batch's level-0 rows, `seed_level` = the seed-level launch
+        that carries the first part of those gathers, and per engine its dominant kernel (pool: K3 on the last
+        hop; attention: K4 on the last hop).  `last_launch_ms()` then returns their durations for the step just
+        replayed: timed in place, on the stream the step runs on."""
+        assert self.capture_mode == "cmdlist" and self.ddp is None
         self._marks = bool(on)
-        self._record_queue()
+        torch.cuda.synchronize()
+        if self.queue is not None:
+            self._record_queue()
+        else:
+            self._record_main()
 
     def last_launch_ms(self):
-        par = (self._qstep - 1) % 2
-        cl = self.g_queue[par].cl
-        out = {"gather": (self.g_qfront[par].cl if self.split else cl).elapsed_ms(0, 1)}
-        if self.fused_tail:
-            out["seed_level"] = cl.elapsed_ms(2, 3)
+        if self.queue is not None:
+            par = (self._qstep - 1) % 2
+            cl = self.g_queue[par].cl
+            front = self.g_qfront[par].cl if getattr(self, "split", False) else cl
+        else:
+            cl = front = self.g_main[0].cl
+        out = {}
+        for name, (a, b) in self.TIMED.items():
+            try:
+                out[name] = (front if name == "gather" else cl).elapsed_ms(a, b)
+            except Exception:                     # this step has no such launch (e.g. nothing is gathered ahead)
+                pass
         return out
 
     def _time_next(self, a, b):

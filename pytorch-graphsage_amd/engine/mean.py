@@ -41,6 +41,7 @@ class FusedMeanTrainStep(FusedTrainStep):
     """
 
     MEAN_ENGINE = True
+    TIMED = {"gather": (0, 1), "seed_level": (2, 3)}
 
 
     @classmethod

@@ -35,6 +35,7 @@ class FusedPoolTrainStep(FusedTrainStep):
     # K5b workgroups per problem: the MLP's weight gradient is 20x the work of the two projections that
     # share its launch, so those take few, long M-slices (fewer partial tiles to write and to sum)
     WG_TARGET = {"m": 240, "x": 40, "n": 40}
+    TIMED = {"gather": (0, 1), "k3": (4, 5), "k5b": (6, 7)}      # K3 = level 0's launch over the LAST hop (the bulk)
 
     @classmethod
     def why_not(cls, model, feats):
@@ -194,6 +195,8 @@ class FusedPoolTrainStep(FusedTrainStep):
                 tail = (self.pooled[l][r0:r1].data_ptr(), Hm, self.argmax[l][r0:r1].data_ptr() if is_max else None,
                         self.pooled_b[l][r0:r1].data_ptr() if is_bf else None, self.pooled_b[l].shape[1],
                         None if is_max else self.argmax[l][a0:].data_ptr(), stream)
+                if l == 0 and k == L - 1:
+                    self._time_next(4, 5)
                 if self.wm_p[l] is not None and ldnb % 64 == 0 and ldnb >= -(-din // 64) * 64:
                     nat.check(lib.gsage_pool_mlp_packed(
                         a_ptr, ldnb, r_ptr, self.wm_p[l].data_ptr(), layer.mlp[0].bias.data_ptr(),
@@ -263,5 +266,7 @@ class FusedPoolTrainStep(FusedTrainStep):
                           T["n"]))
             probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"], nrows))
         for i in range(0, len(probs), 8):
+            if i == 0:
+                self._time_next(6, 7)
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)

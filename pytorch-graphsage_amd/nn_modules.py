@@ -102,6 +102,14 @@ class SparseUniformNeighborSampler(object):
                                        self._host.n_rows, self._host.max_deg)
         return self._dev[key]
 
+    def use_device_csr(self, csr):
+        """Walk `csr` (a store.DeviceCSR already in HBM) on its device instead of uploading the scipy matrix this
+        sampler was built with -- for graphs that only ever exist on the GPU (store.DeviceCSR.synthetic: a
+        papers100M-sized CSR is 14 GB; the plugin API's scipy matrix is then a placeholder)."""
+        dev = csr.device
+        self._dev[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device())] = csr
+        return csr
+
     def __call__(self, ids, n_samples=128):
         assert n_samples > 0, 'SparseUniformNeighborSampler: n_samples must be set explicitly'
         ids = ids.contiguous().view(-1)

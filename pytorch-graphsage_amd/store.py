@@ -79,6 +79,29 @@ class DeviceCSR(object):
             self.err_flag.zero_()
             raise IndexError("sampler: node id out of range of the adjacency")
 
+    @staticmethod
+    def synthetic(n_rows, deg_lo, deg_hi, device, max_deg=None, seed=0, empty_every=0, chunk=1 << 29):
+        """A random graph in the reference's sparse convention built ON THE DEVICE (benchmarks and the
+        BASELINE-size tests: papers100M's 3.2e9 edges are 13 GB of int32 that no host round trip should carry):
+        row 0 = the dummy (no neighbours), degrees uniform in [deg_lo, deg_hi], neighbour ids uniform in
+        [1, n_rows); every `empty_every`-th row (if > 0) has no neighbours -> samples the dummy.  Row offsets are
+        int64 (they pass 2^31), the edge array is filled in chunks (a single randint of > 2^31 elements is not
+        something to rely on)."""
+        gen = torch.Generator(device=device).manual_seed(int(seed))
+        deg = torch.randint(int(deg_lo), int(deg_hi) + 1, (int(n_rows),), dtype=torch.int64, device=device, generator=gen)
+        deg[0] = 0
+        if empty_every:
+            deg[3::int(empty_every)] = 0
+        rowptr = torch.zeros(int(n_rows) + 1, dtype=torch.int64, device=device)
+        torch.cumsum(deg, 0, out=rowptr[1:])
+        del deg
+        nnz = int(rowptr[-1])
+        col = torch.empty(nnz, dtype=torch.int32, device=device)
+        for o in range(0, nnz, chunk):
+            n = min(chunk, nnz - o)
+            col[o:o + n] = torch.randint(1, int(n_rows), (n,), dtype=torch.int32, device=device, generator=gen)
+        return DeviceCSR(rowptr, col, n_rows, max_deg if max_deg is not None else int(deg_hi))
+
 
 class DenseAdj(object):
     """The dense adjacency of the reference's default sampler (UniformNeighborSampler, nn_modules.py:19-49): an
@@ -122,6 +145,20 @@ class FeatureStore(object):
         ld = _round_up(dim, 128 // (2 if dtype == "bf16" else 4))
         data = torch.zeros(n_rows, ld, dtype=tdt, device=device)
         data[:, :dim] = feats.to(device=device, dtype=torch.float32).to(tdt)
+        return FeatureStore(data, dim)
+
+    @staticmethod
+    def synthetic(n_rows, dim, device, dtype="bf16", seed=0, chunk=1 << 23):
+        """N(0, 1) rows generated on the device in chunks (a 111 M x 128 bf16 table is 28 GB; its fp32 staging copy
+        would be twice that); row 0 (the dummy node) is zero."""
+        tdt = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
+        ld = _round_up(int(dim), 128 // (2 if dtype == "bf16" else 4))
+        data = torch.zeros(int(n_rows), ld, dtype=tdt, device=device)
+        gen = torch.Generator(device=device).manual_seed(int(seed))
+        for o in range(0, int(n_rows), chunk):
+            n = min(chunk, int(n_rows) - o)
+            data[o:o + n, :dim] = torch.randn(n, int(dim), device=device, generator=gen).to(tdt)
+        data[0].zero_()
         return FeatureStore(data, dim)
 
     @staticmethod

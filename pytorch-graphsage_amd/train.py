@@ -6,14 +6,22 @@ per-batch / final / test JSON lines on stdout (train.py:151-157,165-170,174-176)
 model repr on stderr, so run.sh / utils/pokec.sh work unchanged.
 
 Additions (all optional): --rng {compat,philox}, --precision {bf16,fp32}, data-parallel execution
-when launched under torch.distributed.run (one process per GPU, RCCL grad all-reduce), and
---engine fused: the epoch runs through engine.Fused{Mean,Pool}TrainStep (five kernel launches per
-step for the Reddit mean configuration instead of one framework op per tensor expression).  The
-fused engines need batches of one fixed size, so that mode shuffles with the same numpy stream but
-cuts the permutation into whole batches of --batch-size (the < batch-size tail of an epoch is
-dropped, where the reference's iterate yields n_chunks near-equal chunks, problem.py:141-153) and
-logs every --log-interval batches (the reference parses that flag and logs every batch,
-train.py:64,150-158 -- a host-side sklearn F1 per step).
+when launched under torch.distributed.run (one process per GPU, RCCL grad all-reduce), and --engine:
+
+  auto (default)  a fused engine (engine.Fused{Mean,Pool,Attn}TrainStep: a handful of kernel launches per step
+                  instead of one framework op per tensor expression) whenever one covers the model, else the
+                  module path -- with one stderr line saying which engine runs or why none does.  The run is
+                  the reference's run: the epoch is shuffled with numpy's legacy stream and cut into the
+                  reference's near-equal `array_split` chunks (problem.py:141-153; a recorded step has one
+                  geometry, so chunks one seed short are padded and the head ignores the padding), the sampler
+                  consumes the SAME generators in the SAME order (--rng compat: numpy's stream, on the device;
+                  dense sampler: torch.randperm), so the sampled frontiers are bit-identical to the module
+                  path's and to the reference's, and one JSON line is printed per batch (train.py:150-158).
+  fused           the same engines, asked for explicitly: a model none covers is an error, and a line is printed
+                  every --log-interval batches only (the reference parses that flag and ignores it,
+                  train.py:64) -- the per-batch readback is the one thing left that costs a host sync per step.
+  eager           the module path (GSSupervised.train_step), one launch per operator.
+Data-parallel runs keep batches of one fixed size (--batch-size / world per rank, counter-based sampler).
 """
 from __future__ import division, print_function
 
@@ -106,7 +114,7 @@ def parse_args(argv=None):
     # build-specific (not in the reference)
     parser.add_argument('--rng', type=str, default='compat', choices=['compat', 'philox'])
     parser.add_argument('--precision', type=str, default='bf16', choices=['bf16', 'fp32'])
-    parser.add_argument('--engine', type=str, default='eager', choices=['eager', 'fused'])
+    parser.add_argument('--engine', type=str, default='auto', choices=['auto', 'eager', 'fused'])
 
     args = parser.parse_args(argv)
     args.cuda = not args.no_cuda
@@ -163,8 +171,17 @@ def main(argv=None):
     start_time = time()
     val_metric = train_metric = None
     epoch = 0
-    if args.engine == 'fused':
-        return train_fused(args, problem, model, ddp, start_time)
+    if args.engine in ('auto', 'fused') and args.cuda:
+        cls = gs.engine.fused_engine_for(model, problem.feats, explain=True)
+        assert cls is not None or args.engine == 'auto', \
+            '--engine fused: no fused engine covers this model (use --engine auto / eager)'
+        if cls is not None and ddp is not None and args.rng != 'philox':
+            print('gsage: data-parallel runs of the fused engines need --rng philox; using the module path',
+                  file=sys.stderr)
+            cls = None
+        if cls is not None:
+            print('gsage: train_step runs on %s' % cls.__name__, file=sys.stderr)
+            return train_fused(args, problem, model, ddp, start_time, cls)
     for epoch in range(args.epochs):
         model.train()
         for ids, targets, epoch_progress in problem.iterate(mode='train', shuffle=True,
@@ -195,53 +212,79 @@ def main(argv=None):
         ddp.close()
 
 
-def train_fused(args, problem, model, ddp, start_time):
-    """--engine fused: the same training run on the fused engines (see the module docstring)."""
-    assert args.cuda and args.rng == 'philox', '--engine fused needs CUDA and --rng philox'
-    cls = gs.engine.fused_engine_for(model, problem.feats)
-    assert cls is not None, '--engine fused: no fused engine covers this model (use --engine eager)'
-    world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
-    B = args.batch_size // world                       # per-rank share of the global batch
-    nodes = problem.nodes['train']
-    n_batches = nodes.shape[0] // (B * world)
-    assert n_batches >= 1, '--engine fused: fewer training nodes than one batch'
-    dev = torch.device('cuda')
+def epoch_chunks(nodes, batch_size):
+    """The reference's batches of one epoch (problem.py:141-153): a permutation from numpy's legacy stream, cut
+    into n // batch_size + 1 near-equal chunks (never all of one size: quirk 6).  -> list of index arrays."""
+    gs.helpers.legacy_stream.release()               # the shuffle is a HOST draw from the shared stream
+    order = np.random.permutation(np.arange(nodes.shape[0]))
+    return np.array_split(order, order.shape[0] // batch_size + 1)
 
-    def epoch_batches():
-        gs.helpers.legacy_stream.release()
-        order = np.random.permutation(np.arange(nodes.shape[0]))[:n_batches * B * world]     # problem.py:146
-        mids = nodes[order].reshape(n_batches, world, B)[:, rank]
-        ids = torch.from_numpy(np.ascontiguousarray(mids)).to(dev)
+
+def train_fused(args, problem, model, ddp, start_time, cls):
+    """The training run on a fused engine (see the module docstring)."""
+    assert args.cuda
+    world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
+    nodes = problem.nodes['train']
+    dev = torch.device('cuda')
+    cls_task = problem.task == 'classification'
+    every = 1 if args.engine == 'auto' else max(args.log_interval, 1)
+
+    def targets_of(mids, shape):
         tg = np.asarray(problem.targets[mids.reshape(-1)])
-        if problem.task == 'classification':
-            tgs = torch.from_numpy(tg.reshape(n_batches, B)).long().to(dev)
-        else:                                        # multilabel: [.., n_classes] floats; regression: [.., 1] floats
-            tgs = torch.from_numpy(tg.reshape(n_batches, B, -1).astype(np.float32)).to(dev)
-        return ids, tgs
-    ids, tgs = epoch_batches()
-    first = tgs[0].view(B, 1) if problem.task == 'classification' else tgs[0]
+        if cls_task:
+            return torch.from_numpy(tg.reshape(shape)).long().to(dev)
+        return torch.from_numpy(tg.reshape(shape + (-1,)).astype(np.float32)).to(dev)   # multilabel / regression
+
+    if world > 1:
+        # data-parallel: batches of one fixed size (the < batch-size tail of an epoch is dropped)
+        B = args.batch_size // world
+        n_batches = nodes.shape[0] // (B * world)
+        assert n_batches >= 1, 'fewer training nodes than one global batch'
+
+        def epoch_batches():
+            gs.helpers.legacy_stream.release()
+            order = np.random.permutation(np.arange(nodes.shape[0]))[:n_batches * B * world]     # problem.py:146
+            mids = nodes[order].reshape(n_batches, world, B)[:, rank]
+            return torch.from_numpy(np.ascontiguousarray(mids)).to(dev), targets_of(mids, (n_batches, B)), None
+    else:
+        # the reference's own chunks, padded to the largest one with the chunk's first seed
+        n_batches = nodes.shape[0] // args.batch_size + 1
+        B = -(-nodes.shape[0] // n_batches)
+        assert B >= 2, 'fewer than two training nodes per batch'
+
+        def epoch_batches():
+            chunks = epoch_chunks(nodes, args.batch_size)
+            mids = np.stack([np.concatenate([nodes[c], np.repeat(nodes[c[:1]], B - c.shape[0])]) for c in chunks])
+            return (torch.from_numpy(mids).to(dev), targets_of(mids, (n_batches, B)),
+                    [int(c.shape[0]) for c in chunks])
+    ids, tgs, live = epoch_batches()
+    first = tgs[0].view(B, 1) if cls_task else tgs[0]
     step = cls(model, problem.feats, problem.loss_fn, ids[0], first, ddp=ddp)
     # engines with the fused classification head walk a device-resident queue of the epoch's batches; the others
-    # (regression / multilabel heads run as stock torch ops inside the captured step) take one batch per call
-    queued = bool(getattr(step, "fused_head", False))
+    # (regression: the fused L1 head; multilabel: stock torch ops inside the captured step) take one batch per call
+    queued = bool(step.fused_head)
+    if live is not None and not (step.fused_head or step.fused_l1) and min(live) < B:
+        raise SystemExit('gsage: this head cannot ignore padded seeds; run with --engine eager')
     val_metric = train_metric = None
     epoch = 0
     for epoch in range(args.epochs):
         model.train()
         if epoch > 0:
-            ids, tgs = epoch_batches()
+            ids, tgs, live = epoch_batches()
         if queued:
-            step.load_epoch(ids, tgs)
+            step.load_epoch(ids, tgs, n_valid=live)          # (compat / dense sampler: draws the epoch's values)
         for b in range(n_batches):
+            nb = live[b] if live is not None else B
             step.set_progress((epoch + b / n_batches) / args.epochs)
-            preds = step.step_queue() if queued else step(ids[b], tgs[b])
-            if (b % max(args.log_interval, 1) == 0 or b == n_batches - 1) and rank == 0:
-                train_metric = batch_metric(problem.task, tgs[b].view(B, -1), preds)
+            preds = step.step_queue() if queued else step(ids[b, :nb], tgs[b, :nb])
+            if (b % every == 0 or b == n_batches - 1) and rank == 0:
+                train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
                 print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
                              "val_metric": val_metric, "time": time() - start_time}))
                 sys.stdout.flush()
         model.eval()
         val_metric = evaluate(model, problem, mode='val')
+    gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host
     print('-- done --', file=sys.stderr)
     if rank == 0:
         print(dumps({"epoch": epoch, "train_metric": train_metric, "val_metric": val_metric,
@@ -251,6 +294,7 @@ def train_fused(args, problem, model, ddp, start_time):
             print(dumps({"test_f1": evaluate(model, problem, mode='test')}))
     if ddp is not None:
         ddp.close()
+    return step
 
 
 if __name__ == "__main__":

@@ -110,8 +110,8 @@ def test_product_never_touches_the_oracle_or_the_reference():
         assert "/root/reference" not in text, f
     bench = open(os.path.join(root, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
-    body = bench[bench.index("def cpu_baseline("):bench.index("def dominant_kernel_roofline(")]
-    assert uses and all(bench.index("def cpu_baseline(") < u < bench.index("def dominant_kernel_roofline(") for u in uses)
+    body = bench[bench.index("def cpu_baseline("):bench.index("def timed_launches(")]
+    assert uses and all(bench.index("def cpu_baseline(") < u < bench.index("def timed_launches(") for u in uses)
     assert "from oracle import" in body
     for f in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(root, f)).read() or f == "__graft_entry__.py"

@@ -97,51 +97,47 @@ def test_gather_rows_beyond_2_31_bytes():
     assert float((mean - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1)
 
 
-def test_three_layer_engine_step_at_papers_scale():
-    """BASELINE configs[4] at full structural scale: 8.4 M nodes, 2.5e9 edges (row offsets beyond 2^31:
-    int64 rowptr), 128-d bf16 features, mean aggregator, THREE layers, fan-out 15/10/5 -- one fused
-    engine step on a graph built on the device.  Checked through properties that do not depend on size:
+def _placeholder_adj():
+    from scipy import sparse
+    return sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
+
+
+@pytest.mark.parametrize("n_rows,deg,B,need_gb", [((1 << 23) + 1, (200, 400), 64, 100),
+                                                  (111_059_956 + 1, (14, 44), 512, 160)])
+def test_three_layer_engine_step_at_papers_scale(n_rows, deg, B, need_gb):
+    """BASELINE configs[4]: 128-d bf16 features, mean aggregator, THREE layers, fan-out 15/10/5 -- one fused
+    engine step on a graph built on the device, at (a) 8.4 M nodes / 2.5e9 edges and (b) the configuration's REAL
+    size: 111 059 956 nodes, 3.2e9 edges (13 GB of int32 + int64 row offsets), a 28 GB feature table, B = 512.
+    Checked through properties that do not depend on size:
       * the engine's frontier == three per-hop launches of the stand-alone sampler with the same Philox
         (seed, call) -- which tests above tie to the definition out = col[rowptr[id] + sel % deg];
       * the step itself against the oracle (bf16 rounding points) fed that frontier and the frontier's
         feature rows: predictions, gradient norm, clipped gradients, and the Adam update."""
-    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+    if torch.cuda.get_device_properties(0).total_memory < need_gb * 2 ** 30:
         pytest.skip("needs a large-memory GPU")
-    import sys
-    from scipy import sparse
     from torch.nn import functional as F
     from oracle import torch_ref as tref
     from util import close, close_fro
-    n_rows, D, C, B, fans, dims = (1 << 23) + 1, 128, 41, 64, (15, 10, 5), (128, 128, 128)
-    deg = torch.randint(200, 401, (n_rows,), dtype=torch.int64, device=DEV)
-    deg[0] = 0
-    deg[3::1000] = 0
-    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=DEV)
-    rowptr[1:] = torch.cumsum(deg, 0)
-    nnz = int(rowptr[-1])
-    assert nnz > 2 ** 31
-    col = torch.randint(1, n_rows, (nnz,), dtype=torch.int32, device=DEV)
-    big = gs.DeviceCSR(rowptr, col, n_rows, 4096)
-    table = torch.zeros(n_rows, D, dtype=torch.bfloat16, device=DEV)
-    table[1:] = torch.randn(n_rows - 1, D, device=DEV).bfloat16()
-    store = gs.FeatureStore(table, D)
+    D, C, fans, dims = 128, 41, (15, 10, 5), (128, 128, 128)
+    big = gs.DeviceCSR.synthetic(n_rows, deg[0], deg[1], torch.device(DEV), max_deg=4096, seed=1, empty_every=1000)
+    rowptr = big.rowptr
+    assert big.nnz > 2 ** 31 and (n_rows < 10 ** 8 or big.nnz >= 3.2e9), big.nnz
+    store = gs.FeatureStore.synthetic(n_rows, D, torch.device(DEV), dtype="bf16", seed=2)
+    table = store.data
 
     # the model is built on a placeholder adjacency (the plugin API takes a scipy matrix, which a
-    # 2.5e9-edge graph is not going to be); the sampler's device CSR is then the big graph
-    tiny = sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
+    # 3.2e9-edge graph is not going to be); the sampler then walks the device-resident graph
     torch.manual_seed(11)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
     specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
               "activation": F.relu if i < 2 else (lambda x: x)} for i, (f, h) in enumerate(zip(fans, dims))]
-    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=tiny,
-                            train_adj=tiny, prep_class=gs.prep_lookup["identity"],
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=_placeholder_adj(),
+                            train_adj=_placeholder_adj(), prep_class=gs.prep_lookup["identity"],
                             aggregator_class=gs.aggregator_lookup["mean"], input_dim=D, n_nodes=n_rows,
                             n_classes=C, layer_specs=specs, lr_init=0.01, weight_decay=1e-4).to(DEV)
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
     model.train_sampler.seed = 31
-    model.train_sampler.csr(DEV)
-    key = next(iter(model.train_sampler._dev))
-    model.train_sampler._dev[key] = big
+    model.train_sampler.use_device_csr(big)
     w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -163,6 +159,7 @@ def test_three_layer_engine_step_at_papers_scale():
         hops.append(ref.cpu().numpy())
         cur, off = ref, off + ref.numel()
     assert off == B * (1 + 15 + 150 + 750)
+    assert int(front.max()) > n_rows // 2                      # the frontier reaches across the whole table
 
     # (2) the step against the oracle on the frontier's rows (ids relabelled to a compact table)
     uniq, inv = np.unique(np.concatenate([ids.cpu().numpy()] + hops), return_inverse=True)
@@ -180,6 +177,96 @@ def test_three_layer_engine_step_at_papers_scale():
         d_eng = v.detach().cpu().numpy() - w0[k].numpy()
         d_ref = w[k].numpy() - w0[k].numpy()
         close_fro(d_eng, d_ref, ("Adam update", k), 5e-2)
+
+
+@pytest.mark.parametrize("capture", ["graph"])
+def test_fused_attention_engine_deferred_rows_at_pokec_scale(capture):
+    """The engine bench.py times for BASELINE configs[3], at the size it is timed at: FusedAttnTrainStep over the
+    trainable 418 MB embedding table of a Pokec-sized graph (1.63 M nodes), B = 512, fan-out 20/15, regression_mae,
+    DEFERRED row updates, captured as hipGraphs -- four consecutive steps on four batches, then sync_rows().
+    Weight decay is on, so the reference's dense Adam moves EVERY row of the table on EVERY step (a row's own
+    wd * p is a gradient): rows outside a step's frontier are exactly what the last[] / hist[] replay has to
+    get right.  Oracle: oracle/torch_ref.train_step x 4 (fp32, dense Adam) on a compact table holding every row
+    any of the four frontiers touched, the spare row, and 4 096 rows no frontier touched; the frontiers are tied
+    to the sampler's definition by per-hop launches."""
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs a large-memory GPU")
+    from torch.nn import functional as F
+    from oracle import torch_ref as tref
+    from util import close, close_rel
+    N, B, fans, dims, steps, wd = 1_632_803, 512, (20, 15), (128, 128), 4, 1e-4
+    n_rows = N + 1
+    big = gs.DeviceCSR.synthetic(n_rows, 10, 70, torch.device(DEV), max_deg=128, seed=3, empty_every=997)
+    ops.set_compute_dtype("fp32")
+    try:
+        torch.manual_seed(21)
+        gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+        specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+                  "activation": F.relu if i < 1 else (lambda x: x)} for i, (f, h) in enumerate(zip(fans, dims))]
+        model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"],
+                                adj=_placeholder_adj(), train_adj=_placeholder_adj(),
+                                prep_class=gs.prep_lookup["node_embedding"],
+                                aggregator_class=gs.aggregator_lookup["attention"], input_dim=None, n_nodes=n_rows,
+                                n_classes=1, layer_specs=specs, lr_init=0.01, weight_decay=wd).to(DEV)
+        gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+        model.train_sampler.seed = 17
+        model.train_sampler.use_device_csr(big)
+        table0 = model.prep.embedding.weight.detach().clone()
+        w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k != "prep.embedding.weight"}
+        g = torch.Generator(device="cpu").manual_seed(9)
+        ids = torch.randint(1, n_rows, (steps, B), generator=g).to(DEV)
+        tg = (30 + 8 * torch.randn(steps, B, 1, generator=g)).to(DEV)
+        eng = gs.engine.FusedAttnTrainStep(model, None, gs.ProblemLosses.regression_mae, ids[0], tg[0], capture=capture)
+        assert eng.emb and eng.lazy_rows and eng.fused_l1 and eng.capture_mode == capture
+        preds, hops = [], []
+        for s in range(steps):
+            eng.set_progress(s / 10.0)
+            preds.append(eng(ids[s], tg[s]).detach().cpu().clone())
+            # the frontier step s sampled: Philox (seed 17, calls 2 s and 2 s + 1), per-hop launches
+            h1 = ops.sample_csr(big, ids[s], fans[0], philox={"seed": 17, "call_base": 2 * s})
+            h2 = ops.sample_csr(big, h1, fans[1], philox={"seed": 17, "call_base": 2 * s + 1})
+            front = eng.ids_set[0]
+            assert torch.equal(front[B:B + h1.numel()], h1) and torch.equal(front[B + h1.numel():], h2), s
+            hops.append((h1.cpu().numpy(), h2.cpu().numpy()))
+        behind = int((eng.row_last < steps).sum())
+        assert behind > n_rows // 2                          # most of the table IS behind before the settle
+        eng.sync_rows()
+        torch.cuda.synchronize()
+        assert int(eng.row_last.min()) == steps
+        big.check()
+        # compact table: every touched row, the spare row, and rows no frontier ever touched
+        touched = np.unique(np.concatenate([ids.cpu().numpy().reshape(-1)] + [h for hh in hops for h in hh] +
+                                           [np.array([n_rows])]))
+        rest = np.setdiff1d(np.arange(1, n_rows), touched)
+        never = rest[np.random.RandomState(0).choice(rest.shape[0], 4096, replace=False)]
+        rows = np.concatenate([touched, never])              # (sorted part first: searchsorted relabels)
+        rl = lambda a: np.searchsorted(touched, a).astype(np.int64)
+        sel = torch.from_numpy(rows).to(DEV)
+        w = {k: v.clone() for k, v in w0.items()}
+        w["prep.embedding.weight"] = table0[sel].cpu()
+        opt = tref.Adam(weight_decay=wd)
+        for s in range(steps):
+            r = tref.train_step(w, opt, float(model.lr_scheduler(s / 10.0)), "regression_mae",
+                                rl(ids[s].cpu().numpy()), None, tg[s].cpu(), None, None, fans, None, "attention",
+                                "node_embedding", int(rl(np.array([n_rows]))[0]), frontier=[rl(hops[s][0]), rl(hops[s][1])])
+            close(preds[s].numpy(), r["preds"].numpy(), ("preds vs oracle (Pokec scale)", s), 5e-4, 5e-4)
+        sd = model.state_dict()
+        for k, v in w.items():
+            if k != "prep.embedding.weight":
+                close_rel(sd[k].detach().cpu().numpy() - w0[k].numpy(), v.numpy() - w0[k].numpy(), ("update", k), 3e-2)
+        new_rows, old_rows = sd["prep.embedding.weight"][sel].cpu().numpy(), table0[sel].cpu().numpy()
+        upd, upd_ref = new_rows - old_rows, w["prep.embedding.weight"].numpy() - old_rows
+        nt = touched.shape[0]
+        for name, sl in (("touched rows", slice(0, nt)), ("rows no frontier touched", slice(nt, None))):
+            err = np.linalg.norm(upd[sl] - upd_ref[sl]) / np.linalg.norm(upd_ref[sl])
+            assert err <= 2e-2, (name, err)
+        assert float(np.abs(upd[nt:]).max()) > 0            # weight decay DID move the untouched rows
+        # Adam's moments of the untouched rows (pure replay): exp_avg after four zero-loss-gradient updates
+        m_eng = eng.flat_m[:eng.n_tab].view(-1, 64)[sel[nt:]].cpu().numpy()
+        m_ref = opt.m["prep.embedding.weight"][nt:].numpy()
+        assert np.linalg.norm(m_eng - m_ref) <= 1e-3 * np.linalg.norm(m_ref)
+    finally:
+        ops.set_compute_dtype("bf16")
 
 
 def test_attention_embedding_step_at_pokec_scale():
