@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <functional>
 #include <tuple>
@@ -26,9 +27,24 @@ extern std::atomic<uint64_t> g_launches;
         }                                        \
     } while (0)
 
+// GSAGE_DEBUG_SYNC=1: wait for every launch and report the kernel that failed; =2: also name every launch on
+// stderr BEFORE waiting for it (a memory fault kills the process inside the wait: the last name is the culprit).
+// Debugging aid only -- launches that are being recorded into a command list are not affected.
+inline int debug_sync_level()
+{
+    static const int level = [] { const char *e = getenv("GSAGE_DEBUG_SYNC"); return e ? atoi(e) : 0; }();
+    return level;
+}
+
+extern thread_local struct CmdList *t_recording;
+
 inline int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug_sync_level() > 0 && !t_recording) {
+        if (debug_sync_level() > 1) { fprintf(stderr, "[gsage] %s\n", what); fflush(stderr); }
+        e = hipDeviceSynchronize();
+    }
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return GSAGE_ELAUNCH;
@@ -60,7 +76,6 @@ struct CmdList {
             if (marks[i]) (void)hipEventDestroy(marks[i]);
     }
 };
-extern thread_local CmdList *t_recording;
 // gsage_head_n_valid_next(): live-row count(s) for the NEXT head launch of this thread (consumed by it)
 extern thread_local const int32_t *t_head_n_valid;
 inline const int32_t *take_head_n_valid()

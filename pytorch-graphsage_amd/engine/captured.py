@@ -30,7 +30,7 @@ class CapturedTrainStep(object):
 
         # clip + Adam over flat buckets (optim.FlatAdam: step count and learning rate live on the
         # device, two launches, capturable; the gradient bucket is also what data-parallel runs exchange)
-        from .optim import FlatAdam
+        from ..optim import FlatAdam
         old = model.optimizer
         if not isinstance(old, FlatAdam):
             wd = old.param_groups[0].get("weight_decay", 0.0)

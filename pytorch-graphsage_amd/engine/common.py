@@ -642,7 +642,7 @@ class FusedTrainStep(object):
         (it also records the refresh descriptor).  Allocates the prep's work buffers; ld0 = self.ldin[0]."""
         prep, dev, T, f32 = self.model.prep, self.dev, self.tdt, torch.float32
         RA0, E, ld0 = self.off[self.L + 1], int(prep.embedding_dim), self.ldin[0]
-        self.wp, self.wpT = copies(prep.fc.weight, True)
+        self.wprep, self.wprepT = copies(prep.fc.weight, True)   # (operand copies of prep.fc.weight)
         self.table = prep.embedding.weight                 # a view of the flat parameter bucket
         assert self.pidx[id(self.table)] == 0 and self.table.shape[1] == E and self.table.numel() % 4 == 0
         self.seed_rows = torch.full((self.B,), int(prep.n_nodes), dtype=torch.int64, device=dev)
@@ -706,7 +706,7 @@ class FusedTrainStep(object):
         # fp32 table rows -> the operand type in the gather itself (seeds read the spare row n_nodes)
         segs = [(tab, self.seed_rows, self.eraw[:B], B, 1), (tab, ids[B:RA0], self.eraw[B:], RA0 - B, 1)]
         ops.gather_mean_multi(segs, E, E, self.eraw.stride(0))
-        ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wp.data_ptr(), self.wp.shape[1],
+        ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wprep.data_ptr(), self.wprep.shape[1],
                            prep.fc.bias.data_ptr(), self.g0_set[s].data_ptr(), self.ldin[0], RA0, E, E, nat.ACT_NONE, 1,
                            0, 0, 0, self.code, self.code)
 
@@ -717,7 +717,7 @@ class FusedTrainStep(object):
         ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.din[0]
         nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
                                             self.bpart.shape[0], stream), "colsum_partials")
-        ops._linear_launch(self.din0.data_ptr(), self.din0.stride(0), None, 0, self.wpT.data_ptr(), self.wpT.shape[1],
+        ops._linear_launch(self.din0.data_ptr(), self.din0.stride(0), None, 0, self.wprepT.data_ptr(), self.wprepT.shape[1],
                            None, self.deraw.data_ptr(), E, RA0, E, E, nat.ACT_NONE, 1, 0, 0, 0, self.code, nat.F32)
         g = self._grad_slice(self.table)
         # every seed reads the SAME spare row: its B gradient rows are summed first (B atomics onto one row took 15 us)

@@ -12,8 +12,16 @@ for w in $WHAT; do
   case $w in
     tests)
       rm -f $OUT/parity_errors.jsonl
-      GSAGE_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl timeout 1700 python -m pytest tests -m gpu -q --tb=short --timeout 900 -p no:cacheprovider --durations=8 > $OUT/tests.log 2>&1
-      echo "== tests rc=$?"; tail -60 $OUT/tests.log ;;
+      # one pytest process per file: a GPU fault (which aborts the process) costs that file's summary only
+      : > $OUT/tests.log; rc_all=0
+      for f in ${GSAGE_TEST_FILES:-tests/test_*.py}; do
+        GSAGE_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl timeout 1700 python -X faulthandler -m pytest $f -m gpu -q --tb=short --timeout 900 -p no:cacheprovider ${GSAGE_PYTEST_ARGS} >> $OUT/tests.log 2>&1
+        rc=$?; [ $rc -ne 0 ] && [ $rc -ne 5 ] && { rc_all=$rc; echo "!! $f rc=$rc" >> $OUT/tests.log; }
+      done
+      echo "== tests rc=$rc_all"; grep -E "passed|failed|^FAILED|^ERROR|!! |Error|error:|assert " $OUT/tests.log | grep -v "^  File" | cut -c1-260 | tail -70 ;;
+    dbg)
+      timeout 600 python tools/debug_r3.py > $OUT/dbg.log 2>&1
+      echo "== dbg rc=$?"; tail -60 $OUT/dbg.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
       echo "== smoke rc=$?"; tail -5 $OUT/smoke.log ;;
