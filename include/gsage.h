@@ -109,6 +109,17 @@ int gsage_cmdlist_time_next(int slot_a, int slot_b);
 int gsage_cmdlist_elapsed(const void *list, int slot_a, int slot_b, float *ms);
 int64_t gsage_cmdlist_size(const void *list);
 int gsage_cmdlist_replay(const void *list, void *stream);
+/* Side sections: launches recorded between _side_begin and _side_end replay on a second stream that belongs to
+ * the list, forked from the main stream at the point of the section (the side stream waits for everything the
+ * main stream was given before it); _join makes the main stream wait for the end of the last side section.
+ * What it is for: a bandwidth-bound job that does not depend on the neighbouring launches (the NEXT batch's
+ * level-0 gathers) beside a latency-bound launch whose workgroups leave registers and the memory pipes of
+ * their CUs idle (the seed-level kernel: one 384-register wave per SIMD) -- two kernels can share a CU where one
+ * kernel's uniform LDS / register footprint cannot.  One section open at a time; the main-stream launches that
+ * follow _side_end and precede _join run concurrently with the section. */
+int gsage_cmdlist_side_begin(void);
+int gsage_cmdlist_side_end(void);
+int gsage_cmdlist_join(void);
 void gsage_cmdlist_destroy(void *list);
 
 /* ------------------------------------------------------------------------------------------

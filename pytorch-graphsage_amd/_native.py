@@ -42,6 +42,9 @@ SIGNATURES = {
     "gsage_cmdlist_elapsed": (_int, [_vp, _int, _int, ctypes.POINTER(_f32)]),
     "gsage_cmdlist_size": (_i64, [_vp]),
     "gsage_cmdlist_replay": (_int, [_vp, _vp]),
+    "gsage_cmdlist_side_begin": (_int, []),
+    "gsage_cmdlist_side_end": (_int, []),
+    "gsage_cmdlist_join": (_int, []),
     "gsage_cmdlist_destroy": (None, [_vp]),
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsage_sample_dense": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),

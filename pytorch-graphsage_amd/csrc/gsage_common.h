@@ -66,14 +66,26 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // when a step has to be cut into several pieces around a collective (engine.py, data-parallel).
 constexpr int CMDLIST_MARKS = 16;
 struct CmdList {
-    std::vector<std::function<void(hipStream_t)>> nodes;
+    typedef std::function<void(hipStream_t)> Node;
+    std::vector<Node> nodes;
     hipEvent_t marks[CMDLIST_MARKS] = {};      // gsage_cmdlist_mark: events recorded between kernels
     int64_t n_marks = 0;                       // mark nodes in `nodes` (not counted as kernel launches)
+    int64_t n_launches = 0;                    // kernel launches recorded (main stream + side sections)
     int time_a = -1, time_b = -1;              // gsage_cmdlist_time_next: events for the next recorded kernel
+    // side sections (gsage_cmdlist_side_begin / _end / _join): launches that replay on a second stream of the
+    // list's own, forked from the main stream where the section was recorded and joined where asked
+    std::vector<Node> *side_open = nullptr;    // != null while a side section is being recorded
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<Node> &target() { return side_open ? *side_open : nodes; }
     ~CmdList()
     {
         for (int i = 0; i < CMDLIST_MARKS; ++i)
             if (marks[i]) (void)hipEventDestroy(marks[i]);
+        delete side_open;
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
     }
 };
 // gsage_head_n_valid_next(): live-row count(s) for the NEXT head launch of this thread (consumed by it)
@@ -97,14 +109,16 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
             // timestamps of the dispatch itself, what a kernel trace reports), nothing else changes
             hipEvent_t ea = t_recording->marks[t_recording->time_a], eb = t_recording->marks[t_recording->time_b];
             t_recording->time_a = t_recording->time_b = -1;
-            t_recording->nodes.emplace_back([kernel, grid, block, lds, packed, ea, eb](hipStream_t s) {
+            t_recording->n_launches += 1;
+            t_recording->target().emplace_back([kernel, grid, block, lds, packed, ea, eb](hipStream_t s) {
                 std::apply([&](const KArgs &...a) {
                     hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, ea, eb, 0u, a...);
                 }, packed);
             });
             return;
         }
-        t_recording->nodes.emplace_back([kernel, grid, block, lds, packed](hipStream_t s) {
+        t_recording->n_launches += 1;
+        t_recording->target().emplace_back([kernel, grid, block, lds, packed](hipStream_t s) {
             std::apply([&](const KArgs &...a) { hipLaunchKernelGGL(kernel, grid, block, lds, s, a...); },
                        packed);
         });

@@ -8,6 +8,7 @@
 
 #include <stdarg.h>
 #include <string.h>
+#include <memory>
 
 namespace gsage {
 
@@ -82,7 +83,7 @@ int gsage_cmdlist_end(void **list)
 int64_t gsage_cmdlist_size(const void *list)
 {
     const CmdList *l = (const CmdList *)list;
-    return l ? (int64_t)l->nodes.size() - l->n_marks : -1;
+    return l ? l->n_launches : -1;
 }
 
 int gsage_cmdlist_replay(const void *list, void *stream)
@@ -97,7 +98,55 @@ int gsage_cmdlist_replay(const void *list, void *stream)
         set_error("cmdlist_replay: %s", hipGetErrorString(e));
         return GSAGE_ELAUNCH;
     }
-    g_launches.fetch_add(l->nodes.size() - (size_t)l->n_marks, std::memory_order_relaxed);
+    g_launches.fetch_add((uint64_t)l->n_launches, std::memory_order_relaxed);
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_side_begin(void)
+{
+    GSAGE_REQUIRE(t_recording, "cmdlist_side_begin: no recording in progress on this thread");
+    CmdList *l = t_recording;
+    GSAGE_REQUIRE(!l->side_open, "cmdlist_side_begin: a side section is already open");
+    if (!l->side_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&l->side_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("cmdlist_side_begin: %s", hipGetErrorString(e));
+            return GSAGE_ELAUNCH;
+        }
+    }
+    l->side_open = new std::vector<CmdList::Node>();
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_side_end(void)
+{
+    GSAGE_REQUIRE(t_recording && t_recording->side_open, "cmdlist_side_end: no side section is open");
+    CmdList *l = t_recording;
+    std::shared_ptr<std::vector<CmdList::Node>> sub(l->side_open);
+    l->side_open = nullptr;
+    hipStream_t side = l->side_stream;
+    hipEvent_t ef = l->ev_fork, ej = l->ev_join;
+    // at replay: the side stream picks up from this point of the main stream, runs the section, marks its end
+    l->nodes.emplace_back([sub, side, ef, ej](hipStream_t s) {
+        (void)hipEventRecord(ef, s);
+        (void)hipStreamWaitEvent(side, ef, 0);
+        for (const auto &node : *sub) node(side);
+        (void)hipEventRecord(ej, side);
+    });
+    l->n_marks += 1;
+    return GSAGE_OK;
+}
+
+int gsage_cmdlist_join(void)
+{
+    GSAGE_REQUIRE(t_recording && !t_recording->side_open && t_recording->ev_join,
+                  "cmdlist_join: needs a closed side section recorded before it");
+    hipEvent_t ej = t_recording->ev_join;
+    t_recording->nodes.emplace_back([ej](hipStream_t s) { (void)hipStreamWaitEvent(s, ej, 0); });
+    t_recording->n_marks += 1;
     return GSAGE_OK;
 }
 

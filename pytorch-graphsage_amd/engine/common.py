@@ -205,6 +205,7 @@ class FusedTrainStep(object):
         self.n_sel = sum(self.fan[1:]) if self.dense else self.off[L + 1] - self.off[1]
         if self.draws != "philox":
             self.sel = torch.zeros(self.n_sel, dtype=torch.int32, device=dev)
+        self._in_list = False                     # True while a native command list is being recorded
         self._sel_user = False                    # set_sel(): the caller's draws win over the engine's own
         # live seeds of the batch (<= B): the reference's `iterate` yields near-equal chunks, never exactly
         # batch_size (problem.py:141-153), so a batch may be one seed short of the recorded geometry.  Padded seeds
@@ -377,8 +378,12 @@ class FusedTrainStep(object):
         """Record the launches of fn() once; returns an object whose replay() re-issues them on the
         current stream (command list) or on the capture stream (hipGraph)."""
         if self.capture_mode == "cmdlist":
-            with nat.CommandList.record() as cl:
-                fn()
+            self._in_list = True
+            try:
+                with nat.CommandList.record() as cl:
+                    fn()
+            finally:
+                self._in_list = False
             return _ListRunner(cl)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._pool, stream=stream):
@@ -528,6 +533,8 @@ class FusedTrainStep(object):
 
     def _head_live_rows(self):
         """tell the next head launch how many seeds of the batch are live (padded chunks, see _pad_batch)"""
+        if os.environ.get("GSAGE_NO_NVALID", "0") == "1":      # (measurement: the head without the live-row word)
+            return
         nat.check(nat.lib().gsage_head_n_valid_next(self._nv_ptr()), "head_n_valid_next")
 
     def _stage_head_ce(self, s):
@@ -571,6 +578,9 @@ class FusedTrainStep(object):
         return 240
 
     def _tail_gather_rows(self):
+        return 0
+
+    def _side_gather_rows(self):
         return 0
 
     def _queue_compute_body(self, par):
@@ -872,6 +882,7 @@ class FusedTrainStep(object):
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
         self.split = bool(self.gather_cus and self.capture_mode == "cmdlist" and self.ddp is None)
         self._tail_rows = 0 if self.split else self._tail_gather_rows()
+        self._side_rows = self._side_gather_rows() if self._tail_rows else 0
         if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
             self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
         self._front_ready, self._qstep = False, 0
@@ -967,11 +978,12 @@ class FusedTrainStep(object):
         self._time_next(0, 1)
         if self.dense:           # (the gather launch's sampler role walks a CSR: the dense frontier is a launch of its own)
             self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
-                               skip_rows=self._tail_rows)
+                               skip_rows=self._tail_rows + getattr(self, "_side_rows", 0))
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)
             return
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
-                           hops=self._hops_desc(self.ids_q[par], True), skip_rows=self._tail_rows)
+                           hops=self._hops_desc(self.ids_q[par], True),
+                           skip_rows=self._tail_rows + getattr(self, "_side_rows", 0))
 
     def _queue_compute(self, par):
         self._q_ids = self.ids_q[par]

@@ -179,7 +179,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
         return max(32, n_cu - self.gather_cus - 8)
 
-    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0, part=None, adam=None):
+    def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0, part=None, adam=None, stop_rows=None):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
         launch; with_adam: the clip + Adam update of the batch just finished rides along; hops: so
         does the sampling of a later batch's frontier (a gsage_hops_desc writing ANOTHER buffer).
@@ -199,10 +199,12 @@ class FusedMeanTrainStep(FusedTrainStep):
         # (tools/kbench.py gmulti: 36.1 us against 41.9 us for copies first at Reddit shapes)
         segs = []
         for k in range(L):
-            n, r0 = self.fan[k + 1], (skip_rows if k == L - 1 else 0)   # rows the seed-level launch gathered
-            if self.size[k] > r0 and (part is None or (part == "means") == (k == L - 1)):
-                segs.append((st.data, ids[self.off[k + 1] + r0 * n:self.off[k + 2]],
-                             xa[1][self.off[k] + r0:self.off[k + 1]], self.size[k] - r0, n))
+            # last hop: rows [skip_rows, stop_rows) -- the seed-level launch and the side section gathered the others
+            n, r0 = self.fan[k + 1], (skip_rows if k == L - 1 else 0)
+            r1 = self.size[k] if (k < L - 1 or stop_rows is None) else min(int(stop_rows), self.size[k])
+            if r1 > r0 and (part is None or (part == "means") == (k == L - 1)):
+                segs.append((st.data, ids[self.off[k + 1] + r0 * n:self.off[k + 1] + r1 * n],
+                             xa[1][self.off[k] + r0:self.off[k] + r1], r1 - r0, n))
         if part != "means" and not self.inplace_x:
             segs.append((st.data, ids[:R], xa[0], R, 1))
         if not segs:
@@ -258,6 +260,15 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.fused_tail:
             C = m.fc.weight.shape[0]
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
+            side = self._side_job if (self._in_list and getattr(self, "_side_job", None)) else None
+            if side is not None:
+                # a second gather of the NEXT batch's last-hop means, as a kernel of its own on the list's side
+                # stream: the seed-level workgroups hold one 384-register wave per SIMD and 136 KB of LDS but leave
+                # their CU's memory pipes idle -- a 72-register, LDS-free gather kernel shares those CUs, which the
+                # launch's own gather role (same kernel, same footprint) cannot
+                nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
+                self._stage_gather(side[0], ids=side[1], part="means", skip_rows=side[2], stop_rows=side[3])
+                nat.check(lib.gsage_cmdlist_side_end(), "cmdlist_side_end")
             self._time_next(2, 3)
             self._head_live_rows()
             nat.check(lib.gsage_mean_tail_ce(
@@ -269,6 +280,8 @@ class FusedMeanTrainStep(FusedTrainStep):
                 self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
                 ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
                 stream), "mean_tail_ce")
+            self._side_pending = side is not None
+            self._side_join("tail")
         else:
             self._stage_head(s)
         self._backward_levels(s)
@@ -328,7 +341,16 @@ class FusedMeanTrainStep(FusedTrainStep):
                                   self.slabs[l][g], self._wg_target(), rows if g == 0 else None))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
+        self._side_join("k5b")
         self._stage_finalize(s)
+        self._side_join("fin")
+
+    def _side_join(self, point):
+        """the main stream waits for the side section (see _stage_compute) at the point GSAGE_SIDE_JOIN names:
+        after the seed-level launch (default), after K5b, or after the finalisation"""
+        if getattr(self, "_side_pending", False) and os.environ.get("GSAGE_SIDE_JOIN", "tail") == point:
+            nat.check(nat.lib().gsage_cmdlist_join(), "cmdlist_join")
+            self._side_pending = False
 
     # ---- split mode: gathers and chain side by side on disjoint halves of the chip ------------------
     # The level-0 gathers of batch i+1 (170 MB of HBM reads, no weights involved) and the chain of batch i
@@ -386,9 +408,10 @@ class FusedMeanTrainStep(FusedTrainStep):
         step: every sampled frontier row is read exactly once, by one of the two."""
         total = self.off[self.L + 1]
         tail = self._tail_rows * self.fan[self.L]
+        side = getattr(self, "_side_rows", 0) * self.fan[self.L]
         if getattr(self, "inplace_x", False):          # K5 / K5b read the x rows themselves
             total -= self.rows[0]
-        return total - tail, tail
+        return total - tail - side, tail
 
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
@@ -406,6 +429,15 @@ class FusedMeanTrainStep(FusedTrainStep):
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
+
+    def _side_gather_rows(self):
+        """Rows of the last hop's neighbour means gathered by the side section that runs beside the seed-level
+        launch (0: none): GSAGE_SIDE_GATHER_FRAC of the hop, single-GPU queue mode on command lists."""
+        if self.ddp is not None or self.capture_mode != "cmdlist" or self.split:
+            return 0
+        frac = float(os.environ.get("GSAGE_SIDE_GATHER_FRAC", "0.0"))
+        left = int(self.size[self.L - 1]) - self._tail_rows
+        return max(0, min(left, int(frac * self.size[self.L - 1])))
 
     def _queue_front_means(self, par):
         self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._tail_rows, part="means")
@@ -432,10 +464,17 @@ class FusedMeanTrainStep(FusedTrainStep):
             d.ld, d.out_ld, d.D, d.rows = st.ld, st.ld, st.dim, self._tail_rows
             d.n, d.n_workgroups = self.fan[L], self._tail_wgs
             self._tail_gather = d
+            if self._side_rows:
+                t0 = self._tail_rows
+                self._side_job = (1 - par, nxt, t0, t0 + self._side_rows)
         try:
             self._stage_compute(self._qset(par))
+            if self._side_rows and not self._in_list:      # (eager launching: the same rows, on the main stream)
+                self._stage_gather(1 - par, ids=self.ids_q[1 - par], part="means", skip_rows=self._tail_rows,
+                                   stop_rows=self._tail_rows + self._side_rows)
         finally:
             self._tail_gather = None
+            self._side_job = None
 
     def _step_queue_split(self):
         user = torch.cuda.current_stream()

@@ -353,3 +353,30 @@ def test_engine_hands_its_adam_state_back_to_train_step_and_checkpoints():
     assert float((opt.flat_v - 0.999 * v3).min()) >= -1e-12    # v4 = 0.999 v3 + 0.001 g^2 >= 0.999 v3
     import pickle
     pickle.dumps(model.state_dict())
+
+
+@pytest.mark.parametrize("join", ["tail", "fin"])
+def test_side_section_gather_equals_the_single_stream_step(monkeypatch, join):
+    """Queue mode with part of the next batch's last-hop means gathered by a kernel of its own on the command
+    list's side stream, beside the seed-level launch (GSAGE_SIDE_GATHER_FRAC; cmdlist side sections): the same
+    rows, the same arithmetic, another stream -- predictions and weights after eight steps are bit-identical to the
+    single-stream step, and the launch count says the side kernel ran."""
+    adj, feats, rng = _problem(n=900, D=40)
+    D, C, B = feats.shape[1], 5, 64
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(10, B))).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(10, B))).to(DEV)
+    outs = []
+    for frac in ("0", "0.3"):
+        monkeypatch.setenv("GSAGE_SIDE_GATHER_FRAC", frac)
+        monkeypatch.setenv("GSAGE_SIDE_JOIN", join)
+        m = _model(adj, D, C, (128, 128), (25, 10))
+        eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1))
+        eng.load_epoch(ids, tg)
+        assert eng._tail_rows > 0 and (eng._side_rows > 0) == (frac != "0")
+        before = gs._native.launch_count()
+        preds = torch.stack([eng.step_queue().clone() for _ in range(8)])
+        torch.cuda.synchronize()
+        outs.append((preds, eng.flat_p.clone(), gs._native.launch_count() - before))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[1][2] == outs[0][2] + 8                       # one more kernel per step
