@@ -223,6 +223,10 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.emb:
             self._cur_ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
             self._prep_forward(s)
+        side_at = os.environ.get("GSAGE_SIDE_AT", "tail")
+        side = self._side_job if (self._in_list and getattr(self, "_side_job", None)) else None
+        if side is not None and side_at == "k5":
+            self._side_section(side)
         for l in range(L - 1 if self.fused_tail else L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             rows = None
@@ -260,15 +264,9 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.fused_tail:
             C = m.fc.weight.shape[0]
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
-            side = self._side_job if (self._in_list and getattr(self, "_side_job", None)) else None
-            if side is not None:
-                # a second gather of the NEXT batch's last-hop means, as a kernel of its own on the list's side
-                # stream: the seed-level workgroups hold one 384-register wave per SIMD and 136 KB of LDS but leave
-                # their CU's memory pipes idle -- a 72-register, LDS-free gather kernel shares those CUs, which the
-                # launch's own gather role (same kernel, same footprint) cannot
-                nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
-                self._stage_gather(side[0], ids=side[1], part="means", skip_rows=side[2], stop_rows=side[3])
-                nat.check(lib.gsage_cmdlist_side_end(), "cmdlist_side_end")
+            self._side_join("k5")
+            if side is not None and side_at == "tail":
+                self._side_section(side)
             self._time_next(2, 3)
             self._head_live_rows()
             nat.check(lib.gsage_mean_tail_ce(
@@ -280,7 +278,6 @@ class FusedMeanTrainStep(FusedTrainStep):
                 self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
                 ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
                 stream), "mean_tail_ce")
-            self._side_pending = side is not None
             self._side_join("tail")
         else:
             self._stage_head(s)
@@ -344,6 +341,18 @@ class FusedMeanTrainStep(FusedTrainStep):
         self._side_join("k5b")
         self._stage_finalize(s)
         self._side_join("fin")
+
+    def _side_section(self, side):
+        """A second gather of the NEXT batch's last-hop means as a kernel of its own on the command list's side
+        stream, concurrent with the main-stream launches that follow until _side_join: GSAGE_SIDE_AT = "k5" (beside
+        the level-0 projection, whose LDS-DMA rings tolerate latency) or "tail" (beside the seed-level launch, whose
+        workgroups hold one 384-register wave per SIMD and leave their CU's memory pipes idle -- but whose chain of
+        dependent loads then queues behind the gather's requests: measured SLOWER)."""
+        lib = nat.lib()
+        nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
+        self._stage_gather(side[0], ids=side[1], part="means", skip_rows=side[2], stop_rows=side[3])
+        nat.check(lib.gsage_cmdlist_side_end(), "cmdlist_side_end")
+        self._side_pending = True
 
     def _side_join(self, point):
         """the main stream waits for the side section (see _stage_compute) at the point GSAGE_SIDE_JOIN names:

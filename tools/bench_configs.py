@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("config", choices=["pokec", "papers"])
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=5)
-ap.add_argument("--papers-nodes", type=int, default=8_000_000)
+ap.add_argument("--papers-nodes", type=int, default=111_059_956)
 ap.add_argument("--precision", type=str, default=None)
 ap.add_argument("--engine", type=str, default="fused", choices=["fused", "autograd"])
 args = ap.parse_args()

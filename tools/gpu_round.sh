@@ -39,6 +39,28 @@ for w in $WHAT; do
       f=$(find $OUT/prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -25 "$f"
       # keep the merged-back payload small
       find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete ;;
+    pmcx)
+      # per-configuration PMC passes for the `extra` rooflines: FETCH_SIZE / WRITE_SIZE separately, one calibration
+      # run per counter; tools/refresh_profiles.py turns the per-kernel summaries into profiles/rNN_pmc_launches.json
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf $OUT/pmcx_cal_$c
+        timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmcx_cal_$c -o f --output-format csv -- python tools/pmc_calib.py > $OUT/pmcx_cal_$c.log 2>&1
+        b=$(find $OUT/pmcx_cal_$c -name "*counter_collection.csv" | head -1)
+        for cfg in reddit max_pool attention papers pokec; do
+          case $cfg in
+            reddit) cmd="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extra '' --min-time 0" ;;
+            max_pool|attention) cmd="python bench.py --aggregator $cfg --steps 20 --warmup 5 --no-cpu-baseline --extra '' --min-time 0" ;;
+            *) cmd="python tools/bench_configs.py $cfg --steps 20" ;;
+          esac
+          rm -rf $OUT/pmcx_${cfg}_$c
+          eval timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmcx_${cfg}_$c -o f --output-format csv -- $cmd > $OUT/pmcx_${cfg}_$c.log 2>&1
+          echo "== pmcx $cfg $c rc=$?"
+          a=$(find $OUT/pmcx_${cfg}_$c -name "*counter_collection.csv" | head -1)
+          [ -n "$a" ] && python tools/pmc_summary.py "$a" $b > $OUT/pmcx_${cfg}_$c.json
+          find $OUT/pmcx_${cfg}_$c -name "*.csv" -size +2M -delete
+        done
+        find $OUT/pmcx_cal_$c -name "*.csv" -size +2M -delete
+      done ;;
     pmc)
       # FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), each with its calibration run
       for c in FETCH_SIZE WRITE_SIZE; do

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def json_line(path):
@@ -56,6 +56,37 @@ if len(per) == 2:
                   "bench.py --steps 20 --warmup 5; tools/pmc_summary.py with the calibration pass tools/pmc_calib.py; "
                   "profiles/%s_pmc_fetch_size.json, %s_pmc_write_size.json" % (tag, tag),
     }, open(os.path.join(PROF, tag + "_pmc_gather_launch.json"), "w"), indent=1)
+
+# per-configuration PMC passes (tools/gpu_round.sh pmcx): the launch each `extra` roofline names
+PICK = {"reddit": ("reddit_gather", "k_gather_multi_adam"), "max_pool": ("maxpool_k3", "k_pool_mlp_packed"),
+        "attention": ("attention_k4", "k_attn_aggregate_grp"), "papers": ("papers_gather", "k_gather_multi_adam"),
+        "pokec": ("pokec_k4", "k_attn_aggregate_grp")}
+launches = {}
+for cfg, (key, kname) in PICK.items():
+    rec = {}
+    for c, field in (("FETCH_SIZE", "hbm_read_bytes_per_launch"), ("WRITE_SIZE", "hbm_write_bytes_per_launch")):
+        pth = os.path.join(OUT, "pmcx_%s_%s.json" % (cfg, c))
+        if not os.path.exists(pth):
+            continue
+        rows = [r for r in json.load(open(pth)) if kname in r["kernel"]]
+        if not rows:
+            continue
+        r = max(rows, key=lambda r: r["grid_threads"])          # the launch over the last hop / the step's gather
+        rec[field] = r[field]
+        rec.setdefault("kernel", r["kernel"])
+        rec.setdefault("grid_threads", r["grid_threads"])
+        rec[c.lower() + "_factor"], rec[c.lower() + "_calibration"] = r["factor"], r["calibration"]
+        rec["launches_sampled"] = r["launches"]
+        # whole step: every gsage kernel's bytes x its launches, per launch of the named kernel (= per step)
+        allr = [q for q in json.load(open(pth)) if "gsage::" in q["kernel"] and "k_gather_mean<" not in q["kernel"]]
+        rec["step_" + field.replace("_per_launch", "")] = sum(q[field] * q["launches"] for q in allr) / r["launches"]
+        shutil.copy(pth, os.path.join(PROF, "%s_pmc_%s_%s.json" % (tag, cfg, c.lower())))
+    if rec:
+        rec["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, one calibration copy "
+                         "each) over the %s configuration; tools/gpu_round.sh pmcx, tools/pmc_summary.py" % cfg)
+        launches[key] = rec
+if launches:
+    json.dump(launches, open(os.path.join(PROF, tag + "_pmc_launches.json"), "w"), indent=1)
 
 p = os.path.join(OUT, "parity_errors.jsonl")
 if os.path.exists(p):

@@ -7,9 +7,9 @@ run() {
 import sys, json
 d = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
 r = d['roofline']
-print('%-46s %.4f ms/step  gather %.1f us  tail %.1f us' % ('$1', d['ms_per_step'], r['avg_launch_us'], r.get('seed_level_launch', {}).get('avg_launch_us', 0)))"
+print('%-46s %.4f ms/step  gather %.1f us  tail %.1f us' % (sys.argv[1], d['ms_per_step'], r['avg_launch_us'], r.get('seed_level_launch', {}).get('avg_launch_us', 0)))" "$1"
 }
-for cfg in "${@:-0:tail:0.4 0.15:tail:0.4 0.25:tail:0.4 0.35:tail:0.4 0.45:tail:0.4 0.25:k5b:0.4 0.35:k5b:0.4 0.35:fin:0.4 0.5:fin:0.4 0.3:tail:0.2 0.5:tail:0.2 0.4:tail:0.3}"; do
-  IFS=: read side join tail <<< "$cfg"
-  GSAGE_SIDE_GATHER_FRAC=$side GSAGE_SIDE_JOIN=$join GSAGE_TAIL_GATHER_FRAC=$tail run "side=$side join=$join tailfrac=$tail"
+for cfg in ${@:-0:tail:tail:0.4 0.1:k5:k5:0.4 0.2:k5:k5:0.4 0.3:k5:k5:0.4 0.2:k5:tail:0.4 0.1:tail:tail:0.4 0.2:k5:fin:0.4}; do
+  IFS=: read side at join tail <<< "$cfg"
+  GSAGE_SIDE_GATHER_FRAC=$side GSAGE_SIDE_AT=$at GSAGE_SIDE_JOIN=$join GSAGE_TAIL_GATHER_FRAC=$tail run "side=$side at=$at join=$join tailfrac=$tail"
 done
