@@ -526,6 +526,12 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
                        const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
                        void *dE, float *preds, void *dH, float *partial,
                        const gsage_tail_gather_desc *gather, int dtype, void *stream);
+/* The same role for the NEXT gsage_linear_nt_packed launch of the calling thread (consumed by it; HOST descriptor, read
+ * before gsage_gather_role_next's caller continues -- it may live on the stack until that launch call returns): one
+ * more z-slice of the projection's grid (as many workgroups as one group has) gathers rows [0, rows) of the segment.
+ * Only with act = ReLU and fan-out 5 or 10 (the level-0 projection of the mean engine: 416 workgroups where 768
+ * fit, streaming at half of what a CU keeps in flight); n_workgroups is ignored.  NULL: no role. */
+int gsage_gather_role_next(const gsage_tail_gather_desc *gather);
 /* dtype = storage type of H, w2, w2t, agg, dE, dH: GSAGE_BF16, or GSAGE_F32 -- the same kernel source
  * instantiated on fp32 storage (every bf16 rounding point becomes a no-op; no gather role), used to
  * replay the reference-generated golden fixtures through this kernel at fp32 tolerance. */

@@ -90,6 +90,14 @@ struct CmdList {
 };
 // gsage_head_n_valid_next(): live-row count(s) for the NEXT head launch of this thread (consumed by it)
 extern thread_local const int32_t *t_head_n_valid;
+// gsage_gather_role_next(): gather-role descriptor for the NEXT gsage_linear_nt_packed launch of this thread
+extern thread_local const gsage_tail_gather_desc *t_gather_role;
+inline const gsage_tail_gather_desc *take_gather_role()
+{
+    const gsage_tail_gather_desc *p = t_gather_role;
+    t_gather_role = nullptr;
+    return p;
+}
 inline const int32_t *take_head_n_valid()
 {
     const int32_t *p = t_head_n_valid;

@@ -6,6 +6,7 @@
 // through LDS.  Same arithmetic, same results as gsage_linear_nt / gsage_pool_mlp
 // (reference nn_modules.py:200-202, :224-226).
 #include "gsage_common.h"
+#include "gsage_gather_dev.h"
 #include "gsage_mma_dev.h"
 
 namespace gsage {
@@ -42,10 +43,17 @@ struct PackedParams {
     int32_t c_dtype;
 };
 
-template <int ACT>
+// GN > 0: gridDim.z is one more than the number of groups, and the workgroups of that last z-slice play the gather
+// role (gsage_gather_dev.h) on fan-out GN: the projection fills 416 of the 768 workgroup slots of the chip at
+// config 2's level 0 and streams its operands at half of what a CU can keep in flight.
+template <int ACT, int GN>
 __global__ void __launch_bounds__(256)
-k_linear_nt_packed(const PackedParams p)
+k_linear_nt_packed(const PackedParams p, const TailGather tg)
 {
+    if (GN > 0 && blockIdx.z + 1 == gridDim.z) {
+        gather_role<(GN > 0 ? GN : 1), 2>(tg, (int)(blockIdx.y * gridDim.x + blockIdx.x));
+        return;
+    }
     constexpr int EPC = 8;
     constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
     __shared__ vec16 smem[(BM * (BN + 4) * 4) / 16 > WP_NBUF * ATILE ? (BM * (BN + 4) * 4) / 16 : WP_NBUF * ATILE];
@@ -544,12 +552,26 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
     p.a_rows_group0_only = a_rows_group0_only; p.c_dtype = c_dtype;
     dim3 grid((unsigned)ceil_div(M, BM), (unsigned)ceil_div(N, BN), (unsigned)groups);
     hipStream_t s = (hipStream_t)stream;
+    // gsage_gather_role_next(): one more z-slice of workgroups gathers part of the next batch's level-0 rows
+    TailGather tg = {};
+    const gsage_tail_gather_desc *gd = take_gather_role();
+    if (gd && gd->rows > 0) {
+        const int rc = fill_gather_role(tg, *gd, "linear_nt_packed (gather role)");
+        if (rc != GSAGE_OK) return rc;
+        GSAGE_REQUIRE(act == ACT_RELU && (gd->n == 10 || gd->n == 5),
+                      "linear_nt_packed: the gather role rides with the ReLU projection, fan-out 5 or 10");
+        tg.n_wg = (int32_t)(grid.x * grid.y);
+        grid.z += 1;
+        if (gd->n == 10) launch(k_linear_nt_packed<ACT_RELU, 10>, grid, dim3(256), 0, s, p, tg);
+        else launch(k_linear_nt_packed<ACT_RELU, 5>, grid, dim3(256), 0, s, p, tg);
+        return check_launch("linear_nt_packed");
+    }
     if (act == ACT_RELU)
-        launch(k_linear_nt_packed<ACT_RELU>, grid, dim3(256), 0, s, p);
+        launch(k_linear_nt_packed<ACT_RELU, 0>, grid, dim3(256), 0, s, p, tg);
     else if (act == ACT_TANH)
-        launch(k_linear_nt_packed<ACT_TANH>, grid, dim3(256), 0, s, p);
+        launch(k_linear_nt_packed<ACT_TANH, 0>, grid, dim3(256), 0, s, p, tg);
     else
-        launch(k_linear_nt_packed<ACT_NONE>, grid, dim3(256), 0, s, p);
+        launch(k_linear_nt_packed<ACT_NONE, 0>, grid, dim3(256), 0, s, p, tg);
     return check_launch("linear_nt_packed");
 }
 

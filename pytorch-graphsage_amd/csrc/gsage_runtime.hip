@@ -16,6 +16,7 @@ static thread_local char t_err[512] = "";
 std::atomic<uint64_t> g_launches{0};
 thread_local CmdList *t_recording = nullptr;
 thread_local const int32_t *t_head_n_valid = nullptr;
+thread_local const gsage_tail_gather_desc *t_gather_role = nullptr;
 
 void set_error(const char *fmt, ...)
 {
@@ -36,6 +37,11 @@ int gsage_abi_version(void) { return GSAGE_ABI_VERSION; }
 int gsage_head_n_valid_next(const int32_t *n_valid)
 {
     t_head_n_valid = n_valid;
+    return GSAGE_OK;
+}
+int gsage_gather_role_next(const gsage_tail_gather_desc *gather)
+{
+    t_gather_role = gather;
     return GSAGE_OK;
 }
 const char *gsage_last_error(void) { return t_err; }

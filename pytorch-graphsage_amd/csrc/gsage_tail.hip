@@ -24,6 +24,7 @@
 // Only the weight gradient of this level (K5b, reads agg + dE written here) stays a launch of its
 // own.  Fixed shape: previous level width 256 (= 2 x 128), this level 2h = 256, n <= 32, C <= 64.
 #include "gsage_common.h"
+#include "gsage_gather_dev.h"
 
 namespace gsage {
 
@@ -65,13 +66,6 @@ __device__ __forceinline__ float tail_wave_max(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// element e (0..7) of a 16-byte vector of bf16
-__device__ __forceinline__ float tail_elem(const vec16 v, int e)
-{
-    const uint32_t w = v[e >> 1];
-    return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
-}
-
 // eight consecutive elements of a row, as one lane holds them
 template <typename T> struct row8;
 template <> struct row8<uint16_t> {
@@ -124,69 +118,7 @@ constexpr size_t tail_lds_floats(int C)
            4 * TAIL_R + 4 + 2 * 8 * TAIL_R * TAIL_D;
 }
 
-// ---- gather role ---------------------------------------------------------------------------------
-// B / 4 workgroups cannot fill the chip (128 of 256 CUs at B = 512) and each is a ~22 us chain of
-// dependent phases.  The CUs they leave idle take part of the NEXT batch's level-0 gather: rows
-// [0, rows) of one gather-mean segment (fan-out N), which the gather launch then skips.  One
-// workgroup per CU (the kernel's LDS footprint), so a lane keeps four work items = 4 N row requests
-// in flight; sums run in neighbour order like gather_mean_chunk (bit-identical means).
-struct TailGather {
-    const uint16_t *table;
-    const int64_t *ids;
-    uint16_t *out;
-    int64_t ld, out_ld;
-    int32_t rows, D, chunks, n_wg;       // n_wg = 0: no gather role in this launch
-};
-
-template <int N>
-__device__ __forceinline__ void tail_gather_role(const TailGather &g, int bx)
-{
-    const int64_t total = (int64_t)g.rows * g.chunks;
-    const int64_t S = (int64_t)g.n_wg * 256;
-    for (int64_t t0 = (int64_t)bx * 256 + threadIdx.x; t0 < total; t0 += 4 * S) {
-        int64_t row[4];
-        int32_t c0[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int64_t t = t0 + u * S;
-            ok[u] = t < total;
-            if (!ok[u]) t = total - 1;
-            row[u] = t / g.chunks;
-            c0[u] = (int32_t)(t - row[u] * g.chunks) * 8;
-        }
-        int64_t id[4][N];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < N; ++j) id[u][j] = g.ids[row[u] * N + j];
-        vec16 v[4][N];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                v[u][j] = *reinterpret_cast<const vec16 *>(g.table + id[u][j] * g.ld + c0[u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float acc[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += tail_elem(v[u][j], e);
-            vec16 o;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float a = (c0[u] + e < g.D) ? acc[e] / (float)N : 0.f;
-                const float b = (c0[u] + e + 1 < g.D) ? acc[e + 1] / (float)N : 0.f;
-                o[e >> 1] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-            }
-            if (ok[u]) *reinterpret_cast<vec16 *>(g.out + row[u] * g.out_ld + c0[u]) = o;
-        }
-    }
-}
-
+// (the gather role some workgroups of this launch play: gsage_gather_dev.h)
 // NBH = neighbour rows per half-wave lane (n <= 2 * NBH); GN = fan-out of the gather role (0: none)
 template <typename T, int NBH, int GN>
 __global__ void __launch_bounds__(256)
@@ -197,7 +129,7 @@ k_mean_tail_ce(const TailParams p, const TailGather tg)
     if (GN > 0) {
         const int n_tail = (p.B + TAIL_R - 1) / TAIL_R;
         if ((int)blockIdx.x >= n_tail) {
-            tail_gather_role<(GN > 0 ? GN : 1)>(tg, (int)blockIdx.x - n_tail);
+            gather_role<(GN > 0 ? GN : 1), 4>(tg, (int)blockIdx.x - n_tail);
             return;
         }
     }
@@ -633,16 +565,8 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     TailGather tg = {};
     const bool fused = gather && gather->rows > 0;
     if (fused) {
-        GSAGE_REQUIRE(gather->n == 5 || gather->n == 10 || gather->n == 15,
-                      "mean_tail_ce: the gather role is built for fan-outs 5, 10 and 15");
-        GSAGE_REQUIRE(gather->table && gather->ids && gather->out && gather->D > 0 && gather->ld % 8 == 0 &&
-                      gather->out_ld % 8 == 0 && ceil_div(gather->D, 8) * 8 <= gather->ld &&
-                      ceil_div(gather->D, 8) * 8 <= gather->out_ld && gather->n_workgroups > 0 &&
-                      (((uintptr_t)gather->table | (uintptr_t)gather->out) & 15) == 0,
-                      "mean_tail_ce: bad gather descriptor");
-        tg.table = (const uint16_t *)gather->table; tg.ids = gather->ids; tg.out = (uint16_t *)gather->out;
-        tg.ld = gather->ld; tg.out_ld = gather->out_ld; tg.rows = (int32_t)gather->rows;
-        tg.D = (int32_t)gather->D; tg.chunks = (int32_t)ceil_div(gather->D, 8); tg.n_wg = gather->n_workgroups;
+        const int rc = fill_gather_role(tg, *gather, "mean_tail_ce");
+        if (rc != GSAGE_OK) return rc;
     }
     const size_t lds = sizeof(float) * tail_lds_floats(C) + 16;
     const int small = n <= 16;

@@ -583,6 +583,14 @@ class FusedTrainStep(object):
     def _side_gather_rows(self):
         return 0
 
+    def _k5_gather_rows(self):
+        return 0
+
+    def _ahead_rows(self):
+        """rows of the next batch's last-hop means that launches of the CURRENT step gather (the seed-level launch's
+        and the level-0 projection's gather roles, the side section): the gather launch skips them"""
+        return self._tail_rows + getattr(self, "_k5_rows", 0) + getattr(self, "_side_rows", 0)
+
     def _queue_compute_body(self, par):
         self._stage_compute(self._qset(par))
 
@@ -882,6 +890,7 @@ class FusedTrainStep(object):
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
         self.split = bool(self.gather_cus and self.capture_mode == "cmdlist" and self.ddp is None)
         self._tail_rows = 0 if self.split else self._tail_gather_rows()
+        self._k5_rows = self._k5_gather_rows() if self._tail_rows else 0
         self._side_rows = self._side_gather_rows() if self._tail_rows else 0
         if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
             self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
@@ -978,12 +987,12 @@ class FusedTrainStep(object):
         self._time_next(0, 1)
         if self.dense:           # (the gather launch's sampler role walks a CSR: the dense frontier is a launch of its own)
             self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
-                               skip_rows=self._tail_rows + getattr(self, "_side_rows", 0))
+                               skip_rows=self._ahead_rows())
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)
             return
         self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
                            hops=self._hops_desc(self.ids_q[par], True),
-                           skip_rows=self._tail_rows + getattr(self, "_side_rows", 0))
+                           skip_rows=self._ahead_rows())
 
     def _queue_compute(self, par):
         self._q_ids = self.ids_q[par]

@@ -250,6 +250,9 @@ class FusedMeanTrainStep(FusedTrainStep):
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
             if self.wp[l] is not None:
+                if l == 0 and getattr(self, "_k5_gather", None) is not None:
+                    # the projection's spare workgroup slots gather part of the NEXT batch's last-hop means
+                    nat.check(lib.gsage_gather_role_next(ctypes.addressof(self._k5_gather)), "gather_role_next")
                 ops._linear_packed_launch(xbuf.data_ptr(), lda, rows, int(rows is not None), self.wp[l].data_ptr(), None,
                                           self.hout[l].data_ptr(), 2 * h, R, h, din,
                                           nat.ACT_NONE if last else nat.ACT_RELU, 2, delta // esz, h,
@@ -417,7 +420,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         step: every sampled frontier row is read exactly once, by one of the two."""
         total = self.off[self.L + 1]
         tail = self._tail_rows * self.fan[self.L]
-        side = getattr(self, "_side_rows", 0) * self.fan[self.L]
+        side = (getattr(self, "_side_rows", 0) + getattr(self, "_k5_rows", 0)) * self.fan[self.L]
         if getattr(self, "inplace_x", False):          # K5 / K5b read the x rows themselves
             total -= self.rows[0]
         return total - tail - side, tail
@@ -439,17 +442,26 @@ class FusedMeanTrainStep(FusedTrainStep):
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
 
+    def _k5_gather_rows(self):
+        """Rows of the last hop's neighbour means that the gather role of the level-0 projection's launch takes
+        (0: none): GSAGE_K5_GATHER_FRAC of the hop (the packed K5 with the ReLU epilogue, fan-out 5 or 10)."""
+        if self.wp[0] is None or self.L < 2 or self.fan[self.L] not in (5, 10) or self.emb:
+            return 0
+        frac = float(os.environ.get("GSAGE_K5_GATHER_FRAC", "0.0"))
+        left = int(self.size[self.L - 1]) - self._tail_rows
+        return max(0, min(left, int(frac * self.size[self.L - 1])))
+
     def _side_gather_rows(self):
         """Rows of the last hop's neighbour means gathered by the side section that runs beside the seed-level
         launch (0: none): GSAGE_SIDE_GATHER_FRAC of the hop, single-GPU queue mode on command lists."""
         if self.ddp is not None or self.capture_mode != "cmdlist" or self.split:
             return 0
         frac = float(os.environ.get("GSAGE_SIDE_GATHER_FRAC", "0.0"))
-        left = int(self.size[self.L - 1]) - self._tail_rows
+        left = int(self.size[self.L - 1]) - self._tail_rows - self._k5_rows
         return max(0, min(left, int(frac * self.size[self.L - 1])))
 
     def _queue_front_means(self, par):
-        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._tail_rows, part="means")
+        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._ahead_rows(), part="means")
 
     def _queue_front_rest(self, par):
         """after the exchange: squared norm of the averaged gradient, then the rest of the gathers || Adam || K1"""
@@ -473,16 +485,26 @@ class FusedMeanTrainStep(FusedTrainStep):
             d.ld, d.out_ld, d.D, d.rows = st.ld, st.ld, st.dim, self._tail_rows
             d.n, d.n_workgroups = self.fan[L], self._tail_wgs
             self._tail_gather = d
+            t0 = self._tail_rows
+            if self._k5_rows:
+                k = nat.TailGatherDesc()
+                k.table, k.ids = st.data.data_ptr(), nxt[self.off[L] + t0 * self.fan[L]:].data_ptr()
+                k.out = self.xa0_set[1 - par][1][self.off[L - 1] + t0:].data_ptr()
+                k.ld, k.out_ld, k.D, k.rows = st.ld, st.ld, st.dim, self._k5_rows
+                k.n, k.n_workgroups = self.fan[L], 1
+                self._k5_gather = k
+                t0 += self._k5_rows
             if self._side_rows:
-                t0 = self._tail_rows
                 self._side_job = (1 - par, nxt, t0, t0 + self._side_rows)
         try:
             self._stage_compute(self._qset(par))
             if self._side_rows and not self._in_list:      # (eager launching: the same rows, on the main stream)
-                self._stage_gather(1 - par, ids=self.ids_q[1 - par], part="means", skip_rows=self._tail_rows,
-                                   stop_rows=self._tail_rows + self._side_rows)
+                t1 = self._tail_rows + self._k5_rows
+                self._stage_gather(1 - par, ids=self.ids_q[1 - par], part="means", skip_rows=t1,
+                                   stop_rows=t1 + self._side_rows)
         finally:
             self._tail_gather = None
+            self._k5_gather = None
             self._side_job = None
 
     def _step_queue_split(self):

@@ -355,6 +355,31 @@ def test_engine_hands_its_adam_state_back_to_train_step_and_checkpoints():
     pickle.dumps(model.state_dict())
 
 
+@pytest.mark.parametrize("mode", [False, "cmdlist"])
+def test_projection_launch_gather_role_equals_the_plain_step(monkeypatch, mode):
+    """Queue mode with part of the next batch's last-hop means gathered by the spare workgroup slots of the level-0
+    projection's launch (gsage_gather_role_next, GSAGE_K5_GATHER_FRAC): the same rows, the same arithmetic, in
+    another launch -- predictions and weights after eight steps are bit-identical to the plain step."""
+    adj, feats, rng = _problem(n=900, D=64)
+    D, C, B = feats.shape[1], 5, 64
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(10, B))).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(10, B))).to(DEV)
+    outs = []
+    monkeypatch.setenv("GSAGE_TAIL_GATHER_FRAC", "0.005")         # (so that the seed-level launch leaves rows over)
+    for frac in ("0", "0.4"):
+        monkeypatch.setenv("GSAGE_K5_GATHER_FRAC", frac)
+        m = _model(adj, D, C, (128, 128), (25, 10))
+        eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1),
+                                           capture=mode)
+        eng.load_epoch(ids, tg)
+        assert eng._tail_rows > 0 and (eng._k5_rows > 0) == (frac != "0") and eng.wp[0] is not None
+        preds = torch.stack([eng.step_queue().clone() for _ in range(8)])
+        torch.cuda.synchronize()
+        outs.append((preds, eng.flat_p.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("join", ["tail", "fin"])
 def test_side_section_gather_equals_the_single_stream_step(monkeypatch, join):
     """Queue mode with part of the next batch's last-hop means gathered by a kernel of its own on the command
