@@ -252,7 +252,12 @@ __device__ __forceinline__ float load_as(const float *p) { return *p; }
 // 64 / lpc groups take different children; two children per group are in flight.  Forward: per-lane partial sums
 // over the group's children, added across groups at the end; backward: per-child dot products reduced inside the
 // group, parked in LDS for the softmax lanes.
-template <typename T, int VEC, int TMAX>
+// NF = children per group in flight (per trip).  Every row request of a trip is issued before anything waits, and
+// the FIRST trip's requests are issued before the attention weights are computed (the rows do not depend on them):
+// with NF >= ceil(n / G) a parent costs one round trip to HBM instead of one for the scores plus one per pair of
+// children (Reddit's last hop, n = 10, G = 2: 4 dependent round trips -> 1; 61 -> ~40 us per launch).  Sums run in
+// the same order for every NF: bit-identical results.
+template <typename T, int VEC, int TMAX, int NF>
 __global__ void __launch_bounds__(256)
 k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
                      const T *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M, int32_t n,
@@ -262,8 +267,6 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= M) return;                                                 // wave-uniform exit
-    const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
-    if (lane < n) ws[i * n + lane] = w;
     const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
     const int chunks = (D + VEC - 1) / VEC;
     const int Tn = (chunks + lpc - 1) / lpc;                            // <= TMAX (host)
@@ -273,35 +276,43 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
         const int c = sub + lpc * t;
         cc[t] = c < chunks ? c : chunks - 1;                            // clamped: loads stay unconditional
     }
+    vec16 raw[NF][TMAX];
+    auto load_trip = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const int j = j0 + u * G + grp;
+            const int jj = j < n ? j : n - 1;
+            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
+        }
+    };
+    load_trip(0);
+    const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
+    if (lane < n) ws[i * n + lane] = w;
     float acc[TMAX][VEC];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-    for (int j0 = 0; j0 < n; j0 += 2 * G) {                             // wave-uniform trip count
-        vec16 raw[2][TMAX];
-        float wj[2];
+    for (int j0 = 0; j0 < n; j0 += NF * G) {                            // wave-uniform trip count
+        if (j0 > 0) load_trip(j0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NF; ++u) {
             const int j = j0 + u * G + grp;
             const int jj = j < n ? j : n - 1;
-            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
             const float wv = __shfl(w, jj, 64);
-            wj[u] = j < n ? wv : 0.f;
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
+            const float wj = j < n ? wv : 0.f;
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
                 if (t < Tn) {
                     float f[VEC];
                     chunk_to_f32<T, VEC>(raw[u][t], f);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[t][e] += wj[u] * f[e];
+                    for (int e = 0; e < VEC; ++e) acc[t][e] += wj * f[e];
                 }
+        }
     }
     for (int off = lpc; off < 64; off <<= 1)                            // add the groups' partial sums
 #pragma unroll
@@ -329,7 +340,7 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
     }
 }
 
-template <typename T, int VEC, int TMAX>
+template <typename T, int VEC, int TMAX, int NF>
 __global__ void __launch_bounds__(256)
 k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restrict__ ws, const float *__restrict__ na,
                int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld, const T *__restrict__ table, int64_t ld,
@@ -354,11 +365,11 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
         for (int e = 0; e < VEC; ++e) gv[t][e] = (live && c * VEC + e < D) ? g[i * g_ld + c * VEC + e] : 0.f;
     }
     volatile float *mine = dws_s[wave];
-    for (int j0 = 0; j0 < n; j0 += 2 * G) {
-        vec16 raw[2][TMAX];
-        int jv[2];
+    for (int j0 = 0; j0 < n; j0 += NF * G) {
+        vec16 raw[NF][TMAX];
+        int jv[NF];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NF; ++u) {
             const int j = j0 + u * G + grp;
             jv[u] = j;
             const int jj = j < n ? j : n - 1;
@@ -368,7 +379,7 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
                 if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NF; ++u) {
             float d = 0.f;
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
@@ -754,6 +765,16 @@ static int attn_group_lanes(int64_t D, int vec)
     return chunks <= 8 ? 8 : chunks <= 16 ? 16 : 32;
 }
 
+// children per group in flight (NF of the grouped kernels): 5 where it saves dependent round trips (a fan-out of
+// more than two children per group: Reddit's hops; GSAGE_ATTN_NF=2 brings the old pairs back), else 2
+static int attn_in_flight(int32_t n, int lpc)
+{
+    static const int force = [] { const char *e = getenv("GSAGE_ATTN_NF"); return e ? atoi(e) : 0; }();
+    if (force == 2 || force == 5) return force;
+    const int G = 64 / lpc;
+    return n > 2 * G ? 5 : 2;
+}
+
 template <typename T, int VEC>
 static bool attn_wide_ok(const void *table, int64_t ld, int64_t D)
 {
@@ -774,11 +795,15 @@ extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, con
     dim3 grid((unsigned)ceil_div(M, 4));
     hipStream_t s = (hipStream_t)stream;
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
-    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b)
-        launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
-               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
-    else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
-        launch(k_attn_bwd_grp<float, 4, ATTN_TMAX>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b) {
+        if (attn_in_flight(n, lpc_b) == 5)
+            launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX, 5>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+                   (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
+        else
+            launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX, 2>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
+                   (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
+    } else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
+        launch(k_attn_bwd_grp<float, 4, ATTN_TMAX, 2>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
                (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_f);
     else if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
         launch(k_attn_bwd_wide<uint16_t, 8, 32>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
@@ -860,13 +885,18 @@ extern "C" int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const flo
     dim3 grid((unsigned)ceil_div(M, 4));
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b && n <= 64) {
-        launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
-               (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
-               (uint16_t *)agg_lp, agg_lp_ld);
+        if (attn_in_flight(n, lpc_b) == 5)
+            launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX, 5>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa,
+                   xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
+                   (uint16_t *)agg_lp, agg_lp_ld);
+        else
+            launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX, 2>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa,
+                   xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
+                   (uint16_t *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");
     }
     if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f && n <= 64) {
-        launch(k_attn_aggregate_grp<float, 4, ATTN_TMAX>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
+        launch(k_attn_aggregate_grp<float, 4, ATTN_TMAX, 2>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
                (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_f, (float *)agg_lp,
                agg_lp_ld);
         return check_launch("attn_aggregate");
