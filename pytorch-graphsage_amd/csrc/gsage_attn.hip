@@ -269,7 +269,7 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
     if (i >= M) return;                                                 // wave-uniform exit
     const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
     const int chunks = (D + VEC - 1) / VEC;
-    const int Tn = (chunks + lpc - 1) / lpc;                            // <= TMAX (host)
+    constexpr int Tn = TMAX;                                            // == ceil(chunks / lpc) (host picks TMAX)
     int cc[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
@@ -277,16 +277,24 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
         cc[t] = c < chunks ? c : chunks - 1;                            // clamped: loads stay unconditional
     }
     vec16 raw[NF][TMAX];
+    // (the ids of a trip first, all in flight together, then every row request: written as one loop, each id ->
+    //  row pair was a dependent round trip of its own -- the compiler waits for vmcnt(0) in front of each)
     auto load_trip = [&](int j0) {
+        int64_t row[NF];
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             const int j = j0 + u * G + grp;
-            const int jj = j < n ? j : n - 1;
-            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
+            row[u] = i * n + (j < n ? j : n - 1);
+        }
+        if (ids) {                                           // (ONE branch around all NF loads: a branch per load
+#pragma unroll                                               //  ends in a wait per load)
+            for (int u = 0; u < NF; ++u) row[u] = ids[row[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
-                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
-        }
+                raw[u][t] = *reinterpret_cast<const vec16 *>(table + row[u] * ld + cc[t] * VEC);
     };
     load_trip(0);
     const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
@@ -353,7 +361,7 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
     if (i >= M) return;
     const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
     const int chunks = (D + VEC - 1) / VEC;
-    const int Tn = (chunks + lpc - 1) / lpc;
+    constexpr int Tn = TMAX;                                            // == ceil(chunks / lpc) (host picks TMAX)
     int cc[TMAX];
     float gv[TMAX][VEC];
 #pragma unroll
@@ -368,16 +376,22 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
     for (int j0 = 0; j0 < n; j0 += NF * G) {
         vec16 raw[NF][TMAX];
         int jv[NF];
+        int64_t row[NF];
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
+        for (int u = 0; u < NF; ++u) {                       // ids first, all in flight (see the forward kernel)
             const int j = j0 + u * G + grp;
             jv[u] = j;
-            const int jj = j < n ? j : n - 1;
-            const int64_t row = ids ? ids[i * n + jj] : i * n + jj;
+            row[u] = i * n + (j < n ? j : n - 1);
+        }
+        if (ids) {
+#pragma unroll
+            for (int u = 0; u < NF; ++u) row[u] = ids[row[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
-                if (t < Tn) raw[u][t] = *reinterpret_cast<const vec16 *>(table + row * ld + cc[t] * VEC);
-        }
+                raw[u][t] = *reinterpret_cast<const vec16 *>(table + row[u] * ld + cc[t] * VEC);
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             float d = 0.f;
@@ -775,6 +789,29 @@ static int attn_in_flight(int32_t n, int lpc)
     return n > 2 * G ? 5 : 2;
 }
 
+// the grouped kernels are instantiated on the exact number of strided chunks per lane (1..3) and on NF
+template <typename T, int VEC, typename... A>
+static void launch_attn_fwd(int tn, int nf, dim3 grid, hipStream_t s, A... a)
+{
+#define GSAGE_ATTN_CASE(TN, NF) \
+    if (tn == TN && nf == NF) { launch(k_attn_aggregate_grp<T, VEC, TN, NF>, grid, dim3(256), 0, s, a...); return; }
+    GSAGE_ATTN_CASE(1, 2) GSAGE_ATTN_CASE(2, 2) GSAGE_ATTN_CASE(3, 2)
+    GSAGE_ATTN_CASE(1, 5) GSAGE_ATTN_CASE(2, 5) GSAGE_ATTN_CASE(3, 5)
+#undef GSAGE_ATTN_CASE
+}
+
+template <typename T, int VEC, typename... A>
+static void launch_attn_bwd(int tn, int nf, dim3 grid, hipStream_t s, A... a)
+{
+#define GSAGE_ATTN_CASE(TN, NF) \
+    if (tn == TN && nf == NF) { launch(k_attn_bwd_grp<T, VEC, TN, NF>, grid, dim3(256), 0, s, a...); return; }
+    GSAGE_ATTN_CASE(1, 2) GSAGE_ATTN_CASE(2, 2) GSAGE_ATTN_CASE(3, 2)
+    GSAGE_ATTN_CASE(1, 5) GSAGE_ATTN_CASE(2, 5) GSAGE_ATTN_CASE(3, 5)
+#undef GSAGE_ATTN_CASE
+}
+
+static int attn_chunks_per_lane(int64_t D, int vec, int lpc) { return (int)ceil_div(ceil_div(D, (int64_t)vec), (int64_t)lpc); }
+
 template <typename T, int VEC>
 static bool attn_wide_ok(const void *table, int64_t ld, int64_t D)
 {
@@ -795,16 +832,14 @@ extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, con
     dim3 grid((unsigned)ceil_div(M, 4));
     hipStream_t s = (hipStream_t)stream;
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
-    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b) {
-        if (attn_in_flight(n, lpc_b) == 5)
-            launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX, 5>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
-                   (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
-        else
-            launch(k_attn_bwd_grp<uint16_t, 8, ATTN_TMAX, 2>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
-                   (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_b);
-    } else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
-        launch(k_attn_bwd_grp<float, 4, ATTN_TMAX, 2>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
-               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld, lpc_f);
+    if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b)
+        launch_attn_bwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b), grid, s, g, g_ld, ws, na,
+                                     na_ld, xa, xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna,
+                                     dna_ld, dxa, dxa_ld, (int32_t)lpc_b);
+    else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
+        launch_attn_bwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f), grid, s, g, g_ld, ws, na, na_ld,
+                                  xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa,
+                                  dxa_ld, (int32_t)lpc_f);
     else if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
         launch(k_attn_bwd_wide<uint16_t, 8, 32>, grid, dim3(256), 0, s, g, g_ld, ws, na, na_ld, xa, xa_ld,
                (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa, dxa_ld);
@@ -885,20 +920,15 @@ extern "C" int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const flo
     dim3 grid((unsigned)ceil_div(M, 4));
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b && n <= 64) {
-        if (attn_in_flight(n, lpc_b) == 5)
-            launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX, 5>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa,
-                   xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
-                   (uint16_t *)agg_lp, agg_lp_ld);
-        else
-            launch(k_attn_aggregate_grp<uint16_t, 8, ATTN_TMAX, 2>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa,
-                   xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_b,
-                   (uint16_t *)agg_lp, agg_lp_ld);
+        launch_attn_fwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b), grid, (hipStream_t)stream,
+                                     na, na_ld, xa, xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D,
+                                     agg, agg_ld, ws, (int32_t)lpc_b, (uint16_t *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");
     }
     if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f && n <= 64) {
-        launch(k_attn_aggregate_grp<float, 4, ATTN_TMAX, 2>, grid, dim3(256), 0, (hipStream_t)stream, na, na_ld, xa, xa_ld,
-               (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld, ws, lpc_f, (float *)agg_lp,
-               agg_lp_ld);
+        launch_attn_fwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f), grid, (hipStream_t)stream, na,
+                                  na_ld, xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld,
+                                  ws, (int32_t)lpc_f, (float *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");
     }
     // the kernels below write fp32 only: the copy in the table's type follows as a cast launch
