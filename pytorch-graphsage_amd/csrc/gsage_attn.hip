@@ -252,11 +252,11 @@ __device__ __forceinline__ float load_as(const float *p) { return *p; }
 // 64 / lpc groups take different children; two children per group are in flight.  Forward: per-lane partial sums
 // over the group's children, added across groups at the end; backward: per-child dot products reduced inside the
 // group, parked in LDS for the softmax lanes.
-// NF = children per group in flight (per trip).  Every row request of a trip is issued before anything waits, and
-// the FIRST trip's requests are issued before the attention weights are computed (the rows do not depend on them):
-// with NF >= ceil(n / G) a parent costs one round trip to HBM instead of one for the scores plus one per pair of
-// children (Reddit's last hop, n = 10, G = 2: 4 dependent round trips -> 1; 61 -> ~40 us per launch).  Sums run in
-// the same order for every NF: bit-identical results.
+// NF = children per group in flight (per trip).  The ids of a trip are loaded first (all in flight, ONE branch on
+// `ids`), then every row request of the trip is issued before anything waits, and the FIRST trip's requests go out
+// before the attention weights are computed (the rows do not depend on them).  Written as "for each child: id ->
+// row chunks" the compiler put a vmcnt(0) in front of every child's rows: a dependent round trip per child
+// (59.8 -> 54.3 us at Reddit's last hop once hoisted).  Sums run in the same order for every NF: bit-identical.
 template <typename T, int VEC, int TMAX, int NF>
 __global__ void __launch_bounds__(256)
 k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
@@ -779,14 +779,16 @@ static int attn_group_lanes(int64_t D, int vec)
     return chunks <= 8 ? 8 : chunks <= 16 ? 16 : 32;
 }
 
-// children per group in flight (NF of the grouped kernels): 5 where it saves dependent round trips (a fan-out of
-// more than two children per group: Reddit's hops; GSAGE_ATTN_NF=2 brings the old pairs back), else 2
+// children per group in flight (NF of the grouped kernels).  Measured at Reddit's last hop (n = 10, two groups of
+// 32 lanes, 154 MB): NF = 2 (80 VGPRs, six waves per SIMD) 54 us forward / 61 us backward, NF = 5 (one trip per
+// parent, 136 VGPRs, three waves per SIMD) 65 / 63 us -- the launch is bound by how many requests a CU keeps in
+// flight across ALL its waves, not by a parent's chain of round trips, so occupancy wins.  GSAGE_ATTN_NF=5 selects
+// the deep variant (kept for fan-outs where a parent's chain is long and rows are short).
 static int attn_in_flight(int32_t n, int lpc)
 {
     static const int force = [] { const char *e = getenv("GSAGE_ATTN_NF"); return e ? atoi(e) : 0; }();
-    if (force == 2 || force == 5) return force;
-    const int G = 64 / lpc;
-    return n > 2 * G ? 5 : 2;
+    (void)n; (void)lpc;
+    return force == 5 ? 5 : 2;
 }
 
 // the grouped kernels are instantiated on the exact number of strided chunks per lane (1..3) and on NF
