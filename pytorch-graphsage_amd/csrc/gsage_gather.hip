@@ -74,32 +74,63 @@ __device__ __forceinline__ void gather_mean_chunk(const TI *__restrict__ table, 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     const int64_t base = row * (int64_t)n;
-    int32_t j = 0;
-    // 8 then 4 independent 16-byte loads in flight per lane (HBM latency ~ 1-2 us under load)
-    for (; j + 8 <= n; j += 8) {
-        int64_t r[8];
+    if (ids) {
+        // Batches of 8 rows, software-pipelined: the ids of batch b+1 are requested BEFORE the rows of batch b
+        // (requests return in order: ids asked for behind 8 row requests would wait for those rows), every batch's
+        // ids and rows are in flight together, and ONE branch covers a batch's id loads.  Written as
+        // `r[u] = ids ? ids[..] : ..` per element, every id load sat in a branch of its own with a vmcnt(0) behind
+        // it: 8 dependent round trips per batch before the first row request, and the < 8 remainder went id -> row
+        // -> id -> row (n = 10: 13 dependent round trips per work item; now 3).
+        // Ids are node ids: < 2^31 (the adjacency's neighbour array is int32), so the low dword of each int64 is
+        // read -- 8 instead of 16 registers per batch in flight, which is what lets two batches' ids coexist under
+        // the register cap of k_gather_multi_adam.  A short last batch repeats its last row (same lines: cache
+        // hits) and drops the repeats at the accumulation: loads stay unconditional, the order j = 0 .. n-1 and
+        // with it every bit of the mean is unchanged.
+        const int32_t *ids32 = reinterpret_cast<const int32_t *>(ids + base);
+        int32_t rc[8], rn[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = ids ? ids[base + j + u] : base + j + u;
-        in_raw v[8];
+        for (int u = 0; u < 8; ++u) rc[u] = ids32[2 * min(u, n - 1)];
+        for (int32_t j = 0; j < n; j += 8) {
+            const int32_t m = min(8, n - j);
+            if (j + 8 < n) {
+                const int32_t m2 = min(8, n - j - 8);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + r[u] * ld + c0);
+                for (int u = 0; u < 8; ++u) rn[u] = ids32[2 * (j + 8 + min(u, m2 - 1))];
+            }
+            in_raw v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) in_io::accumulate(v[u], acc);
-    }
-    for (; j + 4 <= n; j += 4) {
-        int64_t r[4];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + (int64_t)rc[u] * ld + c0);
+            if (m == 8) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = ids ? ids[base + j + u] : base + j + u;
-        in_raw v[4];
+                for (int u = 0; u < 8; ++u) in_io::accumulate(v[u], acc);
+            } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + r[u] * ld + c0);
+                for (int u = 0; u < 8; ++u)
+                    if (u < m) in_io::accumulate(v[u], acc);
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) in_io::accumulate(v[u], acc);
-    }
-    for (; j < n; ++j) {
-        const int64_t r = ids ? ids[base + j] : base + j;
-        const in_raw a = *reinterpret_cast<const in_raw *>(table + r * ld + c0);
-        in_io::accumulate(a, acc);
+            for (int u = 0; u < 8; ++u) rc[u] = rn[u];
+        }
+    } else {
+        int32_t j = 0;
+        for (; j + 8 <= n; j += 8) {
+            in_raw v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + (base + j + u) * ld + c0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) in_io::accumulate(v[u], acc);
+        }
+        for (; j + 4 <= n; j += 4) {
+            in_raw v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + (base + j + u) * ld + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) in_io::accumulate(v[u], acc);
+        }
+        for (; j < n; ++j) {
+            const in_raw a = *reinterpret_cast<const in_raw *>(table + (base + j) * ld + c0);
+            in_io::accumulate(a, acc);
+        }
     }
     const float fn = (float)n;
 #pragma unroll
