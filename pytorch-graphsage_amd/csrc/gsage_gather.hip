@@ -196,7 +196,22 @@ __device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_
                 sg[k] = s;
                 row[k] = u / chunks;
                 c0[k] = (int32_t)(u - row[k] * chunks) * VEC;
-                src[k] = q.ids[s] ? q.ids[s][row[k]] : row[k];
+                src[k] = row[k];
+            }
+            {   // the four ids in flight together: one branch around all of them (a null check per load ends in a
+                // wait per load), the mixed case (some segments without a row list) keeps the per-element form
+                const int64_t *ip[4];
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ip[k] = q.ids[sg[k]]; all = all && ip[k] != nullptr; }
+                if (all) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) src[k] = ip[k][row[k]];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ip[k]) src[k] = ip[k][row[k]];
+                }
             }
             vec16 raw[4];
 #pragma unroll
@@ -229,9 +244,11 @@ __device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_
             const int64_t M = q.M[s];
             int64_t src[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t r = min(row * 4 + k, M - 1);
-                src[k] = q.ids[s] ? q.ids[s][r] : r;
+            for (int k = 0; k < 4; ++k) src[k] = min(row * 4 + k, M - 1);
+            if (q.ids[s]) {                                    // (one branch around the four id loads)
+                const int64_t *ip = q.ids[s];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) src[k] = ip[src[k]];
             }
             vec16 raw[4];
 #pragma unroll

@@ -259,4 +259,6 @@ def test_ring_of_step_constants_wraps_safely(monkeypatch):
             assert settles >= 2 and eng.row_hist.numel() == 16
         outs.append({k: v.detach().clone() for k, v in model.state_dict().items()})
     for k in outs[0]:
-        assert torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=2e-5), (k, float((outs[0][k] - outs[1][k]).abs().max()))
+        # (20 steps: the scatter-add's float atomics land in a different order every run, and Adam amplifies that
+        #  where v is tiny -- two DENSE runs differ by up to ~4e-5 in single table entries)
+        assert torch.allclose(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-4), (k, float((outs[0][k] - outs[1][k]).abs().max()))
