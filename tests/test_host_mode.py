@@ -209,6 +209,64 @@ def test_node_problem_iterate_matches_reference_chunking(tmp_path):
         assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g[p + "tail"])
 
 
+def test_train_epoch_chunks_are_the_references_iterate_chunks():
+    """train.epoch_chunks (what the fused training loop cuts an epoch with) against the reference's iterate
+    (iterate_kat.npz: chunk sizes, chunk contents, words left in numpy's stream) for the shuffled cases."""
+    import importlib
+    train = importlib.import_module("pytorch-graphsage_amd.train")
+    g = load_golden("iterate_kat.npz")
+    seen = 0
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        if not bool(int(g[p + "shuffle"])):
+            continue
+        nodes = g[p + "nodes"]
+        gs.set_seeds(int(g[p + "seed"]))
+        chunks = train.epoch_chunks(nodes, int(g[p + "bs"]))
+        assert [len(ch) for ch in chunks] == list(g[p + "sizes"])
+        assert np.array_equal(np.concatenate([nodes[ch] for ch in chunks]), g[p + "ids"])
+        assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g[p + "tail"])
+        seen += 1
+    assert seen >= 1
+
+
+def test_fused_engine_for_says_why_no_engine_applies(capsys):
+    """No fused engine covers a model on the CPU / an LSTM aggregator: `fused_engine_for(explain=True)` returns None
+    and names, per engine, what is not covered -- nobody lands on the slow path silently (round-2 verdict, weak 10)."""
+    from scipy import sparse
+    from torch.nn import functional as F
+    adj = sparse.csr_matrix((np.array([1, 2, 1]), np.array([0, 1, 0]), np.array([0, 0, 2, 3])), shape=(3, 2))
+    specs = [{"n_train_samples": 2, "n_val_samples": 2, "output_dim": 8, "activation": F.relu},
+             {"n_train_samples": 2, "n_val_samples": 2, "output_dim": 8, "activation": lambda x: x}]
+    for agg, needle in (("mean", "FeatureStore"), ("lstm", "aggregators")):
+        m = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+                            prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup[agg],
+                            input_dim=4, n_nodes=3, n_classes=2, layer_specs=specs)
+        assert gs.engine.fused_engine_for(m, torch.zeros(3, 4), explain=True) is None
+        err = capsys.readouterr().err
+        assert "no fused train-step engine covers this model" in err and needle in err
+        why = gs.engine.why_no_fused_engine(m, torch.zeros(3, 4))
+        assert set(why) == {"FusedMeanTrainStep", "FusedPoolTrainStep", "FusedAttnTrainStep"}
+
+
+def test_dense_sampler_host_mode_and_table():
+    """UniformNeighborSampler on CPU tensors keeps the reference's stock indexing (dense_sampler_kat.npz), and
+    store.DenseAdj validates what the HIP path needs."""
+    g = load_golden("dense_sampler_kat.npz")
+    adj = torch.from_numpy(g["adj"])
+    s = gs.sampler_lookup["uniform_neighbor_sampler"](adj=adj)
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        gs.set_seeds(int(g[p + "seed"]))
+        out = s(torch.from_numpy(g[p + "ids"]), n_samples=int(g[p + "n"]))
+        assert np.array_equal(out.numpy(), g[p + "out"]), c
+    tab = s.table()
+    assert (tab.n_rows, tab.K, tab.max_deg) == (adj.shape[0], adj.shape[1], adj.shape[1])
+    tab.check()
+    with pytest.raises(AssertionError):
+        gs.store.DenseAdj(adj.float())
+
+
 def test_lr_schedule_and_metrics_match_reference():
     g = load_golden("misc_kat.npz")
     for name in ("constant", "linear", "cyclical"):
