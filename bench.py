@@ -30,7 +30,7 @@ Extra objects on the line (tier contract, section 4 of the task):
                for ITS dominant launch, timed the same way inside ITS step: K3 over the last hop (max-pool; MFMA),
                K4 over the last hop (attention, Reddit and Pokec shapes; HBM), the gather launch (papers).
   cpu_baseline two CPU restatements of train_step on the host, bounded sample each: the OpenMP C one
-               (oracle/gsage_train_omp.c, all cores, register-blocked AVX2 GEMMs) and the plain-torch port of the reference's
+               (oracle/gsage_train_omp.c, all cores, vectorised loops without BLAS) and the plain-torch port of the reference's
                op sequence (oracle/torch_ref.py, MKL GEMMs, fixed thread count); `value` is the faster.
 """
 import argparse
@@ -170,7 +170,7 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
     n_t, dt_t = timed(torch_step, budget_s * 0.4)
     omp = {"value": n_omp * batch / dt_omp, "cores": omp_threads,
            "sample": "%d train_steps of %d seeds, fp32, OpenMP C restatement (oracle/gsage_train_omp.c: "
-                     "register-blocked AVX2 GEMMs, no BLAS) on %d threads of %d host threads, %.1f s" % (n_omp, batch, omp_threads, ncpu, dt_omp)}
+                     "vectorised dot-product / axpy loops, no BLAS) on %d threads of %d host threads, %.1f s" % (n_omp, batch, omp_threads, ncpu, dt_omp)}
     tp = {"value": n_t * batch / dt_t, "cores": threads,
           "sample": "%d train_steps of %d seeds, fp32, oracle/torch_ref.py (the reference's op sequence on stock "
                     "torch CPU kernels: MKL GEMMs) + C sampler, torch %d threads (fixed), %.1f s"

@@ -37,82 +37,42 @@ static int64_t pick(const int64_t *indptr, const int64_t *data, int64_t id, int6
     return deg > 0 ? data[beg + s % deg] : 0;      /* numpy: x % 0 == 0 -> the dummy node */
 }
 
-/* ---- dense contractions: register-blocked AVX2 micro-kernels ------------------------------------------------
- * (round 2 had one dot product per output element / one axpy per (row, column): every FMA paid a load and the
- *  128-thread run was 7x SLOWER than the 32-thread torch port.  4 x 4 blocks share their operand loads: 8 loads
- *  per 16 FMAs, accumulators in registers across the whole reduction.) */
-typedef float v8f __attribute__((vector_size(32), aligned(4)));
-
-static inline v8f ld8(const float *p) { v8f v; memcpy(&v, p, 32); return v; }
-static inline void st8(float *p, v8f v) { memcpy(p, &v, 32); }
-static inline float hsum8(v8f v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
-
 /* C[m, n] = sum_k A[m, k] * W[n, k]      (A: [M, lda], W: [N, ldw], C: [M, ldc], columns c0.. of C) */
 static void gemm_nt(int64_t M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw,
                     float *C, int64_t ldc, int c0)
 {
-    const int64_t MB = (M + 3) / 4;
 #pragma omp parallel for schedule(static)
-    for (int64_t mb = 0; mb < MB; ++mb) {
-        const int64_t m0 = mb * 4;
-        const float *a[4];
-        for (int i = 0; i < 4; ++i) a[i] = A + (m0 + i < M ? m0 + i : M - 1) * lda;     /* clamped rows: not stored */
-        for (int n0 = 0; n0 < N; n0 += 4) {
-            const float *w[4];
-            for (int j = 0; j < 4; ++j) w[j] = W + (int64_t)(n0 + j < N ? n0 + j : N - 1) * ldw;
-            v8f acc[4][4];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) acc[i][j] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
-            int k = 0;
-            for (; k + 8 <= K; k += 8) {
-                const v8f a0 = ld8(a[0] + k), a1 = ld8(a[1] + k), a2 = ld8(a[2] + k), a3 = ld8(a[3] + k);
-                for (int j = 0; j < 4; ++j) {
-                    const v8f wv = ld8(w[j] + k);
-                    acc[0][j] += a0 * wv; acc[1][j] += a1 * wv; acc[2][j] += a2 * wv; acc[3][j] += a3 * wv;
-                }
-            }
-            for (int i = 0; i < 4 && m0 + i < M; ++i)
-                for (int j = 0; j < 4 && n0 + j < N; ++j) {
-                    float sum = hsum8(acc[i][j]);
-                    for (int kk = k; kk < K; ++kk) sum += a[i][kk] * w[j][kk];
-                    C[(m0 + i) * ldc + c0 + n0 + j] = sum;
-                }
+    for (int64_t m = 0; m < M; ++m) {
+        const float *a = A + m * lda;
+        for (int n = 0; n < N; ++n) {
+            const float *w = W + (int64_t)n * ldw;
+            float s = 0.f;
+#pragma omp simd reduction(+ : s)
+            for (int k = 0; k < K; ++k) s += a[k] * w[k];
+            C[m * ldc + c0 + n] = s;
         }
     }
 }
 
-/* out[m, k] = sum_n G[m, g0 + n] * W[n, k]   (input gradient of a projection): four rows of out share a W row */
+/* out[m, k] = sum_n G[m, g0 + n] * W[n, k]   (input gradient of a projection) */
 static void gemm_nn(int64_t M, int N, int K, const float *G, int64_t ldg, int g0, const float *W, int64_t ldw,
                     float *out, int64_t ldo)
 {
-    const int64_t MB = (M + 3) / 4;
 #pragma omp parallel for schedule(static)
-    for (int64_t mb = 0; mb < MB; ++mb) {
-        const int64_t m0 = mb * 4;
-        const int rows = (int)(M - m0 < 4 ? M - m0 : 4);
-        for (int i = 0; i < rows; ++i) memset(out + (m0 + i) * ldo, 0, sizeof(float) * (size_t)K);
+    for (int64_t m = 0; m < M; ++m) {
+        float *o = out + m * ldo;
+        for (int k = 0; k < K; ++k) o[k] = 0.f;
         for (int n = 0; n < N; ++n) {
-            float g[4];
-            int any = 0;
-            for (int i = 0; i < 4; ++i) { g[i] = i < rows ? G[(m0 + i) * ldg + g0 + n] : 0.f; any |= g[i] != 0.f; }
-            if (!any) continue;                                                    /* ReLU-masked columns */
+            const float g = G[m * ldg + g0 + n];
+            if (g == 0.f) continue;
             const float *w = W + (int64_t)n * ldw;
-            int k = 0;
-            for (; k + 8 <= K; k += 8) {
-                const v8f wv = ld8(w + k);
-                for (int i = 0; i < rows; ++i) {
-                    float *o = out + (m0 + i) * ldo + k;
-                    st8(o, ld8(o) + g[i] * wv);
-                }
-            }
-            for (; k < K; ++k)
-                for (int i = 0; i < rows; ++i) out[(m0 + i) * ldo + k] += g[i] * w[k];
+#pragma omp simd
+            for (int k = 0; k < K; ++k) o[k] += g * w[k];
         }
     }
 }
 
-/* dW[n, k] += sum_m G[m, g0 + n] * A[m, k]: M split over threads, partial sums reduced in chunk order; four
- * output rows share an A row */
+/* dW[n, k] += sum_m G[m, g0 + n] * A[m, k]: M split over threads, partial sums reduced in chunk order */
 static void wgrad_tn(int64_t M, int N, int K, const float *G, int64_t ldg, int g0, const float *A, int64_t lda,
                      float *dW)
 {
@@ -126,22 +86,12 @@ static void wgrad_tn(int64_t M, int N, int K, const float *G, int64_t ldg, int g
         const int64_t m0 = M * t / T, m1 = M * (t + 1) / T;
         for (int64_t m = m0; m < m1; ++m) {
             const float *a = A + m * lda;
-            for (int n0 = 0; n0 < N; n0 += 4) {
-                float g[4];
-                int any = 0;
-                for (int j = 0; j < 4; ++j) { g[j] = n0 + j < N ? G[m * ldg + g0 + n0 + j] : 0.f; any |= g[j] != 0.f; }
-                if (!any) continue;
-                const int cols = N - n0 < 4 ? N - n0 : 4;
-                int k = 0;
-                for (; k + 8 <= K; k += 8) {
-                    const v8f av = ld8(a + k);
-                    for (int j = 0; j < cols; ++j) {
-                        float *row = p + (size_t)(n0 + j) * K + k;
-                        st8(row, ld8(row) + g[j] * av);
-                    }
-                }
-                for (; k < K; ++k)
-                    for (int j = 0; j < cols; ++j) p[(size_t)(n0 + j) * K + k] += g[j] * a[k];
+            for (int n = 0; n < N; ++n) {
+                const float g = G[m * ldg + g0 + n];
+                if (g == 0.f) continue;
+                float *row = p + (size_t)n * K;
+#pragma omp simd
+                for (int k = 0; k < K; ++k) row[k] += g * a[k];
             }
         }
     }
