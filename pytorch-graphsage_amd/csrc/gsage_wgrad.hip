@@ -187,6 +187,10 @@ __device__ __forceinline__ void wgrad_mainloop_rows(const WgradParams &p, const 
     auto load_data = [&](u32x4 (&cdst)[8], u32x4 (&adst)[8], const u32x4 (&ids)[4], int64_t step) {
         const uint16_t *cp = c_base + step * 32 * p.ldc;
         const uint16_t *ap[8];
+        // Every dword of the id registers counts as read HERE: the high dwords are never used, and a register the
+        // compiler considers dead while its load is still in flight can be handed out as scratch and is then
+        // overwritten when the load lands.
+        asm volatile("" ::"v"(ids[0]), "v"(ids[1]), "v"(ids[2]), "v"(ids[3]));
 #pragma unroll
         for (int r = 0; r < 8; ++r)          // (row ids are < 2^32: the low dword)
             ap[r] = a_col + (int64_t)ids[r >> 1][(r & 1) * 2] * p.lda;

@@ -28,6 +28,23 @@ for w in $WHAT; do
     bench)
       timeout 900 python bench.py > $OUT/bench.log 2>&1
       echo "== bench rc=$?"; tail -3 $OUT/bench.log ;;
+    pool|attn)
+      a=max_pool; [ $w = attn ] && a=attention
+      timeout 600 python bench.py --aggregator $a --steps 50 --warmup 10 --no-cpu-baseline --extra '' > $OUT/bench_$w.log 2>&1
+      echo "== bench $a rc=$?"; tail -1 $OUT/bench_$w.log | cut -c1-900 ;;
+    sq)
+      # where the waves of one configuration wait: SQ counters (one pass), then L2 hit / miss (second pass)
+      a=${GSAGE_SQ_AGG:-max_pool}
+      rocprofv3 -L > $OUT/pmc_list.txt 2>&1
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+        i=$((i+1)); rm -rf $OUT/sq_${a}_$i
+        timeout 600 rocprofv3 --kernel-trace --pmc $set -d $OUT/sq_${a}_$i -o f --output-format csv -- python bench.py --aggregator $a --steps 20 --warmup 5 --no-cpu-baseline --extra '' --min-time 0 > $OUT/sq_${a}_$i.log 2>&1
+        echo "== sq $a pass $i rc=$?"
+        c=$(find $OUT/sq_${a}_$i -name "*counter_collection.csv" | head -1)
+        [ -n "$c" ] && python tools/pmc_any.py "$c" > $OUT/sq_${a}_$i.json
+        find $OUT/sq_${a}_$i -name "*.csv" -size +2M -delete
+      done ;;
     bench20)
       timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1
       echo "== bench20 rc=$?"; tail -2 $OUT/bench20.log ;;
