@@ -33,7 +33,6 @@ class FusedAttnTrainStep(FusedTrainStep):
     MLP, K4, the x projection and two of the four weight gradients all want plain row-major operands."""
 
     HA_LD = 64            # leading dimension of the 32-wide att activations (whole 128-byte bf16 lines)
-    WG_TARGET = 120       # K5b workgroups per problem (eight problems share the launch)
     TIMED = {"gather": (0, 1), "k4": (4, 5), "k4_bwd": (6, 7)}   # K4 / K4' of level 0 over the LAST hop (the bulk)
 
     @classmethod
@@ -137,10 +136,16 @@ class FusedAttnTrainStep(FusedTrainStep):
     def _init_reduce(self):
         dev, f32 = self.dev, torch.float32
         rdesc, self.slabs = [], []
+        # K5b workgroups per problem: the problems go out eight to a launch in the order of _stage_compute and one
+        # workgroup fits per CU, so each launch's problems are sized together to fill the chip once
+        # (ops.wgrad_balance)
+        order = [(l, i, p) for l in range(self.L - 1, -1, -1) for i, p in enumerate(self._wg_problems(l, 0))]
+        targets = ops.wgrad_balance([(p[3], p[4], p[5]) for _l, _i, p in order])
+        self.wg_target = {(l, i): t for (l, i, _p), t in zip(order, targets)}
         for l in range(self.L):
             bufs = []
-            for (dC, A, lda, M, ntot, K, prm, _rows) in self._wg_problems(l, 0):
-                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET)
+            for i, (dC, A, lda, M, ntot, K, prm, _rows) in enumerate(self._wg_problems(l, 0)):
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.wg_target[(l, i)])
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs.append(buf)
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
@@ -255,8 +260,8 @@ class FusedAttnTrainStep(FusedTrainStep):
                     self.dc[l - 1].stride(0), RA, D, L - l + 1, self.off_host, self.fan_host, stream), "attn_merge_bwd")
         probs = []
         for l in range(L - 1, -1, -1):
-            for (dC, A, lda, M, ntot, K, prm, rows), slab in zip(self._wg_problems(l, s), self.slabs[l]):
-                probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.WG_TARGET, rows))
+            for i, ((dC, A, lda, M, ntot, K, prm, rows), slab) in enumerate(zip(self._wg_problems(l, s), self.slabs[l])):
+                probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.wg_target[(l, i)], rows))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)

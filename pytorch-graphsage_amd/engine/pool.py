@@ -32,9 +32,6 @@ class FusedPoolTrainStep(FusedTrainStep):
     """
 
     NPART = 256          # partial rows per hop for the MLP bias gradient (summed by the finalisation)
-    # K5b workgroups per problem: the MLP's weight gradient is 20x the work of the two projections that
-    # share its launch, so those take few, long M-slices (fewer partial tiles to write and to sum)
-    WG_TARGET = {"m": 240, "x": 40, "n": 40}
     TIMED = {"gather": (0, 1), "k3": (4, 5), "k5b": (6, 7)}      # K3 = level 0's launch over the LAST hop (the bulk)
 
     @classmethod
@@ -144,15 +141,27 @@ class FusedPoolTrainStep(FusedTrainStep):
             return self.xn0_set[s], self.store.ld, None
         return self.hout[l - 1][self.off[1]:], self.din[l], None
 
+    def _wg_shapes(self, l):
+        """(key, parameter, M, Ntot, K) of level l's three weight gradients, in the order they are issued"""
+        layer = self.layers[l]
+        R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+        return (("x", layer.fc_x.weight, R, h, din), ("n", layer.fc_neib.weight, R, h, Hm),
+                ("m", layer.mlp[0].weight, NR, Hm, din))
+
     def _init_reduce(self):
         dev, L, f32 = self.dev, self.L, torch.float32
+        # K5b workgroups per problem: the MLP's weight gradients get the chip's worth of slices each (the small one's
+        # many short workgroups fill the tail of the big one's), the two projections few, long ones (fewer partial
+        # tiles to write and to sum).  Sizing all six for ONE round of equal-length slices (ops.wgrad_balance: 232
+        # workgroups, the big problem on 200) measured SLOWER here -- 180 against 150 us: the launch is bound by what
+        # its 240 big workgroups pull from HBM (785 MB per launch), and fewer, longer slices only stretch that.
+        self.wg_target = {(l, key): {"m": 240, "x": 40, "n": 40}[key] for l in range(L) for key in "mxn"}
         rdesc, self.slabs = [], []
         for l, layer in enumerate(self.layers):
-            R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
+            Hm = self.Hm[l]
             bufs = {}
-            for key, prm, M, ntot, K in (("m", layer.mlp[0].weight, NR, Hm, din), ("x", layer.fc_x.weight, R, h, din),
-                                         ("n", layer.fc_neib.weight, R, h, Hm)):
-                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.WG_TARGET[key])
+            for key, prm, M, ntot, K in sorted(self._wg_shapes(l), key=lambda spec: "mxn".index(spec[0])):
+                rps, S, ldk = ops.wgrad_plan(M, ntot, K, self.wg_target[(l, key)])
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs[key] = buf
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
@@ -260,11 +269,11 @@ class FusedPoolTrainStep(FusedTrainStep):
             x, ldx = self._x_operand(l, s)
             nb, ldnb, nrows = self._nb_operand(l, s)
             dc = self.dc[l]
-            T = self.WG_TARGET
-            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"], T["x"]))
+            T = self.wg_target
+            probs.append((dc[:, :h], x, ldx, 0, R, h, din, h, self.slabs[l]["x"], T[(l, "x")]))
             probs.append((dc[:, h:], self.pooled_b[l], self.pooled_b[l].shape[1], 0, R, h, Hm, h, self.slabs[l]["n"],
-                          T["n"]))
-            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T["m"], nrows))
+                          T[(l, "n")]))
+            probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T[(l, "m")], nrows))
         for i in range(0, len(probs), 8):
             if i == 0:
                 self._time_next(6, 7)

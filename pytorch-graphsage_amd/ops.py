@@ -386,6 +386,24 @@ def wgrad_plan(M, Ntot, K, target=240):
     return rps, (M + rps - 1) // rps, ldk
 
 
+def wgrad_balance(shapes, budget=248, group=8):
+    """Workgroup targets for K5b problems that share gsage_wgrad_multi launches (issued `group` at a time, in this
+    order).  One workgroup fits per CU, so a launch with more workgroups than CUs runs in rounds and its small problems
+    then cost a round of their own (the max-pool step's six problems used 572 workgroups: 150 us where the big one
+    alone takes 98).  Per launch: the smallest slice length R (rows, multiple of 16, >= 256) for which
+    sum_i tiles_i * ceil(M_i / R) <= budget -- every problem gets slices of about the same length, so they finish
+    together, in one round.  shapes: [(M, Ntot, K)]; returns the per-problem `target` for wgrad_plan."""
+    targets = []
+    for i in range(0, len(shapes), group):
+        chunk = shapes[i:i + group]
+        tiles = [((nt + 127) // 128) * ((_round_up(k, 4) + 127) // 128) for (_m, nt, k) in chunk]
+        R = 256
+        while sum(t * ((m + R - 1) // R) for t, (m, _nt, _k) in zip(tiles, chunk)) > budget and R < max(m for m, _, _ in chunk):
+            R += 16
+        targets += [t * ((m + R - 1) // R) for t, (m, _nt, _k) in zip(tiles, chunk)]
+    return targets
+
+
 def wgrad(dC, A, lda, a_gstride, M, Ntot, K, n_per_group, out=None, slabs=None, reduce=True):
     """dW_g = dC_g^T @ A_g on the matrix cores (K5b), bf16 operands, fp32 result
     [groups, n_per_group, K].  dC: contiguous bf16 [M, >=Ntot]; A: bf16 [M, lda] row-major.

@@ -317,3 +317,26 @@ def test_shard_refuses_batches_smaller_than_the_world():
     assert dp.shard(ids).tolist() == [2, 3]
     with pytest.raises(ValueError):
         dp.shard(torch.arange(3))
+
+
+def test_wgrad_balance_fits_one_round_with_equal_slices():
+    """ops.wgrad_balance: every launch's problems (eight at a time) together stay within the workgroup budget, each
+    problem's target is a whole number of slices per tile, and slice lengths differ by less than a slice."""
+    ops = gs.ops
+    shapes = [(512, 128, 256), (512, 128, 256), (13312, 32, 32), (13312, 32, 256), (13312, 128, 602), (13312, 128, 602),
+              (141312, 32, 32), (141312, 32, 602), (164352, 64, 64)]
+    targets = ops.wgrad_balance(shapes, budget=248)
+    assert len(targets) == len(shapes)
+    for i in range(0, len(shapes), 8):
+        chunk, tg = shapes[i:i + 8], targets[i:i + 8]
+        assert sum(tg) <= 248 or all(ops.wgrad_plan(m, nt, k, t)[1] == 1 for (m, nt, k), t in zip(chunk, tg))
+        lens = []
+        for (m, nt, k), t in zip(chunk, tg):
+            tiles = ((nt + 127) // 128) * ((k + 3) // 4 * 4 + 127) // 128
+            assert t % tiles == 0 and t >= tiles
+            rps, S, _ldk = ops.wgrad_plan(m, nt, k, t)
+            assert S * tiles <= t
+            if m > 256:
+                lens.append(rps)
+        big = max(lens)
+        assert all(l <= big for l in lens)

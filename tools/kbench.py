@@ -192,3 +192,27 @@ if 'pool' in which:
         t0, t1 = timeit(f0, reps=10), timeit(f1, reps=10)
         fl = 2.0 * M * n * D * Hm / 1e6
         print('pool M=%6d n=%2d: tiles64x128 %.1f us (%.0f TF/s)   packed %.1f us (%.0f TF/s)   max diff %.3g' % (M, n, t0, fl / t0, t1, fl / t1, err))
+
+if 'wgradpool' in which:
+    # the max-pool MLP's weight gradient alone: dW[512 x 602] = ghc[128000 x 512]^T x rows[128000 x 602]
+    M, Nt, K = 128000, 512, 602
+    dC = torch.randn(M, Nt, device=dev).bfloat16()
+    g = torch.Generator(device='cpu'); g.manual_seed(1)
+    lists = {
+        'random rows (as in the step)': torch.randint(0, N, (M,), generator=g).to(dev),
+        'consecutive rows': (torch.arange(M) % N).to(dev),
+        '4096 distinct rows (A hot in L2)': torch.randint(0, 4096, (M,), generator=g).to(dev),
+    }
+    for target in (160, 240, 480):
+        rps, S, ldk = ops.wgrad_plan(M, Nt, K, target)
+        slabs = torch.empty(S, Nt, ldk, device=dev)
+        for name, rows in lists.items():
+            def f():
+                ops.wgrad_multi([(dC, table, ld, 0, M, Nt, K, Nt, slabs, target, rows)])
+            t = timeit(f, reps=10)
+            print('wgrad pool target=%d S=%d (%d workgroups) %s: %.1f us (%.0f TF/s)' % (target, S, S * 20, name, t, 2 * M * Nt * 640 / t / 1e6))
+        A = table[:M].contiguous() if M <= N else torch.randn(M, ld, device=dev).bfloat16()
+        def f():
+            ops.wgrad_multi([(dC, A, ld, 0, M, Nt, K, Nt, slabs, target)])
+        t = timeit(f, reps=10)
+        print('wgrad pool target=%d S=%d contiguous A, no row list: %.1f us' % (target, S, t))
