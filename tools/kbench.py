@@ -216,3 +216,20 @@ if 'wgradpool' in which:
             ops.wgrad_multi([(dC, A, ld, 0, M, Nt, K, Nt, slabs, target)])
         t = timeit(f, reps=10)
         print('wgrad pool target=%d S=%d contiguous A, no row list: %.1f us' % (target, S, t))
+
+if 'wgradcold' in which:
+    # the same problem with its operands NOT resident in the Infinity Cache: a 1 GB fill between launches
+    M, Nt, K = 128000, 512, 602
+    dC = torch.randn(M, Nt, device=dev).bfloat16()
+    g = torch.Generator(device='cpu'); g.manual_seed(1)
+    rows = torch.randint(0, N, (M,), generator=g).to(dev)
+    flush = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+    rps, S, ldk = ops.wgrad_plan(M, Nt, K, 240)
+    slabs = torch.empty(S, Nt, ldk, device=dev)
+    def fl():
+        flush.fill_(1.0)
+    def both():
+        flush.fill_(1.0)
+        ops.wgrad_multi([(dC, table, ld, 0, M, Nt, K, Nt, slabs, 240, rows)])
+    t0, t1 = timeit(fl, reps=10), timeit(both, reps=10)
+    print('wgrad pool cold: fill %.1f us, fill + wgrad %.1f us -> wgrad %.1f us' % (t0, t1, t1 - t0))
