@@ -151,20 +151,40 @@ class FusedMeanTrainStep(FusedTrainStep):
         model, dev, L = self.model, self.dev, self.L
         f32 = torch.float32
         rdesc, self.slabs = [], []
+        # K5b workgroups per problem.  Two layers: every problem aims at the chip (196 + 16 workgroups at Reddit's
+        # shapes).  Deeper models would ask for more workgroups than there are CUs (one fits per CU: config 5's three
+        # levels 240 + 128 + 8) and run in rounds: those are sized together (ops.wgrad_balance), in issue order.
+        def parts_of(l):
+            return [(2 * self.h[l], 0)] if self.h[l] % 128 == 0 else [(self.h[l], 0), (self.h[l], 1)]
+        order = [("prep", 0)] if self.emb else []
+        order += [(l, g) for l in range(L - 1, -1, -1) for _nt, g in parts_of(l)]
+        def shape_of(key):
+            if key[0] == "prep":
+                _dC, _A, _lda, M_, ntot, K, _prm, _rows = self._emb_wgrad_problem()
+                return (M_, ntot, K)
+            return (self.rows[key[0]], parts_of(key[0])[0][0], self.din[key[0]])
+        shapes = [shape_of(k) for k in order]
+        plain = [self._wg_target()] * len(order)
+        def n_wg(targets):
+            return sum((ops.wgrad_plan(m, nt, k, t)[1]) * ((nt + 127) // 128) * ((k + 127) // 128)
+                       for (m, nt, k), t in zip(shapes, targets))
+        cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        balanced = n_wg(plain) > cus and not self.gather_cus
+        self.wg_target = dict(zip(order, ops.wgrad_balance(shapes, budget=cus - 8) if balanced else plain))
         for l in range(L):
             h, din, R = self.h[l], self.din[l], self.rows[l]
             ix = self.pidx[id(self.layers[l].fc_x.weight)]
-            parts = [(2 * h, 0)] if h % 128 == 0 else [(h, 0), (h, 1)]
+            parts = parts_of(l)
             bufs = []
             for ntot, g in parts:
-                rps, S, ldk = ops.wgrad_plan(R, ntot, din, self._wg_target())
+                rps, S, ldk = ops.wgrad_plan(R, ntot, din, self.wg_target[(l, g)])
                 buf = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
                 bufs.append(buf)
                 rdesc.append(_ReduceDesc(buf.data_ptr(), ntot * ldk, self.poff[ix + g], S, ntot, din, ldk))
             self.slabs.append(bufs)
         if self.emb:                                  # prep.fc: weight through K5b, bias through column sums
             dC, A, lda, M_, ntot, K, prm, _rows = self._emb_wgrad_problem()
-            rps, S, ldk = ops.wgrad_plan(M_, ntot, K, self._wg_target())
+            rps, S, ldk = ops.wgrad_plan(M_, ntot, K, self.wg_target[("prep", 0)])
             self.slab_prep = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
             rdesc.append(_ReduceDesc(self.slab_prep.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
             rdesc.append(self._emb_reduce_desc())
@@ -323,7 +343,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         probs = []
         if self.emb:
             dC, A, lda, M_, ntot, K, _prm, _rows = self._emb_wgrad_problem()
-            probs.append((dC, A, lda, 0, M_, ntot, K, ntot, self.slab_prep, self._wg_target(), None))
+            probs.append((dC, A, lda, 0, M_, ntot, K, ntot, self.slab_prep, self.wg_target[("prep", 0)], None))
         for l in range(L - 1, -1, -1):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             dc = self.dc[l]
@@ -334,11 +354,11 @@ class FusedMeanTrainStep(FusedTrainStep):
             aggl = self.xa0_set[s][1] if l == 0 else self.agg[l]
             delta = (aggl.data_ptr() - xbuf.data_ptr()) // esz
             if h % 128 == 0:
-                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0], self._wg_target(), rows))
+                probs.append((dc, xbuf, lda, delta, R, 2 * h, din, h, self.slabs[l][0], self.wg_target[(l, 0)], rows))
             else:
                 for g in range(2):
                     probs.append((dc[:, g * h:], xbuf if g == 0 else aggl, lda, 0, R, h, din, h,
-                                  self.slabs[l][g], self._wg_target(), rows if g == 0 else None))
+                                  self.slabs[l][g], self.wg_target[(l, g)], rows if g == 0 else None))
         for i in range(0, len(probs), 8):
             ops.wgrad_multi(probs[i:i + 8])
         self._side_join("k5b")

@@ -45,6 +45,18 @@ for w in $WHAT; do
         [ -n "$c" ] && python tools/pmc_any.py "$c" > $OUT/sq_${a}_$i.json
         find $OUT/sq_${a}_$i -name "*.csv" -size +2M -delete
       done ;;
+    profx)
+      # kernel-trace stats of one `extra` configuration: GSAGE_PROFX=attention|max_pool|pokec|papers
+      c=${GSAGE_PROFX:-attention}
+      case $c in
+        attention|max_pool) cmd="python bench.py --aggregator $c --steps 50 --warmup 10 --no-cpu-baseline --extra '' --min-time 0" ;;
+        *) cmd="python tools/bench_configs.py $c --steps 50" ;;
+      esac
+      rm -rf $OUT/profx_$c
+      eval timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/profx_$c -o r --output-format csv -- $cmd > $OUT/profx_$c.log 2>&1
+      echo "== profx $c rc=$?"
+      f=$(find $OUT/profx_$c -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/profx_${c}_kernel_stats.csv && head -30 "$f" | cut -c1-150
+      find $OUT/profx_$c -name "*kernel_trace*.csv" -size +20M -delete ;;
     bench20)
       timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1
       echo "== bench20 rc=$?"; tail -2 $OUT/bench20.log ;;
