@@ -257,17 +257,24 @@ __device__ __forceinline__ float load_as(const float *p) { return *p; }
 // before the attention weights are computed (the rows do not depend on them).  Written as "for each child: id ->
 // row chunks" the compiler put a vmcnt(0) in front of every child's rows: a dependent round trip per child
 // (59.8 -> 54.3 us at Reddit's last hop once hoisted).  Sums run in the same order for every NF: bit-identical.
-template <typename T, int VEC, int TMAX, int NF>
+// WPP = waves per parent.  1: a workgroup's four waves take four parents.  4: they share ONE parent (its children go
+// round the 4 * 64 / lpc groups of the workgroup, partial sums meet in LDS in wave order) -- for hops with few parents
+// and long fan-outs, where a parent's chain of dependent trips is all a launch consists of (Reddit's first hop: 512
+// parents x 25 children on 512 waves, seven trips each: 13 us forward / 24 us backward for 15 MB of rows).
+template <typename T, int VEC, int TMAX, int NF, int WPP>
 __global__ void __launch_bounds__(256)
 k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld,
                      const T *__restrict__ table, int64_t ld, const int64_t *__restrict__ ids, int64_t M, int32_t n,
                      int32_t Ha, int32_t D, float *__restrict__ agg, int64_t agg_ld, float *__restrict__ ws, int32_t lpc,
                      T *__restrict__ agg_lp, int64_t lp_ld)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= M) return;                                                 // wave-uniform exit
-    const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
+    __shared__ float part_s[WPP > 1 ? (WPP - 1) * 32 * TMAX * VEC : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = WPP == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+    if (i >= M) return;                                                 // wave-uniform (WPP > 1: block-uniform) exit
+    const int sub = lane & (lpc - 1);
+    const int G = (64 / lpc) * WPP;                                     // groups working on this parent
+    const int grp = lane / lpc + (WPP == 1 ? 0 : wave * (64 / lpc));
     const int chunks = (D + VEC - 1) / VEC;
     constexpr int Tn = TMAX;                                            // == ceil(chunks / lpc) (host picks TMAX)
     int cc[TMAX];
@@ -298,7 +305,7 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
     };
     load_trip(0);
     const float w = attn_weights(na, na_ld, xa, xa_ld, i, n, Ha, lane);
-    if (lane < n) ws[i * n + lane] = w;
+    if (lane < n && (WPP == 1 || wave == 0)) ws[i * n + lane] = w;
     float acc[TMAX][VEC];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t)
@@ -322,13 +329,28 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
                 }
         }
     }
-    for (int off = lpc; off < 64; off <<= 1)                            // add the groups' partial sums
+    for (int off = lpc; off < 64; off <<= 1)                            // add the wave's groups' partial sums
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
             if (t < Tn)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[t][e] += __shfl_xor(acc[t][e], off, 64);
-    if (grp == 0) {
+    if (WPP > 1) {                                                      // ... and the other waves', in wave order
+        if (wave > 0 && lane < lpc)
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) part_s[((wave - 1) * 32 + sub) * (TMAX * VEC) + t * VEC + e] = acc[t][e];
+        __syncthreads();
+        if (wave > 0) return;
+        if (lane < lpc)
+            for (int q = 0; q < WPP - 1; ++q)
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[t][e] += part_s[(q * 32 + sub) * (TMAX * VEC) + t * VEC + e];
+    }
+    if (lane < lpc) {
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
             const int c = sub + lpc * t;
@@ -348,7 +370,7 @@ k_attn_aggregate_grp(const float *__restrict__ na, int64_t na_ld, const float *_
     }
 }
 
-template <typename T, int VEC, int TMAX, int NF>
+template <typename T, int VEC, int TMAX, int NF, int WPP>
 __global__ void __launch_bounds__(256)
 k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restrict__ ws, const float *__restrict__ na,
                int64_t na_ld, const float *__restrict__ xa, int64_t xa_ld, const T *__restrict__ table, int64_t ld,
@@ -357,9 +379,11 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
 {
     __shared__ float dws_s[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t i = WPP == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
     if (i >= M) return;
-    const int G = 64 / lpc, grp = lane / lpc, sub = lane & (lpc - 1);
+    const int sub = lane & (lpc - 1);
+    const int G = (64 / lpc) * WPP;                                     // groups working on this parent
+    const int grp = lane / lpc + (WPP == 1 ? 0 : wave * (64 / lpc));
     const int chunks = (D + VEC - 1) / VEC;
     constexpr int Tn = TMAX;                                            // == ceil(chunks / lpc) (host picks TMAX)
     int cc[TMAX];
@@ -372,7 +396,7 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
 #pragma unroll
         for (int e = 0; e < VEC; ++e) gv[t][e] = (live && c * VEC + e < D) ? g[i * g_ld + c * VEC + e] : 0.f;
     }
-    volatile float *mine = dws_s[wave];
+    volatile float *mine = dws_s[WPP == 1 ? wave : 0];
     for (int j0 = 0; j0 < n; j0 += NF * G) {
         vec16 raw[NF][TMAX];
         int jv[NF];
@@ -407,7 +431,11 @@ k_attn_bwd_grp(const float *__restrict__ g, int64_t g_ld, const float *__restric
             if (sub == 0 && jv[u] < n) mine[jv[u]] = d;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    if (WPP == 1) __builtin_amdgcn_wave_barrier();
+    else {
+        __syncthreads();
+        if (wave > 0) return;
+    }
     // lane j keeps dws[j]; softmax backward
     const float dws = lane < n ? mine[lane] : 0.f;
     const float w = lane < n ? ws[i * n + lane] : 0.f;
@@ -791,24 +819,36 @@ static int attn_in_flight(int32_t n, int lpc)
     return force == 5 ? 5 : 2;
 }
 
-// the grouped kernels are instantiated on the exact number of strided chunks per lane (1..3) and on NF
-template <typename T, int VEC, typename... A>
-static void launch_attn_fwd(int tn, int nf, dim3 grid, hipStream_t s, A... a)
+// waves per parent: one parent per workgroup when a launch has few parents whose children need several trips
+static int attn_waves_per_parent(int64_t M, int32_t n, int lpc, int nf)
 {
-#define GSAGE_ATTN_CASE(TN, NF) \
-    if (tn == TN && nf == NF) { launch(k_attn_aggregate_grp<T, VEC, TN, NF>, grid, dim3(256), 0, s, a...); return; }
-    GSAGE_ATTN_CASE(1, 2) GSAGE_ATTN_CASE(2, 2) GSAGE_ATTN_CASE(3, 2)
-    GSAGE_ATTN_CASE(1, 5) GSAGE_ATTN_CASE(2, 5) GSAGE_ATTN_CASE(3, 5)
+    static const int force = [] { const char *e = getenv("GSAGE_ATTN_WPP"); return e ? atoi(e) : 0; }();
+    if (force == 1 || force == 4) return nf == 2 ? force : 1;
+    return (nf == 2 && M <= 4096 && n > nf * (64 / lpc)) ? 4 : 1;
+}
+
+// the grouped kernels are instantiated on the exact number of strided chunks per lane (1..3), on NF and on WPP
+template <typename T, int VEC, typename... A>
+static void launch_attn_fwd(int tn, int nf, int wpp, int64_t M, hipStream_t s, A... a)
+{
+    const dim3 grid((unsigned)(wpp == 1 ? ceil_div(M, 4) : M));
+#define GSAGE_ATTN_CASE(TN, NF, WPP) \
+    if (tn == TN && nf == NF && wpp == WPP) { launch(k_attn_aggregate_grp<T, VEC, TN, NF, WPP>, grid, dim3(256), 0, s, a...); return; }
+    GSAGE_ATTN_CASE(1, 2, 1) GSAGE_ATTN_CASE(2, 2, 1) GSAGE_ATTN_CASE(3, 2, 1)
+    GSAGE_ATTN_CASE(1, 2, 4) GSAGE_ATTN_CASE(2, 2, 4) GSAGE_ATTN_CASE(3, 2, 4)
+    GSAGE_ATTN_CASE(1, 5, 1) GSAGE_ATTN_CASE(2, 5, 1) GSAGE_ATTN_CASE(3, 5, 1)
 #undef GSAGE_ATTN_CASE
 }
 
 template <typename T, int VEC, typename... A>
-static void launch_attn_bwd(int tn, int nf, dim3 grid, hipStream_t s, A... a)
+static void launch_attn_bwd(int tn, int nf, int wpp, int64_t M, hipStream_t s, A... a)
 {
-#define GSAGE_ATTN_CASE(TN, NF) \
-    if (tn == TN && nf == NF) { launch(k_attn_bwd_grp<T, VEC, TN, NF>, grid, dim3(256), 0, s, a...); return; }
-    GSAGE_ATTN_CASE(1, 2) GSAGE_ATTN_CASE(2, 2) GSAGE_ATTN_CASE(3, 2)
-    GSAGE_ATTN_CASE(1, 5) GSAGE_ATTN_CASE(2, 5) GSAGE_ATTN_CASE(3, 5)
+    const dim3 grid((unsigned)(wpp == 1 ? ceil_div(M, 4) : M));
+#define GSAGE_ATTN_CASE(TN, NF, WPP) \
+    if (tn == TN && nf == NF && wpp == WPP) { launch(k_attn_bwd_grp<T, VEC, TN, NF, WPP>, grid, dim3(256), 0, s, a...); return; }
+    GSAGE_ATTN_CASE(1, 2, 1) GSAGE_ATTN_CASE(2, 2, 1) GSAGE_ATTN_CASE(3, 2, 1)
+    GSAGE_ATTN_CASE(1, 2, 4) GSAGE_ATTN_CASE(2, 2, 4) GSAGE_ATTN_CASE(3, 2, 4)
+    GSAGE_ATTN_CASE(1, 5, 1) GSAGE_ATTN_CASE(2, 5, 1) GSAGE_ATTN_CASE(3, 5, 1)
 #undef GSAGE_ATTN_CASE
 }
 
@@ -835,11 +875,13 @@ extern "C" int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, con
     hipStream_t s = (hipStream_t)stream;
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b)
-        launch_attn_bwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b), grid, s, g, g_ld, ws, na,
+        launch_attn_bwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b),
+                                     attn_waves_per_parent(M, n, lpc_b, attn_in_flight(n, lpc_b)), M, s, g, g_ld, ws, na,
                                      na_ld, xa, xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna,
                                      dna_ld, dxa, dxa_ld, (int32_t)lpc_b);
     else if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f)
-        launch_attn_bwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f), grid, s, g, g_ld, ws, na, na_ld,
+        launch_attn_bwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f),
+                                  attn_waves_per_parent(M, n, lpc_f, attn_in_flight(n, lpc_f)), M, s, g, g_ld, ws, na, na_ld,
                                   xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, dna, dna_ld, dxa,
                                   dxa_ld, (int32_t)lpc_f);
     else if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D))
@@ -922,13 +964,15 @@ extern "C" int gsage_attn_aggregate_lp(const float *na, int64_t na_ld, const flo
     dim3 grid((unsigned)ceil_div(M, 4));
     const int lpc_b = attn_group_lanes(D, 8), lpc_f = attn_group_lanes(D, 4);
     if (dtype == GSAGE_BF16 && attn_wide_ok<uint16_t, 8>(table, ld, D) && lpc_b && n <= 64) {
-        launch_attn_fwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b), grid, (hipStream_t)stream,
+        launch_attn_fwd<uint16_t, 8>(attn_chunks_per_lane(D, 8, lpc_b), attn_in_flight(n, lpc_b),
+                                     attn_waves_per_parent(M, n, lpc_b, attn_in_flight(n, lpc_b)), M, (hipStream_t)stream,
                                      na, na_ld, xa, xa_ld, (const uint16_t *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D,
                                      agg, agg_ld, ws, (int32_t)lpc_b, (uint16_t *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");
     }
     if (dtype == GSAGE_F32 && attn_wide_ok<float, 4>(table, ld, D) && lpc_f && n <= 64) {
-        launch_attn_fwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f), grid, (hipStream_t)stream, na,
+        launch_attn_fwd<float, 4>(attn_chunks_per_lane(D, 4, lpc_f), attn_in_flight(n, lpc_f),
+                                  attn_waves_per_parent(M, n, lpc_f, attn_in_flight(n, lpc_f)), M, (hipStream_t)stream, na,
                                   na_ld, xa, xa_ld, (const float *)table, ld, ids, M, n, (int32_t)Ha, (int32_t)D, agg, agg_ld,
                                   ws, (int32_t)lpc_f, (float *)agg_lp, agg_lp_ld);
         return check_launch("attn_aggregate");

@@ -461,3 +461,47 @@ def test_bf16_engine_trains_like_the_fp32_engine_at_the_bench_shape():
     assert a[-5:].mean() < 0.6 * a[:5].mean() and b[-5:].mean() < 0.6 * b[:5].mean(), (a[:3], a[-3:], b[-3:])
     assert np.abs(a - b).max() <= 0.05 * a[0] + 0.02, float(np.abs(a - b).max())
     assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.03 * a[-10:].mean() + 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,n,dtype", [(602, 25, "bf16"), (256, 25, "bf16"), (64, 20, "bf16"), (602, 25, "fp32"), (100, 32, "fp32")])
+def test_attention_one_parent_per_workgroup_equals_one_per_wave(D, n, dtype):
+    """K4 / K4' give a hop with few parents and long fan-outs one WORKGROUP per parent (four waves share its children;
+    gsage_attn.hip, WPP = 4) instead of one wave: the same parents as the head of a launch large enough to take the
+    one-wave path must come out equal -- the backward bit for bit (per-child dot products are formed the same way),
+    the forward up to the order of the fp32 partial sums (nn_modules.py:309-315)."""
+    dev = torch.device("cuda")
+    ops = gs.ops
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    M_small, M_big, Ha, N = 512, 8192, 32, 50_000
+    vec = 8 if dtype == "bf16" else 4
+    ld = (D + vec - 1) // vec * vec
+    table = torch.zeros(N, ld, dtype=tdt, device=dev)
+    table[:, :D] = torch.randn(N, D, generator=g).to(dev).to(tdt)
+    ids = torch.randint(0, N, (M_big * n,), generator=g).to(dev)
+    na = torch.randn(M_big * n, Ha, generator=g).to(dev)
+    xa = torch.randn(M_big, Ha, generator=g).to(dev)
+    gout = torch.randn(M_big, D, generator=g).to(dev)
+    lib, nat = gs._native.lib(), gs._native
+
+    def run(M):
+        agg = torch.empty(M, D, device=dev); ws = torch.empty(M, n, device=dev)
+        nat.check(lib.gsage_attn_aggregate(na.data_ptr(), Ha, xa.data_ptr(), Ha, table.data_ptr(), ops._code(tdt), ld,
+                                           ids.data_ptr(), M, n, Ha, D, agg.data_ptr(), D, ws.data_ptr(), ops._stream()), "fwd")
+        dna = torch.empty(M * n, Ha, device=dev); dxa = torch.empty(M, Ha, device=dev)
+        nat.check(lib.gsage_attn_bwd(gout.data_ptr(), D, ws.data_ptr(), na.data_ptr(), Ha, xa.data_ptr(), Ha,
+                                     table.data_ptr(), ops._code(tdt), ld, ids.data_ptr(), M, n, Ha, D, dna.data_ptr(), Ha,
+                                     dxa.data_ptr(), Ha, ops._stream()), "bwd")
+        torch.cuda.synchronize()
+        return agg, ws, dna, dxa
+
+    a_s, w_s, dn_s, dx_s = run(M_small)
+    a_b, w_b, dn_b, dx_b = run(M_big)
+    assert torch.equal(w_s, w_b[:M_small])
+    torch.testing.assert_close(a_s, a_b[:M_small], rtol=2e-6, atol=2e-6)
+    assert torch.equal(dn_s, dn_b[:M_small * n]) and torch.equal(dx_s, dx_b[:M_small])
+    # and against the definition
+    rows = table[ids[:M_small * n], :D].float().view(M_small, n, D)
+    w = torch.softmax(torch.bmm(na[:M_small * n].view(M_small, n, Ha), xa[:M_small].unsqueeze(2)).squeeze(2), dim=1)
+    torch.testing.assert_close(a_s, (rows * w.unsqueeze(2)).sum(1), rtol=1e-4, atol=1e-4)
