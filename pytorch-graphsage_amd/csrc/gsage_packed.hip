@@ -254,8 +254,11 @@ drain:
 // One workgroup per CU loses to two even at half the A traffic: all eight waves stall at the same
 // barrier.  The weight-stationary variant moved no W at all and was no faster: its A stream (the
 // same tile requested by four workgroups in lock step) ran at 5.2 TB/s, i.e. every tile still paid
-// the full miss latency with only 4 x 8 KiB in flight per workgroup -- K3 is bound by how many bytes
-// a CU can have in flight towards HBM, not by L2 bandwidth or the matrix pipe (30 % busy).
+// the full miss latency with only 4 x 8 KiB in flight per workgroup.  Round 3's diagnostics (DESIGN.md
+// section 5): with every operand made L1 / L2 resident and no epilogue the main loop still takes 90 of
+// its 130 us -- it is bound by the bytes a CU's vector-memory path moves per MFMA (40 KiB per k-tile
+// and workgroup, 32 of them W fragments), and a 128-row tile per W fragment loses more by running one
+// workgroup per CU (182 us) than it saves.
 // -------------------------------------------------------------------------------------------------
 constexpr int PK_R = 3;                       // tiles in flight
 constexpr int PK_NBUF = PK_R + 1;
