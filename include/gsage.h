@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSAGE_ABI_VERSION 3
+#define GSAGE_ABI_VERSION 4
 
 enum { GSAGE_F32 = 0, GSAGE_BF16 = 1 };
 enum {
@@ -121,6 +121,39 @@ int gsage_cmdlist_side_begin(void);
 int gsage_cmdlist_side_end(void);
 int gsage_cmdlist_join(void);
 void gsage_cmdlist_destroy(void *list);
+/* Host calls inside a list (ABI 4).  A data-parallel step has ONE exchange and a deterministic
+ * row reduction that is a vendor sort: neither is a kernel of this library, both belong INTO the step's list so that a
+ * step stays one C call (no Python between the pieces, no second list around the collective).
+ *   gsage_host_call(fn, ctx, s)      [host] recording: a node that calls fn(ctx, stream) at this point of every replay
+ *                                    (inside a side section: with the side stream); not recording: calls fn(ctx, s)
+ *                                    now.  fn enqueues work on the stream it is given and returns 0, or non-zero to
+ *                                    make the replay fail (GSAGE_ELAUNCH, message "host call failed").  The engines
+ *                                    use it for collectives of backends that have no C entry point (gloo in the
+ *                                    CPU-side tests: a ctypes callback); RCCL goes through gsage_comm_* below. */
+typedef int (*gsage_host_fn)(void *ctx, void *stream);
+int gsage_host_call(gsage_host_fn fn, void *ctx, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The step's collectives, issued by the library itself (ABI 4).  No reference counterpart: the reference is one
+ * process.  One RCCL communicator per process, created from an id that rank 0 makes and the host
+ * language distributes (torch.distributed's store, MPI, a file -- not this library's business):
+ *   gsage_comm_load(path)            [host] dlopen of librccl (path NULL: the loader's search order).  The library has
+ *                                    no link-time dependency on RCCL: single-GPU processes never load it.
+ *   gsage_comm_unique_id(id)         [host] 128 bytes, rank 0 only
+ *   gsage_comm_create(id, r, w, &c)  [host] collective over the w ranks (current HIP device = this rank's GPU)
+ *   gsage_comm_all_reduce_f32        in place over n floats; average != 0: ncclAvg, else ncclSum
+ *   gsage_comm_all_gather            recv[r * bytes : (r + 1) * bytes] = rank r's send[0:bytes]  (bytes % 4 == 0)
+ *   gsage_comm_group(begin)          ncclGroupStart (begin != 0) / ncclGroupEnd: several collectives as one
+ * The three collective calls follow the library's convention: recorded as a node while a command list is being
+ * recorded (side sections included: that is how the exchange overlaps the next batch's gathers), issued on `stream`
+ * otherwise.  Every rank must issue the same sequence. */
+int gsage_comm_load(const char *path);
+int gsage_comm_unique_id(void *id128);
+int gsage_comm_create(const void *id128, int32_t rank, int32_t world, void **comm);
+int gsage_comm_destroy(void *comm);
+int gsage_comm_all_reduce_f32(void *comm, float *buf, int64_t n, int32_t average, void *stream);
+int gsage_comm_all_gather(void *comm, const void *send, void *recv, int64_t bytes, void *stream);
+int gsage_comm_group(void *comm, int32_t begin, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1  neighbour sampler     replaces SparseUniformNeighborSampler.__call__, nn_modules.py:80-101
@@ -250,6 +283,8 @@ void gsage_mt_permutation(void *mt, int64_t n, int64_t *out);
  *     out[i, c] = (1/n) * sum_j table[rows(i,j), c],   rows(i,j) = ids ? ids[i*n+j] : i*n+j
  *     n == 1 is the plain row gather feats[ids].  fp32 accumulation; `out` has `out_dtype`.
  *     Columns [D, round_up(D, vec)) of out are written as zero.
+ *     PRECONDITION: 0 <= ids[.] < 2^31 (the kernels read the low 32-bit word of each int64 id: node ids of a table
+ *     with < 2^31 rows; store.FeatureStore / DeviceCSR refuse larger tables) -- also for gsage_gather_mean_multi(_adam).
  * ---------------------------------------------------------------------------------------- */
 int gsage_gather_mean(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t M,
                       int32_t n, int64_t D, void *out, int out_dtype, int64_t out_ld,
@@ -484,6 +519,13 @@ int gsage_attn_merge_bwd2(const void *H, int h_dtype, int64_t ldh, const float *
 int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t B,
                   int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch, void *stream);
 int gsage_head_l1_scratch(int64_t B, int64_t D);
+/* The same head on ONE SHARD of a data-parallel batch (ABI 4): `targets` holds the T targets of the GLOBAL batch
+ * (every rank's, T <= 8192), E / preds / dE the B rows of this rank.  loss_r = 1/(B T) sum_{i in shard} sum_j |p_i - t_j|,
+ * d loss_r / d p_i = 1/(B T) sum_j sign(p_i - t_j): the AVERAGE over the ranks of loss_r and of its gradients equals
+ * the single-process loss over the global batch, pair for pair (d p_i depends on p_i and the targets only). */
+int gsage_head_l1_sharded(const float *E, int64_t lde, const float *W, const float *bias, const float *targets,
+                          int64_t T, int64_t B, int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd,
+                          float *scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Classification head, forward + backward   replaces F.normalize(dim=1) -> fc -> F.cross_entropy
@@ -665,7 +707,10 @@ typedef struct gsage_row_adam {
     int64_t n_rows;
     int32_t E, hist_cap;            /* E % 4 == 0, E <= 256 */
     float beta1, beta2, eps, weight_decay, max_norm;
-    int32_t reserved;
+    int32_t sorted_ids;             /* ABI 4: != 0: ids0[0:n0] is sorted ascending and n1 == 0 -- the first entry of a run of
+                                       equal ids does the row's work, the others are skipped by comparing neighbours:
+                                       no atomics, `seen` unused, and the order in which gsage_rows_sqnorm adds its
+                                       terms depends on the list alone (data-parallel replicas stay bit-identical) */
 } gsage_row_adam;
 int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
                         int32_t step_off, void *stream);
@@ -674,6 +719,28 @@ int gsage_rows_sqnorm(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, 
                       int32_t step_off, float *partial, int32_t n_partial, void *stream);
 int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
                     int32_t step_off, const float *partial, int32_t n_partial_ready, void *stream);
+
+/* Deterministic gradient of a trainable table (ABI 4): the reference's dense `nn.Embedding` gradient
+ * (nn_modules.py:131-155 under autograd) is the sum of the gradient rows of every occurrence of a node in the frontier.
+ * gsage_scatter_add_rows forms it with fp32 atomics -- an order of additions that changes from run to run and, in a
+ * data-parallel run, from rank to rank (the replicas' tables would drift apart bit by bit).  Here instead:
+ *   gsage_sort_rows      keys[i] = i < n0 ? ids0[i] : tail_id  (i < n0 + n_tail: a frontier's ids followed by n_tail
+ *                        entries of one spare row, e.g. the row every seed reads, nn_modules.py:147-149) sorted
+ *                        ascending, STABLE: ids_sorted[0:n], pos_sorted[0:n] = original positions, ascending within
+ *                        equal ids.  Only the low key_bits bits are compared (ids < 2^key_bits).  rocPRIM radix sort;
+ *                        temp: gsage_sort_rows_temp_bytes(n, key_bits) bytes of device scratch.  Recordable (a host-call
+ *                        node: the vendor's launches are issued at replay).
+ *   gsage_segment_sum_rows   for the first entry i of every run of equal ids:
+ *                        table[ids_sorted[i], 0:E] = scale * sum_{j in run, in order} rows(pos_sorted[j]),
+ *                        rows(p) = p < n0 ? rows0[p * ld0 : ] : rows1[(p - n0) * ld1 : ]     (fp32, E % 4 == 0, E <= 256)
+ *                        -- stores, not atomics: rows of the table that are in no run are not touched.
+ * Then gsage_rows_sqnorm / gsage_rows_adam over ids_sorted with sorted_ids = 1. */
+int64_t gsage_sort_rows_temp_bytes(int64_t n, int32_t key_bits);
+int gsage_sort_rows(const int64_t *ids0, int64_t n0, int64_t tail_id, int64_t n_tail, int32_t key_bits,
+                    int64_t *ids_sorted, int32_t *pos_sorted, void *temp, int64_t temp_bytes, void *stream);
+int gsage_segment_sum_rows(const int64_t *ids_sorted, const int32_t *pos_sorted, int64_t n, const float *rows0,
+                           int64_t ld0, int64_t n0, const float *rows1, int64_t ld1, int32_t E, float scale,
+                           float *table, int64_t ldt, void *stream);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
  * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
 F32, BF16 = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -46,6 +46,18 @@ SIGNATURES = {
     "gsage_cmdlist_side_end": (_int, []),
     "gsage_cmdlist_join": (_int, []),
     "gsage_cmdlist_destroy": (None, [_vp]),
+    "gsage_host_call": (_int, [_vp, _vp, _vp]),
+    "gsage_comm_load": (_int, [ctypes.c_char_p]),
+    "gsage_comm_unique_id": (_int, [_vp]),
+    "gsage_comm_create": (_int, [_vp, _i32, _i32, ctypes.POINTER(_vp)]),
+    "gsage_comm_destroy": (_int, [_vp]),
+    "gsage_comm_all_reduce_f32": (_int, [_vp, _vp, _i64, _i32, _vp]),
+    "gsage_comm_all_gather": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gsage_comm_group": (_int, [_vp, _i32, _vp]),
+    "gsage_sort_rows_temp_bytes": (_i64, [_i64, _i32]),
+    "gsage_sort_rows": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "gsage_segment_sum_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "gsage_head_l1_sharded": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _i64, _vp, _vp]),
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsage_sample_dense": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "gsage_sample_csr_philox": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _u32, _u64, _vp, _u64, _u64,
@@ -203,7 +215,7 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
 class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)
     _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("last", _vp), ("seen", _vp), ("hist", _vp),
                 ("lr", _vp), ("step", _vp), ("n_rows", _i64), ("E", _i32), ("hist_cap", _i32), ("beta1", _f32),
-                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_norm", _f32), ("reserved", _i32)]
+                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_norm", _f32), ("sorted_ids", _i32)]
 
 
 class TailGatherDesc(ctypes.Structure):       # mirrors gsage_tail_gather_desc (include/gsage.h)
@@ -262,6 +274,64 @@ class _Recorder(object):
         if et is None:
             check(rc, "cmdlist_end")
         return False
+
+
+HOST_FN = ctypes.CFUNCTYPE(_int, _vp, _vp)      # gsage_host_fn: int fn(void *ctx, void *stream)
+
+
+def host_call(fn, stream=None):
+    """gsage_host_call: fn(stream_handle) -> None runs at this point of the list being recorded on this thread (at
+    every replay, with the replay's stream -- the side stream inside a side section), or right now on `stream` when
+    nothing is being recorded.  Returns the ctypes callback object: the CALLER keeps it alive as long as the list."""
+    def tramp(_ctx, s):
+        try:
+            fn(s)
+            return 0
+        except Exception:                      # (an exception cannot cross the C frame)
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = HOST_FN(tramp)
+    check(lib().gsage_host_call(ctypes.cast(cb, _vp), None, stream), "host_call")
+    return cb
+
+
+class NativeComm(object):
+    """One RCCL communicator owned by libgsage_hip.so (include/gsage.h, "The step's collectives"): the collectives
+    of a data-parallel step become nodes of the step's command list."""
+
+    def __init__(self, rank, world, exchange_id):
+        """exchange_id(bytes or None) -> bytes: hands rank 0's 128-byte id to every rank (e.g. a broadcast over the
+        process group torch.distributed already has)."""
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy torch itself maps
+        check(lib().gsage_comm_load(cand.encode() if os.path.exists(cand) else None), "comm_load")
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            check(lib().gsage_comm_unique_id(buf), "comm_unique_id")
+        raw = exchange_id(bytes(buf.raw) if rank == 0 else None)
+        assert len(raw) == 128
+        h = _vp()
+        check(lib().gsage_comm_create(ctypes.create_string_buffer(raw, 128), rank, world, ctypes.byref(h)), "comm_create")
+        self._h, self.rank, self.world = h.value, rank, world
+
+    def all_reduce(self, t, average, stream):
+        assert t.dtype.is_floating_point and t.element_size() == 4 and t.is_contiguous()
+        check(lib().gsage_comm_all_reduce_f32(self._h, t.data_ptr(), t.numel(), 1 if average else 0, stream),
+              "comm_all_reduce_f32")
+
+    def all_gather(self, send, recv, stream):
+        nbytes = send.numel() * send.element_size()
+        assert send.is_contiguous() and recv.is_contiguous() and recv.numel() * recv.element_size() == nbytes * self.world
+        check(lib().gsage_comm_all_gather(self._h, send.data_ptr(), recv.data_ptr(), nbytes, stream), "comm_all_gather")
+
+    def group(self, begin, stream):
+        check(lib().gsage_comm_group(self._h, 1 if begin else 0, stream), "comm_group")
+
+    def close(self):
+        if self._h and _LIB is not None:
+            _LIB.gsage_comm_destroy(self._h)
+        self._h = None
 
 
 def masked_stream(cu_bits):

@@ -88,6 +88,8 @@ struct CmdList {
         if (side_stream) (void)hipStreamDestroy(side_stream);
     }
 };
+// set (to 1) by a node that is not a kernel launch and failed during a replay: gsage_cmdlist_replay then fails
+extern thread_local int t_node_error;
 // gsage_head_n_valid_next(): live-row count(s) for the NEXT head launch of this thread (consumed by it)
 extern thread_local const int32_t *t_head_n_valid;
 // gsage_gather_role_next(): gather-role descriptor for the NEXT gsage_linear_nt_packed launch of this thread

@@ -297,6 +297,7 @@ k_head_reduce(const float *__restrict__ partial, int32_t n_wg, int64_t width, in
 // prediction): (a) a wave per row: norm, prediction; (b) 16 rows per workgroup: d p, d E, and one partial row
 // [d W | d b | loss] per workgroup for gsage_finalize_grads.  As stock torch ops the head was ~15 launches per step.
 constexpr int L1_BMAX = 2048;
+constexpr int L1_TMAX = 8192;      // targets of a GLOBAL batch (gsage_head_l1_sharded: every rank's)
 constexpr int L1_ROWS = 16;
 __device__ __forceinline__ void store_out(uint16_t *p, float v) { *p = f32_to_bf16(v); }
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
@@ -327,23 +328,26 @@ template <typename TD>
 __global__ void __launch_bounds__(256)
 k_head_l1_bwd(const float *__restrict__ E, int64_t lde, const float *__restrict__ W, const float *__restrict__ targets,
               const float *__restrict__ preds, const float *__restrict__ inv, int32_t Ball, int32_t D,
-              TD *__restrict__ dE, int64_t ldd, float *__restrict__ partial, const int32_t *__restrict__ n_valid)
+              TD *__restrict__ dE, int64_t ldd, float *__restrict__ partial, const int32_t *__restrict__ n_valid,
+              int32_t T_all)
 {
-    __shared__ float ts[L1_BMAX], dps[L1_ROWS], ivs[L1_ROWS], lss[L1_ROWS];
+    __shared__ float ts[L1_TMAX], dps[L1_ROWS], ivs[L1_ROWS], lss[L1_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * L1_ROWS;
     // rows past B are padding (n_valid): they enter neither the B x B pairs nor the gradient
     const int32_t B = n_valid ? min(max(n_valid[0], 1), Ball) : Ball;
-    for (int j = tid; j < B; j += 256) ts[j] = targets[j];
+    // T_all > 0: one shard of a data-parallel batch -- the pairs are (this rank's rows) x (the GLOBAL batch's targets)
+    const int32_t T = T_all > 0 ? T_all : B;
+    for (int j = tid; j < T; j += 256) ts[j] = targets[j];
     __syncthreads();
-    const float scale = 1.f / ((float)B * (float)B);
+    const float scale = 1.f / ((float)B * (float)T);
     // d p of the workgroup's rows: a wave per row, lanes over the targets
     for (int r = wave; r < L1_ROWS; r += 4) {
         const int i = r0 + r;
         float cnt = 0.f, l = 0.f;
         if (i < B) {
             const float pv = preds[i];
-            for (int j = lane; j < B; j += 64) {
+            for (int j = lane; j < T; j += 64) {
                 const float d = pv - ts[j];
                 cnt += (float)((d > 0.f) - (d < 0.f));
                 l += fabsf(d);
@@ -407,6 +411,7 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
                   int dE_dtype, int64_t ldd, float *dW, float *db, float *loss, float *scratch,
                   const int64_t *batch_idx, int64_t n_batches, void *stream)
 {
+    const int32_t *n_valid = take_head_n_valid();     // (consumed before any return path: never left for a later launch)
     GSAGE_REQUIRE(!batch_idx || n_batches > 0, "head_ce: bad target queue");
     GSAGE_REQUIRE(E && W && bias && targets && preds && dE && scratch, "head_ce: null pointer");
     GSAGE_REQUIRE(B > 0 && C > 0 && C <= HEAD_CMAX && D > 0 && D <= HEAD_DMAX,
@@ -414,7 +419,7 @@ int gsage_head_ce(const float *E, int64_t lde, const float *W, const float *bias
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_ce: bad dE dtype");
     HeadParams p;
     p.E = E; p.W = W; p.bias = bias; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches; p.preds = preds; p.dE = dE;
-    p.n_valid = take_head_n_valid();
+    p.n_valid = n_valid;
     p.partial = scratch; p.lde = lde; p.ldd = ldd; p.B = B; p.C = C; p.D = D; p.rows_per_wg = D <= 256 ? 4 : 1;
     p.dE_dtype = dE_dtype;
     const int n_wg = (B + p.rows_per_wg - 1) / p.rows_per_wg;
@@ -441,11 +446,14 @@ int gsage_head_l1_scratch(int64_t B, int64_t D)
     return (int)(ceil_div(B, (int64_t)L1_ROWS) * (D + 2) + B);
 }
 
-int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t B,
-                  int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch, void *stream)
+static int head_l1_launch(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t T,
+                          int64_t B, int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch,
+                          void *stream)
 {
+    const int32_t *nv = take_head_n_valid();          // (consumed before any return path: never left for a later launch)
     GSAGE_REQUIRE(E && W && bias && targets && preds && dE && scratch, "head_l1: null pointer");
     GSAGE_REQUIRE(B > 0 && B <= L1_BMAX && D > 0 && lde >= D && ldd >= D, "head_l1: needs 1 <= B <= %d", L1_BMAX);
+    GSAGE_REQUIRE(T >= 0 && T <= L1_TMAX, "head_l1_sharded: needs <= %d targets", L1_TMAX);
     GSAGE_REQUIRE(dE_dtype == GSAGE_BF16 || dE_dtype == GSAGE_F32, "head_l1: bad dE dtype");
     const int n_wg = (int)ceil_div(B, (int64_t)L1_ROWS);
     float *inv = scratch + (int64_t)n_wg * (D + 2);
@@ -454,14 +462,27 @@ int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias
            preds, inv);
     int rc = check_launch("head_l1_pred");
     if (rc != GSAGE_OK) return rc;
-    const int32_t *nv = take_head_n_valid();
     if (dE_dtype == GSAGE_BF16)
         launch(k_head_l1_bwd<uint16_t>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
-               (const float *)inv, (int32_t)B, (int32_t)D, (uint16_t *)dE, ldd, scratch, nv);
+               (const float *)inv, (int32_t)B, (int32_t)D, (uint16_t *)dE, ldd, scratch, nv, (int32_t)T);
     else
         launch(k_head_l1_bwd<float>, dim3(n_wg), dim3(256), 0, s, E, lde, W, targets, (const float *)preds,
-               (const float *)inv, (int32_t)B, (int32_t)D, (float *)dE, ldd, scratch, nv);
+               (const float *)inv, (int32_t)B, (int32_t)D, (float *)dE, ldd, scratch, nv, (int32_t)T);
     return check_launch("head_l1_bwd");
+}
+
+int gsage_head_l1(const float *E, int64_t lde, const float *W, const float *bias, const float *targets, int64_t B,
+                  int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd, float *scratch, void *stream)
+{
+    return head_l1_launch(E, lde, W, bias, targets, 0, B, D, preds, dE, dE_dtype, ldd, scratch, stream);
+}
+
+int gsage_head_l1_sharded(const float *E, int64_t lde, const float *W, const float *bias, const float *targets,
+                          int64_t T, int64_t B, int64_t D, float *preds, void *dE, int dE_dtype, int64_t ldd,
+                          float *scratch, void *stream)
+{
+    GSAGE_REQUIRE(T > 0, "head_l1_sharded: needs the global batch's targets");
+    return head_l1_launch(E, lde, W, bias, targets, T, B, D, preds, dE, dE_dtype, ldd, scratch, stream);
 }
 
 }  // extern "C"

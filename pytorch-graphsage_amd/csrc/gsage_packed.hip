@@ -773,6 +773,8 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
                            int64_t M, int64_t N, int64_t K, int act, int groups, int64_t a_gstride,
                            int64_t c_gstride, void *stream)
 {
+    // gsage_gather_role_next(): consumed before any return path, so that it is never left for a later launch
+    const gsage_tail_gather_desc *gd = take_gather_role();
     GSAGE_REQUIRE(A && Wp && C, "linear_nt_packed: null pointer");
     GSAGE_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_nt_packed: bad sizes");
     GSAGE_REQUIRE(c_dtype == GSAGE_BF16 || c_dtype == GSAGE_F32, "linear_nt_packed: bad c_dtype");
@@ -793,7 +795,6 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
     hipStream_t s = (hipStream_t)stream;
     // gsage_gather_role_next(): one more z-slice of workgroups gathers part of the next batch's level-0 rows
     TailGather tg = {};
-    const gsage_tail_gather_desc *gd = take_gather_role();
     if (gd && gd->rows > 0) {
         const int rc = fill_gather_role(tg, *gd, "linear_nt_packed (gather role)");
         if (rc != GSAGE_OK) return rc;

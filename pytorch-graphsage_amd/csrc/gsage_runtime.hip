@@ -17,6 +17,7 @@ std::atomic<uint64_t> g_launches{0};
 thread_local CmdList *t_recording = nullptr;
 thread_local const int32_t *t_head_n_valid = nullptr;
 thread_local const gsage_tail_gather_desc *t_gather_role = nullptr;
+thread_local int t_node_error = 0;      // set by a host-call node that failed during a replay
 
 void set_error(const char *fmt, ...)
 {
@@ -98,10 +99,15 @@ int gsage_cmdlist_replay(const void *list, void *stream)
     GSAGE_REQUIRE(!t_recording, "cmdlist_replay: cannot replay while recording");
     const CmdList *l = (const CmdList *)list;
     if (l->nodes.empty()) return GSAGE_OK;
+    t_node_error = 0;
     for (const auto &node : l->nodes) node((hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("cmdlist_replay: %s", hipGetErrorString(e));
+        return GSAGE_ELAUNCH;
+    }
+    if (t_node_error) {                  // (the node that failed has left its message in gsage_last_error)
+        t_node_error = 0;
         return GSAGE_ELAUNCH;
     }
     g_launches.fetch_add((uint64_t)l->n_launches, std::memory_order_relaxed);
@@ -153,6 +159,26 @@ int gsage_cmdlist_join(void)
     hipEvent_t ej = t_recording->ev_join;
     t_recording->nodes.emplace_back([ej](hipStream_t s) { (void)hipStreamWaitEvent(s, ej, 0); });
     t_recording->n_marks += 1;
+    return GSAGE_OK;
+}
+
+int gsage_host_call(gsage_host_fn fn, void *ctx, void *stream)
+{
+    GSAGE_REQUIRE(fn, "host_call: null function");
+    if (t_recording) {
+        t_recording->target().emplace_back([fn, ctx](hipStream_t s) {
+            if (fn(ctx, (void *)s) != 0) {
+                if (!t_node_error) set_error("host call failed during a command-list replay");
+                t_node_error = 1;
+            }
+        });
+        t_recording->n_marks += 1;
+        return GSAGE_OK;
+    }
+    if (fn(ctx, stream) != 0) {
+        set_error("host_call: the callee reported a failure");
+        return GSAGE_ELAUNCH;
+    }
     return GSAGE_OK;
 }
 

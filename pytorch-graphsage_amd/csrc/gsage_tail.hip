@@ -544,6 +544,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
                        void *dE, float *preds, void *dH, float *partial, const gsage_tail_gather_desc *gather,
                        int dtype, void *stream)
 {
+    const int32_t *n_valid = take_head_n_valid();     // (consumed before any return path: never left for a later launch)
     GSAGE_REQUIRE(dtype == GSAGE_BF16 || dtype == GSAGE_F32, "mean_tail_ce: bad dtype");
     GSAGE_REQUIRE(dtype == GSAGE_BF16 || !(gather && gather->rows > 0),
                   "mean_tail_ce: the gather role exists for bf16 tables only");
@@ -559,7 +560,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
     TailParams p;
     p.H = H; p.w2 = w2; p.w2t = w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
-    p.n_valid = take_head_n_valid();
+    p.n_valid = n_valid;
     p.agg = agg; p.dE = dE; p.preds = preds; p.dH = dH;
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
     TailGather tg = {};

@@ -26,6 +26,28 @@ class DataParallel(object):
         self.rank, self.world, self.device = rank, world, device
         self._owns = owns_group
         self._flat = None
+        # the library's own RCCL communicator (_native.NativeComm, include/gsage.h "The step's collectives"): with it
+        # the fused engines issue the step's collectives as nodes of the step's command list; None (gloo, or
+        # GSAGE_NATIVE_COMM=0): the same nodes call torch.distributed through a host callback
+        self.comm = None
+
+    def create_native_comm(self):
+        """One RCCL communicator owned by libgsage_hip.so, set up over the process group torch.distributed already
+        has (rank 0's 128-byte id travels through broadcast_object_list).  Collective: every rank calls it."""
+        from . import _native as nat
+
+        def exchange(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            self.comm = nat.NativeComm(self.rank, self.world, exchange)
+        except Exception as e:            # (the engines then go through torch.distributed; say so once)
+            import sys
+            print("gsage: no native RCCL communicator (%s); collectives go through torch.distributed" % (e,),
+                  file=sys.stderr)
+            self.comm = None
+        return self.comm
 
     # ---- batch sharding -------------------------------------------------------------------
     def shard(self, ids, targets=None):
@@ -81,6 +103,9 @@ class DataParallel(object):
         dist.barrier()
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         if self._owns and dist.is_initialized():
             dist.destroy_process_group()
 
@@ -111,7 +136,10 @@ def init_from_env(cuda=True):
     owns = not dist.is_initialized()
     if owns:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return DataParallel(rank, world, device, owns)
+    ddp = DataParallel(rank, world, device, owns)
+    if cuda and backend == "nccl" and os.environ.get("GSAGE_NATIVE_COMM", "1") == "1":
+        ddp.create_native_comm()
+    return ddp
 
 
 def attach(model, ddp, seed=0):

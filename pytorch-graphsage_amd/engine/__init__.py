@@ -21,26 +21,27 @@ from .attn import FusedAttnTrainStep
 ENGINES = (FusedMeanTrainStep, FusedPoolTrainStep, FusedAttnTrainStep)
 
 
-def why_no_fused_engine(model, feats):
+def why_no_fused_engine(model, feats, ddp=None):
     """{engine name: what it does not cover} for every fused engine (empty when one covers the model)."""
     out = {}
     for cls in ENGINES:
-        why = cls.why_not(model, feats)
+        why = cls.why_not(model, feats, ddp)
         if why is None:
             return {}
         out[cls.__name__] = why
     return out
 
 
-def fused_engine_for(model, feats, explain=False):
+def fused_engine_for(model, feats, explain=False, ddp=None):
     """The fused train-step engine that covers (model, feats), or None (callers then fall back to
     GSSupervised.train_step, optionally captured by CapturedTrainStep).  explain=True: when none does, say on
-    stderr what each engine misses, so nobody lands on the slow path without knowing."""
+    stderr what each engine misses, so nobody lands on the slow path without knowing.  ddp: the data-parallel handle
+    the engine will be built with (dist.DataParallel), so that what an engine cannot do under it is said HERE."""
     for cls in ENGINES:
-        if cls.supports(model, feats):
+        if cls.supports(model, feats, ddp):
             return cls
     if explain:
-        why = why_no_fused_engine(model, feats)
+        why = why_no_fused_engine(model, feats, ddp)
         print("gsage: no fused train-step engine covers this model -- " +
               "; ".join("%s: %s" % kv for kv in why.items()), file=sys.stderr)
     return None

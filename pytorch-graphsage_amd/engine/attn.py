@@ -36,7 +36,7 @@ class FusedAttnTrainStep(FusedTrainStep):
     TIMED = {"gather": (0, 1), "k4": (4, 5), "k4_bwd": (6, 7)}   # K4 / K4' of level 0 over the LAST hop (the bulk)
 
     @classmethod
-    def why_not(cls, model, feats):
+    def why_not(cls, model, feats, ddp=None):
         why = cls._why_not_common(model, feats, (AttentionAggregator,), "attention") or \
             cls._why_not_input(model, feats)
         if why:

@@ -67,13 +67,37 @@ class FusedTrainStep(object):
 
     # ---- which (model, feature store) pairs an engine covers ----------------------------------------
     @classmethod
-    def why_not(cls, model, feats):
-        """None when this engine covers (model, feats), else one sentence saying what it does not cover."""
+    def why_not(cls, model, feats, ddp=None):
+        """None when this engine covers (model, feats) -- under the data-parallel handle `ddp` when one is given --,
+        else one sentence saying what it does not cover."""
         raise NotImplementedError
 
     @classmethod
-    def supports(cls, model, feats):
-        return cls.why_not(model, feats) is None
+    def supports(cls, model, feats, ddp=None):
+        return cls.why_not(model, feats, ddp) is None
+
+    @classmethod
+    def head_why_not(cls, model, loss_fn, example_targets, batch, padded):
+        """What the head of (model, loss_fn) costs a caller BEFORE an engine is built (train.py decides between the
+        engine and the module path with it): None when a fused head applies (cross-entropy with <= 64 classes and an
+        fc input of <= 1024, or the L1 regression head with <= 2048 seeds), else a sentence.  Without a fused head an
+        engine still trains (stock torch ops for the head inside the captured step) but cannot ignore padded seeds:
+        `padded` says whether the caller will pad short batches (the reference's array_split chunks)."""
+        from ..problem import ProblemLosses
+        C, D2 = model.fc.weight.shape
+        post = _split_activation(list(model.agg_layers.children())[-1].activation)[1]
+        probe = torch.randn(3, 4)
+        ident = post is None or torch.equal(post(probe), probe)
+        if loss_fn is ProblemLosses.classification and ident and C <= 64 and D2 <= 1024 and \
+                example_targets.dtype == torch.int64:
+            return None
+        if loss_fn is ProblemLosses.regression_mae and ident and C == 1 and 1 < batch <= 2048 and \
+                example_targets.dtype == torch.float32:
+            return None
+        if not padded:
+            return None
+        return ("the head of this problem (loss %s, %d outputs) has no fused kernel, and only a fused head can "
+                "ignore the padding of the reference's unequal chunks" % (getattr(loss_fn, "__name__", "?"), int(C)))
 
     @staticmethod
     def _why_not_common(model, feats, agg_types, what):
@@ -122,9 +146,9 @@ class FusedTrainStep(object):
         -- sampling of batch i+2 and the level-0 gathers of batch i+1 -- on a stream restricted to that many
         compute units while the forward / backward / update chain of batch i runs on a stream restricted
         to the others (see _split_* below).  None: GSAGE_GATHER_CUS from the environment, else off."""
-        if not type(self).supports(model, feats):
+        if not type(self).supports(model, feats, ddp):
             raise ValueError("%s does not cover this (model, feature store): %s"
-                             % (type(self).__name__, type(self).why_not(model, feats)))
+                             % (type(self).__name__, type(self).why_not(model, feats, ddp)))
         if not (torch.is_tensor(example_ids) and example_ids.is_cuda and example_ids.dtype == torch.int64
                 and example_ids.dim() == 1):
             raise ValueError("example_ids must be a CUDA int64 vector of seed ids (one batch)")
@@ -153,8 +177,11 @@ class FusedTrainStep(object):
         # trainable node-embedding prep: the level-0 rows are weights (computed per step from the current table)
         self.emb = isinstance(model.prep, NodeEmbeddingPrep)
         self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1"
-        assert not (self.emb and ddp is not None), \
-            "the embedding-prep engines are single-GPU (data-parallel runs use the module path)"
+        # the step's collectives: issued by the library (RCCL through gsage_comm_*, a node of the step's list) when the
+        # handle carries a native communicator, else torch.distributed (gloo in the tests) through a host-call node
+        self.world = int(ddp.world) if ddp is not None else 1
+        self.comm = getattr(ddp, "comm", None) if ddp is not None else None
+        self._host_cbs = []                       # ctypes callbacks recorded into lists (kept alive with the engine)
         self._front_ready, self._qstep = False, 0
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
         self._tail_gather, self._tail_rows = None, 0
@@ -240,6 +267,7 @@ class FusedTrainStep(object):
         self.wd = float(model.optimizer.param_groups[0].get("weight_decay", 0.0))
         self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._import_optimizer_state()
 
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.preds = None
@@ -283,6 +311,12 @@ class FusedTrainStep(object):
                              self.B > 1 and os.environ.get("GSAGE_TORCH_HEAD", "0") != "1")
         if self.fused_l1:
             self.preds = torch.zeros(self.B, 1, dtype=torch.float32, device=self.dev)
+            if self.world > 1:
+                # the reference's L1 loss pairs EVERY prediction with EVERY target of the batch (problem.py:39-42:
+                # [B,1] against [B] broadcasts): a shard needs the global batch's targets -- gathered once per step,
+                # 4 bytes per seed -- for its rows' share of the global loss (gsage_head_l1_sharded)
+                assert self.world * self.B <= 8192, "gsage_head_l1_sharded: the global batch must stay <= 8192 seeds"
+                self.tg_all = torch.zeros(self.world * self.B, dtype=torch.float32, device=self.dev)
 
     def _install_reduce(self, rdesc):
         """Append the head's gradient source, check that every parameter is covered, upload."""
@@ -318,6 +352,7 @@ class FusedTrainStep(object):
         ddp = self.ddp
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
+        saved_opt = (self.flat_m.clone(), self.flat_v.clone(), self.step.clone())     # (zeros, or an imported state)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -326,8 +361,12 @@ class FusedTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.flat_p.copy_(saved)
-        for t in (self.flat_m, self.flat_v, self.step, self.counter) + tuple(getattr(self, "_warm_reset", ())):
+        for t, v in zip((self.flat_m, self.flat_v, self.step), saved_opt):
+            t.copy_(v)
+        for t in (self.counter,) + tuple(getattr(self, "_warm_reset", ())):
             t.zero_()
+        if self.lazy_rows and int(self.step.item()) > 0:      # deferred table rows: every row is current at that count
+            self.row_last.fill_(int(self.step.item()))
         self.refresh_weights()
         torch.cuda.synchronize()
         self.g_main, self.g_opt, self.g_front = None, None, None
@@ -361,17 +400,36 @@ class FusedTrainStep(object):
             self.g_front = [self._record(lambda st_=st_: self._stage_sample_gather(st_), self.s_front)
                             for st_ in range(2)]
 
+        # data-parallel: on command lists the exchange is a node of the step's ONE list (_stage_exchange); hipGraphs
+        # cannot hold it, so "graph" mode (and the two-stream pipelined engine) keep it between two recordings
+        one_list = self._one_list_ddp()
+
         def main(st_):
             if not self.pipelined:
                 self._stage_sample_gather(0)
             self._stage_compute(st_)
-            if ddp is None:
+            if one_list:
+                self._stage_exchange()
+            if ddp is None or one_list:
                 self._stage_opt()
         for st_ in range(self.nset):
             self.g_main.append(self._record(lambda st_=st_: main(st_),
                                             self.s_back if self.pipelined else None))
-        if ddp is not None:
+        self.g_opt = None
+        if ddp is not None and not one_list:
             self.g_opt = self._record(self._stage_opt, self.s_back if self.pipelined else None)
+
+    def _one_list_ddp(self):
+        """data-parallel step as ONE command list (collectives as nodes)?  GSAGE_DDP_ONE_LIST=0: round 3's three
+        lists around a torch.distributed call."""
+        return bool(self.ddp is not None and self.capture_mode == "cmdlist" and not self.pipelined and
+                    os.environ.get("GSAGE_DDP_ONE_LIST", "1") == "1")
+
+    def _ddp_overlap(self):
+        """run the exchange on the list's side stream, beside the next batch's gathers?  Default: whenever there is
+        more than one rank (a 1-rank group's "exchange" has nothing to hide: inline).  GSAGE_DDP_OVERLAP=0 / 1."""
+        e = os.environ.get("GSAGE_DDP_OVERLAP", "")
+        return (self.world > 1) if e == "" else (e == "1")
 
     # ---- helpers ------------------------------------------------------------------------------
     def _record(self, fn, stream=None):
@@ -431,6 +489,32 @@ class FusedTrainStep(object):
         flat_adam.flat_m.copy_(self.flat_m)
         flat_adam.flat_v.copy_(self.flat_v)
         flat_adam.step_count.copy_(self.step)
+
+    def _import_optimizer_state(self):
+        """An engine built AFTER the model has trained through `model.optimizer` (GSSupervised.train_step: FlatAdam
+        or a torch.optim.Adam) continues from that optimizer's exp_avg / exp_avg_sq / step count instead of
+        restarting Adam's moments and bias correction from zero."""
+        try:
+            sd = self.model.optimizer.state_dict()
+        except Exception:
+            return
+        st = sd.get("state") or {}
+        if not st:
+            return
+        if len(st) != len(self.params):
+            import warnings
+            warnings.warn("gsage: the optimizer's state does not match the trainable parameters; the fused engine "
+                          "starts Adam's moments from zero")
+            return
+        steps = set()
+        for i, (p, o) in enumerate(zip(self.params, self.poff)):
+            e = st.get(i, st.get(str(i)))
+            k = p.numel()
+            self.flat_m[o:o + k].copy_(e["exp_avg"].reshape(-1))
+            self.flat_v[o:o + k].copy_(e["exp_avg_sq"].reshape(-1))
+            steps.add(int(e["step"]))
+        assert len(steps) == 1, "the engines keep ONE step count: per-parameter counts differ (%r)" % (steps,)
+        self.step.fill_(steps.pop())
 
     def _grad_slice(self, prm):
         i = self.pidx[id(prm)]
@@ -556,6 +640,14 @@ class FusedTrainStep(object):
         """normalize + fc + F.l1_loss with the reference's [B,1]-vs-[B] broadcast (problem.py:39-42) + gradients"""
         m, L = self.model, self.L
         out = self.hout[L - 1]
+        if self.world > 1:
+            assert self._nv_host == self.B, "data-parallel batches have one fixed size (no padded seeds)"
+            self._x_all_gather(self.tg_set[s].view(-1), self.tg_all)
+            nat.check(nat.lib().gsage_head_l1_sharded(
+                out.data_ptr(), out.stride(0), m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), self.tg_all.data_ptr(),
+                self.tg_all.numel(), self.B, out.shape[1], self.preds.data_ptr(), self.dc[L - 1].data_ptr(), self.code,
+                self.dc[L - 1].stride(0), self.l1_scratch.data_ptr(), ops._stream()), "head_l1_sharded")
+            return
         self._head_live_rows()
         nat.check(nat.lib().gsage_head_l1(out.data_ptr(), out.stride(0), m.fc.weight.data_ptr(), m.fc.bias.data_ptr(),
                                           self.tg_set[s].data_ptr(), self.B, out.shape[1], self.preds.data_ptr(),
@@ -621,8 +713,76 @@ class FusedTrainStep(object):
                                            self.batch_idx.data_ptr() if self.queue else None, 1,
                                            stream), "finalize_grads")
 
+    # ---- the step's collectives (seed shards, ONE exchange per step) -----------------
+    # Three carriers, one call site each: (1) the library's own RCCL communicator (dist.DataParallel.comm,
+    # gsage_comm_*): the collective is a node of the step's command list, on the list's side stream when it
+    # overlaps the next batch's gathers; (2) torch.distributed inside a host-call node (gsage_host_call: backends
+    # without a C entry point -- gloo in the tests -- keep the same list structure); (3) torch.distributed directly
+    # when nothing is being recorded.  None of them may run while a hipGraph is being captured ("graph" mode keeps
+    # the exchange between two graphs).
+    def _on_stream(self, s):
+        import contextlib
+        if not s:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(torch.cuda.ExternalStream(int(s)))
+
+    def _x_all_reduce(self, t):
+        """average t (a contiguous fp32 slice of the gradient bucket) over the ranks, in place"""
+        if self.comm is not None:
+            return self.comm.all_reduce(t, True, ops._stream())
+
+        def run(s=None):
+            with self._on_stream(s):
+                if self._reduce_op == torch.distributed.ReduceOp.SUM:
+                    t.div_(self.world)
+                torch.distributed.all_reduce(t, op=self._reduce_op)
+        if self._in_list:
+            self._host_cbs.append(nat.host_call(run))
+        else:
+            run()
+
+    def _x_all_gather(self, send, recv):
+        """recv[r] = rank r's send (recv: [world * send.numel()] of send's type)"""
+        if self.comm is not None:
+            return self.comm.all_gather(send, recv, ops._stream())
+        outs = list(recv.view(self.world, -1).unbind(0))
+
+        def run(s=None):
+            with self._on_stream(s):
+                torch.distributed.all_gather(outs, send.reshape(-1))
+        if self._in_list:
+            self._host_cbs.append(nat.host_call(run))
+        else:
+            run()
+
+    def _stage_exchange(self):
+        """The step's exchange.  Dense parameters: ONE all-reduce (average) of the flat fp32 gradient bucket.  A
+        trainable embedding table with deferred row updates (configs[3]): its dense 418 MB gradient never travels --
+        every rank contributes the row ids of its frontier and their fp32 gradient rows (all-gather, grouped with
+        the all-reduce of the other parameters), and every rank then reduces the SAME concatenated list in the
+        SAME order (_stage_opt_emb: sort + segment sums), so the replicas' tables stay bit-identical and all of
+        them apply the identical touched-row set to the deferred-row Adam."""
+        if self.ddp is None:
+            return
+        if self.emb and self.lazy_rows:
+            B, RA0 = self.B, self.off[self.L + 1]
+            ids = self._cur_ids
+            if self.comm is not None:
+                self.comm.group(True, ops._stream())
+            self._x_all_reduce(self.flat_g[self.n_tab:])
+            self._x_all_gather(ids[B:RA0], self.xids)
+            self._x_all_gather(self.deraw[B:], self.xrows)
+            self._x_all_gather(self.seed_grad, self.xseed)
+            if self.comm is not None:
+                self.comm.group(False, ops._stream())
+            return
+        self._x_all_reduce(self.flat_g)
+
     def _all_reduce(self, async_op=False):
-        """The step's ONE exchange: average the flat fp32 gradient bucket over the ranks (RCCL)."""
+        """("graph" mode and the pipelined engine: the exchange as a torch.distributed call between two graphs)"""
+        if self.emb and self.lazy_rows:
+            assert not async_op
+            return self._stage_exchange()
         if self._reduce_op == torch.distributed.ReduceOp.SUM:
             self.flat_g.div_(self.ddp.world)
         return torch.distributed.all_reduce(self.flat_g, op=self._reduce_op, async_op=async_op)
@@ -643,8 +803,7 @@ class FusedTrainStep(object):
             self._cur_ids = self.ids_set[s]
         self._stage_sample_gather(s)
         self._stage_compute(s)
-        if self.ddp is not None:
-            self._all_reduce()
+        self._stage_exchange()
         self._stage_opt()
 
 
@@ -690,7 +849,8 @@ class FusedTrainStep(object):
         dev, f32 = self.dev, torch.float32
         self.n_tab = int(self.table.numel())
         self.n_tab_partial = 1024 if self.lazy_rows else nat.lib().gsage_adam_partials(self.n_tab)
-        self.partial = torch.zeros(self.n_partial + self.n_tab_partial, dtype=f32, device=dev)
+        n_dense_sq = nat.lib().gsage_adam_partials(max(1, self.flat_p.numel() - self.n_tab))
+        self.partial = torch.zeros(max(self.n_partial, n_dense_sq) + self.n_tab_partial, dtype=f32, device=dev)
         if not self.lazy_rows:
             return
         # a step touches its frontier's rows, everything else is replayed -- bit for bit -- when it is next read
@@ -709,6 +869,28 @@ class FusedTrainStep(object):
         d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
         self._rows_dirty, self._rows_since = False, 0
         self._warm_reset = (self.row_last, self.row_seen)
+        # The table's gradient, deterministically (csrc/gsage_rowsum.hip): the frontier's ids -- every rank's, in a
+        # data-parallel run -- are sorted, each run of equal ids is summed in list order and stored (no atomics, no
+        # zero-fill), and the norm / Adam passes walk the sorted list (gsage_row_adam.sorted_ids).
+        # GSAGE_SORTED_ROWS=0 (single GPU only): round 3's fp32 atomics (gsage_scatter_add_rows + stamp dedupe).
+        self.sorted_rows = self.ddp is not None or os.environ.get("GSAGE_SORTED_ROWS", "1") != "0"
+        if self.sorted_rows:
+            W, B, RA0, ns = self.world, self.B, self.off[self.L + 1], int(self.seed_grad.shape[0])
+            n0, n1 = W * (RA0 - B), W * ns
+            self.x_n0, self.x_n1 = n0, n1
+            if self.ddp is not None:
+                self.xids = torch.zeros(n0, dtype=torch.int64, device=dev)
+                self.xrows = torch.zeros(n0, E, dtype=f32, device=dev)
+                self.xseed = torch.zeros(n1, E, dtype=f32, device=dev)
+            self.key_bits = max(1, int(n_rows - 1).bit_length())
+            self.sids = torch.zeros(n0 + n1, dtype=torch.int64, device=dev)
+            self.spos = torch.zeros(n0 + n1, dtype=i32, device=dev)
+            nb = int(nat.lib().gsage_sort_rows_temp_bytes(n0 + n1, self.key_bits))
+            assert nb > 0, "gsage_sort_rows_temp_bytes failed"
+            self.sort_temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            ds = self.row_desc_sorted = nat.RowAdamDesc()
+            ctypes.memmove(ctypes.addressof(ds), ctypes.addressof(d), ctypes.sizeof(d))
+            ds.sorted_ids = 1
         self.model._settle_rows = self.sync_rows
         emb_mod = self.model.prep.embedding
         self._row_hooks = [emb_mod.register_forward_pre_hook(lambda *_: self.sync_rows()),
@@ -742,6 +924,8 @@ class FusedTrainStep(object):
         ns = self.seed_grad.shape[0]             # (partial sums: one workgroup summing B rows alone took 14 us)
         nat.check(lib.gsage_colsum_partials(self.deraw.data_ptr(), E, B, E, self.seed_grad.data_ptr(), ns, stream),
                   "colsum_partials")
+        if self.lazy_rows and self.sorted_rows:
+            return            # the rows meet in _stage_opt_emb (after the exchange, in a data-parallel run)
         for rows, idv, M in ((self.seed_grad, self.seed_rows, ns), (self.deraw[B:], ids[B:RA0], RA0 - B)):
             nat.check(lib.gsage_scatter_add_rows(rows.data_ptr(), E, idv.data_ptr(), M, 1, E, 1.0, g.data_ptr(), E,
                                                  stream), "scatter_add_rows")
@@ -753,9 +937,33 @@ class FusedTrainStep(object):
         g = self._grad_slice(self.table)
         n_all = self.n_partial + self.n_tab_partial
         if self.lazy_rows:
-            ids, rd = self._cur_ids, ctypes.byref(self.row_desc)
-            lists = (self.seed_rows.data_ptr(), 1, ids[B:RA0].data_ptr(), RA0 - B, 0)
-            nat.check(lib.gsage_rows_sqnorm(rd, *lists, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+            ids = self._cur_ids
+            base = self.n_partial             # norm partials of the other parameters: the finalisation's ...
+            if self.ddp is not None:          # ... or, after an exchange, those of the AVERAGED gradient
+                nd = self.flat_p.numel() - nt
+                base = lib.gsage_adam_partials(nd)
+                nat.check(lib.gsage_grad_sqnorm(self.flat_g[nt:].data_ptr(), nd, self.partial.data_ptr(), base, stream),
+                          "grad_sqnorm")
+                n_all = base + self.n_tab_partial
+            if self.sorted_rows:
+                # every rank's (ids, gradient rows) in rank order [+ the seeds' spare row, 16 partial rows per rank]:
+                # one stable sort, one segment sum per distinct row (scaled by 1 / world: the all-reduce's average)
+                dp = self.ddp is not None
+                src = self.xids if dp else ids[B:RA0]
+                rows0, rows1 = (self.xrows, self.xseed) if dp else (self.deraw[B:], self.seed_grad)
+                n0, n1 = self.x_n0, self.x_n1
+                nat.check(lib.gsage_sort_rows(src.data_ptr(), n0, int(self.model.prep.n_nodes), n1, self.key_bits,
+                                              self.sids.data_ptr(), self.spos.data_ptr(), self.sort_temp.data_ptr(),
+                                              self.sort_temp.numel(), stream), "sort_rows")
+                nat.check(lib.gsage_segment_sum_rows(self.sids.data_ptr(), self.spos.data_ptr(), n0 + n1,
+                                                     rows0.data_ptr(), E, n0, rows1.data_ptr(), E, E, 1.0 / self.world,
+                                                     g.data_ptr(), E, stream), "segment_sum_rows")
+                rd = ctypes.byref(self.row_desc_sorted)
+                lists = (self.sids.data_ptr(), n0 + n1, None, 0, 0)
+            else:
+                rd = ctypes.byref(self.row_desc)
+                lists = (self.seed_rows.data_ptr(), 1, ids[B:RA0].data_ptr(), RA0 - B, 0)
+            nat.check(lib.gsage_rows_sqnorm(rd, *lists, self.partial[base:].data_ptr(), self.n_tab_partial,
                                             stream), "rows_sqnorm")
             nat.check(lib.gsage_rows_adam(rd, *lists, self.partial.data_ptr(), n_all, stream), "rows_adam")
             o, n = nt, self.flat_p.numel() - nt
@@ -765,7 +973,14 @@ class FusedTrainStep(object):
                                                d.weight_decay, d.max_norm, d.norm_out, 1, n_all, d.prep_descs, d.n_prep,
                                                None, 0, None, 0, stream), "clip_adam_step")
             return
-        nat.check(lib.gsage_grad_sqnorm(g.data_ptr(), nt, self.partial[self.n_partial:].data_ptr(), self.n_tab_partial,
+        base = self.n_partial
+        if self.ddp is not None:              # (dense table, data-parallel: the whole bucket was averaged)
+            nd = self.flat_p.numel() - nt
+            base = lib.gsage_adam_partials(nd)
+            nat.check(lib.gsage_grad_sqnorm(self.flat_g[nt:].data_ptr(), nd, self.partial.data_ptr(), base, stream),
+                      "grad_sqnorm")
+            n_all = base + self.n_tab_partial
+        nat.check(lib.gsage_grad_sqnorm(g.data_ptr(), nt, self.partial[base:].data_ptr(), self.n_tab_partial,
                                         stream), "grad_sqnorm")
         # the table (16-byte lanes, no operand copies), then everything else (operand copies refreshed)
         # (flag 2 on the table: its gradient is zeroed below, no need to write the clipped values back; flag 4: the
@@ -914,12 +1129,19 @@ class FusedTrainStep(object):
             if self.ddp is None:
                 self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(2)]
             else:
-                # data-parallel: three pieces so that the exchange can overlap the NEXT batch's
-                # gathers (see step_queue)
-                self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
-                self._ddp_split = bool(self.MEAN_ENGINE and self.size[self.L - 1] > self._tail_rows
+                self._ddp_split = bool(self.MEAN_ENGINE and not self.emb and self.size[self.L - 1] > self._tail_rows
                                        and os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
-                if self._ddp_split:
+                if self._one_list_ddp():
+                    # ONE list per step, the exchange a node of it (on the side stream when it overlaps the gathers)
+                    self.g_queue = [self._record(lambda par=par: self._queue_step_ddp(par)) for par in range(2)]
+                    self.g_qfront, self.g_opt = None, None
+                    return
+                # "graph" mode: three pieces so that the exchange can overlap the NEXT batch's gathers (see step_queue)
+                self.g_queue = [self._record(lambda par=par: self._queue_compute(par)) for par in range(2)]
+                if self.emb:
+                    self.g_qfront = [self._record(lambda par=par: self._queue_front(par, True)) for par in range(2)]
+                    self.g_opt = None
+                elif self._ddp_split:
                     # the bulk of the gathers runs while the exchange is in flight; what follows the exchange
                     # is ONE norm pass and ONE launch: the remaining gathers with Adam(i) and K1(i+2) riding along
                     self.g_qfront = [self._record(lambda par=par: self._queue_front_means(par)) for par in range(2)]
@@ -1005,6 +1227,36 @@ class FusedTrainStep(object):
         self._queue_compute(par)
         self._queue_front(par, True)              # Adam(i) || gathers(i+1) || sampling(i+2)
 
+    def _queue_step_ddp(self, par):
+        """One data-parallel step of the queue pipeline as ONE sequence of launches and collective nodes:
+        compute(i) -> exchange(i) [side stream] || bulk of the gathers(i+1) + sampling(i+2) -> join -> norm of the
+        averaged gradient -> Adam(i) || rest of the gathers(i+1).  Recorded into one command list (or issued
+        eagerly, then without the side stream)."""
+        lib = nat.lib()
+        self._queue_compute(par)
+        if self.emb:
+            # the level-0 rows are weights: nothing of batch i+1 can run before Adam(i) -- exchange, then update
+            self._cur_ids = self.ids_q[par]
+            self._stage_exchange()
+            self._queue_front(par, True)
+            return
+        side = self._in_list and self._ddp_overlap()
+        if side:
+            nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
+        self._stage_exchange()
+        if side:
+            nat.check(lib.gsage_cmdlist_side_end(), "cmdlist_side_end")
+        if self._ddp_split:
+            self._queue_front_means(par)
+        else:
+            self._queue_front(par, False)
+        if side:
+            nat.check(lib.gsage_cmdlist_join(), "cmdlist_join")
+        if self._ddp_split:
+            self._queue_front_rest(par)
+        else:
+            self._stage_opt()
+
     def step_queue(self):
         """One train_step on the next batch of the loaded epoch queue -> preds (static buffer).
 
@@ -1035,31 +1287,28 @@ class FusedTrainStep(object):
             else:
                 self._queue_step(par)
             return self.preds
-        if rec:
-            self.g_queue[par].replay()
-        else:
-            self._queue_compute(par)
+        if self._one_list_ddp() or not rec:
+            if rec:
+                self.g_queue[par].replay()
+            else:
+                self._queue_step_ddp(par)
+            return self.preds
+        self.g_queue[par].replay()
         # Order matters: the collective is submitted BEFORE the gathers.  Submitted after them (from a
         # side stream that only waits for the gradients, which would hide the ~25 us the collective
         # call costs the host) it did not start until the 8 320-workgroup gather launch had been
         # dispatched completely -- no overlap at all (tools/overlap_check.py).
         # (Order and priority were measured on one rank, 0.1205 ms/step as written: the means submitted BEFORE
         # the collective 0.137; RCCL's stream at high priority 0.46 -- its kernel then preempts the gathers.)
-        split = getattr(self, "_ddp_split", False)
-        work = self._all_reduce(async_op=True)
-        if rec:                                      # batch i+1's gathers overlap the exchange
+        if self.emb:
+            self._cur_ids = self.ids_q[par]
+            self._stage_exchange()
             self.g_qfront[par].replay()
-        elif split:
-            self._queue_front_means(par)
-        else:
-            self._queue_front(par, False)
+            return self.preds
+        work = self._all_reduce(async_op=True)
+        self.g_qfront[par].replay()                  # batch i+1's gathers overlap the exchange
         work.wait()                                  # stream-level wait, the host does not block
-        if rec:
-            (self.g_opt[par] if isinstance(self.g_opt, list) else self.g_opt).replay()
-        elif getattr(self, "_ddp_split", False):
-            self._queue_front_rest(par)
-        else:
-            self._stage_opt()
+        (self.g_opt[par] if isinstance(self.g_opt, list) else self.g_opt).replay()
         return self.preds
 
     def _pad_batch(self, ids, targets):

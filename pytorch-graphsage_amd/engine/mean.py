@@ -45,7 +45,7 @@ class FusedMeanTrainStep(FusedTrainStep):
 
 
     @classmethod
-    def why_not(cls, model, feats):
+    def why_not(cls, model, feats, ddp=None):
         # bf16 storage = the production path; fp32 storage = the exact-arithmetic parity mode (same engine, same
         # kernel sources instantiated on fp32: golden fixtures replay at 2e-4).  With the node-embedding prep
         # (utils/pokec.sh:5-13) the level-0 rows are weights: computed per step, nothing is gathered ahead.
@@ -480,8 +480,15 @@ class FusedMeanTrainStep(FusedTrainStep):
         left = int(self.size[self.L - 1]) - self._tail_rows - self._k5_rows
         return max(0, min(left, int(frac * self.size[self.L - 1])))
 
+    def _k1_early(self):
+        """data-parallel order: K1(i+2) rides in the launch that gathers the bulk of batch i+1 WHILE the exchange is in
+        flight instead of in the launch that follows it (its ~9 us chain of dependent loads would otherwise sit on
+        the critical path behind the collective, beside Adam).  Sampling reads no weights: same frontier either way."""
+        return (not self.dense) and os.environ.get("GSAGE_DDP_K1_EARLY", "1") == "1"
+
     def _queue_front_means(self, par):
-        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._ahead_rows(), part="means")
+        self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], skip_rows=self._ahead_rows(), part="means",
+                           hops=self._hops_desc(self.ids_q[par], True) if self._k1_early() else None)
 
     def _queue_front_rest(self, par):
         """after the exchange: squared norm of the averaged gradient, then the rest of the gathers || Adam || K1"""
@@ -492,7 +499,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         d = self._adam_desc()
         d.n_partial_ready = n_sq
         self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], part="rest", adam=d,
-                           hops=None if self.dense else self._hops_desc(self.ids_q[par], True))
+                           hops=None if (self.dense or self._k1_early()) else self._hops_desc(self.ids_q[par], True))
         if self.dense:
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)
 

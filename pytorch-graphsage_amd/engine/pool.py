@@ -35,7 +35,7 @@ class FusedPoolTrainStep(FusedTrainStep):
     TIMED = {"gather": (0, 1), "k3": (4, 5), "k5b": (6, 7)}      # K3 = level 0's launch over the LAST hop (the bulk)
 
     @classmethod
-    def why_not(cls, model, feats):
+    def why_not(cls, model, feats, ddp=None):
         why = cls._why_not_common(model, feats, (MaxPoolAggregator, MeanPoolAggregator), "max-pool / mean-pool")
         if why:
             return why

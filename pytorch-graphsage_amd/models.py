@@ -125,6 +125,18 @@ class GSSupervised(nn.Module):
                     eng.export_optimizer_state(opt)   # ... and the engine's exp_avg / exp_avg_sq / step count
             return opt
         if opt is not self._init_optimizer or opt.state or os.environ.get("GSAGE_TORCH_ADAM", "0") == "1":
+            if trained and getattr(self, "_handed_over", None) != id(eng):
+                # the stock route takes over from a fused engine: Adam continues from the engine's exp_avg /
+                # exp_avg_sq / step count when this optimizer has no state of its own, else say what is lost
+                self._handed_over = id(eng)
+                try:
+                    if opt.state:
+                        raise RuntimeError("the optimizer already holds state of its own")
+                    opt.load_state_dict(eng.optimizer_state_dict())
+                except Exception as e:
+                    import warnings
+                    warnings.warn("gsage: %s -- Adam's moments of the fused engine's steps are NOT carried over "
+                                  "into model.optimizer" % (e,))
             return None
         params = [p for p in self.parameters() if p.requires_grad]
         if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):

@@ -134,6 +134,9 @@ class FeatureStore(object):
 
     def __init__(self, data, dim):
         assert data.dim() == 2 and data.is_contiguous()
+        if int(data.shape[0]) >= 2 ** 31:            # the gather kernels read the low 32-bit word of a node id
+            raise ValueError("FeatureStore: %d rows; node ids must stay below 2^31 (include/gsage.h, gsage_gather_mean)"
+                             % int(data.shape[0]))
         self.data = data               # [n_rows, ld]
         self.dim = int(dim)            # logical D (columns [D, ld) are zero)
 

@@ -172,13 +172,7 @@ def main(argv=None):
     val_metric = train_metric = None
     epoch = 0
     if args.engine in ('auto', 'fused') and args.cuda:
-        cls = gs.engine.fused_engine_for(model, problem.feats, explain=True)
-        assert cls is not None or args.engine == 'auto', \
-            '--engine fused: no fused engine covers this model (use --engine auto / eager)'
-        if cls is not None and ddp is not None and args.rng != 'philox':
-            print('gsage: data-parallel runs of the fused engines need --rng philox; using the module path',
-                  file=sys.stderr)
-            cls = None
+        cls = choose_engine(args, problem, model, ddp)
         if cls is not None:
             print('gsage: train_step runs on %s' % cls.__name__, file=sys.stderr)
             return train_fused(args, problem, model, ddp, start_time, cls)
@@ -210,6 +204,41 @@ def main(argv=None):
             print(dumps({"test_f1": evaluate(model, problem, mode='test')}))
     if ddp is not None:
         ddp.close()
+
+
+def choose_engine(args, problem, model, ddp):
+    """The fused engine this run gets, or None for the module path.  Everything that could stop an engine AFTER it
+    has re-pointed the model's Parameters into its buckets is decided here: the model / feature store / process
+    group (engine.why_not), the head (engine.head_why_not: only a fused head can ignore the padding of the
+    reference's unequal chunks) and the batch geometry.  --engine auto: one stderr line says why the module path
+    runs; --engine fused: the same sentence is an error."""
+    def give_up(why):
+        if args.engine == 'fused':
+            raise SystemExit('gsage: --engine fused: %s (use --engine auto / eager)' % why)
+        print('gsage: %s; using the module path' % why, file=sys.stderr)
+        return None
+    cls = gs.engine.fused_engine_for(model, problem.feats, explain=True, ddp=ddp)
+    if cls is None:
+        return give_up('no fused engine covers this model')
+    if ddp is not None and args.rng != 'philox':
+        return give_up('data-parallel runs of the fused engines need --rng philox')
+    nodes = problem.nodes['train']
+    world = ddp.world if ddp is not None else 1
+    if world > 1:
+        B, padded = args.batch_size // world, False
+        if B < 2 or nodes.shape[0] < B * world:
+            return give_up('fewer training nodes (or a smaller --batch-size) than two seeds per rank')
+    else:
+        n_batches = nodes.shape[0] // args.batch_size + 1
+        B = -(-nodes.shape[0] // n_batches)
+        padded = nodes.shape[0] % n_batches != 0
+        if nodes.shape[0] // n_batches < 2:           # the smallest of the reference's array_split chunks
+            return give_up('chunks of fewer than two training nodes')
+    example = torch.zeros(1, dtype=torch.int64 if problem.task == 'classification' else torch.float32)
+    why = cls.head_why_not(model, problem.loss_fn, example, B, padded)
+    if why is not None:
+        return give_up(why)
+    return cls
 
 
 def epoch_chunks(nodes, batch_size):
@@ -263,8 +292,8 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     # engines with the fused classification head walk a device-resident queue of the epoch's batches; the others
     # (regression: the fused L1 head; multilabel: stock torch ops inside the captured step) take one batch per call
     queued = bool(step.fused_head)
-    if live is not None and not (step.fused_head or step.fused_l1) and min(live) < B:
-        raise SystemExit('gsage: this head cannot ignore padded seeds; run with --engine eager')
+    # (choose_engine has made sure that a head without a fused kernel never meets padded chunks)
+    assert live is None or step.fused_head or step.fused_l1 or min(live) == B
     val_metric = train_metric = None
     epoch = 0
     for epoch in range(args.epochs):
