@@ -276,6 +276,21 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
             out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
                                         "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * st.dim * elem,
                                         "avg_launch_us": us["seed_level"]}
+        # MFMA utilisation of the step's two contractions (north_star: "MFMA utilisation on the GEMM"): K5 = the
+        # level-0 projection [R0 x D] x [D x h], both concat halves in one grouped launch; K5b = every level's weight
+        # gradient in one launch (the same FLOPs as the forward projections of those levels)
+        if "k5" in us:
+            fl = 2.0 * 2 * eng.rows[0] * eng.h[0] * eng.din[0]
+            out["k5_launch"] = {"kernel": "k_linear_nt_packed (level-0 projection, x | mean against Wx | Wn)",
+                                "alg_flops_per_launch": fl, "avg_launch_us": us["k5"],
+                                "achieved_tflops": fl / (us["k5"] * 1e-6) / 1e12,
+                                "frac_of_mfma_peak": fl / (us["k5"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS}
+        if "k5b" in us:
+            fl = sum(2.0 * 2 * eng.rows[l] * eng.h[l] * eng.din[l] for l in range(L))
+            out["k5b_launch"] = {"kernel": "k_wgrad_multi (every level's weight gradient, one grouped launch)",
+                                 "alg_flops_per_launch": fl, "avg_launch_us": us["k5b"],
+                                 "achieved_tflops": fl / (us["k5b"] * 1e-6) / 1e12,
+                                 "frac_of_mfma_peak": fl / (us["k5b"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS}
         return out
     rows = eng.size[L]                                    # rows of the last hop
     if kind == "FusedPoolTrainStep":
@@ -460,6 +475,35 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
     return rec
 
 
+def extra_ddp_1rank(args):
+    """The data-parallel form of the headline step with a ONE-rank RCCL group on this GPU (GSAGE_FORCE_DDP=1): the
+    step as one command list whose exchange is an RCCL call issued by the library (gsage_comm_all_reduce_f32), the
+    norm of the averaged gradient a pass of its own and Adam behind it -- once in the order a multi-GPU run uses (the
+    exchange on the list's side stream beside the next batch's gathers: GSAGE_DDP_OVERLAP=1) and once inline.  What
+    the driver's 1-GPU box can record of the multi-GPU tax, every round; the process group lives in a child
+    process."""
+    out = {}
+    for name, ov in (("overlapped", "1"), ("inline", "0")):
+        env = dict(os.environ)
+        env.update({"GSAGE_FORCE_DDP": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(_free_port()), "GSAGE_DDP_OVERLAP": ov, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--no-cpu-baseline", "--extra", "", "--min-time", "0.3", "--batch-size", str(args.batch_size),
+               "--precision", args.precision]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out[name] = {"ms_per_step": line["ms_per_step"], "value": line["value"],
+                         "collective": line["config"].get("collective"), "native_comm": line["config"].get("native_comm"),
+                         "one_list": line["config"].get("one_list"),
+                         "kernel_launches_per_step": line["config"].get("kernel_launches_per_step")}
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    out["config"] = ("BASELINE configs[1] step with a 1-rank RCCL group (GSAGE_FORCE_DDP=1): `overlapped` is the order "
+                     "multi-GPU runs use, `inline` what a 1-rank group gets by default")
+    return out
+
+
 def _free_port():
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
@@ -511,7 +555,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec",
+    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank",
                     help="comma-separated additional configurations measured after the main line (N=1 only) and "
                          "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
                          "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
@@ -659,6 +703,8 @@ def main():
                        "pipelined": bool(res["engine"] == "fused" and args.pipeline),
                        "batch_queue": bool(res["queued"]), "parallelism": "dp%d" % world,
                        "ranks": world, "collective": (torch.distributed.get_backend() if ddp is not None else None),
+                       "native_comm": bool(getattr(step_fn, "comm", None) is not None) if ddp is not None else None,
+                       "one_list": bool(step_fn._one_list_ddp()) if (ddp is not None and hasattr(step_fn, "_one_list_ddp")) else None,
                        "kernel_launches_per_step": res["launches_per_step"] if args.launch != "graph" else None,
                        "timing": {"repeats": len(res["times"]), "steps_per_repeat": args.steps,
                                   "median_s": elapsed, "min_s": min(res["times"]), "max_s": max(res["times"]),
@@ -673,7 +719,7 @@ def main():
             del res, step_fn, model
             torch.cuda.empty_cache()
             names = [a for a in args.extra.split(",") if a and a != args.aggregator]
-            for agg in [a for a in names if a not in ("papers", "pokec")]:
+            for agg in [a for a in names if a not in ("papers", "pokec", "ddp_1rank", "cli")]:
                 r2 = measure(agg, min(args.min_time, 0.3))
                 e2 = r2["elapsed"]
                 rec = {"config": {"max_pool": "BASELINE configs[2] shape on one GPU",
@@ -700,6 +746,8 @@ def main():
                     except Exception as e:                      # never lose the main line to an extra
                         extra[name] = {"error": repr(e)}
                     torch.cuda.empty_cache()
+            if "ddp_1rank" in names and ddp is None:
+                extra["ddp_1rank"] = extra_ddp_1rank(args)
         line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)

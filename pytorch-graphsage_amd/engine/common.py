@@ -383,6 +383,9 @@ class FusedTrainStep(object):
         assert self.capture_mode in (None, "cmdlist", "graph")
         if self.capture_mode == "cmdlist" and not (self.fused_head or self.fused_l1):
             self.capture_mode = "graph"              # the stock-torch head cannot be recorded
+        if self.capture_mode == "graph" and self.world > 1 and self.fused_l1:
+            self.capture_mode = "cmdlist"            # (the sharded L1 head gathers the global targets INSIDE the step:
+            #                                           a collective cannot sit in a hipGraph, it can in a list)
         self._pool = None
         if self.capture_mode:
             self._record_main()
@@ -1117,6 +1120,10 @@ class FusedTrainStep(object):
 
     def _record_queue(self):
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        # data-parallel, mean engine: the gathers are cut around the exchange (bulk before the join, rest with Adam)
+        self._ddp_split = bool(self.ddp is not None and self.MEAN_ENGINE and not self.emb and
+                               self.size[self.L - 1] > self._tail_rows and
+                               os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
         if getattr(self, "split", False):
             torch.cuda.synchronize()
             self.g_prime = self._record(self._split_prime)
@@ -1129,8 +1136,6 @@ class FusedTrainStep(object):
             if self.ddp is None:
                 self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(2)]
             else:
-                self._ddp_split = bool(self.MEAN_ENGINE and not self.emb and self.size[self.L - 1] > self._tail_rows
-                                       and os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
                 if self._one_list_ddp():
                     # ONE list per step, the exchange a node of it (on the side stream when it overlaps the gathers)
                     self.g_queue = [self._record(lambda par=par: self._queue_step_ddp(par)) for par in range(2)]

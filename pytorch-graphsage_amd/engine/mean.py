@@ -41,7 +41,7 @@ class FusedMeanTrainStep(FusedTrainStep):
     """
 
     MEAN_ENGINE = True
-    TIMED = {"gather": (0, 1), "seed_level": (2, 3)}
+    TIMED = {"gather": (0, 1), "seed_level": (2, 3), "k5": (4, 5), "k5b": (6, 7)}
 
 
     @classmethod
@@ -273,6 +273,8 @@ class FusedMeanTrainStep(FusedTrainStep):
                 if l == 0 and getattr(self, "_k5_gather", None) is not None:
                     # the projection's spare workgroup slots gather part of the NEXT batch's last-hop means
                     nat.check(lib.gsage_gather_role_next(ctypes.addressof(self._k5_gather)), "gather_role_next")
+                if l == 0:
+                    self._time_next(4, 5)
                 ops._linear_packed_launch(xbuf.data_ptr(), lda, rows, int(rows is not None), self.wp[l].data_ptr(), None,
                                           self.hout[l].data_ptr(), 2 * h, R, h, din,
                                           nat.ACT_NONE if last else nat.ACT_RELU, 2, delta // esz, h,
@@ -360,6 +362,8 @@ class FusedMeanTrainStep(FusedTrainStep):
                     probs.append((dc[:, g * h:], xbuf if g == 0 else aggl, lda, 0, R, h, din, h,
                                   self.slabs[l][g], self.wg_target[(l, g)], rows if g == 0 else None))
         for i in range(0, len(probs), 8):
+            if i == 0:
+                self._time_next(6, 7)
             ops.wgrad_multi(probs[i:i + 8])
         self._side_join("k5b")
         self._stage_finalize(s)

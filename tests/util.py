@@ -113,3 +113,74 @@ def build_model(gs, g, p, device="cpu", feats_dtype=None):
     model.optimizer = torch.optim.Adam(model.parameters(), lr=model.lr,
                                        weight_decay=float(g[p + "weight_decay"]))
     return model, feats, task
+
+
+# ---- small models for the data-parallel tests (tests/test_gpu_dist.py, tests/_ddp1_worker.py) ---------------------
+DP_CASES = {
+    # name: (aggregator, prep, task, output dims, fan-outs, storage precision)
+    "mean": ("mean", "identity", "classification", (128, 128), (5, 3), "bf16"),
+    "max_pool": ("max_pool", "identity", "classification", (128, 128), (5, 3), "bf16"),
+    "attention": ("attention", "identity", "classification", (64, 64), (5, 3), "bf16"),
+    "attention_emb": ("attention", "node_embedding", "classification", (64, 64), (4, 3), "fp32"),
+    "attention_emb_mae": ("attention", "node_embedding", "regression_mae", (64, 64), (4, 3), "fp32"),
+    "attention_emb_bf16": ("attention", "node_embedding", "regression_mae", (64, 64), (4, 3), "bf16"),
+    "mean_emb": ("mean", "node_embedding", "classification", (64, 64), (4, 3), "fp32"),
+}
+
+
+def dp_case(gs, case, n_batch=3, global_batch=32, device="cuda"):
+    """-> (model, feats or None, loss_fn, ids [n_batch, global_batch], targets, precision) of DP_CASES[case]: a 500-node
+    graph with empty rows and duplicates, Philox sampler (seed 77), weight decay on."""
+    agg, prep, task, dims, fan, prec = DP_CASES[case]
+    rng = np.random.RandomState(0)
+    n, D, C = 500, 40, 5
+    deg = rng.randint(0, 30, size=n + 1)
+    deg[0], deg[n] = 0, 3
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    data = rng.randint(1, n + 1, size=int(indptr[-1]))
+    adj = sparse.csr_matrix((data, gs.store.row_positions(indptr), indptr), shape=(n + 1, int(deg.max())))
+    emb = prep == "node_embedding"
+    feats = None
+    if not emb:
+        feats = rng.normal(size=(n + 1, D)).astype(np.float32)
+        feats[0] = 0
+    torch.manual_seed(5)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": fan[0], "n_val_samples": fan[0], "output_dim": dims[0], "activation": F.relu},
+             {"n_train_samples": fan[1], "n_val_samples": fan[1], "output_dim": dims[1], "activation": lambda x: x}]
+    cls = task == "classification"
+    model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj,
+                            train_adj=adj, prep_class=gs.prep_lookup[prep],
+                            aggregator_class=gs.aggregator_lookup[agg], input_dim=None if emb else D, n_nodes=n + 1,
+                            n_classes=C if cls else 1, layer_specs=specs, lr_init=0.01, weight_decay=1e-4)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    model.train_sampler.seed = model.val_sampler.seed = 77
+    ids = torch.from_numpy(rng.randint(1, n + 1, size=(n_batch, global_batch)))
+    if cls:
+        tg = torch.from_numpy(rng.randint(0, C, size=(n_batch, global_batch, 1)))
+    else:
+        tg = torch.from_numpy(rng.normal(size=(n_batch, global_batch, 1)).astype(np.float32) * 2)
+    loss_fn = gs.ProblemLosses.classification if cls else gs.ProblemLosses.regression_mae
+    return model.to(device), feats, loss_fn, ids.to(device), tg.to(device), prec
+
+
+def dp_run(gs, case, model, feats, loss_fn, ids, tg, prec, ddp, steps=4, capture=True):
+    """`steps` train steps of the fused engine that covers the case (queue mode with the fused classification head,
+    one call per batch otherwise) -> (predictions [steps, B, C], flat parameters with settled table rows, engine)."""
+    gs.ops.set_compute_dtype(prec)
+    gs.ops.warmup(torch.device("cuda"))
+    store = gs.FeatureStore.from_array(feats, torch.device("cuda"), dtype=prec) if feats is not None else None
+    cls = gs.engine.fused_engine_for(model, store, ddp=ddp)
+    assert cls is not None, gs.engine.why_no_fused_engine(model, store, ddp)
+    eng = cls(model, store, loss_fn, ids[0], tg[0], ddp=ddp, capture=capture)
+    preds = []
+    if eng.fused_head:
+        eng.load_epoch(ids, tg)
+        for _ in range(steps):
+            preds.append(eng.step_queue().clone())
+    else:
+        for k in range(steps):
+            preds.append(eng(ids[k % ids.shape[0]], tg[k % ids.shape[0]]).clone())
+    eng.sync_rows()
+    torch.cuda.synchronize()
+    return torch.stack(preds).cpu(), eng.flat_p.clone().cpu(), eng

@@ -57,6 +57,9 @@ for w in $WHAT; do
       echo "== profx $c rc=$?"
       f=$(find $OUT/profx_$c -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/profx_${c}_kernel_stats.csv && head -30 "$f" | cut -c1-150
       find $OUT/profx_$c -name "*kernel_trace*.csv" -size +20M -delete ;;
+    gemmref)
+      timeout 600 python tools/kbench.py gemmref > $OUT/gemmref.log 2>&1
+      echo "== gemmref rc=$?"; grep gemmref $OUT/gemmref.log ;;
     bench20)
       timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1
       echo "== bench20 rc=$?"; tail -2 $OUT/bench20.log ;;

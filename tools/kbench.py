@@ -233,3 +233,43 @@ if 'wgradcold' in which:
         ops.wgrad_multi([(dC, table, ld, 0, M, Nt, K, Nt, slabs, 240, rows)])
     t0, t1 = timeit(fl, reps=10), timeit(both, reps=10)
     print('wgrad pool cold: fill %.1f us, fill + wgrad %.1f us -> wgrad %.1f us' % (t0, t1, t1 - t0))
+
+if 'gemmref' in which:
+    # Reference point for K3 / K5b (round-3 verdict, item 3): the vendor's bf16 GEMM (torch.mm -> hipBLASLt) at the
+    # max-pool step's two big contractions, warm (operands re-read from the Infinity Cache launch after launch) and
+    # cold (a 1 GB fill between launches: operands come from HBM, as inside the step).  Bench tooling only -- never
+    # a product path.  Writes gpurun_out/gemmref.json.
+    import json
+    Mbig, K, Nh = 128000, 640, 512
+    out = {}
+    A = torch.randn(Mbig, K, device=dev).bfloat16()
+    Wt = torch.randn(K, Nh, device=dev).bfloat16()
+    dC = torch.randn(Mbig, Nh, device=dev).bfloat16()
+    fill = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+    def cold(fn, reps=12):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            fill.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        return float(np.median(ts))
+    shapes = {
+        "k3_fwd  [128000 x 640] x [640 x 512]": (lambda: torch.mm(A, Wt), 2.0 * Mbig * K * Nh),
+        "k5b_mlp [512 x 128000] x [128000 x 640] (dC^T A)": (lambda: torch.mm(dC.t(), A), 2.0 * Mbig * K * Nh),
+        "k5b_mlp, fp32 result (out_dtype)": (lambda: torch.mm(dC.t(), A, out_dtype=torch.float32), 2.0 * Mbig * K * Nh),
+    }
+    for name, (fn, flops) in shapes.items():
+        try:
+            tw = timeit(fn, reps=10)
+            tc = cold(fn)
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+            continue
+        out[name] = {"warm_us": tw, "cold_us": tc, "warm_tflops": flops / tw / 1e6, "cold_tflops": flops / tc / 1e6,
+                     "frac_of_2500_warm": flops / tw / 1e6 / 2500.0, "frac_of_2500_cold": flops / tc / 1e6 / 2500.0}
+        print('gemmref %s: warm %.1f us (%.0f TF/s), cold %.1f us (%.0f TF/s)' % (name, tw, flops / tw / 1e6, tc, flops / tc / 1e6))
+    import os
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(out, open('gpurun_out/gemmref.json', 'w'), indent=1)
