@@ -78,9 +78,10 @@ def test_sort_rows_is_stable_and_segment_sums_are_the_in_order_sums(n0, n_tail, 
     touched = torch.zeros(n_rows, dtype=torch.bool, device=DEV)
     touched[keys] = True
     assert torch.equal(table[~touched], torch.full_like(table[~touched], 7.0))          # stores only where a run is
-    assert torch.allclose(table[touched].double(), ref[touched], rtol=1e-5, atol=1e-5)
-    # the order of additions is the list's: sequential fp32 sums on the host for the longest runs
     uniq, counts = torch.unique(keys, return_counts=True)
+    # (fp32 sums of up to max(counts) terms against float64: the bound grows with the run; bit-exactness is below)
+    assert torch.allclose(table[touched].double(), ref[touched], rtol=1e-5, atol=1e-5 + 2e-6 * int(counts.max()))
+    # the order of additions is the list's: sequential fp32 sums on the host for the longest runs
     rows_cpu, keys_cpu = allrows.cpu().numpy(), keys.cpu().numpy()
     for r in uniq[torch.argsort(counts, descending=True)[:3]].tolist():
         acc = None
