@@ -1,0 +1,104 @@
+"""-m gpu: the HEADLINE configurations checked against the oracle at the size they are benched (round-3 verdict,
+"what's weak" #1): BASELINE configs[1] (mean) and configs[2] (max-pool) on bench.py's Reddit-shaped graph --
+N = 232 965, D = 602 (rows padded to 640), B = 512, fan-out 25/10, hidden 128 -- in the launch mode the bench times
+(command lists, device-resident batch queue, software-pipelined steps: the `k_mean_tail_ce<16,10>` seed level, the
+gather roles, Adam riding in the gather launch), bf16 storage against the rounding-aware oracle and fp32 storage
+against the plain fp32 oracle.  The oracle runs on the frontier's rows relabelled to a compact table (the technique
+of test_gpu_large.py): two consecutive train steps, predictions / gradient norm / weights after each."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from util import close, close_fro, close_update
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops, nat = gs.ops, gs._native
+DEV = "cuda"
+B, FAN, SEED = 512, (25, 10), 123
+
+
+@pytest.fixture(scope="module")
+def reddit():
+    """the bench's Reddit-shaped synthetic graph + features (built once: ~25 s of host time)"""
+    import bench
+    return bench.synthetic_reddit(seed=0)
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    yield
+    ops.set_compute_dtype("bf16")
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+
+
+def _frontier(csr, seeds, batch, L=2):
+    """the queue pipeline's frontier of batch `batch`: hop k is Philox call batch * L + k of the sampler's seed"""
+    cur, hops = seeds, []
+    for k, f in enumerate(FAN):
+        cur = ops.sample_csr(csr, cur, f, philox={"seed": SEED, "call_base": batch * L + k})
+        hops.append(cur)
+    return hops
+
+
+@pytest.mark.parametrize("agg,prec", [("mean", "bf16"), ("mean", "fp32"), ("max_pool", "bf16")])
+def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
+    import bench
+    from oracle import torch_ref as tref
+    data, dev = reddit, torch.device(DEV)
+    ops.set_compute_dtype(prec)
+    store = data["feats"](dev, prec)
+    assert store.dim == 602 and store.ld == 640 and store.data.shape[0] == 232966
+    n_steps = 2
+    rng = np.random.RandomState(17)
+    pick = rng.randint(0, len(data["train_ids"]), size=(n_steps + 2, B))
+    ids = torch.from_numpy(data["train_ids"][pick]).to(dev)
+    tg = torch.from_numpy(data["targets"][data["train_ids"][pick]]).to(dev).view(n_steps + 2, B, 1)
+    torch.manual_seed(11)
+    model = bench.build_model(gs, data["adj"], aggregator=agg, rng="philox", seed=SEED).to(dev)
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    csr = model.train_sampler.csr(dev)
+    eng = gs.engine.fused_engine_for(model, store)(model, store, gs.ProblemLosses.classification, ids[0], tg[0],
+                                                   capture="cmdlist")
+    assert eng.capture_mode == "cmdlist" and eng.fused_head
+    if agg == "mean":
+        assert eng.fused_tail and eng.B == B and eng.fan[1:] == [25, 10]        # k_mean_tail_ce<16, 10> at B = 512
+    eng.load_epoch(ids, tg)
+    preds, norms = [], []
+    before = nat.launch_count()
+    for s in range(n_steps):
+        preds.append(eng.step_queue().detach().float().cpu().numpy().copy())
+        norms.append(float(eng.gnorm.item()))
+        if s == 0:
+            # the pipeline's buffers: batch 1 sampled by the prime launch, batch 2 by step 0's gather launch
+            torch.cuda.synchronize()
+            for b, buf in ((1, eng.ids_q[1]), (2, eng.ids_q[0])):
+                hops = _frontier(csr, ids[b], b)
+                assert torch.equal(buf[B:B + B * 25], hops[0]) and torch.equal(buf[B + B * 25:], hops[1]), b
+    torch.cuda.synchronize()
+    assert nat.launch_count() - before >= 5 * n_steps
+    csr.check()
+    if agg == "mean" and prec == "bf16":
+        assert eng._tail_rows > 0                         # the seed-level launch's gather role is part of the step
+
+    # the oracle on the frontier's rows, relabelled to a compact table, step after step from the same weights
+    w = {k: v.clone() for k, v in w0.items()}
+    opt = tref.Adam()
+    bf = prec == "bf16"
+    for s in range(n_steps):
+        hops = [h.cpu().numpy() for h in _frontier(csr, ids[s], s)]
+        uniq, inv = np.unique(np.concatenate([ids[s].cpu().numpy()] + hops), return_inverse=True)
+        small = store.data[torch.from_numpy(uniq).to(dev), :store.dim].float().cpu()
+        parts = np.split(inv, np.cumsum([B, hops[0].shape[0]]))
+        r = tref.train_step(w, opt, 0.01, "classification", parts[0], small, tg[s].cpu(), None, None, FAN, None, agg,
+                            "identity", 232966, rounding="bf16" if bf else None, frontier=parts[1:])
+        close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *((3e-3, 3e-3) if bf else (2e-4, 2e-4)))
+        assert abs(norms[s] - r["gradnorm"]) <= (5e-3 if bf else 2e-4) * max(1.0, r["gradnorm"]), (s, norms[s], r["gradnorm"])
+    for k, v in model.named_parameters():
+        if bf:
+            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k), 5e-2)
+        else:
+            close_update(v.detach().cpu().numpy(), w[k].numpy(), w0[k].numpy(), ("weights after 2 steps", k))

@@ -179,11 +179,11 @@ def test_three_layer_engine_step_at_papers_scale(n_rows, deg, B, need_gb):
         close_fro(d_eng, d_ref, ("Adam update", k), 5e-2)
 
 
-@pytest.mark.parametrize("capture", ["graph"])
+@pytest.mark.parametrize("capture", ["graph", "cmdlist"])      # (cmdlist: the launch mode bench.py times)
 def test_fused_attention_engine_deferred_rows_at_pokec_scale(capture):
     """The engine bench.py times for BASELINE configs[3], at the size it is timed at: FusedAttnTrainStep over the
     trainable 418 MB embedding table of a Pokec-sized graph (1.63 M nodes), B = 512, fan-out 20/15, regression_mae,
-    DEFERRED row updates, captured as hipGraphs -- four consecutive steps on four batches, then sync_rows().
+    DEFERRED row updates, captured as hipGraphs and as command lists -- four consecutive steps on four batches, then sync_rows().
     Weight decay is on, so the reference's dense Adam moves EVERY row of the table on EVERY step (a row's own
     wd * p is a gradient): rows outside a step's frontier are exactly what the last[] / hist[] replay has to
     get right.  Oracle: oracle/torch_ref.train_step x 4 (fp32, dense Adam) on a compact table holding every row
