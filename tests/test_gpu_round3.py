@@ -339,7 +339,15 @@ def test_fp32_mean_engine_over_the_dense_sampler_replays_reference_train_steps(c
 def _toy_problem(tmp_path, kind, n=900, D=12, C=4):
     rng = np.random.RandomState(0)
     folds = np.array(["train"] * 700 + ["val"] * 150 + ["test"] * (n + 1 - 850))
-    if kind == "dense":                                   # utils/convert.py:71-98: 0-based ids, dummy = last row
+    if kind == "pokec_dense":                             # utils/convert-pokec.py -> problem.h5: dense adjacency, NO features
+        K = 16
+        adj = rng.randint(0, n, size=(n + 1, K))
+        adj[n] = n
+        folds[n] = "dummy"
+        targets = (20.0 + 10.0 * (np.arange(n + 1) % 3)).astype(np.float32).reshape(-1, 1)
+        prob = {"task": "regression_mae", "n_classes": 1, "folds": folds, "targets": targets, "sparse": False,
+                "adj": adj, "train_adj": adj}
+    elif kind == "dense":                                 # utils/convert.py:71-98: 0-based ids, dummy = last row
         K = 16
         adj = rng.randint(0, n, size=(n + 1, K))
         adj[n] = n
@@ -385,6 +393,9 @@ def _run_cli(argv, capsys):
      "FusedMeanTrainStep"),
     ("pokec.sh:5-8", "pokec", ["--aggregator-class", "mean", "--sampler-class", "sparse_uniform_neighbor_sampler",
                                "--prep-class", "node_embedding", "--epochs", "3"], "FusedMeanTrainStep"),
+    # the command behind the reference's only published number (utils/pokec.sh:11-15): DEFAULT dense sampler
+    ("pokec.sh:11-13", "pokec_dense", ["--aggregator-class", "mean", "--prep-class", "node_embedding", "--epochs", "3"],
+     "FusedMeanTrainStep"),
 ])
 def test_reference_run_scripts_reach_the_fused_engines(tmp_path, capsys, script, kind, extra, engine):
     """The argument lists of the reference's run scripts, unchanged (only --problem-path points at a toy problem in
@@ -408,7 +419,7 @@ def test_reference_run_scripts_reach_the_fused_engines(tmp_path, capsys, script,
     assert torch.equal(torch_tail, torch_tail2), "torch's CPU generator ends elsewhere"
     logged2 = [o for o in out2 if "epoch_progress" in o]
     assert [o["epoch_progress"] for o in logged] == [o["epoch_progress"] for o in logged2]
-    if kind == "pokec":
+    if kind.startswith("pokec"):
         a, b = out[-1]["train_metric"], out2[-1]["train_metric"]
         assert abs(a - b) <= 0.15 * abs(b) + 0.5, (a, b)
         assert out[-1]["train_metric"] < logged[0]["train_metric"]            # the MAE falls
