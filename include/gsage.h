@@ -622,6 +622,14 @@ typedef struct gsage_adam_desc {
     int64_t inc1;
     int64_t *tick2;
     int64_t inc2;
+    /* ABI 4, gsage_gather_mean_multi_adam only: the update's workgroups form the squared norm of g THEMSELVES
+     * (n_partial_ready == 0): each writes the partial of the elements it is about to update to norm_slots[its index],
+     * announces itself on *arrive (a device counter, zero-initialised once, never reset) and waits until all have --
+     * they are few (<= 1024, all resident at once, dispatched first) -- then every one of them adds the slots in
+     * index order.  For the data-parallel step: the norm of the AVERAGED gradient exists only after the exchange, and
+     * a launch of its own for it sat on the critical path behind the collective.  norm_slots: >= 1024 floats. */
+    float *norm_slots;
+    uint64_t *arrive;
 } gsage_adam_desc;
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
  * Philox call index and batch-queue index, when nothing in the same launch reads them). */
@@ -638,7 +646,8 @@ int gsage_head_n_valid_next(const int32_t *n_valid);
  * to two short latency-bound jobs riding in the same launch, each a few hundred workgroups that are
  * free next to the HBM-bound gather:
  *   adam (may be NULL)  the clip + Adam update of the CURRENT batch (~8 us alone).  n_partial_ready
- *                       must be > 0 (norm partials from gsage_finalize_grads) and step_is_current != 0.
+ *                       must be > 0 (norm partials from gsage_finalize_grads) -- or 0 with norm_slots / arrive
+ *                       given (the norm is formed inside the launch) -- and step_is_current != 0.
  *   hops (may be NULL)  gsage_sample_hops_philox of the batch AFTER the next one (~9 us alone) into
  *                       its own frontier buffer (hops->ids must not alias the ids being gathered).
  *                       adam's ticks must then not touch hops->call_ctr / hops->batch_idx: address the

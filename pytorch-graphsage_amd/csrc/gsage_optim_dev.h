@@ -66,6 +66,8 @@ struct AdamParams {
     int32_t discard_clipped;       // != 0: the clipped gradient is not written back (the caller zeroes g next)
     int32_t replay_math;           // != 0: the deferred-row arithmetic (adam_update<true>), for a table whose rows
                                    // may also be updated by gsage_rows_*: both must produce the same bits
+    float *norm_slots;             // != null (with arrive): the workgroups form the squared norm themselves
+    unsigned long long *arrive;    // device counter the workgroups meet on (never reset: gx arrivals per launch)
 };
 
 // The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
@@ -113,7 +115,28 @@ template <bool REPLAY_OK = true>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
-    for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
+    if (!REPLAY_OK && a.arrive) {
+        // The norm of a gradient that exists only now (data-parallel: after the exchange), formed by the update's own
+        // workgroups: (1) the partial of the elements THIS workgroup updates, (2) a meeting of the gx workgroups --
+        // they are dispatched first and are few, so all of them are resident --, (3) every workgroup adds the gx
+        // partials in index order: the same bits in every workgroup and on every rank.
+        const int64_t stride1 = (int64_t)gx * 256;
+        float q = 0.f;
+        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride1) { const float g = a.g[i]; q += g * g; }
+        const float mine = block_sum_256(q, red);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.norm_slots + bx, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (old / (unsigned long long)gx + 1ull) * (unsigned long long)gx;
+            while (__hip_atomic_load(a.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        lds_barrier();
+        for (int i = threadIdx.x; i < gx; i += 256)
+            s += __hip_atomic_load(a.norm_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
+    }
     const float sq = block_sum_256(s, red);
     const float total = sqrtf(sq);
     float coef = a.max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
@@ -204,7 +227,8 @@ inline int adam_grid(int64_t items, int cap)
 inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
 {
     GSAGE_REQUIRE(d.p && d.g && d.m && d.v && d.partial && d.lr && d.step, "clip_adam_step: null pointer");
-    GSAGE_REQUIRE(d.n > 0 && d.n_partial_ready > 0 && d.n_prep >= 0, "clip_adam_step: bad sizes");
+    GSAGE_REQUIRE(d.n > 0 && (d.n_partial_ready > 0 || (d.norm_slots && d.arrive)) && d.n_prep >= 0,
+                  "clip_adam_step: bad sizes (norm partials must be ready, or norm_slots / arrive given)");
     a.prep = (const PrepDesc *)d.prep_descs; a.n_prep = d.prep_descs ? d.n_prep : 0;
     a.tick1 = d.tick1; a.inc1 = d.inc1; a.tick2 = d.tick2; a.inc2 = d.inc2;
     a.p = d.p; a.g = d.g; a.m = d.m; a.v = d.v; a.partial = d.partial; a.lr = d.lr; a.step = d.step;
@@ -213,6 +237,9 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.step_off = d.step_is_current ? 0 : 1;
     a.discard_clipped = 0;
     a.replay_math = 0;
+    const bool inside = d.n_partial_ready == 0 && d.norm_slots && d.arrive;
+    a.norm_slots = inside ? d.norm_slots : nullptr;
+    a.arrive = inside ? (unsigned long long *)d.arrive : nullptr;
     return GSAGE_OK;
 }
 

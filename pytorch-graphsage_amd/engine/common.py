@@ -86,7 +86,7 @@ class FusedTrainStep(object):
         from ..problem import ProblemLosses
         C, D2 = model.fc.weight.shape
         post = _split_activation(list(model.agg_layers.children())[-1].activation)[1]
-        probe = torch.randn(3, 4)
+        probe = torch.linspace(-2.0, 2.0, 12).view(3, 4)          # (no draw from torch's generator: the run's own)
         ident = post is None or torch.equal(post(probe), probe)
         if loss_fn is ProblemLosses.classification and ident and C <= 64 and D2 <= 1024 and \
                 example_targets.dtype == torch.int64:
@@ -616,7 +616,21 @@ class FusedTrainStep(object):
         d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
         d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
         d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
+        if self.ddp is not None and self._norm_in_launch():
+            # data-parallel: the norm of the AVERAGED gradient is formed by the update's own workgroups inside the
+            # launch that carries Adam (gsage_adam_desc.norm_slots / arrive) -- no norm launch behind the collective
+            if getattr(self, "_norm_slots", None) is None:
+                self._norm_slots = torch.zeros(1024, dtype=torch.float32, device=self.dev)
+                self._arrive = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            d.norm_slots, d.arrive = self._norm_slots.data_ptr(), self._arrive.data_ptr()
         return d
+
+    def _norm_in_launch(self):
+        """can the launch that carries Adam form the gradient norm itself?  (the mean engine's gather launch; its
+        update workgroups -- one per 1 024 parameters -- must all be resident at once: <= 1 024 of them)"""
+        n_wg = -(-(-(-self.flat_p.numel() // 4)) // 256)
+        return bool(self.MEAN_ENGINE and not self.emb and n_wg <= 1024 and
+                    os.environ.get("GSAGE_DDP_NORM_IN_LAUNCH", "1") == "1")
 
     def _head_live_rows(self):
         """tell the next head launch how many seeds of the batch are live (padded chunks, see _pad_batch)"""
@@ -875,8 +889,10 @@ class FusedTrainStep(object):
         # The table's gradient, deterministically (csrc/gsage_rowsum.hip): the frontier's ids -- every rank's, in a
         # data-parallel run -- are sorted, each run of equal ids is summed in list order and stored (no atomics, no
         # zero-fill), and the norm / Adam passes walk the sorted list (gsage_row_adam.sorted_ids).
-        # GSAGE_SORTED_ROWS=0 (single GPU only): round 3's fp32 atomics (gsage_scatter_add_rows + stamp dedupe).
-        self.sorted_rows = self.ddp is not None or os.environ.get("GSAGE_SORTED_ROWS", "1") != "0"
+        # Single GPU: opt-in (GSAGE_SORTED_ROWS=1) -- the vendor sort of 164 k keys is five short launches (~0.13 ms of
+        # the Pokec-shaped step) where the atomics cost ~0.05; data-parallel: always (replicas
+        # that add the same rows in different orders would drift apart).
+        self.sorted_rows = self.ddp is not None or os.environ.get("GSAGE_SORTED_ROWS", "0") == "1"
         if self.sorted_rows:
             W, B, RA0, ns = self.world, self.B, self.off[self.L + 1], int(self.seed_grad.shape[0])
             n0, n1 = W * (RA0 - B), W * ns
@@ -1246,6 +1262,12 @@ class FusedTrainStep(object):
             self._queue_front(par, True)
             return
         side = self._in_list and self._ddp_overlap()
+        if not side and self._norm_in_launch():
+            # nothing to hide the exchange behind (one rank, or GSAGE_DDP_OVERLAP=0): the single-GPU order -- ONE launch
+            # for the gathers of batch i+1, Adam(i) with the norm formed in the launch, and the sampling of batch i+2
+            self._stage_exchange()
+            self._queue_front(par, True)
+            return
         if side:
             nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
         self._stage_exchange()

@@ -495,13 +495,15 @@ class FusedMeanTrainStep(FusedTrainStep):
                            hops=self._hops_desc(self.ids_q[par], True) if self._k1_early() else None)
 
     def _queue_front_rest(self, par):
-        """after the exchange: squared norm of the averaged gradient, then the rest of the gathers || Adam || K1"""
-        n = self.flat_g.numel()
-        n_sq = nat.lib().gsage_adam_partials(n)
-        nat.check(nat.lib().gsage_grad_sqnorm(self.flat_g.data_ptr(), n, self.partial.data_ptr(), n_sq, ops._stream()),
-                  "grad_sqnorm")
+        """after the exchange: the rest of the gathers || Adam (which forms the norm of the averaged gradient inside
+        the launch) [|| K1, unless it rode with the bulk of the gathers]"""
         d = self._adam_desc()
-        d.n_partial_ready = n_sq
+        if not d.norm_slots:             # (a bucket too large for the in-launch norm: a norm pass of its own)
+            n = self.flat_g.numel()
+            n_sq = nat.lib().gsage_adam_partials(n)
+            nat.check(nat.lib().gsage_grad_sqnorm(self.flat_g.data_ptr(), n, self.partial.data_ptr(), n_sq, ops._stream()),
+                      "grad_sqnorm")
+            d.n_partial_ready = n_sq
         self._stage_gather(self._qset(1 - par), ids=self.ids_q[1 - par], part="rest", adam=d,
                            hops=None if (self.dense or self._k1_early()) else self._hops_desc(self.ids_q[par], True))
         if self.dense:

@@ -75,8 +75,9 @@ def test_eager_fused_eager_keeps_the_trained_weights():
     torch.cuda.synchronize()
     assert model.optimizer.owns()
     for k, v in model.state_dict().items():
-        # one Adam step of lr 0.01 away from the engine's weights, not back at the pre-engine copy
-        assert float((v - after_engine[k]).abs().max()) <= 0.0101, k
+        # one Adam step of lr 0.01 away from the engine's weights, not back at the pre-engine copy (Adam's moments
+        # now continue through all five steps -- eager, 3 x engine, eager --: |m_hat / sqrt(v_hat)| may pass 1 by a little)
+        assert float((v - after_engine[k]).abs().max()) <= 0.011, k
     moved = torch.cat([v.reshape(-1) for v in after_engine.values()])
     assert float((moved - stale).abs().max()) > 0.015      # the engine really had moved them
 

@@ -292,7 +292,7 @@ def test_one_rank_data_parallel_step_equals_the_plain_step(case, overlap):
 # the command behind the reference's only published number (utils/pokec.sh:11-13) through the fused engine
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", [0, 1])
-@pytest.mark.parametrize("table", ["deferred", "dense"])
+@pytest.mark.parametrize("table", ["deferred", "sorted", "dense"])
 @pytest.mark.parametrize("capture", [False, "cmdlist"])
 def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_train_steps(case, table, capture):
     """utils/pokec.sh:11-13 -- the reference's DEFAULT dense sampler + the trainable node-embedding prep (no
@@ -304,8 +304,11 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
     from conftest import load_golden
     from util import close, close_rel, close_update, weights
     os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
+    os.environ.pop("GSAGE_SORTED_ROWS", None)
     if table == "dense":
         os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
+    if table == "sorted":             # the table's gradient by sort + segment sums (what data-parallel runs use)
+        os.environ["GSAGE_SORTED_ROWS"] = "1"
     try:
         g = load_golden("round4_kat.npz")
         p = "q%d_" % case
@@ -328,8 +331,8 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
         cls = gs.engine.fused_engine_for(model, None)
         assert cls is gs.engine.FusedMeanTrainStep
         eng = cls(model, None, gs.ProblemLosses.regression_mae, ids, tg, capture=capture)
-        assert eng.draws == "dense" and eng.emb and eng.fused_l1 and eng.lazy_rows == (table == "deferred")
-        assert eng.tdt == torch.float32 and (not eng.lazy_rows or eng.sorted_rows)
+        assert eng.draws == "dense" and eng.emb and eng.fused_l1 and eng.lazy_rows == (table != "dense")
+        assert eng.tdt == torch.float32 and (not eng.lazy_rows or eng.sorted_rows == (table == "sorted"))
         torch.manual_seed(int(g[p + "torch_seed"]))
         for step in range(2):
             eng.set_progress(0.25 * step)
@@ -351,6 +354,7 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
         model.train_sampler.table(DEV).check()
     finally:
         os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -134,36 +134,42 @@ def test_attention_embedding_engine_deferred_rows_equal_dense_table_updates(capt
     (The two sides differ in the summation order of the table's share of the gradient norm, and the scatter-add
     uses float atomics: 1e-6, not bit-identity.)"""
     res = {}
-    for mode in ("dense", "deferred"):
+    for mode in ("dense", "deferred", "sorted"):
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
         if mode == "dense":
             os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
         else:
             os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
+        if mode == "sorted":          # gradient rows by sort + segment sums (ABI 4; what data-parallel runs use)
+            os.environ["GSAGE_SORTED_ROWS"] = "1"
         ops.set_compute_dtype("fp32")
         model, ids, tg = _emb_model()
         eng = gs.engine.FusedAttnTrainStep(model, None, gs.ProblemLosses.regression_mae, ids[0], tg[0], capture=capture)
-        assert eng.emb and eng.lazy_rows == (mode == "deferred")
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
+        assert eng.emb and eng.lazy_rows == (mode != "dense") and (mode == "dense" or eng.sorted_rows == (mode == "sorted"))
         preds = []
         for s in range(10):
             eng.set_progress(s / 10.0)
             preds.append(eng(ids[s], tg[s]).detach().clone())
-        if mode == "deferred":
+        if mode != "dense":
             assert int(eng.row_last.min()) < 10 and int(eng.row_last.max()) == 10     # rows ARE behind
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-        if mode == "deferred":
+        if mode != "dense":
             assert int(eng.row_last.min()) == 10                                      # state_dict settled them
         nt = eng.n_tab
         res[mode] = (preds, sd, eng.flat_m[:nt].clone(), eng.flat_v[:nt].clone(), float(eng.gnorm.item()))
-    a, b = res["dense"], res["deferred"]
-    for s in range(10):
-        assert torch.allclose(a[0][s], b[0][s], rtol=1e-5, atol=1e-5), s
-    for k in a[1]:
-        # (two DENSE runs differ by up to 3e-6 in the table: atomics order, amplified where Adam's v is tiny)
-        assert torch.allclose(a[1][k], b[1][k], rtol=1e-5, atol=2e-5), (k, float((a[1][k] - b[1][k]).abs().max()))
+    a = res["dense"]
+    for other in ("deferred", "sorted"):
+        b = res[other]
+        for s in range(10):
+            assert torch.allclose(a[0][s], b[0][s], rtol=1e-5, atol=1e-5), (other, s)
+        for k in a[1]:
+            # (two DENSE runs differ by up to 3e-6 in the table: atomics order, amplified where Adam's v is tiny)
+            assert torch.allclose(a[1][k], b[1][k], rtol=1e-5, atol=2e-5), (other, k, float((a[1][k] - b[1][k]).abs().max()))
+        assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-9)
+        assert abs(a[4] - b[4]) <= 1e-5 * max(1.0, a[4])
     moved = (a[1]["prep.embedding.weight"] != _emb_model()[0].state_dict()["prep.embedding.weight"]).any(dim=1)
     assert int(moved.sum()) > 500                      # Adam's moments keep moving rows after their last gradient
-    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-9)
-    assert abs(a[4] - b[4]) <= 1e-5 * max(1.0, a[4])
 
 
 def test_module_forward_settles_deferred_rows():

@@ -60,6 +60,16 @@ for w in $WHAT; do
     gemmref)
       timeout 600 python tools/kbench.py gemmref > $OUT/gemmref.log 2>&1
       echo "== gemmref rc=$?"; grep gemmref $OUT/gemmref.log ;;
+    benchx)
+      # bench.py with caller-chosen arguments: GSAGE_BENCH_ARGS="--extra ddp_1rank,pokec --no-cpu-baseline"
+      timeout 900 python bench.py ${GSAGE_BENCH_ARGS} > $OUT/benchx.log 2>&1
+      echo "== benchx rc=$?"; tail -1 $OUT/benchx.log | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('ms_per_step', d['ms_per_step'])
+for k, v in d.get('extra', {}).items():
+    print(k, {a: (b if not isinstance(b, dict) else {x: y for x, y in b.items() if x in ('ms_per_step', 'error')}) for a, b in v.items() if a in ('ms_per_step', 'overlapped', 'inline', 'error', 'cli_seeds_per_s', 'wall_s')})
+" ;;
     bench20)
       timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1
       echo "== bench20 rc=$?"; tail -2 $OUT/bench20.log ;;
