@@ -475,6 +475,93 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
     return rec
 
 
+def _run_cli(gs, argv, problem):
+    """train.main on a problem held in memory, stdout captured -> (list of JSON lines, wall seconds)"""
+    import contextlib
+    import io
+    train = importlib.import_module("pytorch-graphsage_amd.train")
+    buf, err = io.StringIO(), io.StringIO()
+    t0 = time.time()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
+        train.main(argv, problem=problem)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    lines = [json.loads(ln) for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    engine = [ln for ln in err.getvalue().splitlines() if ln.startswith("gsage:")]
+    return lines, wall, engine
+
+
+def _epoch_rates(lines, n_train, epochs):
+    """seed-nodes/s of the training loop per epoch, from the `time` stamps of the per-batch JSON lines (the first line
+    of an epoch to the last: n_batches - 1 steps, every one followed by its log line and metric readback)"""
+    out = []
+    for e in range(epochs):
+        ts = [ln["time"] for ln in lines if ln.get("epoch") == e and "epoch_progress" in ln]
+        if len(ts) >= 3:
+            out.append(n_train * (len(ts) - 1) / len(ts) / (ts[-1] - ts[0]))
+    return out
+
+
+def extra_cli(gs, dev, data, store):
+    """The drop-in surface itself (round-3 verdict, item 6): the reference's command lines through train.main --
+    --engine auto, the reference's chunks and generators, one JSON line and one device-metric readback PER BATCH
+    (train.py:150-158) -- on problems held in memory (NodeProblem.from_arrays; loading a problem file is not timed).
+      reddit   run.sh:14-17 (sparse sampler, mean) on the bench's Reddit-shaped graph, 2 epochs: seed-nodes/s of the
+               training loop (per-batch log included) beside the engine's own figure
+      pokec    utils/pokec.sh:11-13 (DEFAULT dense sampler, node_embedding, mean, 3 epochs) on a Pokec-shaped problem
+               (1.63 M nodes, K = 128 dense adjacency, 50 / 50 train / val as utils/convert-pokec.py:48): wall seconds
+               of the whole command incl. its three validation passes, beside the reference's published 147.33 s
+               (utils/pokec.sh:15 -- unknown hardware: context, not a baseline)."""
+    out = {}
+    N = data["adj"].shape[0] - 1
+    folds = np.array(["test"] * (N + 1), dtype="<U5")
+    folds[data["train_ids"]] = "train"
+    rest = np.setdiff1d(np.arange(1, N + 1), data["train_ids"])
+    folds[rest[:23_000]] = "val"
+    folds[0] = "dummy"
+    prob = gs.NodeProblem.from_arrays("classification", N_CLASSES, data["adj"], data["adj"], store, folds,
+                                      data["targets"], cuda=True)
+    epochs = 2
+    try:
+        lines, wall, eng = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
+                                         "sparse_uniform_neighbor_sampler", "--epochs", str(epochs)], prob)
+        n_train = int((folds == "train").sum())
+        rates = _epoch_rates(lines, n_train, epochs)
+        out["reddit"] = {"command": "run.sh:14-17 (--aggregator-class mean --sampler-class sparse_uniform_neighbor_sampler), "
+                                    "--epochs %d, defaults otherwise (--engine auto, --rng compat, per-batch JSON)" % epochs,
+                         "engine": eng[-1] if eng else None, "train_nodes": n_train,
+                         "batches_per_epoch": len([ln for ln in lines if ln.get("epoch") == 0 and "epoch_progress" in ln]),
+                         "cli_seeds_per_s": rates[-1] if rates else None, "cli_seeds_per_s_by_epoch": rates,
+                         "wall_s": wall, "val_metric": lines[-1].get("val_metric") if lines else None}
+    except Exception as e:
+        out["reddit"] = {"error": repr(e)}
+    del prob
+    torch.cuda.empty_cache()
+    try:
+        rng = np.random.default_rng(3)
+        Np, K = 1_632_803, 128
+        adj = rng.integers(0, Np, size=(Np + 1, K), dtype=np.int64)
+        adj[Np] = Np
+        targets = rng.normal(25.0, 8.0, size=(Np + 1, 1)).astype(np.float64)
+        pf = rng.choice(np.array(["train", "val"]), size=Np + 1)
+        pf[Np] = "dummy"
+        prob = gs.NodeProblem.from_arrays("regression_mae", None, adj, adj, None, pf, targets, cuda=True)
+        lines, wall, eng = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--prep-class",
+                                         "node_embedding", "--epochs", "3"], prob)
+        n_train = int((pf == "train").sum())
+        rates = _epoch_rates(lines, n_train, 3)
+        out["pokec"] = {"command": "utils/pokec.sh:11-13 (--aggregator-class mean --prep-class node_embedding --epochs 3; "
+                                   "DEFAULT dense sampler), defaults otherwise",
+                        "engine": eng[-1] if eng else None, "train_nodes": n_train, "wall_s": wall,
+                        "cli_seeds_per_s_by_epoch": rates, "final": lines[-1] if lines else None,
+                        "reference_published_wall_s": 147.32675504684448,
+                        "reference_note": "utils/pokec.sh:15, the reference's only published figure: unknown hardware, "
+                                          "real Pokec data -- context only"}
+    except Exception as e:
+        out["pokec"] = {"error": repr(e)}
+    return out
+
+
 def extra_ddp_1rank(args):
     """The data-parallel form of the headline step with a ONE-rank RCCL group on this GPU (GSAGE_FORCE_DDP=1): the
     step as one command list whose exchange is an RCCL call issued by the library (gsage_comm_all_reduce_f32), the
@@ -555,7 +642,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank",
+    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank,cli",
                     help="comma-separated additional configurations measured after the main line (N=1 only) and "
                          "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
                          "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
@@ -737,6 +824,11 @@ def main():
                 extra[agg] = rec
                 del r2
                 torch.cuda.empty_cache()
+            if "cli" in names:
+                try:
+                    extra["cli"] = extra_cli(gs, dev, data, store)
+                except Exception as e:
+                    extra["cli"] = {"error": repr(e)}
             store = None                         # the other shapes bring their own graphs and tables
             torch.cuda.empty_cache()
             for name, fn in (("papers", extra_papers), ("pokec", extra_pokec)):

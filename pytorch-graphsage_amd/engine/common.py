@@ -208,6 +208,11 @@ class FusedTrainStep(object):
         L = self.L = len(self.layers)
         self.post = _split_activation(self.layers[-1].activation)[1]
         self.fan = [1] + [fn.keywords["n_samples"] for fn in model.train_sample_fns]
+        if isinstance(model.train_sampler, UniformNeighborSampler):
+            # the dense sampler keeps `perm[:n_samples]` of the adjacency's K columns (nn_modules.py:43-49): asking for
+            # more than K yields K -- the frontier's real geometry (run.sh:8-10's defaults 25 / 10 on a K = 16 file)
+            K = int(model.train_sampler.adj.size(1))
+            self.fan = [1] + [min(int(n), K) for n in self.fan[1:]]
         B = self.B = int(example_ids.shape[0])
         self.size = [B]
         for k in range(1, L + 1):

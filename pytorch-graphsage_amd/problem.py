@@ -188,6 +188,30 @@ class NodeProblem(object):
         self.metric_fn = getattr(ProblemMetrics, self.task)
         print('NodeProblem: loading finished')
 
+    @classmethod
+    def from_arrays(cls, task, n_classes, adj, train_adj, feats, folds, targets, cuda=True):
+        """The same object from arrays already in memory (the keys of utils/convert.py:192-202): adj / train_adj a
+        scipy csr_matrix in the (v, r, c) convention (sparse problems) or an int array [n + 1, K] (dense), feats a
+        float array / FeatureStore / None.  What bench.py's CLI measurements and the tests use instead of writing a
+        multi-GB problem file first; everything downstream of the loader is the code path of `NodeProblem(path)`."""
+        self = object.__new__(cls)
+        self.task, self.n_classes = str(task), int(n_classes) if n_classes is not None else 1
+        self.feats, self.folds, self.targets = feats, np.asarray(folds), targets
+        self.adj, self.train_adj = adj, train_adj
+        self.feats_dim = feats.shape[1] if feats is not None else None
+        self.n_nodes = self.adj.shape[0]
+        self.cuda = cuda
+        if isinstance(feats, FeatureStore):
+            self.feats = None
+            self._to_device()
+            self.feats = feats
+        else:
+            self._to_device()
+        self.nodes = {mode: np.where(self.folds == mode)[0] for mode in ("train", "val", "test")}
+        self.loss_fn = getattr(ProblemLosses, self.task)
+        self.metric_fn = getattr(ProblemMetrics, self.task)
+        return self
+
     def _to_device(self):
         if not sparse.issparse(self.adj):
             self.adj = torch.LongTensor(np.asarray(self.adj))

@@ -147,7 +147,8 @@ def build_model(args, problem):
         weight_decay=args.weight_decay)
 
 
-def main(argv=None):
+def main(argv=None, problem=None):
+    """problem: a NodeProblem already in memory (NodeProblem.from_arrays) instead of --problem-path's file."""
     args = parse_args(argv)
     set_seeds(args.seed)
     gs.ops.set_compute_dtype(args.precision)
@@ -158,7 +159,8 @@ def main(argv=None):
                                             os.environ.get("GSAGE_HOST_SEL", "0") != "1")
 
     ddp = gs.dist.init_from_env(args.cuda)            # no-op outside torch.distributed.run
-    problem = NodeProblem(problem_path=args.problem_path, cuda=args.cuda)
+    if problem is None:
+        problem = NodeProblem(problem_path=args.problem_path, cuda=args.cuda)
     model = build_model(args, problem)
     if args.cuda:
         model = model.cuda()

@@ -51,7 +51,7 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
     data, dev = reddit, torch.device(DEV)
     ops.set_compute_dtype(prec)
     store = data["feats"](dev, prec)
-    assert store.dim == 602 and store.ld == 640 and store.data.shape[0] == 232966
+    assert store.dim == 602 and store.ld == (640 if prec == "bf16" else 608) and store.data.shape[0] == 232966
     n_steps = 2
     rng = np.random.RandomState(17)
     pick = rng.randint(0, len(data["train_ids"]), size=(n_steps + 2, B))
