@@ -125,11 +125,18 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride1) { const float g = a.g[i]; q += g * g; }
         const float mine = block_sum_256(q, red);
         if (threadIdx.x == 0) {
+            // RELAXED device-scope atomics only, ordered by hand: a release / acquire FENCE at device scope writes back
+            // and invalidates the XCD's whole L2 -- beside a gather role that is filling it with 15 MB of means that
+            // cost ~20 us per launch (measured: the launch took 32 us instead of ~10).  The slot store is itself a
+            // device-scope atomic (write-through); waiting for its acknowledgement before the arrival is announced
+            // is all the ordering the readers need, and they read the slots with device-scope atomic loads.
             __hip_atomic_store(a.norm_slots + bx, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long target = (old / (unsigned long long)gx + 1ull) * (unsigned long long)gx;
-            while (__hip_atomic_load(a.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-                __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
         }
         lds_barrier();
         for (int i = threadIdx.x; i < gx; i += 256)
