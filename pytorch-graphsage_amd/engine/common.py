@@ -434,10 +434,14 @@ class FusedTrainStep(object):
                     os.environ.get("GSAGE_DDP_ONE_LIST", "1") == "1")
 
     def _ddp_overlap(self):
-        """run the exchange on the list's side stream, beside the next batch's gathers?  Default: whenever there is
-        more than one rank (a 1-rank group's "exchange" has nothing to hide: inline).  GSAGE_DDP_OVERLAP=0 / 1."""
-        e = os.environ.get("GSAGE_DDP_OVERLAP", "")
-        return (self.world > 1) if e == "" else (e == "1")
+        """run the exchange on the list's side stream, beside the bulk of the next batch's gathers (GSAGE_DDP_OVERLAP=1)?
+        Default: no -- inline, on the step's own stream.  Measured on the MI355X (profiles/r04_ddp_1rank_timeline_*,
+        DESIGN.md section 6): a fork to the side stream delays the collective's kernel by ~13 us, the fork and the
+        join each leave a ~7 us hole on the main stream, and the launch that follows the join is as long as its Adam
+        role (~19 us: nothing left to hide it behind) -- 46 us of fixed cost to hide at most the ~23 us the bulk of
+        the gathers takes.  Inline, the step is the single-GPU step plus the collective: everything else (Adam with
+        the norm formed in the launch, the sampler) still rides in the ONE gather launch."""
+        return os.environ.get("GSAGE_DDP_OVERLAP", "0") == "1"
 
     # ---- helpers ------------------------------------------------------------------------------
     def _record(self, fn, stream=None):

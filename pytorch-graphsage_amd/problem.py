@@ -113,6 +113,65 @@ class DeviceMetrics:
         return float(out.item())
 
 
+class PendingMetric(object):
+    """problem.metric_fn of one batch, scored on the device with the 8-24 bytes of the result landing in pinned host
+    memory: `get()` waits for THAT batch's event only.  train.py prints the line of batch b after it has issued batch
+    b + 1, so the per-batch log (train.py:150-158: the reference scores every batch on the host) no longer drains the
+    GPU once per step -- same JSON lines, same order, same values.  The finalising workgroup of the metric kernel
+    stores straight into the pinned buffer (host memory mapped into the device's address space: no copy packet on
+    the step's stream); the first use of a process checks that such stores arrive and falls back to a copy if not.
+    Targets with class ids outside [0, C) need the reference's host route (DeviceMetrics._f1): callers with such
+    targets use batch_metric instead."""
+    zero_copy = None                 # None: not probed yet
+
+    def __init__(self, task, y_true, y_pred):
+        from . import _native as nat
+        self.task = task
+        preds = y_pred.detach()
+        assert preds.dtype == torch.float32 and preds.is_contiguous()
+        dev = preds.device
+        n_out = 1 if task == "regression_mae" else 3
+        cls = PendingMetric
+        self._host = torch.full((n_out,), float("nan"), dtype=torch.float64).pin_memory()
+        direct = cls.zero_copy is not False
+        self._out = self._host if direct else torch.empty(n_out, dtype=torch.float64, device=dev)
+        if task == "regression_mae":
+            a = y_true.detach().float().contiguous().view(-1)
+            b = preds.view(-1)
+            assert a.shape == b.shape, "regression_mae: y_true and y_pred must have the same number of elements"
+            self._args = (a,)
+            nat.check(nat.lib().gsage_metric_mae(a.data_ptr(), b.data_ptr(), a.numel(), self._out.data_ptr(),
+                                                 ops._stream()), "metric_mae")
+        else:
+            multilabel = task == "multilabel_classification"
+            B, C = preds.shape
+            f32 = bool(multilabel and y_true.dtype.is_floating_point)
+            y = y_true.detach().contiguous().float() if f32 else y_true.detach().contiguous().long()
+            y = y.view(B, C) if multilabel else y.view(-1)
+            assert y.shape[0] == B
+            self._args = (y, torch.empty(3 * C + 1, dtype=torch.int32, device=dev))
+            nat.check(nat.lib().gsage_metric_f1(preds.data_ptr(), preds.stride(0), y.data_ptr(), int(multilabel), int(f32),
+                                                C if multilabel else 0, B, C, self._args[1].data_ptr(),
+                                                self._out.data_ptr(), ops._stream()), "metric_f1")
+        if not direct:
+            self._host.copy_(self._out, non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+        if cls.zero_copy is None:        # first use: did the kernel's stores reach the pinned buffer?
+            self._ev.synchronize()
+            cls.zero_copy = not bool(torch.isnan(self._host).any())
+            if not cls.zero_copy:
+                again = PendingMetric(task, y_true, y_pred)
+                self._host, self._ev, self._args = again._host, again._ev, again._args
+
+    def get(self):
+        self._ev.synchronize()
+        vals = self._host.tolist()
+        if self.task == "regression_mae":
+            return float(vals[0])
+        return {"micro": float(vals[0]), "macro": float(vals[1])}
+
+
 def batch_metric(task, y_true, y_pred):
     """problem.metric_fn for a batch that may live on the GPU: CUDA tensors are scored by the device
     kernels, anything else by the reference's host route (ProblemMetrics on numpy copies)."""

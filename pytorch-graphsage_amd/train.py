@@ -304,15 +304,39 @@ def train_fused(args, problem, model, ddp, start_time, cls):
             ids, tgs, live = epoch_batches()
         if queued:
             step.load_epoch(ids, tgs, n_valid=live)          # (compat / dense sampler: draws the epoch's values)
+        # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right
+        # behind its step, its result travels to pinned memory, and its line is printed once batch b + 1 has been
+        # issued -- same lines, same order, same values; the GPU never waits for the log.
+        pending = []
+        # (class ids outside [0, C) are scored the reference's way, on the host: the synchronous route)
+        tg_ok = problem.task != 'classification' or (int(np.min(problem.targets)) >= 0 and
+                                                     int(np.max(problem.targets)) < problem.n_classes)
+
+        def flush(keep):
+            nonlocal train_metric
+            while len(pending) > keep:
+                prog, metric = pending.pop(0)
+                train_metric = metric.get()
+                print(dumps({"epoch": epoch, "epoch_progress": prog, "train_metric": train_metric,
+                             "val_metric": val_metric, "time": time() - start_time}))
+            if keep == 0:
+                sys.stdout.flush()
         for b in range(n_batches):
             nb = live[b] if live is not None else B
             step.set_progress((epoch + b / n_batches) / args.epochs)
             preds = step.step_queue() if queued else step(ids[b, :nb], tgs[b, :nb])
             if (b % every == 0 or b == n_batches - 1) and rank == 0:
-                train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
-                print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
-                             "val_metric": val_metric, "time": time() - start_time}))
-                sys.stdout.flush()
+                if tg_ok and preds.dtype == torch.float32 and preds.is_contiguous():
+                    pending.append((b / n_batches, gs.problem.PendingMetric(problem.task, tgs[b, :nb].view(nb, -1),
+                                                                            preds[:nb])))
+                else:
+                    flush(0)
+                    train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
+                    print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
+                                 "val_metric": val_metric, "time": time() - start_time}))
+                    sys.stdout.flush()
+            flush(1)
+        flush(0)
         model.eval()
         val_metric = evaluate(model, problem, mode='val')
     gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host

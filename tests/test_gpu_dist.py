@@ -36,6 +36,9 @@ def _worker(rank, world, port, out_dir, case, capture):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world),
                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GSAGE_DIST_BACKEND": "gloo"})
+    if capture == "cmdlist+overlap":          # the exchange on the list's side stream, beside the bulk of the gathers
+        os.environ["GSAGE_DDP_OVERLAP"] = "1"
+        capture = "cmdlist"
     gs = pkg()
     ddp = gs.dist.init_from_env(cuda=True)
     assert ddp is not None and ddp.world == world and ddp.comm is None
@@ -53,6 +56,7 @@ def _worker(rank, world, port, out_dir, case, capture):
 @pytest.mark.parametrize("case,capture", [("mean", "cmdlist"), ("max_pool", "cmdlist"), ("attention", "cmdlist"),
                                           ("attention_emb", "cmdlist"), ("attention_emb_mae", "cmdlist"),
                                           ("attention_emb_bf16", "cmdlist"), ("mean_emb", "cmdlist"),
+                                          ("mean", "cmdlist+overlap"), ("max_pool", "cmdlist+overlap"),
                                           ("mean", "graph"), ("mean", False), ("attention_emb_mae", False)])
 def test_two_rank_engine_equals_single_process_global_batch(tmp_path, case, capture):
     gs = pkg()
@@ -62,7 +66,7 @@ def test_two_rank_engine_equals_single_process_global_batch(tmp_path, case, capt
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), case, capture), nprocs=2, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "r0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "r1.pt"))
-    assert r0["one_list"] == (capture == "cmdlist")
+    assert r0["one_list"] == (capture in ("cmdlist", "cmdlist+overlap"))
     assert torch.equal(r0["w"], r1["w"]), "replicas diverged: %g" % float((r0["w"] - r1["w"]).abs().max())
     got = torch.cat([r0["preds"], r1["preds"]], dim=1)
     tol = 2e-5 if prec == "fp32" else 3e-3
