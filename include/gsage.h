@@ -623,13 +623,14 @@ typedef struct gsage_adam_desc {
     int64_t *tick2;
     int64_t inc2;
     /* ABI 4, gsage_gather_mean_multi_adam only: the update's workgroups form the squared norm of g THEMSELVES
-     * (n_partial_ready == 0): each writes the partial of the elements it is about to update to norm_slots[its index],
-     * announces itself on *arrive (a device counter, zero-initialised once, never reset) and waits until all have --
-     * they are few (<= 1024, all resident at once, dispatched first) -- then every one of them adds the slots in
-     * index order.  For the data-parallel step: the norm of the AVERAGED gradient exists only after the exchange, and
-     * a launch of its own for it sat on the critical path behind the collective.  norm_slots: >= 1024 floats. */
-    float *norm_slots;
-    uint64_t *arrive;
+     * (n_partial_ready == 0 and norm_slots given).  They are few (one per 1 024 elements, <= 1 024 of them, dispatched
+     * first, all resident at once).  Each loads the elements it is about to update, publishes their partial as
+     * norm_slots[its index] = (update number << 32 | float bits) with ONE device-scope store, and polls the slots of
+     * the others until all carry this update's number; every workgroup then adds the same partials in the same order.
+     * No counter, no reset between launches (*step must change from launch to launch: it is the update number).  For
+     * the data-parallel step: the norm of the AVERAGED gradient exists only after the exchange, and a launch of its
+     * own for it sat on the critical path behind the collective.  norm_slots: >= 1 024 x 8 bytes, zero-initialised. */
+    uint64_t *norm_slots;
 } gsage_adam_desc;
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
  * Philox call index and batch-queue index, when nothing in the same launch reads them). */
@@ -646,8 +647,8 @@ int gsage_head_n_valid_next(const int32_t *n_valid);
  * to two short latency-bound jobs riding in the same launch, each a few hundred workgroups that are
  * free next to the HBM-bound gather:
  *   adam (may be NULL)  the clip + Adam update of the CURRENT batch (~8 us alone).  n_partial_ready
- *                       must be > 0 (norm partials from gsage_finalize_grads) -- or 0 with norm_slots / arrive
- *                       given (the norm is formed inside the launch) -- and step_is_current != 0.
+ *                       must be > 0 (norm partials from gsage_finalize_grads) -- or 0 with norm_slots given
+ *                       (the norm is formed inside the launch) -- and step_is_current != 0.
  *   hops (may be NULL)  gsage_sample_hops_philox of the batch AFTER the next one (~9 us alone) into
  *                       its own frontier buffer (hops->ids must not alias the ids being gathered).
  *                       adam's ticks must then not touch hops->call_ctr / hops->batch_idx: address the

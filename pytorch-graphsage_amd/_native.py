@@ -210,7 +210,7 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
                 ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
                 ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
                 ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64),
-                ("norm_slots", _vp), ("arrive", _vp)]
+                ("norm_slots", _vp)]
 
 
 class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)

@@ -495,8 +495,9 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
         if (rc != GSAGE_OK) return rc;
         n_adam = adam_grid(a.n_prep > 0 ? ceil_div(adam->n, 4) : adam->n, 2048);
         // (the in-launch norm is a meeting of the update's workgroups: all of them must be resident at once)
-        GSAGE_REQUIRE(!a.arrive || n_adam <= 1024, "gather_mean_multi_adam: too many update workgroups (%d) for the "
-                                                  "in-launch norm; pass norm partials instead", n_adam);
+        GSAGE_REQUIRE(!a.norm_slots || (n_adam <= 1024 && a.n_prep > 0 && (int64_t)n_adam * 1024 >= adam->n),
+                      "gather_mean_multi_adam: the in-launch norm needs <= 1024 update workgroups covering the bucket in "
+                      "one trip (got %d); pass norm partials instead", n_adam);
         GSAGE_REQUIRE(!hops || (adam->tick1 != (int64_t *)hops->call_ctr && adam->tick2 != (int64_t *)hops->batch_idx) ||
                       (!adam->tick1 && !adam->tick2),
                       "gather_mean_multi_adam: the update may not tick a counter the sampler reads");

@@ -773,7 +773,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay; d.max_norm = max_norm;
     d.norm_out = norm_out; d.step_is_current = step_is_current; d.n_partial_ready = n_partial_ready;
     d.prep_descs = prep_descs; d.n_prep = n_prep; d.tick1 = tick1; d.inc1 = inc1; d.tick2 = tick2;
-    d.inc2 = inc2; d.norm_slots = nullptr; d.arrive = nullptr;
+    d.inc2 = inc2; d.norm_slots = nullptr;
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
     hipStream_t s = (hipStream_t)stream;

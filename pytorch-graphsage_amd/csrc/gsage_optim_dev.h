@@ -66,8 +66,7 @@ struct AdamParams {
     int32_t discard_clipped;       // != 0: the clipped gradient is not written back (the caller zeroes g next)
     int32_t replay_math;           // != 0: the deferred-row arithmetic (adam_update<true>), for a table whose rows
                                    // may also be updated by gsage_rows_*: both must produce the same bits
-    float *norm_slots;             // != null (with arrive): the workgroups form the squared norm themselves
-    unsigned long long *arrive;    // device counter the workgroups meet on (never reset: gx arrivals per launch)
+    unsigned long long *norm_slots;   // != null: the workgroups form the squared norm themselves (slot = update << 32 | partial)
 };
 
 // The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
@@ -115,32 +114,40 @@ template <bool REPLAY_OK = true>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
-    if (!REPLAY_OK && a.arrive) {
+    // the first (with the in-launch norm: the only) trip's operands, requested before anything else
+    const int64_t stride = (int64_t)gx * 256;
+    const int64_t i_first = (int64_t)bx * 256 + threadIdx.x;
+    float gv0[4], pv0[4], mv0[4], vv0[4];
+    const bool meet = !REPLAY_OK && a.norm_slots != nullptr;
+    if (meet) {
         // The norm of a gradient that exists only now (data-parallel: after the exchange), formed by the update's own
-        // workgroups: (1) the partial of the elements THIS workgroup updates, (2) a meeting of the gx workgroups --
-        // they are dispatched first and are few, so all of them are resident --, (3) every workgroup adds the gx
-        // partials in index order: the same bits in every workgroup and on every rank.
-        const int64_t stride1 = (int64_t)gx * 256;
+        // workgroups.  They are dispatched first and are few, so all of them are resident: each publishes the partial
+        // of the elements it updates with ONE device-scope store tagged with the update number, every thread polls
+        // one slot until it carries that number, and all workgroups add the same partials in the same order (the
+        // same bits in every workgroup and on every rank).  RELAXED device-scope atomics only -- a release / acquire
+        // FENCE at device scope writes back / invalidates the XCD's whole L2 beside a gather role that is filling
+        // it (measured: 32 us per launch) -- and no counter: the tag makes a slot's value self-describing.
         float q = 0.f;
-        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < a.n; i += stride1) { const float g = a.g[i]; q += g * g; }
-        const float mine = block_sum_256(q, red);
-        if (threadIdx.x == 0) {
-            // RELAXED device-scope atomics only, ordered by hand: a release / acquire FENCE at device scope writes back
-            // and invalidates the XCD's whole L2 -- beside a gather role that is filling it with 15 MB of means that
-            // cost ~20 us per launch (measured: the launch took 32 us instead of ~10).  The slot store is itself a
-            // device-scope atomic (write-through); waiting for its acknowledgement before the arrival is announced
-            // is all the ordering the readers need, and they read the slots with device-scope atomic loads.
-            __hip_atomic_store(a.norm_slots + bx, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long target = (old / (unsigned long long)gx + 1ull) * (unsigned long long)gx;
-            while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-                __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i_first + u * stride;
+            const int64_t ic = i < a.n ? i : i_first < a.n ? i_first : 0;
+            gv0[u] = a.g[ic]; pv0[u] = a.p[ic]; mv0[u] = a.m[ic]; vv0[u] = a.v[ic];
+            if (i < a.n) q += gv0[u] * gv0[u];
         }
-        lds_barrier();
-        for (int i = threadIdx.x; i < gx; i += 256)
-            s += __hip_atomic_load(a.norm_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float mine = block_sum_256(q, red);
+        const unsigned long long tag = (unsigned long long)(uint32_t)(*a.step + a.step_off) << 32;
+        if (threadIdx.x == 0)
+            __hip_atomic_store(a.norm_slots + bx, tag | (unsigned long long)__float_as_uint(mine), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < gx; i += 256) {
+            unsigned long long v = __hip_atomic_load(a.norm_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((v >> 32) != (tag >> 32)) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(a.norm_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s += __uint_as_float((uint32_t)v);
+        }
     } else {
         for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
     }
@@ -156,7 +163,6 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         if (a.tick2) *a.tick2 += a.inc2;
     }
 
-    const int64_t stride = (int64_t)gx * 256;
     const bool clipped = coef < 1.f && !a.discard_clipped;   // (block-uniform) unclipped gradients are not rewritten
     if (a.n_prep == 0 && (a.n & 3) == 0 &&
         ((((uintptr_t)a.p | (uintptr_t)a.g | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0)) {
@@ -186,10 +192,14 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
     }
     // four elements per thread and trip, their 16 loads in flight together: a quarter of the workgroups
     // (each a chain of dependent round trips: partials -> norm -> loads -> stores) for the same update
-    for (int64_t i0 = (int64_t)bx * 256 + threadIdx.x; i0 < a.n; i0 += 4 * stride) {
+    for (int64_t i0 = i_first; i0 < a.n; i0 += 4 * stride) {
         float gv[4], pv[4], mv[4], vv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (meet) {      // (one trip: the host admits the in-launch norm only when gx * 1 024 covers the bucket)
+                gv[u] = gv0[u]; pv[u] = pv0[u]; mv[u] = mv0[u]; vv[u] = vv0[u];
+                continue;
+            }
             const int64_t i = i0 + u * stride;
             const int64_t ic = i < a.n ? i : i0;
             gv[u] = a.g[ic]; pv[u] = a.p[ic]; mv[u] = a.m[ic]; vv[u] = a.v[ic];
@@ -234,8 +244,8 @@ inline int adam_grid(int64_t items, int cap)
 inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
 {
     GSAGE_REQUIRE(d.p && d.g && d.m && d.v && d.partial && d.lr && d.step, "clip_adam_step: null pointer");
-    GSAGE_REQUIRE(d.n > 0 && (d.n_partial_ready > 0 || (d.norm_slots && d.arrive)) && d.n_prep >= 0,
-                  "clip_adam_step: bad sizes (norm partials must be ready, or norm_slots / arrive given)");
+    GSAGE_REQUIRE(d.n > 0 && (d.n_partial_ready > 0 || d.norm_slots) && d.n_prep >= 0,
+                  "clip_adam_step: bad sizes (norm partials must be ready, or norm_slots given)");
     a.prep = (const PrepDesc *)d.prep_descs; a.n_prep = d.prep_descs ? d.n_prep : 0;
     a.tick1 = d.tick1; a.inc1 = d.inc1; a.tick2 = d.tick2; a.inc2 = d.inc2;
     a.p = d.p; a.g = d.g; a.m = d.m; a.v = d.v; a.partial = d.partial; a.lr = d.lr; a.step = d.step;
@@ -244,9 +254,8 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.step_off = d.step_is_current ? 0 : 1;
     a.discard_clipped = 0;
     a.replay_math = 0;
-    const bool inside = d.n_partial_ready == 0 && d.norm_slots && d.arrive;
-    a.norm_slots = inside ? d.norm_slots : nullptr;
-    a.arrive = inside ? (unsigned long long *)d.arrive : nullptr;
+    const bool inside = d.n_partial_ready == 0 && d.norm_slots;
+    a.norm_slots = inside ? (unsigned long long *)d.norm_slots : nullptr;
     return GSAGE_OK;
 }
 

@@ -627,11 +627,10 @@ class FusedTrainStep(object):
         d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
         if self.ddp is not None and self._norm_in_launch():
             # data-parallel: the norm of the AVERAGED gradient is formed by the update's own workgroups inside the
-            # launch that carries Adam (gsage_adam_desc.norm_slots / arrive) -- no norm launch behind the collective
+            # launch that carries Adam (gsage_adam_desc.norm_slots) -- no norm launch behind the collective
             if getattr(self, "_norm_slots", None) is None:
-                self._norm_slots = torch.zeros(1024, dtype=torch.float32, device=self.dev)
-                self._arrive = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            d.norm_slots, d.arrive = self._norm_slots.data_ptr(), self._arrive.data_ptr()
+                self._norm_slots = torch.zeros(1024, dtype=torch.int64, device=self.dev)
+            d.norm_slots = self._norm_slots.data_ptr()
         return d
 
     def _norm_in_launch(self):
@@ -1057,8 +1056,11 @@ class FusedTrainStep(object):
     # ---- per-batch entry --------------------------------------------------------------------------
     def set_progress(self, progress):
         self.model.lr = self.model.lr_scheduler(progress)
-        self.lr.fill_(float(self.model.lr))
-        self._user_dirty = True           # split mode: the chain stream must see this write
+        lr = float(self.model.lr)
+        if lr != getattr(self, "_lr_host", None):      # (a constant schedule costs no launch per batch)
+            self._lr_host = lr
+            self.lr.fill_(lr)
+            self._user_dirty = True       # split mode: the chain stream must see this write
 
     def set_sel(self, sels):
         """Replace the Philox draws of the sampler by caller-supplied ones for the following steps

@@ -123,6 +123,7 @@ class PendingMetric(object):
     Targets with class ids outside [0, C) need the reference's host route (DeviceMetrics._f1): callers with such
     targets use batch_metric instead."""
     zero_copy = None                 # None: not probed yet
+    _pool = {}
 
     def __init__(self, task, y_true, y_pred):
         from . import _native as nat
@@ -132,7 +133,16 @@ class PendingMetric(object):
         dev = preds.device
         n_out = 1 if task == "regression_mae" else 3
         cls = PendingMetric
-        self._host = torch.full((n_out,), float("nan"), dtype=torch.float64).pin_memory()
+        # (pinned buffer, count buffer, event) triples are recycled: no allocation per batch on the host
+        self._key = (task, int(preds.shape[1]) if preds.dim() == 2 else 1, str(dev))
+        pool = cls._pool.setdefault(self._key, [])
+        if pool:
+            self._host, self._counts, self._ev = pool.pop()
+            self._host.fill_(float("nan"))
+        else:
+            self._host = torch.full((n_out,), float("nan"), dtype=torch.float64).pin_memory()
+            self._counts = None
+            self._ev = torch.cuda.Event()
         direct = cls.zero_copy is not False
         self._out = self._host if direct else torch.empty(n_out, dtype=torch.float64, device=dev)
         if task == "regression_mae":
@@ -149,24 +159,26 @@ class PendingMetric(object):
             y = y_true.detach().contiguous().float() if f32 else y_true.detach().contiguous().long()
             y = y.view(B, C) if multilabel else y.view(-1)
             assert y.shape[0] == B
-            self._args = (y, torch.empty(3 * C + 1, dtype=torch.int32, device=dev))
+            if self._counts is None:
+                self._counts = torch.empty(3 * C + 1, dtype=torch.int32, device=dev)
+            self._args = (y,)
             nat.check(nat.lib().gsage_metric_f1(preds.data_ptr(), preds.stride(0), y.data_ptr(), int(multilabel), int(f32),
-                                                C if multilabel else 0, B, C, self._args[1].data_ptr(),
+                                                C if multilabel else 0, B, C, self._counts.data_ptr(),
                                                 self._out.data_ptr(), ops._stream()), "metric_f1")
         if not direct:
             self._host.copy_(self._out, non_blocking=True)
-        self._ev = torch.cuda.Event()
         self._ev.record()
         if cls.zero_copy is None:        # first use: did the kernel's stores reach the pinned buffer?
             self._ev.synchronize()
             cls.zero_copy = not bool(torch.isnan(self._host).any())
             if not cls.zero_copy:
                 again = PendingMetric(task, y_true, y_pred)
-                self._host, self._ev, self._args = again._host, again._ev, again._args
+                self._host, self._ev, self._args, self._counts = again._host, again._ev, again._args, again._counts
 
     def get(self):
         self._ev.synchronize()
         vals = self._host.tolist()
+        PendingMetric._pool.setdefault(self._key, []).append((self._host, self._counts, self._ev))
         if self.task == "regression_mae":
             return float(vals[0])
         return {"micro": float(vals[0]), "macro": float(vals[1])}
