@@ -196,7 +196,7 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
 
 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_launches.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_launches.json", "r03_pmc_launches.json")]
 TIMING_METHOD = ("HIP start/stop events attached to the launch's dispatch inside the step's command list "
                  "(hipExtLaunchKernel), one read per step")
 
@@ -223,16 +223,18 @@ def timed_launches(eng, run_step, n_steps=48):
 
 def pmc_traffic(key):
     """HBM bytes per launch of a timed kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
-    and WRITE_SIZE in separate passes, the guide's gfx950 corrections, a calibration copy per pass):
-    profiles/r03_pmc_launches.json, written by tools/refresh_profiles.py from the same bench command."""
-    if not os.path.exists(PMC_FILE):
-        return None, None, None
-    with open(PMC_FILE) as f:
-        rec = json.load(f).get(key)
-    if not rec:
-        return None, None, None
-    return rec.get("hbm_read_bytes_per_launch"), rec.get("hbm_write_bytes_per_launch"), \
-        "profiles/r03_pmc_launches.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" % key
+    and WRITE_SIZE in separate passes, the guide's gfx950 corrections, a calibration copy per pass): the newest
+    profiles/rNN_pmc_launches.json that holds the key (written by tools/refresh_profiles.py from the same bench
+    command; a kernel that did not change keeps the round it was last profiled in)."""
+    for path in PMC_FILES:
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rec = json.load(f).get(key)
+        if rec:
+            return rec.get("hbm_read_bytes_per_launch"), rec.get("hbm_write_bytes_per_launch"), \
+                "profiles/%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)" % (os.path.basename(path), key)
+    return None, None, None
 
 
 def hbm_roofline(kernel, alg_bytes, us, pmc_key, n_steps, **more):
@@ -533,6 +535,13 @@ def extra_cli(gs, dev, data, store):
                          "batches_per_epoch": len([ln for ln in lines if ln.get("epoch") == 0 and "epoch_progress" in ln]),
                          "cli_seeds_per_s": rates[-1] if rates else None, "cli_seeds_per_s_by_epoch": rates,
                          "wall_s": wall, "val_metric": lines[-1].get("val_metric") if lines else None}
+        # the same run with a line every 100 000 batches only (--engine fused honours --log-interval): the loop itself
+        lines2, wall2, _eng2 = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
+                                             "sparse_uniform_neighbor_sampler", "--epochs", str(epochs), "--engine", "fused",
+                                             "--log-interval", "100000"], prob)
+        ts = [ln["time"] for ln in lines2 if "epoch_progress" in ln]
+        if len(ts) >= 4:      # (first and last batch of every epoch are logged: last epoch = ts[-2] .. ts[-1])
+            out["reddit"]["cli_seeds_per_s_without_per_batch_log"] = n_train * (299.0 / 300.0) / (ts[-1] - ts[-2])
     except Exception as e:
         out["reddit"] = {"error": repr(e)}
     del prob
