@@ -192,6 +192,16 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.emb:
             self._init_emb_optimizer()
 
+    def _fin_in_launch(self):
+        """Single GPU, queue mode: the gradient finalisation rides in the gather launch (its workgroups go first, the
+        update's workgroups poll their slots): four launches per step instead of five.  Needs the gather launch to
+        exist and to carry Adam (feature-store input, not the dense sampler's separate path), and every side
+        workgroup resident at once.  GSAGE_FIN_IN_LAUNCH=0: the finalisation as a launch of its own."""
+        if self.ddp is not None or self.emb or self.queue is None or getattr(self, "split", False):
+            return False
+        n_side = self.n_rdesc * min(-(-self.r_max // 256), 256) + min(-(-(-(-self.flat_p.numel() // 4)) // 256), 2048)
+        return bool(n_side <= 1536 and os.environ.get("GSAGE_FIN_IN_LAUNCH", "1") == "1")
+
     def _wg_target(self):
         """K5b workgroups to plan for: the chip, or the chain's share of it in split mode."""
         if not self.gather_cus:
@@ -364,6 +374,8 @@ class FusedMeanTrainStep(FusedTrainStep):
         for i in range(0, len(probs), 8):
             if i == 0:
                 self._time_next(6, 7)
+            if self._fin_fused and i + 8 >= len(probs):
+                self._finalize_ticks_next()      # (no finalisation launch: the last K5b launch ticks the step's counters)
             ops.wgrad_multi(probs[i:i + 8])
         self._side_join("k5b")
         self._stage_finalize(s)
