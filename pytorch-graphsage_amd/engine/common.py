@@ -182,6 +182,8 @@ class FusedTrainStep(object):
         self.world = int(ddp.world) if ddp is not None else 1
         self.comm = getattr(ddp, "comm", None) if ddp is not None else None
         self._host_cbs = []                       # ctypes callbacks recorded into lists (kept alive with the engine)
+        self._fin_fused = False                   # True while a queue step is issued whose finalisation rides with Adam
+        self._fin_slots = self._norm_slots = None
         self._front_ready, self._qstep = False, 0
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
         self._tail_gather, self._tail_rows = None, 0
