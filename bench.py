@@ -574,12 +574,12 @@ def extra_cli(gs, dev, data, store):
 def extra_ddp_1rank(args):
     """The data-parallel form of the headline step with a ONE-rank RCCL group on this GPU (GSAGE_FORCE_DDP=1): the
     step as one command list whose exchange is an RCCL call issued by the library (gsage_comm_all_reduce_f32), the
-    norm of the averaged gradient a pass of its own and Adam behind it -- once in the order a multi-GPU run uses (the
-    exchange on the list's side stream beside the next batch's gathers: GSAGE_DDP_OVERLAP=1) and once inline.  What
-    the driver's 1-GPU box can record of the multi-GPU tax, every round; the process group lives in a child
-    process."""
+    norm of the averaged gradient formed inside the launch that carries Adam -- in the order data-parallel runs use
+    (inline) and in the opt-in order with the exchange on the list's side stream beside the next batch's gathers
+    (GSAGE_DDP_OVERLAP=1).  What the driver's 1-GPU box can record of the multi-GPU tax, every round; the process
+    group lives in a child process."""
     out = {}
-    for name, ov in (("overlapped", "1"), ("inline", "0")):
+    for name, ov in (("inline", "0"), ("overlapped", "1")):
         env = dict(os.environ)
         env.update({"GSAGE_FORCE_DDP": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(_free_port()), "GSAGE_DDP_OVERLAP": ov, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
@@ -595,8 +595,10 @@ def extra_ddp_1rank(args):
                          "kernel_launches_per_step": line["config"].get("kernel_launches_per_step")}
         except Exception as e:
             out[name] = {"error": repr(e)}
-    out["config"] = ("BASELINE configs[1] step with a 1-rank RCCL group (GSAGE_FORCE_DDP=1): `overlapped` is the order "
-                     "multi-GPU runs use, `inline` what a 1-rank group gets by default")
+    out["config"] = ("BASELINE configs[1] step with a 1-rank RCCL group (GSAGE_FORCE_DDP=1): `inline` is the order "
+                     "data-parallel runs use (the collective on the step's own stream, Adam with the norm formed in the "
+                     "gather launch), `overlapped` the opt-in order with the collective on the list's side stream "
+                     "(GSAGE_DDP_OVERLAP=1: measured slower on this platform, DESIGN.md section 6)")
     return out
 
 

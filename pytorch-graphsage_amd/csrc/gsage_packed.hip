@@ -468,241 +468,6 @@ drain:
     }
 }
 
-// ---- K3 with BOTH operands through LDS: eight waves on a 128-row x 256-column workgroup tile ---------------------
-// k_pool_mlp_packed is bound by the bytes a CU's vector-memory path moves per MFMA: every wave
-// fetches its own 8 KiB of W fragments per k-tile for 64 rows of output.  Here the workgroup's two 64-row sub-tiles
-// (wave quartets q = 0, 1; quartet-local wave = column group) share ONE copy of the k-tile's W in LDS -- the packed
-// fragments are 1 KiB contiguous per lane set, so one LDS-DMA instruction moves a fragment and a wave reads it back at
-// lane x 16 bytes, conflict free -- 16 + 32 KiB per k-tile for eight waves instead of 2 x 40.
-// Loads complete in order PER WAVE, so the two operands are fetched by different waves: quartet 0 issues the A rows
-// (random table rows: HBM latency, a ring of five k-tiles, four in flight), quartet 1 the W fragments (L2 resident: a
-// ring of two).  One barrier per k-tile:
-//     lgkmcnt(0) [fragments of tile kt in registers]  vmcnt [my DMAs of tile kt+1 landed]  s_barrier
-//     issue A(kt+5) / W(kt+2) into the buffers tile kt just left  |  ds_read the fragments of tile kt+1 (second
-//     register set)  |  16 MFMAs of tile kt
-// so LDS reads (128 KiB per k-tile and CU, as long as the MFMAs take) run under the MFMAs of the same wave, and the two
-// waves of a SIMD (same column group, the two quartets) share its matrix pipe.  The epilogue is k_pool_mlp_packed's,
-// run by each quartet on its own 67.5 KiB output tile.
-// STATUS (round 3): bit-identical to k_pool_mlp_packed, 38 % fewer L2 requests -- and SLOWER at Reddit's last hop (155 vs
-// 130 us): one workgroup per CU whose eight waves meet at one barrier per k-tile leaves the matrix pipes as idle as
-// before (SQ counters: 27 % issuing, 38 % issue-stalled, 35 % parked).  Not selected; GSAGE_K3_LDS=1 runs it (parity
-// test: tests/test_gpu_round3.py).  What it still lacks is the two quartets running a k-tile apart.
-constexpr int PL_NBA = 5;                                  // A stages (2 sub-tiles x 8 KiB) in the LDS ring
-constexpr int PL_NBW = 2;                                  // W stages (32 KiB)
-constexpr int PL_ASTAGE = 2 * BM * CH;                     // vec16 slots
-constexpr int PL_WSTAGE = 32 * 64;
-
-__global__ void __launch_bounds__(512)
-k_pool_mlp_lds(const PoolPackedParams p)
-{
-    constexpr int EPC = 8;
-    constexpr int PK_BN = 256;
-    constexpr int PK_LDT = PK_BN + 8;
-    constexpr int ATILE = BM * CH;
-    constexpr int LDS_SLOTS = PL_NBA * PL_ASTAGE + PL_NBW * PL_WSTAGE;
-    static_assert(LDS_SLOTS * 16 >= 2 * BM * PK_LDT * 4, "the rings must cover both output tiles");
-    __shared__ vec16 smem[LDS_SLOTS];                    // 144 KiB
-    vec16 *const ringA = smem, *const ringW = smem + PL_NBA * PL_ASTAGE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;                           // 0..7
-    const int q = wave >> 2, cg = wave & 3;              // quartet (sub-tile / loader role), column group
-    const int rows_per_sub = p.pool_groups * p.pool_n;
-    const int64_t sub0 = (int64_t)blockIdx.x * 2;
-    const int64_t n0 = (int64_t)blockIdx.y * PK_BN;
-    const int nk = (int)((p.K + 63) / 64);
-    const int64_t jb_last = (p.N - 1) >> 5;
-
-    // quartet 0: A DMA, four instructions per wave and k-tile: instruction I = 4 d + cg fills sub-tile I >> 3, LDS rows
-    // 8 (I & 7) + (lane >> 3), slot lane & 7, from the swizzled source
-    const uint16_t *a_src[4];
-    int a_dst[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int I = 4 * d + cg;
-        const int R = 8 * (I & 7) + (lane >> 3);
-        const int row = (R & ~9) | ((R & 1) << 3) | ((R >> 3) & 1);
-        int64_t m = (sub0 + (I >> 3)) * rows_per_sub + min(row, rows_per_sub - 1);
-        if (m >= p.M) m = p.M - 1;
-        const int64_t r = (q == 0 && p.a_rows) ? p.a_rows[m] : m;
-        a_src[d] = p.A + r * p.lda + ((lane & 7) ^ (row & 7)) * EPC;
-        a_dst[d] = (I >> 3) * ATILE + (8 * (I & 7)) * CH;
-    }
-    // quartet 1: W DMA, eight instructions per wave and k-tile: the fragments of this wave's own column group
-    const vec16 *w_src[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-        w_src[b] = reinterpret_cast<const vec16 *>(p.Wp) + (min((n0 >> 5) + 2 * cg + b, jb_last) * p.kc_total) * 64 + lane;
-
-    // (handing a tile's DMA instructions out BETWEEN the MFMAs of the tile being computed was measured: 172 vs 155 us)
-    auto issue_a_piece = [&](int kt, int piece) {
-        vec16 *base = ringA + (kt % PL_NBA) * PL_ASTAGE;
-        __builtin_amdgcn_global_load_lds((global_void_t *)(a_src[piece] + (int64_t)kt * 64),
-                                         (lds_void_t *)(base + a_dst[piece]), 16, 0, 0);
-    };
-    auto issue_w_piece = [&](int kt, int piece) {
-        vec16 *base = ringW + (kt % PL_NBW) * PL_WSTAGE;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-            __builtin_amdgcn_global_load_lds((global_void_t *)(w_src[b] + (int64_t)(kt * 4 + piece) * 64),
-                                             (lds_void_t *)(base + ((2 * cg + b) * 4 + piece) * 64), 16, 0, 0);
-    };
-    auto issue_a = [&](int kt) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) issue_a_piece(kt, d);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto issue_w = [&](int kt) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) issue_w_piece(kt, d);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    f32x16_t acc[2][2];                                  // [row block][column block]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int arow0 = lane & 31, arow1 = arow0 + 32;
-
-    struct Frags { vec16 a0[4], a1[4], w0[4], w1[4]; };
-    auto read_frags = [&](int kt, Frags &f) {
-        const vec16 *sA = ringA + (kt % PL_NBA) * PL_ASTAGE + q * ATILE;
-        const vec16 *sW = ringW + (kt % PL_NBW) * PL_WSTAGE + lane;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = kk * 2 + (lane >> 5);
-            f.a0[kk] = sA[lds_slot(arow0, ch)];
-            f.a1[kk] = sA[lds_slot(arow1, ch)];
-            f.w0[kk] = sW[((2 * cg) * 4 + kk) * 64];
-            f.w1[kk] = sW[((2 * cg + 1) * 4 + kk) * 64];
-        }
-    };
-    auto mma_tile = [&](const Frags &f) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            mma_chunk<uint16_t>::run(f.a0[kk], f.w0[kk], acc[0][0]);
-            mma_chunk<uint16_t>::run(f.a0[kk], f.w1[kk], acc[0][1]);
-            mma_chunk<uint16_t>::run(f.a1[kk], f.w0[kk], acc[1][0]);
-            mma_chunk<uint16_t>::run(f.a1[kk], f.w1[kk], acc[1][1]);
-        }
-    };
-    // "my DMAs of the next tile have landed": vector-memory loads complete in order per wave, so the count is what
-    // this wave issued AFTER them.  simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
-    auto a_landed = [&](int later_tiles) {               // A loader: four instructions per tile
-        if (later_tiles >= 4) __builtin_amdgcn_s_waitcnt(0x4F70);        // vmcnt(16)
-        else if (later_tiles == 3) __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12)
-        else if (later_tiles == 2) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8)
-        else if (later_tiles == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-    };
-    auto w_landed = [&](int later_tiles) {               // W loader: eight instructions per tile
-        if (later_tiles >= 1) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-    };
-
-    Frags fr[2];
-    if (q == 0) {
-#pragma unroll
-        for (int t = 0; t < PL_NBA; ++t)
-            if (t < nk) issue_a(t);
-        a_landed(min(nk - 1, PL_NBA - 1));
-    } else {
-#pragma unroll
-        for (int t = 0; t < PL_NBW; ++t)
-            if (t < nk) issue_w(t);
-        w_landed(min(nk - 1, PL_NBW - 1));
-    }
-    __builtin_amdgcn_s_barrier();
-    read_frags(0, fr[0]);
-    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kt = kt0 + h;
-            if (kt < nk) {
-                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments of tile kt are in registers
-                if (kt + 1 < nk) {
-                    // tile kt+1 has landed (mine; after the barrier: everybody's), and nobody reads tile kt's buffers
-                    if (q == 0) a_landed(min(nk - 2 - kt, PL_NBA - 2));
-                    else w_landed(min(nk - 2 - kt, PL_NBW - 2));
-                    __builtin_amdgcn_s_barrier();
-                    if (q == 0) { if (kt + PL_NBA < nk) issue_a(kt + PL_NBA); }
-                    else if (kt + PL_NBW < nk) issue_w(kt + PL_NBW);
-                    read_frags(kt + 1, fr[h ^ 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mma_tile(fr[h]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // ---- epilogue (k_pool_mlp_packed's, one quartet per sub-tile) ----------------------------------------
-    const int tq = tid & 255;
-    const int64_t m0 = (sub0 + q) * rows_per_sub;
-    float *tile = reinterpret_cast<float *>(smem) + q * (BM * PK_LDT);
-    __syncthreads();                                     // the ring is free
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int jl = cg * 64 + cb * 32 + (lane & 31);
-        const int64_t j = n0 + jl;
-        const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = acc[rb][cb][r] + bj;
-                tile[i * PK_LDT + jl] = v > 0.f ? v : 0.f;
-            }
-    }
-    __syncthreads();
-    if (p.relu_mask) {
-        // sign bits of the hidden activations: one task = 32 channels of one tile row
-        for (int task = tq; task < BM * (PK_BN / 32); task += 256) {
-            const int i = task / (PK_BN / 32), qq = task % (PK_BN / 32);
-            const int64_t row = m0 + i;
-            if (i < rows_per_sub && row < p.M && n0 + qq * 32 < p.N) {
-                uint32_t bits = 0;
-#pragma unroll
-                for (int e0 = 0; e0 < 32; ++e0) {
-                    const int e = (e0 + i) & 31;           // rotate per row: spreads the LDS banks
-                    bits |= (tile[i * PK_LDT + qq * 32 + e] > 0.f ? 1u : 0u) << e;
-                }
-                p.relu_mask[row * (p.N / 32) + (n0 >> 5) + qq] = bits;
-            }
-        }
-    }
-    const int64_t j = n0 + tq;                           // thread t of the quartet owns hidden column t of the tile
-    if (j < p.N) {
-        for (int sg = 0; sg < p.pool_groups; ++sg) {
-            const int64_t seg = (sub0 + q) * p.pool_groups + sg;
-            if (seg * p.pool_n >= p.M) break;
-            const float *colp = tile + (sg * p.pool_n) * PK_LDT + tq;
-            float best = colp[0];
-            int arg = 0;
-            float sum = best;
-            for (int r = 1; r < p.pool_n; ++r) {
-                const float v = colp[r * PK_LDT];
-                sum += v;
-                if (v > best) { best = v; arg = r; }
-            }
-            if (p.pool_mode == GSAGE_POOL_MAX) {
-                p.pooled[seg * p.pooled_ld + j] = best;
-                if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(best);
-                if (p.argmax) p.argmax[seg * p.N + j] = arg;
-            } else {
-                p.pooled[seg * p.pooled_ld + j] = sum / (float)p.pool_n;
-                if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(sum / (float)p.pool_n);
-            }
-        }
-    }
-}
 
 // W [groups][N][ldw] (fp32 or bf16) -> packed operand; one thread per 16-byte lane slot
 template <typename TW>
@@ -835,13 +600,7 @@ int gsage_pool_mlp_packed(const void *A, int64_t lda, const int64_t *a_rows, con
     p.pool_n = n; p.pool_groups = BM / n; p.pool_mode = pool; p.pooled = pooled; p.pooled_ld = pooled_ld;
     p.pooled_b = (uint16_t *)pooled_bf16; p.pooled_b_ld = pooled_bf16_ld; p.argmax = argmax;
     p.relu_mask = relu_mask;
-    static const int use_lds = getenv("GSAGE_K3_LDS") ? atoi(getenv("GSAGE_K3_LDS")) : 0;
     const int64_t subs = ceil_div(M, p.pool_groups);
-    if (use_lds) {
-        dim3 grid((unsigned)ceil_div(subs, 2), (unsigned)ceil_div(H, 256), 1);
-        launch(k_pool_mlp_lds, grid, dim3(512), 0, (hipStream_t)stream, p);
-        return check_launch("pool_mlp_packed");
-    }
     dim3 grid((unsigned)subs, (unsigned)ceil_div(H, 256), 1);
     launch(k_pool_mlp_packed<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("pool_mlp_packed");

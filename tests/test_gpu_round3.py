@@ -516,18 +516,3 @@ def test_attention_one_parent_per_workgroup_equals_one_per_wave(D, n, dtype):
     rows = table[ids[:M_small * n], :D].float().view(M_small, n, D)
     w = torch.softmax(torch.bmm(na[:M_small * n].view(M_small, n, Ha), xa[:M_small].unsqueeze(2)).squeeze(2), dim=1)
     torch.testing.assert_close(a_s, (rows * w.unsqueeze(2)).sum(1), rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.gpu
-def test_k3_with_both_operands_through_lds_is_bit_identical():
-    """k_pool_mlp_lds (eight waves on a 128 x 256 tile, W shared through LDS; not selected: DESIGN.md section 5) must stay
-    bit-identical to the kernel that runs: the packed-vs-plain equality test of tests/test_gpu_kernels.py again in a
-    process that selects it (the choice is read once per process: GSAGE_K3_LDS=1)."""
-    import subprocess, sys
-    env = dict(os.environ, GSAGE_K3_LDS="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x",
-                        "-p", "no:cacheprovider", "-k", "test_pool_mlp_packed_equals_pool_mlp"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
