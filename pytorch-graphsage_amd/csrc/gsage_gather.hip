@@ -536,7 +536,7 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
                                         "by gsage_sample_hops (a launch of its own)");
         rc = fill_hops(h, lds, *hops);
         if (rc != GSAGE_OK) return rc;
-        n_smp = (int)ceil_div(hops->B, HOPS_SPW);
+        n_smp = (int)ceil_div(hops->B, h.spw);
     }
     // where the side roles sit in the grid (fraction of the gather workgroups dispatched before them).
     // Measured in-step at config 2 (tools/role_sweep.sh): 0.0 -> 33.1 us, 0.5 -> 34.8 us, 1.0 -> 37.2 us:

@@ -363,7 +363,7 @@ int gsage_sample_hops(const gsage_hops_desc *hops, void *stream)
     size_t lds = 0;
     int rc = fill_hops(p, lds, *hops);
     if (rc != GSAGE_OK || hops->B == 0) return rc;
-    launch(k_sample_hops, dim3((unsigned)ceil_div(hops->B, HOPS_SPW)), dim3(256), lds, (hipStream_t)stream, p);
+    launch(k_sample_hops, dim3((unsigned)ceil_div(hops->B, p.spw)), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("sample_hops");
 }
 

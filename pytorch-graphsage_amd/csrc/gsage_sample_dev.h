@@ -77,24 +77,32 @@ struct HopsParams {
     int32_t fan[6];               // fan[k]: samples per parent at hop k (k >= 1)
     int32_t n_hops, B;
     uint32_t max_deg, seed_lo, seed_hi;
+    int32_t spw;                  // seeds per workgroup (hops_spw())
 };
 
-constexpr int HOPS_SPW = 1;       // seeds per workgroup: hop 2 of a 25x10 frontier is one pass of
-                                  // 250 lanes, so a seed's whole sub-tree costs two dependent
-                                  // (rowptr -> col) round trips
+// Seeds per workgroup of the fused multi-hop sampler.  1 (default): hop 2 of a 25x10 frontier is one pass of 250
+// lanes, so a seed's whole sub-tree costs two dependent (rowptr -> col) round trips.  GSAGE_HOPS_SPW=2 / 4 (read once):
+// fewer, fatter workgroups -- as a ROLE of k_gather_multi_adam the sampler's B workgroups hold B of the launch's 1 792
+// resident slots while their chains run (what the finalisation role ran into).
+inline int hops_spw()
+{
+    static const int v = [] { const char *e = getenv("GSAGE_HOPS_SPW"); const int x = e ? atoi(e) : 1;
+                              return x >= 1 && x <= 16 ? x : 1; }();
+    return v;
+}
 
-// frontier: two ping-pong LDS buffers of the widest hop; wg: which group of HOPS_SPW seeds.
+// frontier: two ping-pong LDS buffers of the widest hop; wg: which group of p.spw seeds.
 // DENSE_OK = false compiles the dense-adjacency mode out: k_gather_multi_adam (gsage_gather.hip) runs this body
 // beside the HBM-bound gather role under a 72-VGPR cap it already sits on -- two more live values spill.
 template <bool DENSE_OK = true>
 __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int wg, int64_t *frontier)
 {
-    const int seed0 = wg * HOPS_SPW;
-    const int nseed = min(HOPS_SPW, p.B - seed0);
+    const int seed0 = wg * p.spw;
+    const int nseed = min(p.spw, p.B - seed0);
     if (nseed <= 0) return;
     int width = 1, widest = 1;
     for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
-    int64_t *cur = frontier, *nxt = frontier + (int64_t)HOPS_SPW * widest;
+    int64_t *cur = frontier, *nxt = frontier + (int64_t)p.spw * widest;
     const int32_t *sel = p.sel;
     if (p.seed_queue) {           // take the seeds from the queue (and publish them as hop 0)
         const int64_t b = (int64_t)((uint64_t)(*p.batch_idx + p.batch_base) % (uint64_t)p.n_batches);
@@ -184,7 +192,8 @@ inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
         p.g0[k] = d.rank * (uint64_t)size;
         if (k <= d.n_hops) off += size;
     }
-    lds = sizeof(int64_t) * 2 * HOPS_SPW * (size_t)widest;
+    p.spw = hops_spw();
+    lds = sizeof(int64_t) * 2 * (size_t)p.spw * (size_t)widest;
     GSAGE_REQUIRE(lds <= 160 * 1024, "sample_hops_philox: fan-out product too large for the fused kernel");
     return GSAGE_OK;
 }
