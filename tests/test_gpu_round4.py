@@ -455,3 +455,32 @@ def test_finalisation_as_a_role_of_the_gather_launch_is_bit_identical(monkeypatc
     for i in range(4):
         assert torch.equal(a[i], b[i]), i
     assert a[4] == b[4] and torch.equal(a[5], b[5])
+
+
+def test_one_launch_batch_metric_and_pending_metric_equal_the_reference_route():
+    """A training batch (B x C <= 64 k) is scored by ONE single-workgroup launch, larger inputs by the three-launch
+    route: both equal the reference's host route (ProblemMetrics: sklearn) on the same data, for classification and
+    both multilabel target types; PendingMetric (the result stored straight into pinned memory, read one batch later)
+    returns the same values as the synchronous call."""
+    gen = torch.Generator().manual_seed(3)
+    for B, C in ((512, 41), (4096, 41), (37, 7), (300, 500)):
+        logits = torch.randn(B, C, generator=gen).to(DEV)
+        y = torch.randint(0, C, (B,), generator=gen).to(DEV)
+        before = nat.launch_count()
+        dev = gs.DeviceMetrics.classification(y, logits)
+        assert nat.launch_count() - before == (1 if B * C <= 64 * 1024 else 3), (B, C)
+        host = gs.ProblemMetrics.classification(y.cpu().numpy(), logits.cpu().numpy())
+        assert abs(dev["micro"] - host["micro"]) < 1e-9 and abs(dev["macro"] - host["macro"]) < 1e-9, (B, C)
+        pend = gs.problem.PendingMetric("classification", y.view(B, 1), logits)
+        got = pend.get()
+        assert got == dev, (got, dev)
+        for cast in (torch.float32, torch.int64):
+            ym = (torch.rand(B, C, generator=gen) < 0.3).to(cast).to(DEV)
+            dev = gs.DeviceMetrics.multilabel_classification(ym, logits)
+            host = gs.ProblemMetrics.multilabel_classification(ym.cpu().numpy(), logits.cpu().numpy())
+            assert abs(dev["micro"] - host["micro"]) < 1e-9 and abs(dev["macro"] - host["macro"]) < 1e-9, (B, C, cast)
+            assert gs.problem.PendingMetric("multilabel_classification", ym, logits).get() == dev
+    a, b = torch.randn(777, 1, generator=gen).to(DEV), torch.randn(777, 1, generator=gen).to(DEV)
+    mae = gs.DeviceMetrics.regression_mae(a, b)
+    assert gs.problem.PendingMetric("regression_mae", a, b).get() == mae
+    assert gs.problem.PendingMetric.zero_copy in (True, False)
