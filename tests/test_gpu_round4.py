@@ -484,3 +484,17 @@ def test_one_launch_batch_metric_and_pending_metric_equal_the_reference_route():
     mae = gs.DeviceMetrics.regression_mae(a, b)
     assert gs.problem.PendingMetric("regression_mae", a, b).get() == mae
     assert gs.problem.PendingMetric.zero_copy in (True, False)
+
+
+@pytest.mark.parametrize("spw", ["2", "4"])
+def test_fused_sampler_with_several_seeds_per_workgroup(spw):
+    """GSAGE_HOPS_SPW (seeds per workgroup of the fused multi-hop sampler; read once per process): the frontier does
+    not depend on it -- the reference-stream test of tests/test_gpu_round3.py (frontiers equal to the reference's
+    golden ones) and the queue-mode tests of tests/test_gpu_engine.py (the sampler as a role of the gather launch
+    against the stand-alone launch) again, in a process that sets it."""
+    env = dict(os.environ, GSAGE_HOPS_SPW=spw)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_round3.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_engine.py"), "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        "-k", "fused_sampler_consumes or queue"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
