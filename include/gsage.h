@@ -382,11 +382,6 @@ typedef struct gsage_wgrad_desc {
                                  * read A + g * a_gstride row by row, like gsage_linear_nt's a_rows_group0_only) */
 } gsage_wgrad_desc;
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
-/* Counters for the NEXT gsage_wgrad_multi launch of the calling thread to advance when it starts (consumed by it;
- * recorded with it while a command list is being recorded): *tick += 1, *tick1 += inc1, *tick2 += inc2 (NULL: skip).
- * The step's ticks -- Adam's update number, the Philox call index, the batch-queue index -- when no
- * gsage_finalize_grads launch exists to carry them (gsage_adam_desc.fin_descs): K5b reads none of the three. */
-int gsage_wgrad_ticks_next(int64_t *tick, int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2);
 /* dtype (both entry points) = type of dC and A: GSAGE_BF16 (the MFMA kernel described above) or
  * GSAGE_F32 (plain fp32 FMAs, same decomposition and slab layout: the exact-arithmetic parity mode in
  * which the golden fixtures generated from the reference are replayed through the fused engines). */
@@ -636,18 +631,6 @@ typedef struct gsage_adam_desc {
      * the data-parallel step: the norm of the AVERAGED gradient exists only after the exchange, and a launch of its
      * own for it sat on the critical path behind the collective.  norm_slots: >= 1 024 x 8 bytes, zero-initialised. */
     uint64_t *norm_slots;
-    /* ABI 4, gsage_gather_mean_multi_adam only: the gradient FINALISATION (gsage_finalize_grads: partial tiles of
-     * K5b + head partials -> flat gradient, squared-norm partials) as a role of the same launch, dispatched before the
-     * update's workgroups: fin_descs / n_fin_desc / fin_max_elems as for gsage_finalize_grads (g = the flat gradient).
-     * Its workgroups store with device-scope stores and publish fin_slots[w] = (update number << 32 | bits of the
-     * squared-norm partial); the update's workgroups poll the slots, then read g with device-scope loads.  One launch
-     * and ~6.5 us less per step of the single-GPU mean engine; the finalisation's ticks move to the K5b launch
-     * (gsage_wgrad_ticks_next).  fin_slots: >= n_fin_desc * min(ceil(fin_max_elems / 256), 256) x 8 bytes, zeroed once;
-     * n_partial_ready and norm_slots are ignored. */
-    const void *fin_descs;
-    int32_t n_fin_desc;
-    int64_t fin_max_elems;
-    uint64_t *fin_slots;
 } gsage_adam_desc;
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
  * Philox call index and batch-queue index, when nothing in the same launch reads them). */

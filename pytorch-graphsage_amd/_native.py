@@ -93,7 +93,6 @@ SIGNATURES = {
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
     "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _int, _i64, _vp]),
     "gsage_wgrad_multi": (_int, [_i32, _vp, _int, _vp]),
-    "gsage_wgrad_ticks_next": (_int, [_vp, _vp, _i64, _vp, _i64]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
                              _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
@@ -211,7 +210,7 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
                 ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
                 ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
                 ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64),
-                ("norm_slots", _vp), ("fin_descs", _vp), ("n_fin_desc", _i32), ("fin_max_elems", _i64), ("fin_slots", _vp)]
+                ("norm_slots", _vp)]
 
 
 class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)

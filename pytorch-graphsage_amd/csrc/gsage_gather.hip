@@ -292,27 +292,17 @@ k_gather_mean_multi(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
 template <typename TI, typename TO, int VEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
-                    int n_adam, const AdamParams a, int n_smp, const HopsParams h, int first, const FinParams f)
+                    int n_adam, const AdamParams a, int n_smp, const HopsParams h, int first)
 {
     extern __shared__ int64_t frontier[];
     __shared__ float red[4];
-    __shared__ float red4[256];
-    // side roles, in dispatch order: [finalisation of batch i's gradient] | Adam(i) | sampler(i+2).  The finalisation
-    // goes first: the update's workgroups poll its slots, so its workgroups must never queue behind them.
-    const int n_fin = f.n_desc * f.gx;
-    const int n_side = n_fin + n_adam + n_smp;
+    const int n_side = n_adam + n_smp;
     const int n_gather = (int)gridDim.x - n_side;
     const int bx = (int)blockIdx.x;
-    if (bx >= first && bx < first + n_fin)
-        finalize_workgroup<true, 4>(f.descs, f.flat_g, nullptr, f.slots, f.slots ? (unsigned long long)(uint32_t)(*a.step + a.step_off) << 32 : 0ull,
-                                 (bx - first) % f.gx, (bx - first) / f.gx, f.gx, red, red4);
-    else if (bx >= first + n_fin && bx < first + n_fin + n_adam) {
-        if (a.fin_slots) adam_workgroup<false, ADAM_FIN>(a, bx - first - n_fin, n_adam, red);
-        else if (a.norm_slots) adam_workgroup<false, ADAM_MEET>(a, bx - first - n_fin, n_adam, red);
-        else adam_workgroup<false, ADAM_PARTIALS>(a, bx - first - n_fin, n_adam, red);
-    }
-    else if (bx >= first + n_fin + n_adam && bx < first + n_side)
-        sample_hops_workgroup<false>(h, bx - first - n_fin - n_adam, frontier);
+    if (bx >= first && bx < first + n_adam)
+        adam_workgroup<false>(a, bx - first, n_adam, red);
+    else if (bx >= first + n_adam && bx < first + n_side)
+        sample_hops_workgroup<false>(h, bx - first - n_adam, frontier);
     else
         gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_side, n_gather);
 }
@@ -512,23 +502,6 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
                       (!adam->tick1 && !adam->tick2),
                       "gather_mean_multi_adam: the update may not tick a counter the sampler reads");
     }
-    FinParams f = {};
-    if (adam && adam->fin_descs) {
-        // the gradient finalisation as a role of this launch (include/gsage.h, gsage_adam_desc.fin_descs)
-        GSAGE_REQUIRE(adam->n_fin_desc > 0 && adam->fin_max_elems > 0 && adam->fin_slots,
-                      "gather_mean_multi_adam: fin_descs needs n_fin_desc, fin_max_elems and fin_slots");
-        f.descs = (const ReduceDesc *)adam->fin_descs;
-        f.n_desc = adam->n_fin_desc;
-        f.gx = adam_grid(adam->fin_max_elems, 256);         // (= gsage_finalize_grads' workgroups per descriptor)
-        f.flat_g = adam->g;
-        f.slots = (unsigned long long *)adam->fin_slots;
-        a.fin_slots = f.slots;
-        a.n_fin_slots = f.n_desc * f.gx;
-        a.norm_slots = nullptr;
-        // (every side workgroup must be resident while the update's workgroups poll: 7 workgroups fit per CU)
-        GSAGE_REQUIRE(a.n_fin_slots + n_adam <= 1536, "gather_mean_multi_adam: too many side workgroups (%d + %d) for the "
-                                                     "finalisation role", a.n_fin_slots, n_adam);
-    }
     HopsParams h = {};
     size_t lds = 0;
     if (hops) {
@@ -545,14 +518,12 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
     const int n_gather = grid_for(q.first[n_seg]);
     int first = (int)(n_gather * side_pos);
     first = first < 0 ? 0 : (first > n_gather ? n_gather : first);
-    if (f.descs) first = 0;                 // (the polled role must be dispatched before anything that could starve it)
-    const int n_fin = f.n_desc * f.gx;
     if (dtype == GSAGE_F32)
-        launch(k_gather_multi_adam<float, float, 4>, dim3(n_gather + n_fin + n_adam + n_smp),
-               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first, f);
+        launch(k_gather_multi_adam<float, float, 4>, dim3(n_gather + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
     else
-        launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(n_gather + n_fin + n_adam + n_smp),
-               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first, f);
+        launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(n_gather + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
     return check_launch("gather_mean_multi_adam");
 }
 

@@ -79,6 +79,110 @@ k_adam_clip(const AdamParams a)
     adam_workgroup(a, blockIdx.x, gridDim.x, red);
 }
 
+// ---- gradient finalisation: sum partial buffers into the flat bucket + squared-norm partials ------
+struct ReduceDesc {
+    const float *src;       // S partial buffers, `stride` floats apart, each [rows, ld]
+    int64_t stride;
+    int64_t out_off;        // destination offset in the flat gradient bucket ([rows, cols] contiguous)
+    int32_t S, rows, cols, ld;
+};
+
+// one workgroup of the finalisation: descriptor `by`, grid-stride slice bx of gx
+__device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
+                                                   float *__restrict__ flat_g,
+                                                   float *__restrict__ partial_sq, int bx, int by, int gx,
+                                                   float *red, float *red4)
+{
+    const ReduceDesc d = descs[by];
+    const int64_t gstride = (int64_t)gx * 256;
+    float sq = 0.f;
+    // 16-byte loads whenever the partial buffers allow it (the K5b slabs do: ld, stride % 4 == 0);
+    // a wave-wide load costs the same issue slot whatever its width
+    // -- and the descriptor has enough 4-column chunks to keep every thread of its grid row busy
+    // (small descriptors with many partials want all the threads they can get instead)
+    const bool vec = d.ld % 4 == 0 && d.stride % 4 == 0 && ((uintptr_t)d.src & 15) == 0 &&
+                     (int64_t)d.rows * ((d.cols + 3) / 4) >= gstride / 2;
+    if (vec) {
+        const int cpr = (d.cols + 3) / 4;                  // 4-column chunks per row (last may be ragged)
+        const int64_t total = (int64_t)d.rows * cpr;
+        for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
+            const int64_t r = t / cpr;
+            const int c = (int)(t - r * cpr) * 4;           // c + 3 < ld because ld % 4 == 0 and c < cols <= ld
+            const float *src = d.src + r * d.ld + c;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int i = 0;
+            for (; i + 8 <= d.S; i += 8) {                  // 8 independent 16-byte loads in flight
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(i + u) * d.stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; i < d.S; ++i) s += *reinterpret_cast<const f32x4 *>(src + (int64_t)i * d.stride);
+            float *dst = flat_g + d.out_off + r * d.cols + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < d.cols) {
+                    dst[e] = s[e];
+                    sq += s[e] * s[e];
+                }
+        }
+    } else if (d.S >= 32 && (int64_t)d.rows * d.cols * 4 <= gstride) {
+        // few elements, many partials (the seed-level kernel's per-workgroup head gradients: 10.5 k
+        // elements x 128 partials): one thread per element would walk all S partials alone -- 16
+        // rounds of 8 loads, the longest dependent chain of the launch.  The four waves of a
+        // workgroup take a quarter of the partials each for the same 64 elements and meet in LDS.
+        const int64_t total = (int64_t)d.rows * d.cols;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int s0 = (d.S * wave) / 4, s1 = (d.S * (wave + 1)) / 4;
+        for (int64_t t0 = (int64_t)bx * 64; t0 < total; t0 += (int64_t)gx * 64) {
+            const int64_t t = t0 + lane;
+            float s = 0.f;
+            if (t < total) {
+                const int64_t r = t / d.cols;
+                const float *src = d.src + r * d.ld + (t - r * d.cols);
+                int i = s0;
+                for (; i + 8 <= s1; i += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; i < s1; ++i) s += src[(int64_t)i * d.stride];
+            }
+            lds_barrier();
+            red4[threadIdx.x] = s;
+            lds_barrier();
+            if (wave == 0 && t < total) {
+                const float tot = (red4[lane] + red4[64 + lane]) + (red4[128 + lane] + red4[192 + lane]);
+                flat_g[d.out_off + t] = tot;
+                sq += tot * tot;
+            }
+        }
+    } else {
+        const int64_t total = (int64_t)d.rows * d.cols;
+        for (int64_t t = (int64_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
+            const int64_t r = t / d.cols;
+            const float *src = d.src + r * d.ld + (t - r * d.cols);
+            float s = 0.f;
+            int i = 0;
+            for (; i + 8 <= d.S; i += 8) {                 // 8 independent loads in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; i < d.S; ++i) s += src[(int64_t)i * d.stride];
+            flat_g[d.out_off + t] = s;
+            sq += s * s;
+        }
+    }
+    const float tot = block_sum_256(sq, red);
+    if (threadIdx.x == 0) partial_sq[by * gx + bx] = tot;
+}
+
 __global__ void __launch_bounds__(256)
 k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_g,
                  float *__restrict__ partial_sq, int64_t *tick, int64_t *tick1, int64_t inc1,
@@ -91,7 +195,7 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
         if (tick1) *tick1 += inc1;
         if (tick2) *tick2 += inc2;
     }
-    finalize_workgroup<false>(descs, flat_g, partial_sq, nullptr, 0ull, blockIdx.x, blockIdx.y, gridDim.x, red, red4);
+    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red, red4);
 }
 
 __global__ void k_step_inc(int64_t *step) { *step += 1; }
@@ -669,7 +773,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay; d.max_norm = max_norm;
     d.norm_out = norm_out; d.step_is_current = step_is_current; d.n_partial_ready = n_partial_ready;
     d.prep_descs = prep_descs; d.n_prep = n_prep; d.tick1 = tick1; d.inc1 = inc1; d.tick2 = tick2;
-    d.inc2 = inc2; d.norm_slots = nullptr; d.fin_descs = nullptr; d.n_fin_desc = 0; d.fin_max_elems = 0; d.fin_slots = nullptr;
+    d.inc2 = inc2; d.norm_slots = nullptr;
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
     hipStream_t s = (hipStream_t)stream;

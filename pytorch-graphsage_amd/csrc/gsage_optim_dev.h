@@ -3,7 +3,6 @@
 // side by side with the level-0 gathers of batch i+1.
 #pragma once
 #include "gsage_common.h"
-#include <type_traits>
 
 namespace gsage {
 
@@ -17,145 +16,6 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
     lds_barrier();
     return red[0] + red[1] + red[2] + red[3];
 }
-
-// ---- gradient finalisation: sum partial buffers into the flat bucket + squared-norm partials ------
-struct ReduceDesc {
-    const float *src;       // S partial buffers, `stride` floats apart, each [rows, ld]
-    int64_t stride;
-    int64_t out_off;        // destination offset in the flat gradient bucket ([rows, cols] contiguous)
-    int32_t S, rows, cols, ld;
-};
-
-// one workgroup of the finalisation: descriptor `by`, grid-stride slice bx of gx
-// PUBLISH (the finalisation as a ROLE of k_gather_multi_adam, beside the update that consumes it): the sums are
-// stored with device-scope (write-through) stores and, once every store of the workgroup is acknowledged, the
-// workgroup publishes slots[by * gx + bx] = (tag << 32 | bits of its squared-norm partial) -- the update's workgroups
-// poll the slots (gsage_optim_dev.h, adam_workgroup) instead of waiting for a kernel boundary.
-template <bool PUBLISH>
-__device__ __forceinline__ void fin_store(float *dst, float v)
-{
-    if (PUBLISH) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *dst = v;
-}
-
-// DEPTH: 16-byte loads a thread keeps in flight in the slab path (8 in the kernel of its own; 4 inside
-// k_gather_multi_adam, whose 72-register cap belongs to the HBM-bound gather role: 8 spilled 24 registers there)
-template <bool PUBLISH, int DEPTH = 8>
-__device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
-                                                   float *__restrict__ flat_g,
-                                                   float *__restrict__ partial_sq, unsigned long long *slots,
-                                                   unsigned long long tag, int bx, int by, int gx,
-                                                   float *red, float *red4)
-{
-    const ReduceDesc d = descs[by];
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    // (index arithmetic: 64-bit in the kernel of its own; 32-bit as a role of k_gather_multi_adam -- a descriptor holds
-    //  < 2^31 elements, and the 64-bit division routine alone spilled 24 registers under that kernel's 72-register cap)
-    typedef typename std::conditional<PUBLISH, int32_t, int64_t>::type idx_t;
-    const idx_t gstride = (idx_t)gx * 256;
-    float sq = 0.f;
-    // 16-byte loads whenever the partial buffers allow it (the K5b slabs do: ld, stride % 4 == 0);
-    // a wave-wide load costs the same issue slot whatever its width
-    // -- and the descriptor has enough 4-column chunks to keep every thread of its grid row busy
-    // (small descriptors with many partials want all the threads they can get instead)
-    const bool vec = d.ld % 4 == 0 && d.stride % 4 == 0 && ((uintptr_t)d.src & 15) == 0 &&
-                     (idx_t)d.rows * ((d.cols + 3) / 4) >= gstride / 2;
-    if (vec) {
-        const int cpr = (d.cols + 3) / 4;                  // 4-column chunks per row (last may be ragged)
-        const idx_t total = (idx_t)d.rows * cpr;
-        for (idx_t t = (idx_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
-            const idx_t r = t / cpr;
-            const int c = (int)(t - r * cpr) * 4;           // c + 3 < ld because ld % 4 == 0 and c < cols <= ld
-            const float *src = d.src + (int64_t)r * d.ld + c;
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            int i = 0;
-            for (; i + DEPTH <= d.S; i += DEPTH) {          // DEPTH independent 16-byte loads in flight
-                f32x4 v[DEPTH];
-#pragma unroll
-                for (int u = 0; u < DEPTH; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(i + u) * d.stride);
-#pragma unroll
-                for (int u = 0; u < DEPTH; ++u) s += v[u];
-            }
-            for (; i < d.S; ++i) s += *reinterpret_cast<const f32x4 *>(src + (int64_t)i * d.stride);
-            float *dst = flat_g + d.out_off + (int64_t)r * d.cols + c;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < d.cols) {
-                    fin_store<PUBLISH>(dst + e, s[e]);
-                    sq += s[e] * s[e];
-                }
-        }
-    } else if (d.S >= 32 && (idx_t)d.rows * d.cols * 4 <= gstride) {
-        // few elements, many partials (the seed-level kernel's per-workgroup head gradients: 10.5 k
-        // elements x 128 partials): one thread per element would walk all S partials alone -- 16
-        // rounds of 8 loads, the longest dependent chain of the launch.  The four waves of a
-        // workgroup take a quarter of the partials each for the same 64 elements and meet in LDS.
-        const idx_t total = (idx_t)d.rows * d.cols;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int s0 = (d.S * wave) / 4, s1 = (d.S * (wave + 1)) / 4;
-        for (idx_t t0 = (idx_t)bx * 64; t0 < total; t0 += (idx_t)gx * 64) {
-            const idx_t t = t0 + lane;
-            float s = 0.f;
-            if (t < total) {
-                const idx_t r = t / d.cols;
-                const float *src = d.src + (int64_t)r * d.ld + (t - r * d.cols);
-                int i = s0;
-                for (; i + DEPTH <= s1; i += DEPTH) {
-                    float v[DEPTH];
-#pragma unroll
-                    for (int u = 0; u < DEPTH; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
-#pragma unroll
-                    for (int u = 0; u < DEPTH; ++u) s += v[u];
-                }
-                for (; i < s1; ++i) s += src[(int64_t)i * d.stride];
-            }
-            lds_barrier();
-            red4[threadIdx.x] = s;
-            lds_barrier();
-            if (wave == 0 && t < total) {
-                const float tot = (red4[lane] + red4[64 + lane]) + (red4[128 + lane] + red4[192 + lane]);
-                fin_store<PUBLISH>(flat_g + d.out_off + t, tot);
-                sq += tot * tot;
-            }
-        }
-    } else {
-        const idx_t total = (idx_t)d.rows * d.cols;
-        for (idx_t t = (idx_t)bx * 256 + threadIdx.x; t < total; t += gstride) {
-            const idx_t r = t / d.cols;
-            const float *src = d.src + (int64_t)r * d.ld + (t - r * d.cols);
-            float s = 0.f;
-            int i = 0;
-            for (; i + DEPTH <= d.S; i += DEPTH) {         // DEPTH independent loads in flight
-                float v[DEPTH];
-#pragma unroll
-                for (int u = 0; u < DEPTH; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
-#pragma unroll
-                for (int u = 0; u < DEPTH; ++u) s += v[u];
-            }
-            for (; i < d.S; ++i) s += src[(int64_t)i * d.stride];
-            fin_store<PUBLISH>(flat_g + d.out_off + t, s);
-            sq += s * s;
-        }
-    }
-    if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every thread: its stores have landed)
-    const float tot = block_sum_256(sq, red);                            // (two workgroup barriers inside)
-    if (threadIdx.x == 0) {
-        if (PUBLISH)
-            __hip_atomic_store(slots + (by * gx + bx), tag | (unsigned long long)__float_as_uint(tot), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        else
-            partial_sq[by * gx + bx] = tot;
-    }
-}
-
-
-// the finalisation as a role of k_gather_multi_adam (gsage_gather.hip): gx workgroups per descriptor
-struct FinParams {
-    const ReduceDesc *descs;
-    float *flat_g;
-    unsigned long long *slots;
-    int32_t n_desc, gx;
-};
 
 // ---- weight operand copies ------------------------------------------------------------------------
 struct PrepDesc {
@@ -207,8 +67,6 @@ struct AdamParams {
     int32_t replay_math;           // != 0: the deferred-row arithmetic (adam_update<true>), for a table whose rows
                                    // may also be updated by gsage_rows_*: both must produce the same bits
     unsigned long long *norm_slots;   // != null: the workgroups form the squared norm themselves (slot = update << 32 | partial)
-    const unsigned long long *fin_slots;   // != null: the finalisation is a role of the SAME launch: wait for its n_fin_slots
-    int32_t n_fin_slots;                   //          workgroups (slot = update << 32 | squared-norm partial), read g coherently
 };
 
 // The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
@@ -252,13 +110,7 @@ __device__ __forceinline__ float adam_update(float g, float p, float &m, float &
 
 // one workgroup of the clip + Adam update: grid-stride slice bx of gx.  REPLAY_OK = false: the caller never sets
 // a.replay_math (k_gather_multi_adam: only the exact arithmetic is compiled in, its registers are the gather role's)
-// MODE (where the squared norm of g comes from): ADAM_PARTIALS = a.partial (gsage_finalize_grads / gsage_grad_sqnorm
-// ran before), ADAM_MEET = the update's own workgroups form it (a.norm_slots), ADAM_FIN = the finalisation is a role of
-// the same launch (a.fin_slots).  A compile-time mode: with all three in one body the allocator spilled 24 registers
-// under k_gather_multi_adam's 72-register cap.
-enum { ADAM_PARTIALS = 0, ADAM_MEET = 1, ADAM_FIN = 2 };
-
-template <bool REPLAY_OK = true, int MODE = ADAM_PARTIALS>
+template <bool REPLAY_OK = true>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
@@ -266,8 +118,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
     const int64_t stride = (int64_t)gx * 256;
     const int64_t i_first = (int64_t)bx * 256 + threadIdx.x;
     float gv0[4], pv0[4], mv0[4], vv0[4];
-    constexpr bool meet = !REPLAY_OK && MODE == ADAM_MEET;
-    constexpr bool fin = !REPLAY_OK && MODE == ADAM_FIN;
+    const bool meet = !REPLAY_OK && a.norm_slots != nullptr;
     if (meet) {
         // The norm of a gradient that exists only now (data-parallel: after the exchange), formed by the update's own
         // workgroups.  They are dispatched first and are few, so all of them are resident: each publishes the partial
@@ -294,19 +145,6 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             while ((v >> 32) != (tag >> 32)) {
                 __builtin_amdgcn_s_sleep(1);
                 v = __hip_atomic_load(a.norm_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s += __uint_as_float((uint32_t)v);
-        }
-    } else if (fin) {
-        // the gradient is being finalised by workgroups of THIS launch (dispatched before this one): poll their slots --
-        // a slot that carries this update's number means its workgroup's sums are in memory -- and take the
-        // squared-norm partials from the same words
-        const unsigned long long tag = (unsigned long long)(uint32_t)(*a.step + a.step_off);
-        for (int i = threadIdx.x; i < a.n_fin_slots; i += 256) {
-            unsigned long long v = __hip_atomic_load(a.fin_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((v >> 32) != tag) {
-                __builtin_amdgcn_s_sleep(1);
-                v = __hip_atomic_load(a.fin_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s += __uint_as_float((uint32_t)v);
         }
@@ -364,9 +202,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             }
             const int64_t i = i0 + u * stride;
             const int64_t ic = i < a.n ? i : i0;
-            // (finalised by workgroups of this launch, possibly on another XCD: a device-scope load, not this L2's copy)
-            gv[u] = fin ? __hip_atomic_load(a.g + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.g[ic];
-            pv[u] = a.p[ic]; mv[u] = a.m[ic]; vv[u] = a.v[ic];
+            gv[u] = a.g[ic]; pv[u] = a.p[ic]; mv[u] = a.m[ic]; vv[u] = a.v[ic];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -408,8 +244,8 @@ inline int adam_grid(int64_t items, int cap)
 inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
 {
     GSAGE_REQUIRE(d.p && d.g && d.m && d.v && d.partial && d.lr && d.step, "clip_adam_step: null pointer");
-    GSAGE_REQUIRE(d.n > 0 && (d.n_partial_ready > 0 || d.norm_slots || d.fin_descs) && d.n_prep >= 0,
-                  "clip_adam_step: bad sizes (norm partials must be ready, or norm_slots / fin_descs given)");
+    GSAGE_REQUIRE(d.n > 0 && (d.n_partial_ready > 0 || d.norm_slots) && d.n_prep >= 0,
+                  "clip_adam_step: bad sizes (norm partials must be ready, or norm_slots given)");
     a.prep = (const PrepDesc *)d.prep_descs; a.n_prep = d.prep_descs ? d.n_prep : 0;
     a.tick1 = d.tick1; a.inc1 = d.inc1; a.tick2 = d.tick2; a.inc2 = d.inc2;
     a.p = d.p; a.g = d.g; a.m = d.m; a.v = d.v; a.partial = d.partial; a.lr = d.lr; a.step = d.step;
@@ -418,10 +254,8 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.step_off = d.step_is_current ? 0 : 1;
     a.discard_clipped = 0;
     a.replay_math = 0;
-    const bool inside = d.n_partial_ready == 0 && d.norm_slots && !d.fin_descs;
+    const bool inside = d.n_partial_ready == 0 && d.norm_slots;
     a.norm_slots = inside ? (unsigned long long *)d.norm_slots : nullptr;
-    a.fin_slots = nullptr;                       // (set by gsage_gather_mean_multi_adam when it carries the finalisation)
-    a.n_fin_slots = 0;
     return GSAGE_OK;
 }
 

@@ -363,11 +363,7 @@ k_wgrad_bf16(const WgradParams p)
 // alone occupies a fraction of the chip for the length of its M-slice (Reddit shapes: 196 and 16
 // workgroups on 256 CUs), so side by side they cost the longest one instead of the sum.
 constexpr int WGRAD_MAX_PROBLEMS = 8;
-struct WgradTicks { int64_t *tick, *tick1, *tick2; int64_t inc1, inc2; };
-static thread_local WgradTicks t_wgrad_ticks = {nullptr, nullptr, nullptr, 0, 0};
-
 struct WgradMulti {
-    WgradTicks ticks;                          // gsage_wgrad_ticks_next: counters advanced when the launch starts
     WgradParams p[WGRAD_MAX_PROBLEMS];
     int32_t first[WGRAD_MAX_PROBLEMS + 1];     // workgroups [first[s], first[s+1]) belong to problem s
     int32_t S[WGRAD_MAX_PROBLEMS], ny[WGRAD_MAX_PROBLEMS];
@@ -377,11 +373,6 @@ struct WgradMulti {
 __global__ void __launch_bounds__(256, 1)
 k_wgrad_multi(const WgradMulti q)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (q.ticks.tick) *q.ticks.tick += 1;
-        if (q.ticks.tick1) *q.ticks.tick1 += q.ticks.inc1;
-        if (q.ticks.tick2) *q.ticks.tick2 += q.ticks.inc2;
-    }
     int s = 0;
 #pragma unroll
     for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
@@ -458,11 +449,6 @@ k_wgrad_f32(const WgradParams p)
 __global__ void __launch_bounds__(256)
 k_wgrad_multi_f32(const WgradMulti q)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (q.ticks.tick) *q.ticks.tick += 1;
-        if (q.ticks.tick1) *q.ticks.tick1 += q.ticks.inc1;
-        if (q.ticks.tick2) *q.ticks.tick2 += q.ticks.inc2;
-    }
     int s = 0;
 #pragma unroll
     for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
@@ -552,20 +538,11 @@ static int wgrad_fill(WgradParams &p, int dtype, const void *dC, int64_t ldc, co
 
 extern "C" {
 
-int gsage_wgrad_ticks_next(int64_t *tick, int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2)
-{
-    t_wgrad_ticks = WgradTicks{tick, tick1, tick2, inc1, inc2};
-    return GSAGE_OK;
-}
-
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream)
 {
-    const WgradTicks ticks = t_wgrad_ticks;         // (consumed before any return path: never left for a later launch)
-    t_wgrad_ticks = WgradTicks{nullptr, nullptr, nullptr, 0, 0};
     GSAGE_REQUIRE(probs && n_prob >= 1 && n_prob <= WGRAD_MAX_PROBLEMS, "wgrad_multi: 1..%d problems",
                   WGRAD_MAX_PROBLEMS);
     WgradMulti q;
-    q.ticks = ticks;
     q.n_prob = n_prob;
     q.first[0] = 0;
     for (int s = 0; s < WGRAD_MAX_PROBLEMS; ++s) {

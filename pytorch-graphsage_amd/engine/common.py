@@ -182,8 +182,6 @@ class FusedTrainStep(object):
         self.world = int(ddp.world) if ddp is not None else 1
         self.comm = getattr(ddp, "comm", None) if ddp is not None else None
         self._host_cbs = []                       # ctypes callbacks recorded into lists (kept alive with the engine)
-        self._fin_fused = False                   # True while a queue step is issued whose finalisation rides with Adam
-        self._fin_slots = self._norm_slots = None
         self._front_ready, self._qstep = False, 0
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
         self._tail_gather, self._tail_rows = None, 0
@@ -627,15 +625,7 @@ class FusedTrainStep(object):
         d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
         d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
         d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
-        if getattr(self, "_fin_fused", False):
-            # single GPU, queue mode: the gradient finalisation is a ROLE of the launch that carries Adam (dispatched
-            # before the update's workgroups, which poll its slots) -- no launch of its own, its ticks ride in K5b
-            if getattr(self, "_fin_slots", None) is None:
-                n_slots = self.n_rdesc * min(-(-self.r_max // 256), 256)
-                self._fin_slots = torch.zeros(n_slots, dtype=torch.int64, device=self.dev)
-            d.fin_descs, d.n_fin_desc, d.fin_max_elems = self.rdescs.data_ptr(), self.n_rdesc, self.r_max
-            d.fin_slots, d.n_partial_ready = self._fin_slots.data_ptr(), 0
-        elif self.ddp is not None and self._norm_in_launch():
+        if self.ddp is not None and self._norm_in_launch():
             # data-parallel: the norm of the AVERAGED gradient is formed by the update's own workgroups inside the
             # launch that carries Adam (gsage_adam_desc.norm_slots) -- no norm launch behind the collective
             if getattr(self, "_norm_slots", None) is None:
@@ -737,23 +727,9 @@ class FusedTrainStep(object):
             self.preds = torch.empty_like(preds)
         self.preds.copy_(preds.detach())
 
-    def _fin_in_launch(self):
-        """may the queue pipeline fold the finalisation into the launch that carries Adam?  (engines whose backward
-        hands its ticks to the K5b launch: _finalize_ticks_next)"""
-        return False
-
-    def _finalize_ticks_next(self):
-        """the finalisation's ticks (Adam's update number, the Philox call counter, the batch-queue index) for the NEXT
-        gsage_wgrad_multi launch, when no finalisation launch exists to carry them"""
-        nat.check(nat.lib().gsage_wgrad_ticks_next(
-            self.step.data_ptr(), None if self.pipelined else self.counter.data_ptr(), self.L,
-            self.batch_idx.data_ptr() if self.queue else None, 1), "wgrad_ticks_next")
-
     def _stage_finalize(self, s):
         """Every partial buffer -> flat gradient bucket, + squared-norm partials, + the step's ticks:
         Adam step, Philox call counter, batch-queue index (nothing else in this launch reads them)."""
-        if getattr(self, "_fin_fused", False):
-            return                      # (a role of the launch that carries Adam: _adam_desc)
         L, lib, stream = self.L, nat.lib(), ops._stream()
         nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
                                            self.flat_g.data_ptr(), self.partial.data_ptr(),
@@ -1280,12 +1256,8 @@ class FusedTrainStep(object):
             self._q_ids = None
 
     def _queue_step(self, par):
-        self._fin_fused = self._fin_in_launch()   # finalisation(i) as a role of the launch below
-        try:
-            self._queue_compute(par)
-            self._queue_front(par, True)          # [finalisation(i) ->] Adam(i) || gathers(i+1) || sampling(i+2)
-        finally:
-            self._fin_fused = False
+        self._queue_compute(par)
+        self._queue_front(par, True)              # Adam(i) || gathers(i+1) || sampling(i+2)
 
     def _queue_step_ddp(self, par):
         """One data-parallel step of the queue pipeline as ONE sequence of launches and collective nodes:

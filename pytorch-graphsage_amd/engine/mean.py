@@ -192,19 +192,6 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.emb:
             self._init_emb_optimizer()
 
-    def _fin_in_launch(self):
-        """Single GPU, queue mode, OPT-IN (GSAGE_FIN_IN_LAUNCH=1): the gradient finalisation rides in the gather launch
-        (its workgroups go first, the update's workgroups poll their slots): four launches per step instead of five,
-        bit-identical results (tests/test_gpu_round4.py).  Measured SLOWER on the MI355X (0.0945 against 0.0921 ms/step
-        at config 2, 0.183 against 0.180 at the papers shape): the 768 finalisation workgroups, the 225 spinning
-        update workgroups and the 512 sampler workgroups together hold 1 505 of the launch's 1 792 resident
-        workgroup slots for its first ~8 us, during which the HBM-bound gather role runs on the remaining 16 % --
-        the 6.5 us launch it saves costs the gather role more than that."""
-        if self.ddp is not None or self.emb or self.queue is None or getattr(self, "split", False):
-            return False
-        n_side = self.n_rdesc * min(-(-self.r_max // 256), 256) + min(-(-(-(-self.flat_p.numel() // 4)) // 256), 2048)
-        return bool(n_side <= 1536 and os.environ.get("GSAGE_FIN_IN_LAUNCH", "0") == "1")
-
     def _wg_target(self):
         """K5b workgroups to plan for: the chip, or the chain's share of it in split mode."""
         if not self.gather_cus:
@@ -377,8 +364,6 @@ class FusedMeanTrainStep(FusedTrainStep):
         for i in range(0, len(probs), 8):
             if i == 0:
                 self._time_next(6, 7)
-            if self._fin_fused and i + 8 >= len(probs):
-                self._finalize_ticks_next()      # (no finalisation launch: the last K5b launch ticks the step's counters)
             ops.wgrad_multi(probs[i:i + 8])
         self._side_join("k5b")
         self._stage_finalize(s)

@@ -410,53 +410,6 @@ def test_default_cli_run_of_a_multilabel_problem_trains(tmp_path, capsys):
     assert out[-1]["train_metric"]["micro"] > 0.5
 
 
-@pytest.mark.parametrize("case", ["mean", "mean3"])
-def test_finalisation_as_a_role_of_the_gather_launch_is_bit_identical(monkeypatch, case):
-    """Single GPU, queue mode: the gradient finalisation rides in the launch that carries Adam (its workgroups are
-    dispatched first and publish update-number-tagged slots, the update's workgroups poll them; the step's ticks move
-    to the K5b launch) -- four launches per step instead of five.  Same partial sums added in the same order:
-    predictions, weights, Adam's moments and the gradient norm are bit-identical to the run with the finalisation
-    as a launch of its own (GSAGE_FIN_IN_LAUNCH=0), step after step, also across an epoch boundary."""
-    import util
-    from torch.nn import functional as F
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("GSAGE_FIN_IN_LAUNCH", mode)
-        model, feats, loss_fn, ids, tg, prec = util.dp_case(gs, "mean", n_batch=5, global_batch=64)
-        if case == "mean3":          # three levels, generic (unfused) seed level: four descriptors
-            torch.manual_seed(5)
-            gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
-            specs = [{"n_train_samples": n, "n_val_samples": n, "output_dim": 32, "activation": a}
-                     for n, a in ((4, F.relu), (3, F.relu), (2, lambda x: x))]
-            model = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"],
-                                    adj=model.train_sampler.adj, train_adj=model.train_sampler.adj,
-                                    prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup["mean"],
-                                    input_dim=feats.shape[1], n_nodes=feats.shape[0], n_classes=5, layer_specs=specs,
-                                    lr_init=0.01, weight_decay=1e-4).to(DEV)
-            gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
-            model.train_sampler.seed = 77
-        ops.set_compute_dtype(prec)
-        store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype=prec)
-        eng = gs.engine.FusedMeanTrainStep(model, store, loss_fn, ids[0], tg[0], capture="cmdlist")
-        preds, norms = [], []
-        for _epoch in range(2):
-            eng.load_epoch(ids, tg)
-            before = nat.launch_count()
-            for _ in range(5):
-                preds.append(eng.step_queue().clone())
-                norms.append(float(eng.gnorm.item()))
-            torch.cuda.synchronize()
-            per_step = (nat.launch_count() - before - 3) / 5.0          # (the prime launch: two samplings + a gather)
-        assert eng._fin_in_launch() == (mode == "1")
-        outs[mode] = (torch.stack(preds), eng.flat_p.clone(), eng.flat_m.clone(), eng.flat_v.clone(), norms,
-                      eng.flat_g.clone(), int(eng.step.item()), per_step)
-    a, b = outs["0"], outs["1"]
-    assert a[6] == b[6] == 10 and b[7] == a[7] - 1, (a[6], b[6], a[7], b[7])
-    for i in range(4):
-        assert torch.equal(a[i], b[i]), i
-    assert a[4] == b[4] and torch.equal(a[5], b[5])
-
-
 def test_one_launch_batch_metric_and_pending_metric_equal_the_reference_route():
     """A training batch (B x C <= 64 k) is scored by ONE single-workgroup launch, larger inputs by the three-launch
     route: both equal the reference's host route (ProblemMetrics: sklearn) on the same data, for classification and
