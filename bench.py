@@ -535,13 +535,6 @@ def extra_cli(gs, dev, data, store):
                          "batches_per_epoch": len([ln for ln in lines if ln.get("epoch") == 0 and "epoch_progress" in ln]),
                          "cli_seeds_per_s": rates[-1] if rates else None, "cli_seeds_per_s_by_epoch": rates,
                          "wall_s": wall, "val_metric": lines[-1].get("val_metric") if lines else None}
-        # the same run with a line every 100 000 batches only (--engine fused honours --log-interval): the loop itself
-        lines2, wall2, _eng2 = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
-                                             "sparse_uniform_neighbor_sampler", "--epochs", str(epochs), "--engine", "fused",
-                                             "--log-interval", "100000"], prob)
-        ts = [ln["time"] for ln in lines2 if "epoch_progress" in ln]
-        if len(ts) >= 4:      # (first and last batch of every epoch are logged: last epoch = ts[-2] .. ts[-1])
-            out["reddit"]["cli_seeds_per_s_without_per_batch_log"] = n_train * (299.0 / 300.0) / (ts[-1] - ts[-2])
     except Exception as e:
         out["reddit"] = {"error": repr(e)}
     del prob
