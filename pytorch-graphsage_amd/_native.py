@@ -301,12 +301,18 @@ class NativeComm(object):
     """One RCCL communicator owned by libgsage_hip.so (include/gsage.h, "The step's collectives"): the collectives
     of a data-parallel step become nodes of the step's command list."""
 
+    @staticmethod
+    def load():
+        """dlopen RCCL (the copy torch itself maps when there is one).  Separate from __init__ so that the ranks can
+        agree that EVERY rank has it before any of them enters the collective ncclCommInitRank."""
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        check(lib().gsage_comm_load(cand.encode() if os.path.exists(cand) else None), "comm_load")
+
     def __init__(self, rank, world, exchange_id):
         """exchange_id(bytes or None) -> bytes: hands rank 0's 128-byte id to every rank (e.g. a broadcast over the
         process group torch.distributed already has)."""
-        import torch
-        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy torch itself maps
-        check(lib().gsage_comm_load(cand.encode() if os.path.exists(cand) else None), "comm_load")
+        self.load()
         buf = ctypes.create_string_buffer(128)
         if rank == 0:
             check(lib().gsage_comm_unique_id(buf), "comm_unique_id")

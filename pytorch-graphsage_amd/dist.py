@@ -31,22 +31,46 @@ class DataParallel(object):
         # GSAGE_NATIVE_COMM=0): the same nodes call torch.distributed through a host callback
         self.comm = None
 
+    def _all_agree(self, ok):
+        """True iff `ok` holds on every rank (one tiny all-reduce over the process group)."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     def create_native_comm(self):
         """One RCCL communicator owned by libgsage_hip.so, set up over the process group torch.distributed already
-        has (rank 0's 128-byte id travels through broadcast_object_list).  Collective: every rank calls it."""
+        has (rank 0's 128-byte id travels through broadcast_object_list).  Collective: every rank calls it.  The
+        ranks agree after each stage -- a rank that cannot load RCCL must not leave the others waiting inside
+        ncclCommInitRank, and either every rank issues the step's collectives through the library or none does."""
+        import sys
         from . import _native as nat
 
         def exchange(raw):
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
+        why = None
+        try:
+            nat.NativeComm.load()
+        except Exception as e:
+            why = e
+        if not self._all_agree(why is None):
+            if self.rank == 0:
+                print("gsage: no native RCCL communicator (%s); collectives go through torch.distributed"
+                      % (why if why is not None else "another rank could not load RCCL"), file=sys.stderr)
+            self.comm = None
+            return None
         try:
             self.comm = nat.NativeComm(self.rank, self.world, exchange)
-        except Exception as e:            # (the engines then go through torch.distributed; say so once)
-            import sys
-            print("gsage: no native RCCL communicator (%s); collectives go through torch.distributed" % (e,),
-                  file=sys.stderr)
+        except Exception as e:
+            why, self.comm = e, None
+        if not self._all_agree(self.comm is not None):
+            if self.comm is not None:
+                self.comm.close()
             self.comm = None
+            if self.rank == 0:
+                print("gsage: the native RCCL communicator could not be created on every rank (%s); collectives go "
+                      "through torch.distributed" % (why,), file=sys.stderr)
         return self.comm
 
     # ---- batch sharding -------------------------------------------------------------------

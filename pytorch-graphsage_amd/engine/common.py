@@ -399,6 +399,7 @@ class FusedTrainStep(object):
     def _record_main(self):
         """(Re-)record the per-call command lists / graphs of __call__."""
         ddp = self.ddp
+        self._host_cbs = self._cbs_main = []      # (callbacks of the lists recorded below live as long as those lists)
         if self.capture_mode == "graph":
             # re-recording: let go of the old hipGraphs (and their private pool) before capturing new ones
             self.g_main, self.g_opt, self.g_front, self._pool = None, None, None, None
@@ -1147,6 +1148,7 @@ class FusedTrainStep(object):
 
     def _record_queue(self):
         self.g_prime, self.g_qfront, self.g_queue = None, None, None
+        self._host_cbs = self._cbs_queue = []     # (the previous epoch's lists, and their callbacks, are let go)
         # data-parallel, mean engine: the gathers are cut around the exchange (bulk before the join, rest with Adam)
         self._ddp_split = bool(self.ddp is not None and self.MEAN_ENGINE and not self.emb and
                                self.size[self.L - 1] > self._tail_rows and
