@@ -298,29 +298,31 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     assert live is None or step.fused_head or step.fused_l1 or min(live) == B
     val_metric = train_metric = None
     epoch = 0
+    # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right behind
+    # its step, its result lands in pinned memory, and its line is printed once batch b + 1 has been issued -- same
+    # lines, same order, same values; the GPU never waits for the log (stdout is flushed twice a second and at the end
+    # of every epoch instead of once per line).
+    pending, last_flush = [], [time()]
+    # (class ids outside [0, C) are scored the reference's way, on the host: the synchronous route)
+    tg_ok = problem.task != 'classification' or (int(np.min(problem.targets)) >= 0 and
+                                                 int(np.max(problem.targets)) < problem.n_classes)
+
+    def flush(keep):
+        nonlocal train_metric
+        while len(pending) > keep:
+            prog, metric = pending.pop(0)
+            train_metric = metric.get()
+            print(dumps({"epoch": epoch, "epoch_progress": prog, "train_metric": train_metric,
+                         "val_metric": val_metric, "time": time() - start_time}))
+        if keep == 0 or time() - last_flush[0] > 0.5:
+            sys.stdout.flush()
+            last_flush[0] = time()
     for epoch in range(args.epochs):
         model.train()
         if epoch > 0:
             ids, tgs, live = epoch_batches()
         if queued:
             step.load_epoch(ids, tgs, n_valid=live)          # (compat / dense sampler: draws the epoch's values)
-        # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right
-        # behind its step, its result travels to pinned memory, and its line is printed once batch b + 1 has been
-        # issued -- same lines, same order, same values; the GPU never waits for the log.
-        pending = []
-        # (class ids outside [0, C) are scored the reference's way, on the host: the synchronous route)
-        tg_ok = problem.task != 'classification' or (int(np.min(problem.targets)) >= 0 and
-                                                     int(np.max(problem.targets)) < problem.n_classes)
-
-        def flush(keep):
-            nonlocal train_metric
-            while len(pending) > keep:
-                prog, metric = pending.pop(0)
-                train_metric = metric.get()
-                print(dumps({"epoch": epoch, "epoch_progress": prog, "train_metric": train_metric,
-                             "val_metric": val_metric, "time": time() - start_time}))
-            if keep == 0:
-                sys.stdout.flush()
         for b in range(n_batches):
             nb = live[b] if live is not None else B
             step.set_progress((epoch + b / n_batches) / args.epochs)

@@ -340,3 +340,62 @@ def test_wgrad_balance_fits_one_round_with_equal_slices():
                 lens.append(rps)
         big = max(lens)
         assert all(l <= big for l in lens)
+
+
+def test_head_coverage_is_decided_before_an_engine_is_built():
+    """Engine.head_why_not (what train.choose_engine asks BEFORE an engine re-points the model's Parameters; round-3
+    advisor finding): cross-entropy with <= 64 classes and the L1 regression head are fused and may meet padded
+    chunks; multilabel / wide heads are not -- they are refused only when the caller will pad."""
+    from scipy import sparse
+    from torch.nn import functional as F
+    adj = sparse.csr_matrix((np.array([1, 2, 1]), np.array([0, 1, 0]), np.array([0, 0, 2, 3])), shape=(3, 2))
+    specs = [{"n_train_samples": 2, "n_val_samples": 2, "output_dim": 8, "activation": F.relu},
+             {"n_train_samples": 2, "n_val_samples": 2, "output_dim": 8, "activation": lambda x: x}]
+
+    def model(n_classes):
+        return gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+                               prep_class=gs.prep_lookup["identity"], aggregator_class=gs.aggregator_lookup["mean"],
+                               input_dim=4, n_nodes=3, n_classes=n_classes, layer_specs=specs)
+    E = gs.engine.FusedMeanTrainStep
+    L = gs.ProblemLosses
+    i64, f32 = torch.zeros(1, dtype=torch.int64), torch.zeros(1)
+    state = torch.get_rng_state()
+    assert E.head_why_not(model(5), L.classification, i64, 512, True) is None
+    assert E.head_why_not(model(1), L.regression_mae, f32, 512, True) is None
+    assert E.head_why_not(model(4), L.multilabel_classification, f32, 512, False) is None          # nothing is padded
+    assert "no fused kernel" in E.head_why_not(model(4), L.multilabel_classification, f32, 512, True)
+    assert "no fused kernel" in E.head_why_not(model(100), L.classification, i64, 512, True)       # > 64 classes
+    assert "no fused kernel" in E.head_why_not(model(1), L.regression_mae, f32, 4096, True)        # > 2048 seeds
+    state2 = torch.get_rng_state()
+    m = model(5)                                     # (building a model draws; head_why_not itself must not)
+    torch.set_rng_state(state2)
+    E.head_why_not(m, L.classification, i64, 512, True)
+    assert torch.equal(torch.get_rng_state(), state2), "head_why_not consumed torch's generator (the run's own)"
+    torch.set_rng_state(state)
+
+
+def test_train_main_takes_a_problem_held_in_memory(capsys):
+    """NodeProblem.from_arrays + train.main(problem=...): the reference's loop on arrays already in memory (what
+    bench.py's CLI measurements use instead of writing a multi-GB problem file) -- host mode, same JSON protocol."""
+    from scipy import sparse
+    rng = np.random.RandomState(0)
+    n, D, C = 120, 8, 3
+    degs = rng.randint(1, 6, size=n + 1)
+    degs[0] = 0
+    rows = np.repeat(np.arange(n + 1), degs)
+    cols = np.concatenate([np.arange(d) for d in degs])
+    adj = sparse.csr_matrix((rng.randint(1, n + 1, size=rows.shape[0]), (rows, cols)))
+    feats = rng.normal(size=(n + 1, D)).astype(np.float32)
+    feats[0] = 0
+    folds = np.array(["train"] * 80 + ["val"] * 25 + ["test"] * (n + 1 - 105))
+    folds[0] = "dummy"
+    prob = gs.NodeProblem.from_arrays("classification", C, adj, adj, feats, folds, feats[:, :C].argmax(1).reshape(-1, 1),
+                                      cuda=False)
+    assert prob.feats_dim == D and prob.n_nodes == adj.shape[0] and prob.nodes["train"].shape[0] == 79
+    train = __import__("importlib").import_module("pytorch-graphsage_amd.train")
+    train.main(["--problem-path", "<memory>", "--no-cuda", "--epochs", "2", "--batch-size", "32", "--sampler-class",
+                "sparse_uniform_neighbor_sampler", "--n-train-samples", "3,2", "--n-val-samples", "3,2",
+                "--output-dims", "8,8"], problem=prob)
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    per_batch = [l for l in lines if "epoch_progress" in l]
+    assert len(per_batch) == 2 * (79 // 32 + 1) and per_batch[-1]["val_metric"] is not None
