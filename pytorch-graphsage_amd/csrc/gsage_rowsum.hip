@@ -126,7 +126,7 @@ k_rows_link(const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restr
         }
         // behind the head: find the last entry with a smaller position and link in behind it
         int32_t prev = (int32_t)(uint32_t)h;
-        for (int64_t g2 = 0; g2 <= 2 * n + 1; ++g2) {       // (<= n advances + <= n lost races: a walk always ends)
+        for (int64_t g2 = 0; g2 <= n; ++g2) {
             int32_t nx = ld_i32(next + prev);
             if (nx != -1 && nx < e) { prev = nx; continue; }
             publish_i32(next + e, nx);

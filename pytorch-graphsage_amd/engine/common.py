@@ -933,9 +933,6 @@ class FusedTrainStep(object):
                 self.row_err = torch.zeros(1, dtype=i32, device=dev)
                 self.tail_ids = torch.full((n1,), int(self.model.prep.n_nodes), dtype=torch.int64, device=dev)
                 ds.sorted_ids, ds.head = 2, self.row_head.data_ptr()
-                # (the warm-up steps of _finish_init run under update numbers that the real steps use again: their
-                #  lists must not survive it -- a list's tag is only as unique as the update number)
-                self._warm_reset = self._warm_reset + (self.row_head, self.row_err)
         self.model._settle_rows = self.sync_rows
         emb_mod = self.model.prep.embedding
         self._row_hooks = [emb_mod.register_forward_pre_hook(lambda *_: self.sync_rows()),
