@@ -717,13 +717,10 @@ typedef struct gsage_row_adam {
     int64_t n_rows;
     int32_t E, hist_cap;            /* E % 4 == 0, E <= 256 */
     float beta1, beta2, eps, weight_decay, max_norm;
-    int32_t sorted_ids;             /* ABI 4: 1: ids0[0:n0] is sorted ascending and n1 == 0 -- the first entry of a run of
-                                       equal ids does the row's work, the others are skipped by comparing neighbours;
-                                       2: `head` holds the lists of gsage_rows_link (tag = this call's update number):
-                                       the entry that heads a row's list does the row's work.  Either way no atomics,
-                                       `seen` unused, and the order in which gsage_rows_sqnorm adds its terms depends
-                                       on the list alone (data-parallel replicas stay bit-identical) */
-    const uint64_t *head;           /* sorted_ids == 2 */
+    int32_t sorted_ids;             /* ABI 4: != 0: ids0[0:n0] is sorted ascending and n1 == 0 -- the first entry of a run of
+                                       equal ids does the row's work, the others are skipped by comparing neighbours:
+                                       no atomics, `seen` unused, and the order in which gsage_rows_sqnorm adds its
+                                       terms depends on the list alone (data-parallel replicas stay bit-identical) */
 } gsage_row_adam;
 int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1,
                         int32_t step_off, void *stream);
@@ -754,29 +751,6 @@ int gsage_sort_rows(const int64_t *ids0, int64_t n0, int64_t tail_id, int64_t n_
 int gsage_segment_sum_rows(const int64_t *ids_sorted, const int32_t *pos_sorted, int64_t n, const float *rows0,
                            int64_t ld0, int64_t n0, const float *rows1, int64_t ld1, int32_t E, float scale,
                            float *table, int64_t ldt, void *stream);
-/* The same deterministic gradient WITHOUT a sort (ABI 4): per distinct id a linked list of the list positions that
- * hold it, ascending -- built by insert-only compare-and-swap (the order of the insertions varies from run to run,
- * the finished list does not), then walked by the position that heads it.  Entry e of the list is ids0[e] for
- * e < n0 and ids1[e - n0] beyond (the two-list form of gsage_rows_*: a frontier + the spare row's entries).
- *   head   uint64 [n_rows]: (tag << 32 | first position) of a row's list; a word with another tag is an empty list,
- *          so nothing is reset between steps -- tag = *step + step_off, the update number (must differ from call to
- *          call); zero-initialise once
- *   next   int32 [n0 + n1]: position of the next entry of the same row, -1 at the end (written by gsage_rows_link)
- *   gsage_rows_link          builds the lists (one compare-and-swap per entry when the row occurs once)
- *   gsage_rows_sum_linked    for every entry that heads a list: table[id, 0:E] = scale * (rows of the list added in
- *                            ascending position): rows(p) = p < n0 ? rows0[p * ld0 :] : rows1[(p - n0) * ld1 :] --
- *                            the same bits as gsage_sort_rows + gsage_segment_sum_rows, two short launches instead of
- *                            the vendor sort's five
- * Then gsage_rows_sqnorm / gsage_rows_adam with gsage_row_adam.sorted_ids = 2 and .head = head: the entry that
- * heads a row's list does the row's work (which lane -- hence which norm partial -- depends on the list alone).
- * err_flag (device int32, may be NULL): set to 1 if a walk exceeds the list's length (a corrupted list: never
- * observed; the walks are bounded so that it cannot hang the device). */
-int gsage_rows_link(const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1, int64_t n_rows, uint64_t *head,
-                    int32_t *next, const int64_t *step, int32_t step_off, int32_t *err_flag, void *stream);
-int gsage_rows_sum_linked(const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1, const uint64_t *head,
-                          const int32_t *next, const int64_t *step, int32_t step_off, const float *rows0, int64_t ld0,
-                          const float *rows1, int64_t ld1, int32_t E, float scale, float *table, int64_t ldt,
-                          int32_t *err_flag, void *stream);
 
 /* One launch converting fp32 parameters into the bf16 operand copies K5 / K5b read:
  * dst[r, c] = bf16(src[r, c]) with leading dimension dst_ld, and/or the transposed copy

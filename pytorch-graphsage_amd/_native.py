@@ -57,9 +57,6 @@ SIGNATURES = {
     "gsage_sort_rows_temp_bytes": (_i64, [_i64, _i32]),
     "gsage_sort_rows": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     "gsage_segment_sum_rows": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
-    "gsage_rows_link": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "gsage_rows_sum_linked": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp,
-                                     _i64, _vp, _vp]),
     "gsage_head_l1_sharded": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _i64, _vp, _vp]),
     "gsage_sample_csr_sel": (_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "gsage_sample_dense": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
@@ -219,7 +216,7 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
 class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)
     _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("last", _vp), ("seen", _vp), ("hist", _vp),
                 ("lr", _vp), ("step", _vp), ("n_rows", _i64), ("E", _i32), ("hist_cap", _i32), ("beta1", _f32),
-                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_norm", _f32), ("sorted_ids", _i32), ("head", _vp)]
+                ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("max_norm", _f32), ("sorted_ids", _i32)]
 
 
 class TailGatherDesc(ctypes.Structure):       # mirrors gsage_tail_gather_desc (include/gsage.h)

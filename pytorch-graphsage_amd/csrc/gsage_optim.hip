@@ -226,9 +226,7 @@ struct RowAdam {
     int32_t *last, *seen;
     float *hist;                 // [2 * hist_cap]
     int32_t hist_cap, E, lpr;    // lanes per row: power of two >= E / 4
-    int32_t sorted;              // 1: ids0 is sorted ascending (n1 == 0): runs settled by comparing neighbours;
-                                 // 2: `head` holds gsage_rows_link's lists: the entry that heads a row's list works
-    const unsigned long long *head;
+    int32_t sorted;              // != 0: ids0 is sorted ascending (n1 == 0): runs settled by comparing neighbours
     int64_t n_rows;
     const float *lr;
     const int64_t *step;
@@ -336,17 +334,9 @@ __device__ __forceinline__ float rows_pass(const RowAdam &a, const int64_t *__re
         if (valid) {
             if (MODE == ROWS_CATCH_UP_ALL) { old_l = a.last[r_l]; if (old_l < target) a.last[r_l] = target; }
             else if (a.sorted) {
-                // sorted list: the first entry of a run of equal ids does the row's work; linked lists: the entry that
-                // heads the row's list does -- no atomics, and which lane (hence which norm partial) a row lands on
-                // depends on the list alone
-                bool leader;
-                if (a.sorted == 2) {
-                    const unsigned long long h = __hip_atomic_load(a.head + r_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    leader = (uint32_t)(h >> 32) == (uint32_t)target && (int64_t)(uint32_t)h == e;
-                } else {
-                    leader = e == 0 || (int32_t)ids0[e - 1] != r_l;
-                }
-                if (leader) {
+                // sorted list: the first entry of a run of equal ids does the row's work -- no atomics, and which
+                // lane (hence which norm partial) a row lands on depends on the list alone
+                if (e == 0 || (int32_t)ids0[e - 1] != r_l) {
                     if (MODE == ROWS_SQNORM) old_l = target - 1;
                     else { old_l = a.last[r_l]; if (old_l < target) a.last[r_l] = target; }
                 }
@@ -836,8 +826,6 @@ static int fill_rows(RowAdam &a, const gsage_row_adam *d, const char *who)
     a.hist_cap = d->hist_cap; a.E = d->E; a.n_rows = d->n_rows; a.lr = d->lr; a.step = d->step;
     a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.weight_decay = d->weight_decay; a.max_norm = d->max_norm;
     a.sorted = d->sorted_ids;
-    a.head = (const unsigned long long *)d->head;
-    GSAGE_REQUIRE(a.sorted != 2 || a.head, who);
     GSAGE_REQUIRE(d->n_rows < ((int64_t)1 << 31), who);
     const int per = d->E <= 64 ? 1 : 4;          // elements per lane (rows_vec)
     a.lpr = 1;
@@ -859,7 +847,7 @@ int gsage_rows_catch_up(const gsage_row_adam *d, const int64_t *ids0, int64_t n0
     int rc = fill_rows(a, d, "rows_catch_up: bad descriptor");
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1), "rows_catch_up: bad id lists");
-    GSAGE_REQUIRE(a.sorted != 1 || n1 == 0, "rows_catch_up: a sorted list is ONE list (n1 == 0)");
+    GSAGE_REQUIRE(!a.sorted || n1 == 0, "rows_catch_up: a sorted list is ONE list (n1 == 0)");
     if (n0 + n1 == 0) return GSAGE_OK;
     const dim3 grid(rows_grid(a, n0 + n1, 4096));
     hipStream_t s = (hipStream_t)stream;
@@ -894,7 +882,7 @@ int gsage_rows_sqnorm(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, 
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial >= 1 &&
                   n_partial <= 1024, "rows_sqnorm: bad arguments");
-    GSAGE_REQUIRE(a.sorted != 1 || n1 == 0, "rows_sqnorm: a sorted list is ONE list (n1 == 0)");
+    GSAGE_REQUIRE(!a.sorted || n1 == 0, "rows_sqnorm: a sorted list is ONE list (n1 == 0)");
     if (rows_vec4(a))
         launch(k_rows_sqnorm<4>, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, a, ids0, n0, ids1, n1, step_off, partial);
     else
@@ -910,7 +898,7 @@ int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, co
     if (rc != GSAGE_OK) return rc;
     GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && (n0 == 0 || ids0) && (n1 == 0 || ids1) && partial && n_partial_ready >= 1,
                   "rows_adam: bad arguments");
-    GSAGE_REQUIRE(a.sorted != 1 || n1 == 0, "rows_adam: a sorted list is ONE list (n1 == 0)");
+    GSAGE_REQUIRE(!a.sorted || n1 == 0, "rows_adam: a sorted list is ONE list (n1 == 0)");
     // (always launched, also for empty lists: the launch records the step's constants)
     const dim3 grid(rows_grid(a, n0 + n1 > 0 ? n0 + n1 : 1, 4096));
     hipStream_t s = (hipStream_t)stream;

@@ -71,107 +71,6 @@ k_segment_sum_rows(const int64_t *__restrict__ ids, const int32_t *__restrict__ 
     *reinterpret_cast<v4 *>(table + id * ldt + sub * 4) = acc * scale;
 }
 
-// ---- the same reduction without a sort: per distinct id an ascending linked list of its list positions --------------
-// Insert-only sorted lists under compare-and-swap: the order of the insertions varies from run to run, the finished
-// list -- positions ascending -- does not, so the sum that walks it is the same bits every time and on every rank.
-// head[r] = (tag << 32 | first position): a word whose tag is not this call's update number is an empty list (nothing
-// is reset between steps).  Every access to head / next is a device-scope atomic (RMWs where a value is published:
-// the value an exchange returns proves it has been performed), never a fence: a device-scope fence flushes the XCD's
-// L2.  Walks are bounded by the list's length so that a corrupted list cannot hang the device.
-__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int32_t ld_i32(const int32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// next[e] = v, PERFORMED before anything that follows is issued: an exchange whose returned value is consumed (the
-// wait for the value is the wait for the operation; a plain store's acknowledgement is not proof of visibility to
-// another XCD's device-scope accesses -- round 4's finalisation-role experiment)
-__device__ __forceinline__ void publish_i32(int32_t *p, int32_t v)
-{
-    const int32_t old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" : : "v"(old) : "memory");
-}
-
-__global__ void __launch_bounds__(256)
-k_rows_link(const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1, int64_t n1, int64_t n_rows,
-            unsigned long long *__restrict__ head, int32_t *__restrict__ next, const int64_t *__restrict__ step,
-            int32_t step_off, int32_t *__restrict__ err_flag)
-{
-    const int64_t n = n0 + n1;
-    const int64_t e64 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e64 >= n) return;
-    const int32_t e = (int32_t)e64;
-    const int64_t r = e64 < n0 ? ids0[e64] : ids1[e64 - n0];
-    if (r < 0 || r >= n_rows) {
-        if (err_flag) *err_flag = 1;
-        return;
-    }
-    const unsigned long long tag = (unsigned long long)(uint32_t)(*step + step_off) << 32;
-    const unsigned long long mine = tag | (uint32_t)e;
-    for (int64_t guard = 0; guard <= n; ++guard) {
-        const unsigned long long h = ld_u64(head + r);
-        if ((h >> 32) != (tag >> 32) || (int32_t)(uint32_t)h > e) {
-            // empty list, or this entry goes in front: publish next[e] (an exchange: performed when it returns), then
-            // swing the head
-            const int32_t nx = (h >> 32) == (tag >> 32) ? (int32_t)(uint32_t)h : -1;
-            publish_i32(next + e, nx);
-            unsigned long long expect = h;
-            if (__hip_atomic_compare_exchange_strong(head + r, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-                return;
-            continue;
-        }
-        // behind the head: find the last entry with a smaller position and link in behind it
-        int32_t prev = (int32_t)(uint32_t)h;
-        for (int64_t g2 = 0; g2 <= n; ++g2) {
-            int32_t nx = ld_i32(next + prev);
-            if (nx != -1 && nx < e) { prev = nx; continue; }
-            publish_i32(next + e, nx);
-            if (__hip_atomic_compare_exchange_strong(next + prev, &nx, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-                return;
-            // (somebody linked in behind `prev` meanwhile: look again from `prev`)
-        }
-        break;
-    }
-    if (err_flag) *err_flag = 1;
-}
-
-// One group of E / 4 lanes per list entry; the group whose entry heads its row's list walks it (positions ascending)
-// and stores scale * the sum; every other group leaves at once.
-__global__ void __launch_bounds__(256)
-k_rows_sum_linked(const int64_t *__restrict__ ids0, int64_t n0, const int64_t *__restrict__ ids1, int64_t n1,
-                  const unsigned long long *__restrict__ head, const int32_t *__restrict__ next,
-                  const int64_t *__restrict__ step, int32_t step_off, const float *__restrict__ rows0, int64_t ld0,
-                  const float *__restrict__ rows1, int64_t ld1, int32_t lpr, int32_t chunks, float scale,
-                  float *__restrict__ table, int64_t ldt, int32_t *__restrict__ err_flag)
-{
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const int64_t n = n0 + n1;
-    const int64_t gpb = 256 / lpr;
-    const int64_t g = (int64_t)blockIdx.x * gpb + threadIdx.x / lpr;
-    const int sub = threadIdx.x % lpr;
-    if (g >= n || sub >= chunks) return;
-    const int64_t r = g < n0 ? ids0[g] : ids1[g - n0];
-    const unsigned long long h = ld_u64(head + r);
-    const uint32_t tag = (uint32_t)(*step + step_off);
-    if ((uint32_t)(h >> 32) != tag || (int64_t)(uint32_t)h != g) return;
-    auto row = [&](int64_t p) -> const float * { return p < n0 ? rows0 + p * ld0 : rows1 + (p - n0) * ld1; };
-    v4 acc = *reinterpret_cast<const v4 *>(row(g) + sub * 4);
-    int32_t p = ld_i32(next + g);
-    int64_t guard = 0;
-    while (p != -1 && guard++ <= n) {
-        const int32_t pn = ld_i32(next + p);                 // (the next link is requested before this row is added)
-        acc += *reinterpret_cast<const v4 *>(row(p) + sub * 4);
-        p = pn;
-    }
-    if (p != -1 && err_flag && sub == 0) *err_flag = 1;
-    *reinterpret_cast<v4 *>(table + r * ldt + sub * 4) = acc * scale;
-}
-
 }  // namespace gsage
 
 using namespace gsage;
@@ -239,38 +138,6 @@ int gsage_segment_sum_rows(const int64_t *ids_sorted, const int32_t *pos_sorted,
     launch(k_segment_sum_rows, dim3((unsigned)ceil_div(n, gpb)), dim3(256), 0, (hipStream_t)stream, ids_sorted,
            pos_sorted, n, rows0, ld0, n0, rows1 ? rows1 : rows0, ld1, (int32_t)lpr, (int32_t)chunks, scale, table, ldt);
     return check_launch("segment_sum_rows");
-}
-
-int gsage_rows_link(const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1, int64_t n_rows, uint64_t *head,
-                    int32_t *next, const int64_t *step, int32_t step_off, int32_t *err_flag, void *stream)
-{
-    GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && n0 + n1 > 0 && n0 + n1 < ((int64_t)1 << 31) && n_rows > 0,
-                  "rows_link: bad sizes");
-    GSAGE_REQUIRE((ids0 || n0 == 0) && (ids1 || n1 == 0) && head && next && step, "rows_link: null pointer");
-    launch(k_rows_link, dim3((unsigned)ceil_div(n0 + n1, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, ids0, n0, ids1,
-           n1, n_rows, (unsigned long long *)head, next, step, step_off, err_flag);
-    return check_launch("rows_link");
-}
-
-int gsage_rows_sum_linked(const int64_t *ids0, int64_t n0, const int64_t *ids1, int64_t n1, const uint64_t *head,
-                          const int32_t *next, const int64_t *step, int32_t step_off, const float *rows0, int64_t ld0,
-                          const float *rows1, int64_t ld1, int32_t E, float scale, float *table, int64_t ldt,
-                          int32_t *err_flag, void *stream)
-{
-    const int64_t n = n0 + n1;
-    GSAGE_REQUIRE(n0 >= 0 && n1 >= 0 && n > 0, "rows_sum_linked: bad sizes");
-    GSAGE_REQUIRE((ids0 || n0 == 0) && (ids1 || n1 == 0) && head && next && step && table && (rows0 || n0 == 0) &&
-                  (rows1 || n1 == 0), "rows_sum_linked: null pointer");
-    GSAGE_REQUIRE(E > 0 && E % 4 == 0 && E <= 256 && ld0 % 4 == 0 && ld1 % 4 == 0 && ldt % 4 == 0 && ldt >= E,
-                  "rows_sum_linked: rows of whole 16-byte chunks, E <= 256");
-    const int chunks = E / 4;
-    int lpr = 1;
-    while (lpr < chunks) lpr *= 2;
-    const int64_t gpb = 256 / lpr;
-    launch(k_rows_sum_linked, dim3((unsigned)ceil_div(n, gpb)), dim3(256), 0, (hipStream_t)stream, ids0, n0, ids1, n1,
-           (const unsigned long long *)head, next, step, step_off, rows0 ? rows0 : rows1, ld0, rows1 ? rows1 : rows0, ld1,
-           (int32_t)lpr, (int32_t)chunks, scale, table, ldt, err_flag);
-    return check_launch("rows_sum_linked");
 }
 
 }  // extern "C"

@@ -895,20 +895,13 @@ class FusedTrainStep(object):
         d.beta1, d.beta2, d.eps, d.weight_decay, d.max_norm = 0.9, 0.999, 1e-8, self.wd, 5.0
         self._rows_dirty, self._rows_since = False, 0
         self._warm_reset = (self.row_last, self.row_seen)
-        # The table's gradient (csrc/gsage_rowsum.hip), three routes (GSAGE_ROW_GRAD):
-        #   linked   (default) per distinct id an ascending linked list of its frontier positions (insert-only
-        #            compare-and-swap), walked by the position that heads it: the rows of a node are added in ONE order
-        #            -- the same bits from run to run and, in a data-parallel run, on every rank -- in two short
-        #            launches, no atomics on the gradient, no zero-fill; the norm / Adam passes take the heads
-        #   sorted   the same sums through the vendor's radix sort + segment sums (five more launches: the cross-check)
-        #   atomics  round 3's K6: fp32 atomics + stamp dedupe (single GPU only: replicas that add the same rows in
-        #            different orders would drift apart)
-        mode = os.environ.get("GSAGE_ROW_GRAD", "sorted" if os.environ.get("GSAGE_SORTED_ROWS", "0") == "1" else "linked")
-        assert mode in ("linked", "sorted", "atomics"), "GSAGE_ROW_GRAD: linked | sorted | atomics"
-        if self.ddp is not None and mode == "atomics":
-            mode = "linked"
-        self.row_grad = mode
-        self.sorted_rows = mode != "atomics"          # (deterministic route: _prep_backward leaves the rows to _stage_opt_emb)
+        # The table's gradient, deterministically (csrc/gsage_rowsum.hip): the frontier's ids -- every rank's, in a
+        # data-parallel run -- are sorted, each run of equal ids is summed in list order and stored (no atomics, no
+        # zero-fill), and the norm / Adam passes walk the sorted list (gsage_row_adam.sorted_ids).
+        # Single GPU: opt-in (GSAGE_SORTED_ROWS=1) -- the vendor sort of 164 k keys is five short launches (~0.13 ms of
+        # the Pokec-shaped step) where the atomics cost ~0.05; data-parallel: always (replicas
+        # that add the same rows in different orders would drift apart).
+        self.sorted_rows = self.ddp is not None or os.environ.get("GSAGE_SORTED_ROWS", "0") == "1"
         if self.sorted_rows:
             W, B, RA0, ns = self.world, self.B, self.off[self.L + 1], int(self.seed_grad.shape[0])
             n0, n1 = W * (RA0 - B), W * ns
@@ -917,22 +910,15 @@ class FusedTrainStep(object):
                 self.xids = torch.zeros(n0, dtype=torch.int64, device=dev)
                 self.xrows = torch.zeros(n0, E, dtype=f32, device=dev)
                 self.xseed = torch.zeros(n1, E, dtype=f32, device=dev)
+            self.key_bits = max(1, int(n_rows - 1).bit_length())
+            self.sids = torch.zeros(n0 + n1, dtype=torch.int64, device=dev)
+            self.spos = torch.zeros(n0 + n1, dtype=i32, device=dev)
+            nb = int(nat.lib().gsage_sort_rows_temp_bytes(n0 + n1, self.key_bits))
+            assert nb > 0, "gsage_sort_rows_temp_bytes failed"
+            self.sort_temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
             ds = self.row_desc_sorted = nat.RowAdamDesc()
             ctypes.memmove(ctypes.addressof(ds), ctypes.addressof(d), ctypes.sizeof(d))
-            if mode == "sorted":
-                self.key_bits = max(1, int(n_rows - 1).bit_length())
-                self.sids = torch.zeros(n0 + n1, dtype=torch.int64, device=dev)
-                self.spos = torch.zeros(n0 + n1, dtype=i32, device=dev)
-                nb = int(nat.lib().gsage_sort_rows_temp_bytes(n0 + n1, self.key_bits))
-                assert nb > 0, "gsage_sort_rows_temp_bytes failed"
-                self.sort_temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
-                ds.sorted_ids = 1
-            else:
-                self.row_head = torch.zeros(n_rows, dtype=torch.int64, device=dev)
-                self.row_next = torch.zeros(n0 + n1, dtype=i32, device=dev)
-                self.row_err = torch.zeros(1, dtype=i32, device=dev)
-                self.tail_ids = torch.full((n1,), int(self.model.prep.n_nodes), dtype=torch.int64, device=dev)
-                ds.sorted_ids, ds.head = 2, self.row_head.data_ptr()
+            ds.sorted_ids = 1
         self.model._settle_rows = self.sync_rows
         emb_mod = self.model.prep.embedding
         self._row_hooks = [emb_mod.register_forward_pre_hook(lambda *_: self.sync_rows()),
@@ -987,26 +973,9 @@ class FusedTrainStep(object):
                 nat.check(lib.gsage_grad_sqnorm(self.flat_g[nt:].data_ptr(), nd, self.partial.data_ptr(), base, stream),
                           "grad_sqnorm")
                 n_all = base + self.n_tab_partial
-            if self.sorted_rows and self.row_grad == "linked":
+            if self.sorted_rows:
                 # every rank's (ids, gradient rows) in rank order [+ the seeds' spare row, 16 partial rows per rank]:
-                # per distinct row an ascending list of its positions, summed by the position that heads it (scaled
-                # by 1 / world: the all-reduce's average)
-                dp = self.ddp is not None
-                src = self.xids if dp else ids[B:RA0]
-                rows0, rows1 = (self.xrows, self.xseed) if dp else (self.deraw[B:], self.seed_grad)
-                n0, n1 = self.x_n0, self.x_n1
-                nat.check(lib.gsage_rows_link(src.data_ptr(), n0, self.tail_ids.data_ptr(), n1, int(self.table.shape[0]),
-                                              self.row_head.data_ptr(), self.row_next.data_ptr(), self.step.data_ptr(), 0,
-                                              self.row_err.data_ptr(), stream), "rows_link")
-                nat.check(lib.gsage_rows_sum_linked(src.data_ptr(), n0, self.tail_ids.data_ptr(), n1,
-                                                    self.row_head.data_ptr(), self.row_next.data_ptr(),
-                                                    self.step.data_ptr(), 0, rows0.data_ptr(), E, rows1.data_ptr(), E, E,
-                                                    1.0 / self.world, g.data_ptr(), E, self.row_err.data_ptr(), stream),
-                          "rows_sum_linked")
-                rd = ctypes.byref(self.row_desc_sorted)
-                lists = (src.data_ptr(), n0, self.tail_ids.data_ptr(), n1, 0)
-            elif self.sorted_rows:
-                # the same sums through one stable sort + one segment sum per distinct row
+                # one stable sort, one segment sum per distinct row (scaled by 1 / world: the all-reduce's average)
                 dp = self.ddp is not None
                 src = self.xids if dp else ids[B:RA0]
                 rows0, rows1 = (self.xrows, self.xseed) if dp else (self.deraw[B:], self.seed_grad)
@@ -1063,9 +1032,6 @@ class FusedTrainStep(object):
             return
         nat.check(nat.lib().gsage_rows_catch_up_all(ctypes.byref(self.row_desc), 0, ops._stream()), "rows_catch_up_all")
         self._rows_dirty, self._rows_since = False, 0
-        if getattr(self, "row_grad", None) == "linked" and int(self.row_err.item()) != 0:
-            raise RuntimeError("gsage_rows_link / gsage_rows_sum_linked reported a corrupted row list or an id outside "
-                               "the table")
 
     def close(self):
         """Settle the deferred rows and detach from the model (hooks on the embedding module, model._settle_rows):

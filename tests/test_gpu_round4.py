@@ -123,110 +123,6 @@ def test_sort_and_segment_sum_replay_from_a_command_list():
         assert torch.allclose(table.double(), ref, rtol=1e-5, atol=1e-5), trial
 
 
-@pytest.mark.parametrize("n0,n1,n_rows,E,hot", [(5000, 16, 700, 64, 14), (164_000, 32, 1_632_805, 64, 3000),
-                                                  (3000, 7, 40, 200, 2), (1, 0, 9, 8, 2), (0, 5, 100, 64, 2),
-                                                  (60_000, 64, 5000, 64, 3)])
-def test_linked_row_lists_give_the_sorted_sums_bit_for_bit(n0, n1, n_rows, E, hot):
-    """gsage_rows_link + gsage_rows_sum_linked (per distinct id an ascending linked list of its positions, built by
-    insert-only compare-and-swap, walked by the position that heads it) against gsage_sort_rows +
-    gsage_segment_sum_rows on the same list: the same sums BIT FOR BIT (both add a node's rows in ascending position),
-    with heavy contention (half of the entries fall on `hot` ids: thousands of concurrent insertions into one list),
-    over three steps without resetting `head` (the update-number tag makes stale lists empty), the error flag stays
-    clear, and `next` holds exactly the ascending chains."""
-    lib, st = nat.lib(), _stream()
-    gen = torch.Generator().manual_seed(n0 + E + hot)
-    head = torch.zeros(n_rows, dtype=torch.int64, device=DEV)
-    nxt = torch.zeros(n0 + n1, dtype=torch.int32, device=DEV)
-    err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    step = torch.zeros(1, dtype=torch.int64, device=DEV)
-    tail_id = n_rows - 1
-    tails = torch.full((max(n1, 1),), tail_id, dtype=torch.int64, device=DEV)
-    key_bits = max(1, int(n_rows - 1).bit_length())
-    for t in range(1, 4):
-        step.fill_(t)
-        ids = torch.where(torch.rand(n0, generator=gen) < 0.5, torch.randint(1, hot, (n0,), generator=gen),
-                          torch.randint(1, n_rows - 1, (n0,), generator=gen)).to(DEV)
-        rows0 = torch.randn(max(n0, 1), E, generator=gen).to(DEV)
-        rows1 = torch.randn(max(n1, 1), E, generator=gen).to(DEV)
-        a = torch.full((n_rows, E), 7.0, device=DEV)
-        b = torch.full((n_rows, E), 7.0, device=DEV)
-        nat.check(lib.gsage_rows_link(ids.data_ptr(), n0, tails.data_ptr(), n1, n_rows, head.data_ptr(), nxt.data_ptr(),
-                                      step.data_ptr(), 0, err.data_ptr(), st), "rows_link")
-        nat.check(lib.gsage_rows_sum_linked(ids.data_ptr(), n0, tails.data_ptr(), n1, head.data_ptr(), nxt.data_ptr(),
-                                            step.data_ptr(), 0, rows0.data_ptr(), E, rows1.data_ptr(), E, E, 0.5,
-                                            a.data_ptr(), E, err.data_ptr(), st), "rows_sum_linked")
-        sids, spos, _tmp = _sort(ids, tail_id, n1, key_bits)
-        nat.check(lib.gsage_segment_sum_rows(sids.data_ptr(), spos.data_ptr(), n0 + n1, rows0.data_ptr(), E, n0,
-                                             rows1.data_ptr(), E, E, 0.5, b.data_ptr(), E, st), "segsum")
-        torch.cuda.synchronize()
-        assert int(err.item()) == 0
-        assert torch.equal(a, b), (t, float((a - b).abs().max()))
-        # the chains: next[p] = the next larger position holding the same id, -1 at the end
-        keys = torch.cat([ids, tails[:n1]])
-        k_sorted, p_sorted = torch.sort(keys, stable=True)
-        want = torch.full((n0 + n1,), -1, dtype=torch.int64, device=DEV)
-        same = k_sorted[1:] == k_sorted[:-1]
-        want[p_sorted[:-1][same]] = p_sorted[1:][same]
-        assert torch.equal(nxt.long(), want), t
-        first = torch.ones_like(k_sorted, dtype=torch.bool)
-        first[1:] = ~same
-        assert torch.equal(head[k_sorted[first]] & 0xFFFFFFFF, p_sorted[first]) and bool(((head[k_sorted[first]] >> 32) == t).all())
-    if n0 > 1:                         # an id outside the table raises the flag instead of writing anywhere
-        bad = ids.clone()
-        bad[0] = n_rows + 5
-        step.fill_(9)
-        nat.check(lib.gsage_rows_link(bad.data_ptr(), n0, tails.data_ptr(), n1, n_rows, head.data_ptr(), nxt.data_ptr(),
-                                      step.data_ptr(), 0, err.data_ptr(), st), "rows_link")
-        torch.cuda.synchronize()
-        assert int(err.item()) == 1
-
-
-def test_row_lists_headed_by_links_equal_the_sorted_lists():
-    """gsage_rows_sqnorm / gsage_rows_adam over the unsorted frontier with gsage_row_adam.sorted_ids = 2 (the entry that
-    heads a row's linked list does the row's work) against the sorted list (sorted_ids = 1): same table, exp_avg,
-    exp_avg_sq bit for bit over eight updates with duplicates, clipping and weight decay; the norm partials of the
-    linked route are identical from launch to launch."""
-    from test_gpu_rows import _Rows
-    lib, st = nat.lib(), _stream()
-    n_rows, E, n = 5000, 64, 3000
-    gen = torch.Generator().manual_seed(8)
-    p0 = torch.randn(n_rows, E, generator=gen).to(DEV)
-    a, b = _Rows(p0, E, 0.01, 0.7), _Rows(p0, E, 0.01, 0.7)
-    a.d.sorted_ids = 1
-    head = torch.zeros(n_rows, dtype=torch.int64, device=DEV)
-    nxt = torch.zeros(n, dtype=torch.int32, device=DEV)
-    err = torch.zeros(1, dtype=torch.int32, device=DEV)
-    b.d.sorted_ids, b.d.head = 2, head.data_ptr()
-    for t in range(1, 9):
-        for r in (a, b):
-            r.lr.fill_(0.01 + 0.001 * t)
-        ids = torch.randint(0, 400 if t % 2 else n_rows, (n,), generator=gen).to(DEV)
-        sids, _pos, _tmp = _sort(ids, 0, 0, 13)
-        uniq = torch.unique(ids)
-        grad = torch.randn(uniq.shape[0], E, generator=gen).to(DEV) * (0.05 if t % 3 else 3.0)
-        for r in (a, b):
-            r.g[uniq] = grad
-            r.step += 1
-        nat.check(lib.gsage_rows_link(ids.data_ptr(), n, None, 0, n_rows, head.data_ptr(), nxt.data_ptr(), b.step.data_ptr(),
-                                      0, err.data_ptr(), st), "rows_link")
-        for r, lst in ((a, sids), (b, ids)):
-            nat.check(lib.gsage_rows_sqnorm(ctypes.byref(r.d), lst.data_ptr(), n, None, 0, 0, r.partial.data_ptr(), 64, st), "sq")
-        first = b.partial.clone()
-        nat.check(lib.gsage_rows_sqnorm(ctypes.byref(b.d), ids.data_ptr(), n, None, 0, 0, b.partial.data_ptr(), 64, st), "sq")
-        assert torch.equal(first, b.partial)
-        want = float((grad.double() ** 2).sum())
-        assert abs(float(b.partial.double().sum()) - want) <= 1e-5 * want
-        a.partial.copy_(b.partial)              # (the two lists give different partial LAYOUTS: one clip factor for both)
-        for r, lst in ((a, sids), (b, ids)):
-            nat.check(lib.gsage_rows_adam(ctypes.byref(r.d), lst.data_ptr(), n, None, 0, 0, r.partial.data_ptr(), 64, st), "ra")
-    for r in (a, b):
-        nat.check(lib.gsage_rows_catch_up_all(ctypes.byref(r.d), 0, st), "all")
-    torch.cuda.synchronize()
-    assert int(err.item()) == 0
-    assert torch.equal(a.p, b.p) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
-    assert float(b.g.abs().max()) == 0.0 and int(b.last.min()) == 8
-
-
 def test_sorted_row_lists_equal_the_stamped_lists_and_are_deterministic():
     """gsage_rows_* over a SORTED list (gsage_row_adam.sorted_ids: runs settled by comparing neighbours, no atomics)
     against the same list unsorted (stamps + atomicMax): same table, exp_avg, exp_avg_sq bit for bit; the sorted
@@ -396,7 +292,7 @@ def test_one_rank_data_parallel_step_equals_the_plain_step(case, overlap):
 # the command behind the reference's only published number (utils/pokec.sh:11-13) through the fused engine
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", [0, 1])
-@pytest.mark.parametrize("table", ["linked", "atomics", "sorted", "dense"])
+@pytest.mark.parametrize("table", ["deferred", "sorted", "dense"])
 @pytest.mark.parametrize("capture", [False, "cmdlist"])
 def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_train_steps(case, table, capture):
     """utils/pokec.sh:11-13 -- the reference's DEFAULT dense sampler + the trainable node-embedding prep (no
@@ -408,11 +304,11 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
     from conftest import load_golden
     from util import close, close_rel, close_update, weights
     os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
-    os.environ.pop("GSAGE_ROW_GRAD", None)
+    os.environ.pop("GSAGE_SORTED_ROWS", None)
     if table == "dense":
         os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
-    else:                             # the table's gradient rows: linked lists (default) / fp32 atomics / vendor sort
-        os.environ["GSAGE_ROW_GRAD"] = table
+    if table == "sorted":             # the table's gradient by sort + segment sums (what data-parallel runs use)
+        os.environ["GSAGE_SORTED_ROWS"] = "1"
     try:
         g = load_golden("round4_kat.npz")
         p = "q%d_" % case
@@ -436,7 +332,7 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
         assert cls is gs.engine.FusedMeanTrainStep
         eng = cls(model, None, gs.ProblemLosses.regression_mae, ids, tg, capture=capture)
         assert eng.draws == "dense" and eng.emb and eng.fused_l1 and eng.lazy_rows == (table != "dense")
-        assert eng.tdt == torch.float32 and (not eng.lazy_rows or eng.row_grad == table)
+        assert eng.tdt == torch.float32 and (not eng.lazy_rows or eng.sorted_rows == (table == "sorted"))
         torch.manual_seed(int(g[p + "torch_seed"]))
         for step in range(2):
             eng.set_progress(0.25 * step)
@@ -458,7 +354,7 @@ def test_fp32_mean_embedding_engine_over_the_dense_sampler_replays_reference_tra
         model.train_sampler.table(DEV).check()
     finally:
         os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
-        os.environ.pop("GSAGE_ROW_GRAD", None)
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,6 @@ def _setup():
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
     ops.set_compute_dtype("bf16")
     os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
-    os.environ.pop("GSAGE_ROW_GRAD", None)
 
 
 class _Rows(object):
@@ -135,18 +134,19 @@ def test_attention_embedding_engine_deferred_rows_equal_dense_table_updates(capt
     (The two sides differ in the summation order of the table's share of the gradient norm, and the scatter-add
     uses float atomics: 1e-6, not bit-identity.)"""
     res = {}
-    for mode in ("dense", "atomics", "sorted", "linked"):
+    for mode in ("dense", "deferred", "sorted"):
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
         if mode == "dense":
             os.environ["GSAGE_DENSE_TABLE_ADAM"] = "1"
         else:
             os.environ.pop("GSAGE_DENSE_TABLE_ADAM", None)
-            # the table's gradient rows: fp32 atomics (round 3's K6), vendor sort + segment sums, linked lists (default)
-            os.environ["GSAGE_ROW_GRAD"] = mode
+        if mode == "sorted":          # gradient rows by sort + segment sums (ABI 4; what data-parallel runs use)
+            os.environ["GSAGE_SORTED_ROWS"] = "1"
         ops.set_compute_dtype("fp32")
         model, ids, tg = _emb_model()
         eng = gs.engine.FusedAttnTrainStep(model, None, gs.ProblemLosses.regression_mae, ids[0], tg[0], capture=capture)
-        os.environ.pop("GSAGE_ROW_GRAD", None)
-        assert eng.emb and eng.lazy_rows == (mode != "dense") and (mode == "dense" or eng.row_grad == mode)
+        os.environ.pop("GSAGE_SORTED_ROWS", None)
+        assert eng.emb and eng.lazy_rows == (mode != "dense") and (mode == "dense" or eng.sorted_rows == (mode == "sorted"))
         preds = []
         for s in range(10):
             eng.set_progress(s / 10.0)
@@ -158,13 +158,8 @@ def test_attention_embedding_engine_deferred_rows_equal_dense_table_updates(capt
             assert int(eng.row_last.min()) == 10                                      # state_dict settled them
         nt = eng.n_tab
         res[mode] = (preds, sd, eng.flat_m[:nt].clone(), eng.flat_v[:nt].clone(), float(eng.gnorm.item()))
-    # (no atomics on either side: the vendor sort and the linked lists add a node's rows in the same order)
-    for x, y in zip(res["sorted"][0], res["linked"][0]):
-        assert torch.equal(x, y)
-    for k in res["sorted"][1]:
-        assert torch.equal(res["sorted"][1][k], res["linked"][1][k]), k
     a = res["dense"]
-    for other in ("atomics", "sorted", "linked"):
+    for other in ("deferred", "sorted"):
         b = res[other]
         for s in range(10):
             assert torch.allclose(a[0][s], b[0][s], rtol=1e-5, atol=1e-5), (other, s)
