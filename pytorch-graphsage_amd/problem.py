@@ -156,9 +156,11 @@ class PendingMetric(object):
             multilabel = task == "multilabel_classification"
             B, C = preds.shape
             f32 = bool(multilabel and y_true.dtype.is_floating_point)
-            y = y_true.detach().contiguous().float() if f32 else y_true.detach().contiguous().long()
-            y = y.view(B, C) if multilabel else y.view(-1)
-            assert y.shape[0] == B
+            want = torch.float32 if f32 else torch.int64
+            y = y_true                           # (the common case costs no tensor op: this runs once per batch)
+            if y.dtype != want or not y.is_contiguous() or y.requires_grad:
+                y = y.detach().contiguous().to(want)
+            assert y.numel() == (B * C if multilabel else B)
             if self._counts is None:
                 self._counts = torch.empty(3 * C + 1, dtype=torch.int32, device=dev)
             self._args = (y,)

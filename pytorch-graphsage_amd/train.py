@@ -329,8 +329,10 @@ def train_fused(args, problem, model, ddp, start_time, cls):
             preds = step.step_queue() if queued else step(ids[b, :nb], tgs[b, :nb])
             if (b % every == 0 or b == n_batches - 1) and rank == 0:
                 if tg_ok and preds.dtype == torch.float32 and preds.is_contiguous():
-                    pending.append((b / n_batches, gs.problem.PendingMetric(problem.task, tgs[b, :nb].view(nb, -1),
-                                                                            preds[:nb])))
+                    # (a full batch costs one indexing op here: the loop's host time per batch is what bounds the CLI)
+                    full = nb == B
+                    pending.append((b / n_batches, gs.problem.PendingMetric(
+                        problem.task, tgs[b] if full else tgs[b, :nb], preds if full else preds[:nb])))
                 else:
                     flush(0)
                     train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
