@@ -99,7 +99,7 @@ k_metric_f1(const int32_t *__restrict__ counts, int32_t C, int present_only, dou
 // (zero-fill, counts, finalisation: ~13 us of a 92 us step).  MODE 0: classification (int64 class ids), 1 / 2:
 // multilabel with float / int64 indicator targets.  Same integer counts, same doubles as the three-launch route.
 constexpr int METRIC_SMALL_C = 1024;
-constexpr int METRIC_SMALL_B = 4096;      // rows of the one-launch classification route (a 64-bit LDS word per row)
+constexpr int METRIC_TILE = 10496;        // floats of the one-launch classification route's LDS tile (41 KiB: 256 rows x 41)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__restrict__ yv, int64_t ldy, int32_t B,
@@ -107,40 +107,44 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
 {
     __shared__ int32_t cnt[3 * METRIC_SMALL_C + 1];
     __shared__ double s_tp[256], s_fp[256], s_fn[256], s_f1[256], s_n[256];
-    __shared__ unsigned long long best_key[MODE == 0 ? METRIC_SMALL_B : 1];
+    __shared__ float tile[MODE == 0 ? METRIC_TILE : 1];
     for (int i = threadIdx.x; i < 3 * C + 1; i += 256) cnt[i] = 0;
-    if (MODE == 0)
-        for (int i = threadIdx.x; i < B; i += 256) best_key[i] = 0ull;
     __syncthreads();
     if (MODE == 0) {
-        // argmax per row with COALESCED loads: thread t walks the flat [B, C] block (a thread per row reads with a
-        // stride of C floats: 64 lines per wave-wide load -- that version took 20 us at 512 x 41, most of what the
-        // per-batch log cost the CLI) and every element competes for its row with one 64-bit LDS atomic max on
-        // (order-preserving bits of the value << 32 | C - 1 - c): the largest value wins, among equals the FIRST column
-        // (np.argmax); a NaN beats everything, the first NaN wins; -0 == +0.
-        const int total = B * C;
-        const bool dense = ld == C;
-        for (int t = threadIdx.x; t < total; t += 256) {
-            const int i = t / C, c = t - i * C;
-            float v = logits[dense ? (int64_t)t : (int64_t)i * ld + c];
-            v += 0.f;                                               // -0 -> +0
-            uint32_t u = __float_as_uint(v);
-            u = (v != v) ? 0xFFFFFFFFu : (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-            atomicMax(best_key + i, ((unsigned long long)u << 32) | (uint32_t)(C - 1 - c));
-        }
-        __syncthreads();
+        // argmax per row, a thread per row -- out of an LDS tile that the workgroup fills with COALESCED loads (a thread
+        // reading its own row from HBM strides C floats: 64 lines per wave-wide load; that version took 20 us at
+        // 512 x 41, most of what the per-batch log cost the CLI; competing for the row with LDS atomics took 31: forty
+        // lanes of a wave hit the same word).  Rows sit Cp = C | 1 floats apart: an odd stride has no bank conflicts.
+        const int Cp = C | 1;
+        const int rows_per_tile = min(256, METRIC_TILE / Cp);
         const int64_t *y = (const int64_t *)yv;
-        for (int i = threadIdx.x; i < B; i += 256) {
-            const int best = C - 1 - (int)(uint32_t)best_key[i];
-            const int64_t t = y[i];
-            if (t < 0 || t >= C) {
-                atomicAdd(cnt + 3 * C, 1);
-            } else if (t == best) {
-                atomicAdd(cnt + best, 1);
-            } else {
-                atomicAdd(cnt + C + best, 1);
-                atomicAdd(cnt + 2 * C + (int)t, 1);
+        for (int row0 = 0; row0 < B; row0 += rows_per_tile) {
+            const int rows = min(rows_per_tile, B - row0);
+            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+                const int r = idx / C, c = idx - r * C;
+                tile[r * Cp + c] = logits[(int64_t)(row0 + r) * ld + c];
             }
+            __syncthreads();
+            if ((int)threadIdx.x < rows) {
+                const float *row = tile + threadIdx.x * Cp;
+                int best = 0;
+                float bv = row[0];
+                for (int c = 1; c < C; ++c) {   // first maximum wins, like np.argmax -- and so does the first NaN
+                    const float v = row[c];
+                    if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }
+                }
+                const int i = row0 + threadIdx.x;
+                const int64_t t = y[i];
+                if (t < 0 || t >= C) {
+                    atomicAdd(cnt + 3 * C, 1);
+                } else if (t == best) {
+                    atomicAdd(cnt + best, 1);
+                } else {
+                    atomicAdd(cnt + C + best, 1);
+                    atomicAdd(cnt + 2 * C + (int)t, 1);
+                }
+            }
+            __syncthreads();
         }
     } else {
         const int total = B * C;
@@ -223,8 +227,7 @@ int gsage_metric_f1(const float *logits, int64_t ld, const void *targets, int mu
     GSAGE_REQUIRE(B >= 0 && C >= 1 && ld >= C && (!multilabel || ldy >= C), "metric_f1: bad sizes");
     GSAGE_REQUIRE(multilabel || !targets_f32, "metric_f1: classification targets are int64 class ids");
     hipStream_t s = (hipStream_t)stream;
-    if (B > 0 && C <= METRIC_SMALL_C && B * (int64_t)C <= 64 * 1024 && (multilabel || B <= METRIC_SMALL_B)) {
-        // a training batch: one launch
+    if (B > 0 && C <= METRIC_SMALL_C && B * (int64_t)C <= 64 * 1024) {       // a training batch: one launch
         if (!multilabel)
             launch(k_metric_f1_small<0>, dim3(1), dim3(256), 0, s, logits, ld, targets, ldy, (int32_t)B, C, out);
         else if (targets_f32)
