@@ -484,24 +484,23 @@ def _run_cli(gs, argv, problem):
     train = importlib.import_module("pytorch-graphsage_amd.train")
     buf, err = io.StringIO(), io.StringIO()
     t0 = time.time()
-    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
-        train.main(argv, problem=problem)
+    os.environ["GSAGE_TRAIN_TIMING"] = "1"            # (train_fused then brackets every epoch's batch loop)
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
+            step = train.main(argv, problem=problem)
+    finally:
+        os.environ.pop("GSAGE_TRAIN_TIMING", None)
     torch.cuda.synchronize()
     wall = time.time() - t0
     lines = [json.loads(ln) for ln in buf.getvalue().splitlines() if ln.startswith("{")]
     engine = [ln for ln in err.getvalue().splitlines() if ln.startswith("gsage:")]
-    return lines, wall, engine
+    return lines, wall, engine, list(getattr(step, "timing", []) or [])
 
 
-def _epoch_rates(lines, n_train, epochs):
-    """seed-nodes/s of the training loop per epoch, from the `time` stamps of the per-batch JSON lines (the first line
-    of an epoch to the last: n_batches - 1 steps, every one followed by its log line and metric readback)"""
-    out = []
-    for e in range(epochs):
-        ts = [ln["time"] for ln in lines if ln.get("epoch") == e and "epoch_progress" in ln]
-        if len(ts) >= 3:
-            out.append(n_train * (len(ts) - 1) / len(ts) / (ts[-1] - ts[0]))
-    return out
+def _epoch_rates(timing):
+    """seed-nodes/s of every epoch's batch loop (train_fused's own bracket: per-batch log and metric included, the
+    epoch's sampler draws and the validation pass not), and the same with the epoch's draws"""
+    return ([t["seeds"] / t["loop_s"] for t in timing], [t["seeds"] / t["with_draws_s"] for t in timing])
 
 
 def extra_cli(gs, dev, data, store):
@@ -525,15 +524,17 @@ def extra_cli(gs, dev, data, store):
                                       data["targets"], cuda=True)
     epochs = 2
     try:
-        lines, wall, eng = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
-                                         "sparse_uniform_neighbor_sampler", "--epochs", str(epochs)], prob)
+        lines, wall, eng, timing = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean",
+                                                 "--sampler-class", "sparse_uniform_neighbor_sampler", "--epochs",
+                                                 str(epochs)], prob)
         n_train = int((folds == "train").sum())
-        rates = _epoch_rates(lines, n_train, epochs)
+        rates, rates_draws = _epoch_rates(timing)
         out["reddit"] = {"command": "run.sh:14-17 (--aggregator-class mean --sampler-class sparse_uniform_neighbor_sampler), "
                                     "--epochs %d, defaults otherwise (--engine auto, --rng compat, per-batch JSON)" % epochs,
                          "engine": eng[-1] if eng else None, "train_nodes": n_train,
                          "batches_per_epoch": len([ln for ln in lines if ln.get("epoch") == 0 and "epoch_progress" in ln]),
                          "cli_seeds_per_s": rates[-1] if rates else None, "cli_seeds_per_s_by_epoch": rates,
+                         "cli_seeds_per_s_incl_epoch_draws": rates_draws,
                          "wall_s": wall, "val_metric": lines[-1].get("val_metric") if lines else None}
     except Exception as e:
         out["reddit"] = {"error": repr(e)}
@@ -548,10 +549,10 @@ def extra_cli(gs, dev, data, store):
         pf = rng.choice(np.array(["train", "val"]), size=Np + 1)
         pf[Np] = "dummy"
         prob = gs.NodeProblem.from_arrays("regression_mae", None, adj, adj, None, pf, targets, cuda=True)
-        lines, wall, eng = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--prep-class",
-                                         "node_embedding", "--epochs", "3"], prob)
+        lines, wall, eng, timing = _run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--prep-class",
+                                                 "node_embedding", "--epochs", "3"], prob)
         n_train = int((pf == "train").sum())
-        rates = _epoch_rates(lines, n_train, 3)
+        rates, _rd = _epoch_rates(timing)
         out["pokec"] = {"command": "utils/pokec.sh:11-13 (--aggregator-class mean --prep-class node_embedding --epochs 3; "
                                    "DEFAULT dense sampler), defaults otherwise",
                         "engine": eng[-1] if eng else None, "train_nodes": n_train, "wall_s": wall,

@@ -113,47 +113,37 @@ class DeviceMetrics:
         return float(out.item())
 
 
-class PendingMetric(object):
-    """problem.metric_fn of one batch, scored on the device with the 8-24 bytes of the result landing in pinned host
-    memory: `get()` waits for THAT batch's event only.  train.py prints the line of batch b after it has issued batch
-    b + 1, so the per-batch log (train.py:150-158: the reference scores every batch on the host) no longer drains the
-    GPU once per step -- same JSON lines, same order, same values.  The finalising workgroup of the metric kernel
-    stores straight into the pinned buffer (host memory mapped into the device's address space: no copy packet on
-    the step's stream); the first use of a process checks that such stores arrive and falls back to a copy if not.
-    Targets with class ids outside [0, C) need the reference's host route (DeviceMetrics._f1): callers with such
-    targets use batch_metric instead."""
-    zero_copy = None                 # None: not probed yet
-    _pool = {}
+class MetricRing(object):
+    """problem.metric_fn of the batches of a training loop, scored on the device and read back a RING at a time.
+    The reference scores every batch on the host (train.py:150-158); scoring on the device but reading the 24 bytes
+    back per batch still costs a host sync per step (33 % of a Reddit-shaped run), and letting the metric kernel store
+    straight into pinned host memory costs the step's stream ~15 us per batch (the kernel cannot retire before the
+    PCIe write has).  So: `score()` launches ONE single-workgroup kernel that writes its three doubles into the next
+    slot of a small device ring, `results()` -- called when `pending == capacity` or at the end of an epoch -- copies
+    the ring once and returns the pending batches' metrics in order.  Same JSON lines, same order, same values; the
+    lines reach stdout `capacity` at a time.  Targets with class ids outside [0, C) need the reference's host route
+    (DeviceMetrics._f1): callers with such targets use batch_metric instead."""
 
-    def __init__(self, task, y_true, y_pred):
+    def __init__(self, task, device, capacity=32):
+        self.task, self.capacity = task, int(capacity)
+        self.ring = torch.zeros(self.capacity, 3, dtype=torch.float64, device=device)
+        self.pending = 0
+        self._counts = None
+
+    def score(self, y_true, y_pred):
         from . import _native as nat
-        self.task = task
+        assert self.pending < self.capacity, "MetricRing: call results() before the ring wraps"
         preds = y_pred.detach()
-        assert preds.dtype == torch.float32 and preds.is_contiguous()
-        dev = preds.device
-        n_out = 1 if task == "regression_mae" else 3
-        cls = PendingMetric
-        # (pinned buffer, count buffer, event) triples are recycled: no allocation per batch on the host
-        self._key = (task, int(preds.shape[1]) if preds.dim() == 2 else 1, str(dev))
-        pool = cls._pool.setdefault(self._key, [])
-        if pool:
-            self._host, self._counts, self._ev = pool.pop()
-            self._host.fill_(float("nan"))
-        else:
-            self._host = torch.full((n_out,), float("nan"), dtype=torch.float64).pin_memory()
-            self._counts = None
-            self._ev = torch.cuda.Event()
-        direct = cls.zero_copy is not False
-        self._out = self._host if direct else torch.empty(n_out, dtype=torch.float64, device=dev)
-        if task == "regression_mae":
+        assert preds.dtype == torch.float32 and preds.is_contiguous() and preds.is_cuda
+        out = self.ring[self.pending]
+        if self.task == "regression_mae":
             a = y_true.detach().float().contiguous().view(-1)
             b = preds.view(-1)
             assert a.shape == b.shape, "regression_mae: y_true and y_pred must have the same number of elements"
-            self._args = (a,)
-            nat.check(nat.lib().gsage_metric_mae(a.data_ptr(), b.data_ptr(), a.numel(), self._out.data_ptr(),
-                                                 ops._stream()), "metric_mae")
+            nat.check(nat.lib().gsage_metric_mae(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), ops._stream()),
+                      "metric_mae")
         else:
-            multilabel = task == "multilabel_classification"
+            multilabel = self.task == "multilabel_classification"
             B, C = preds.shape
             f32 = bool(multilabel and y_true.dtype.is_floating_point)
             want = torch.float32 if f32 else torch.int64
@@ -162,28 +152,21 @@ class PendingMetric(object):
                 y = y.detach().contiguous().to(want)
             assert y.numel() == (B * C if multilabel else B)
             if self._counts is None:
-                self._counts = torch.empty(3 * C + 1, dtype=torch.int32, device=dev)
-            self._args = (y,)
+                self._counts = torch.empty(3 * C + 1, dtype=torch.int32, device=preds.device)
             nat.check(nat.lib().gsage_metric_f1(preds.data_ptr(), preds.stride(0), y.data_ptr(), int(multilabel), int(f32),
-                                                C if multilabel else 0, B, C, self._counts.data_ptr(),
-                                                self._out.data_ptr(), ops._stream()), "metric_f1")
-        if not direct:
-            self._host.copy_(self._out, non_blocking=True)
-        self._ev.record()
-        if cls.zero_copy is None:        # first use: did the kernel's stores reach the pinned buffer?
-            self._ev.synchronize()
-            cls.zero_copy = not bool(torch.isnan(self._host).any())
-            if not cls.zero_copy:
-                again = PendingMetric(task, y_true, y_pred)
-                self._host, self._ev, self._args, self._counts = again._host, again._ev, again._args, again._counts
+                                                C if multilabel else 0, B, C, self._counts.data_ptr(), out.data_ptr(),
+                                                ops._stream()), "metric_f1")
+        self.pending += 1
 
-    def get(self):
-        self._ev.synchronize()
-        vals = self._host.tolist()
-        PendingMetric._pool.setdefault(self._key, []).append((self._host, self._counts, self._ev))
+    def results(self):
+        """the metrics of the batches scored since the last call, in order (ONE device-to-host copy)"""
+        n, self.pending = self.pending, 0
+        if n == 0:
+            return []
+        vals = self.ring[:n].tolist()
         if self.task == "regression_mae":
-            return float(vals[0])
-        return {"micro": float(vals[0]), "macro": float(vals[1])}
+            return [float(v[0]) for v in vals]
+        return [{"micro": float(v[0]), "macro": float(v[1])} for v in vals]
 
 
 def batch_metric(task, y_true, y_pred):

@@ -299,30 +299,37 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     val_metric = train_metric = None
     epoch = 0
     # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right behind
-    # its step, its result lands in pinned memory, and its line is printed once batch b + 1 has been issued -- same
-    # lines, same order, same values; the GPU never waits for the log (stdout is flushed twice a second and at the end
-    # of every epoch instead of once per line).
-    pending, last_flush = [], [time()]
+    # its step into a small device ring (problem.MetricRing), and the ring is read back -- one copy -- every 32 batches
+    # and at the end of every epoch: same lines, same order, same values, printed 32 at a time.
+    ring = gs.problem.MetricRing(problem.task, dev)
+    pending = []
     # (class ids outside [0, C) are scored the reference's way, on the host: the synchronous route)
     tg_ok = problem.task != 'classification' or (int(np.min(problem.targets)) >= 0 and
                                                  int(np.max(problem.targets)) < problem.n_classes)
 
-    def flush(keep):
+    def flush():
         nonlocal train_metric
-        while len(pending) > keep:
-            prog, metric = pending.pop(0)
-            train_metric = metric.get()
+        for prog, metric in zip(pending, ring.results()):
+            train_metric = metric
             print(dumps({"epoch": epoch, "epoch_progress": prog, "train_metric": train_metric,
                          "val_metric": val_metric, "time": time() - start_time}))
-        if keep == 0 or time() - last_flush[0] > 0.5:
-            sys.stdout.flush()
-            last_flush[0] = time()
+        del pending[:]
+        sys.stdout.flush()
+    # GSAGE_TRAIN_TIMING=1 (bench.py's CLI measurement): wall seconds of every epoch's batch loop, bracketed by device
+    # synchronisations, in step.timing -- the log lines reach stdout a ring at a time, their `time` stamps do not
+    # resolve single batches any more
+    timing = os.environ.get("GSAGE_TRAIN_TIMING", "0") == "1"
+    step.timing = []
     for epoch in range(args.epochs):
         model.train()
+        t_epoch = time()
         if epoch > 0:
             ids, tgs, live = epoch_batches()
         if queued:
             step.load_epoch(ids, tgs, n_valid=live)          # (compat / dense sampler: draws the epoch's values)
+        if timing:
+            torch.cuda.synchronize()
+        t_loop = time()
         for b in range(n_batches):
             nb = live[b] if live is not None else B
             step.set_progress((epoch + b / n_batches) / args.epochs)
@@ -331,16 +338,21 @@ def train_fused(args, problem, model, ddp, start_time, cls):
                 if tg_ok and preds.dtype == torch.float32 and preds.is_contiguous():
                     # (a full batch costs one indexing op here: the loop's host time per batch is what bounds the CLI)
                     full = nb == B
-                    pending.append((b / n_batches, gs.problem.PendingMetric(
-                        problem.task, tgs[b] if full else tgs[b, :nb], preds if full else preds[:nb])))
+                    ring.score(tgs[b] if full else tgs[b, :nb], preds if full else preds[:nb])
+                    pending.append(b / n_batches)
+                    if ring.pending == ring.capacity:
+                        flush()
                 else:
-                    flush(0)
+                    flush()
                     train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
                     print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
                                  "val_metric": val_metric, "time": time() - start_time}))
                     sys.stdout.flush()
-            flush(1)
-        flush(0)
+        flush()
+        if timing:
+            torch.cuda.synchronize()
+            step.timing.append({"epoch": epoch, "batches": n_batches, "seeds": int(sum(live)) if live is not None
+                                else n_batches * B * world, "loop_s": time() - t_loop, "with_draws_s": time() - t_epoch})
         model.eval()
         val_metric = evaluate(model, problem, mode='val')
     gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host

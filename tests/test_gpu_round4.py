@@ -410,13 +410,13 @@ def test_default_cli_run_of_a_multilabel_problem_trains(tmp_path, capsys):
     assert out[-1]["train_metric"]["micro"] > 0.5
 
 
-def test_one_launch_batch_metric_and_pending_metric_equal_the_reference_route():
+def test_one_launch_batch_metric_and_metric_ring_equal_the_reference_route():
     """A training batch (B x C <= 64 k) is scored by ONE single-workgroup launch, larger inputs by the three-launch
     route: both equal the reference's host route (ProblemMetrics: sklearn) on the same data, for classification and
-    both multilabel target types; PendingMetric (the result stored straight into pinned memory, read one batch later)
-    returns the same values as the synchronous call."""
+    both multilabel target types; MetricRing (results written into a device ring, read back a ring at a time) returns
+    the same values, in order, as the synchronous calls."""
     gen = torch.Generator().manual_seed(3)
-    for B, C in ((512, 41), (4096, 41), (37, 7), (300, 500)):
+    for B, C in ((512, 41), (4096, 41), (37, 7), (300, 500), (256, 64)):
         logits = torch.randn(B, C, generator=gen).to(DEV)
         y = torch.randint(0, C, (B,), generator=gen).to(DEV)
         before = nat.launch_count()
@@ -424,19 +424,25 @@ def test_one_launch_batch_metric_and_pending_metric_equal_the_reference_route():
         assert nat.launch_count() - before == (1 if B * C <= 64 * 1024 else 3), (B, C)
         host = gs.ProblemMetrics.classification(y.cpu().numpy(), logits.cpu().numpy())
         assert abs(dev["micro"] - host["micro"]) < 1e-9 and abs(dev["macro"] - host["macro"]) < 1e-9, (B, C)
-        pend = gs.problem.PendingMetric("classification", y.view(B, 1), logits)
-        got = pend.get()
-        assert got == dev, (got, dev)
+        ring = gs.problem.MetricRing("classification", torch.device(DEV), capacity=4)
+        want = []
+        for k in range(4):
+            lg = logits.roll(k, dims=1).contiguous()
+            ring.score(y.view(B, 1), lg)
+            want.append(gs.DeviceMetrics.classification(y, lg))
+        assert ring.results() == want and ring.results() == []
         for cast in (torch.float32, torch.int64):
             ym = (torch.rand(B, C, generator=gen) < 0.3).to(cast).to(DEV)
             dev = gs.DeviceMetrics.multilabel_classification(ym, logits)
             host = gs.ProblemMetrics.multilabel_classification(ym.cpu().numpy(), logits.cpu().numpy())
             assert abs(dev["micro"] - host["micro"]) < 1e-9 and abs(dev["macro"] - host["macro"]) < 1e-9, (B, C, cast)
-            assert gs.problem.PendingMetric("multilabel_classification", ym, logits).get() == dev
+            mr = gs.problem.MetricRing("multilabel_classification", torch.device(DEV))
+            mr.score(ym, logits)
+            assert mr.results() == [dev]
     a, b = torch.randn(777, 1, generator=gen).to(DEV), torch.randn(777, 1, generator=gen).to(DEV)
-    mae = gs.DeviceMetrics.regression_mae(a, b)
-    assert gs.problem.PendingMetric("regression_mae", a, b).get() == mae
-    assert gs.problem.PendingMetric.zero_copy in (True, False)
+    mr = gs.problem.MetricRing("regression_mae", torch.device(DEV))
+    mr.score(a, b)
+    assert mr.results() == [gs.DeviceMetrics.regression_mae(a, b)]
 
 
 @pytest.mark.parametrize("spw", ["2", "4"])

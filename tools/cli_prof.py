@@ -15,7 +15,6 @@ folds[data["train_ids"]] = "train"
 rest = np.setdiff1d(np.arange(1, N + 1), data["train_ids"])
 folds[rest[:23_000]] = "val"; folds[0] = "dummy"
 prob = gs.NodeProblem.from_arrays("classification", bench.N_CLASSES, data["adj"], data["adj"], store, folds, data["targets"], cuda=True)
-lines, wall, eng = bench._run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
+lines, wall, eng, timing = bench._run_cli(gs, ["--problem-path", "<memory>", "--aggregator-class", "mean", "--sampler-class",
                                        "sparse_uniform_neighbor_sampler", "--epochs", "3"] + sys.argv[1:], prob)
-n_train = int((folds == "train").sum())
-print("rates", bench._epoch_rates(lines, n_train, 3), "wall", wall, eng)
+print("rates", bench._epoch_rates(timing), "wall", wall, eng)
