@@ -120,9 +120,23 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
         const int64_t *y = (const int64_t *)yv;
         for (int row0 = 0; row0 < B; row0 += rows_per_tile) {
             const int rows = min(rows_per_tile, B - row0);
-            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
-                const int r = idx / C, c = idx - r * C;
-                tile[r * Cp + c] = logits[(int64_t)(row0 + r) * ld + c];
+            // (eight loads in flight per thread: a loop of single load -> LDS store pairs pays one memory round trip per
+            //  element -- 82 of them per thread at 512 x 41, the 20 us the first versions of this kernel took)
+            const int total = rows * C;
+            for (int base = threadIdx.x; base < total; base += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    const int ic = idx < total ? idx : base;
+                    const int r = ic / C, c = ic - r * C;
+                    v[u] = logits[(int64_t)(row0 + r) * ld + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total) { const int r = idx / C, c = idx - r * C; tile[r * Cp + c] = v[u]; }
+                }
             }
             __syncthreads();
             if ((int)threadIdx.x < rows) {
@@ -148,14 +162,25 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
         }
     } else {
         const int total = B * C;
-        for (int t = threadIdx.x; t < total; t += 256) {
-            const int i = t / C, c = t - i * C;
-            const bool pred = logits[(int64_t)i * ld + c] > 0.f;
-            const bool truth = MODE == 1 ? ((const float *)yv)[(int64_t)i * ldy + c] != 0.f
-                                         : ((const int64_t *)yv)[(int64_t)i * ldy + c] != 0;
-            if (pred && truth) atomicAdd(cnt + c, 1);
-            else if (pred) atomicAdd(cnt + C + c, 1);
-            else if (truth) atomicAdd(cnt + 2 * C + c, 1);
+        for (int base = threadIdx.x; base < total; base += 256 * 4) {       // (four element pairs in flight per thread)
+            bool pred[4], truth[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * 256 < total ? base + u * 256 : base;
+                const int i = t / C, c = t - i * C;
+                pred[u] = logits[(int64_t)i * ld + c] > 0.f;
+                truth[u] = MODE == 1 ? ((const float *)yv)[(int64_t)i * ldy + c] != 0.f
+                                     : ((const int64_t *)yv)[(int64_t)i * ldy + c] != 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * 256;
+                if (t >= total) continue;
+                const int c = t - (t / C) * C;
+                if (pred[u] && truth[u]) atomicAdd(cnt + c, 1);
+                else if (pred[u]) atomicAdd(cnt + C + c, 1);
+                else if (truth[u]) atomicAdd(cnt + 2 * C + c, 1);
+            }
         }
     }
     __syncthreads();
