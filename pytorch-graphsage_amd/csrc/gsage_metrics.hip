@@ -120,23 +120,23 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
         const int64_t *y = (const int64_t *)yv;
         for (int row0 = 0; row0 < B; row0 += rows_per_tile) {
             const int rows = min(rows_per_tile, B - row0);
-            // (eight loads in flight per thread: a loop of single load -> LDS store pairs pays one memory round trip per
-            //  element -- 82 of them per thread at 512 x 41, the 20 us the first versions of this kernel took)
+            // (EVERY load of the tile in flight at once -- 41 per thread: one workgroup cannot hide a memory round trip
+            //  (~1.5 us) behind anything, so the kernel costs as many of them as it makes dependent rounds: a loop of
+            //  single load -> LDS store pairs made 82 (20 us at 512 x 41), batches of eight 12)
             const int total = rows * C;
-            for (int base = threadIdx.x; base < total; base += 256 * 8) {
-                float v[8];
+            constexpr int PER = METRIC_TILE / 256;
+            float v[PER];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = base + u * 256;
-                    const int ic = idx < total ? idx : base;
-                    const int r = ic / C, c = ic - r * C;
-                    v[u] = logits[(int64_t)(row0 + r) * ld + c];
-                }
+            for (int u = 0; u < PER; ++u) {
+                const int idx = (int)threadIdx.x + u * 256;
+                const int ic = idx < total ? idx : 0;
+                const int r = ic / C, c = ic - r * C;
+                v[u] = logits[(int64_t)(row0 + r) * ld + c];
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int idx = base + u * 256;
-                    if (idx < total) { const int r = idx / C, c = idx - r * C; tile[r * Cp + c] = v[u]; }
-                }
+            for (int u = 0; u < PER; ++u) {
+                const int idx = (int)threadIdx.x + u * 256;
+                if (idx < total) { const int r = idx / C, c = idx - r * C; tile[r * Cp + c] = v[u]; }
             }
             __syncthreads();
             if ((int)threadIdx.x < rows) {
