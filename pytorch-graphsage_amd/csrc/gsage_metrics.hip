@@ -125,19 +125,24 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
             //  single load -> LDS store pairs made 82 (20 us at 512 x 41), batches of eight 12)
             const int total = rows * C;
             constexpr int PER = METRIC_TILE / 256;
+            // (r, c) of element threadIdx.x + 256 u without a division per element: ONE workgroup runs one wave per
+            // SIMD, so every instruction of a dependent chain costs its full latency -- 164 runtime divisions per
+            // thread were ~10 us of this kernel
+            const int dr = 256 / C, dc = 256 - dr * C;
+            int r = (int)threadIdx.x / C, c = (int)threadIdx.x - r * C;
             float v[PER];
+            int off[PER];
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                const int idx = (int)threadIdx.x + u * 256;
-                const int ic = idx < total ? idx : 0;
-                const int r = ic / C, c = ic - r * C;
-                v[u] = logits[(int64_t)(row0 + r) * ld + c];
+                const bool ok = (int)threadIdx.x + u * 256 < total;
+                off[u] = ok ? r * Cp + c : -1;
+                v[u] = logits[ok ? (int64_t)(row0 + r) * ld + c : (int64_t)row0 * ld];
+                r += dr; c += dc;
+                if (c >= C) { c -= C; r += 1; }
             }
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int idx = (int)threadIdx.x + u * 256;
-                if (idx < total) { const int r = idx / C, c = idx - r * C; tile[r * Cp + c] = v[u]; }
-            }
+            for (int u = 0; u < PER; ++u)
+                if (off[u] >= 0) tile[off[u]] = v[u];
             __syncthreads();
             if ((int)threadIdx.x < rows) {
                 const float *row = tile + threadIdx.x * Cp;
@@ -162,24 +167,28 @@ k_metric_f1_small(const float *__restrict__ logits, int64_t ld, const void *__re
         }
     } else {
         const int total = B * C;
-        for (int base = threadIdx.x; base < total; base += 256 * 4) {       // (four element pairs in flight per thread)
-            bool pred[4], truth[4];
+        // (row, column) of element threadIdx.x + 256 k stepped, not divided (see MODE 0); eight element pairs in flight
+        const int dr = 256 / C, dc = 256 - dr * C;
+        int i = (int)threadIdx.x / C, c = (int)threadIdx.x - i * C;
+        for (int base = threadIdx.x; base < total; base += 256 * 8) {
+            bool pred[8], truth[8];
+            int col[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = base + u * 256 < total ? base + u * 256 : base;
-                const int i = t / C, c = t - i * C;
-                pred[u] = logits[(int64_t)i * ld + c] > 0.f;
-                truth[u] = MODE == 1 ? ((const float *)yv)[(int64_t)i * ldy + c] != 0.f
-                                     : ((const int64_t *)yv)[(int64_t)i * ldy + c] != 0;
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = base + u * 256 < total;
+                col[u] = ok ? c : -1;
+                const int64_t lo = ok ? (int64_t)i * ld + c : 0, yo = ok ? (int64_t)i * ldy + c : 0;
+                pred[u] = logits[lo] > 0.f;
+                truth[u] = MODE == 1 ? ((const float *)yv)[yo] != 0.f : ((const int64_t *)yv)[yo] != 0;
+                i += dr; c += dc;
+                if (c >= C) { c -= C; i += 1; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = base + u * 256;
-                if (t >= total) continue;
-                const int c = t - (t / C) * C;
-                if (pred[u] && truth[u]) atomicAdd(cnt + c, 1);
-                else if (pred[u]) atomicAdd(cnt + C + c, 1);
-                else if (truth[u]) atomicAdd(cnt + 2 * C + c, 1);
+            for (int u = 0; u < 8; ++u) {
+                if (col[u] < 0) continue;
+                if (pred[u] && truth[u]) atomicAdd(cnt + col[u], 1);
+                else if (pred[u]) atomicAdd(cnt + C + col[u], 1);
+                else if (truth[u]) atomicAdd(cnt + 2 * C + col[u], 1);
             }
         }
     }
