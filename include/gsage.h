@@ -53,6 +53,11 @@ const char *gsage_last_error(void);
 /* Number of kernels this library has launched since load (tests use it to prove the HIP path
  * ran instead of some fallback). */
 uint64_t gsage_launch_count(void);
+/* [host] debugging aid: from now on a SIGABRT first writes the native backtrace of the aborting thread to the
+ * file descriptor `fd` (< 0: stderr), then runs whatever handler was installed before.  The HSA runtime reports a
+ * GPU memory fault by calling abort() on a thread of its own, with a message that a test runner capturing fd 2
+ * swallows: the backtrace says who aborted (tests/conftest.py installs it for -m gpu sessions). */
+int gsage_debug_abort_trace(int fd);
 /* [host] device name / CU count of the current device; returns GSAGE_ENODEV without a GPU. */
 int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size);
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "gsage_abi_version": (_int, []),
     "gsage_last_error": (ctypes.c_char_p, []),
     "gsage_launch_count": (_u64, []),
+    "gsage_debug_abort_trace": (_int, [_int]),
     "gsage_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "gsage_stream_create_masked": (_int, [_vp, _i32, ctypes.POINTER(_vp)]),
     "gsage_stream_destroy": (_int, [_vp]),

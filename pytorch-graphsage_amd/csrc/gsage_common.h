@@ -29,7 +29,8 @@ extern std::atomic<uint64_t> g_launches;
 
 // GSAGE_DEBUG_SYNC=1: wait for every launch and report the kernel that failed; =2: also name every launch on
 // stderr BEFORE waiting for it (a memory fault kills the process inside the wait: the last name is the culprit).
-// Debugging aid only -- launches that are being recorded into a command list are not affected.
+// Debugging aid only -- launches that are being recorded into a command list, or captured into a hipGraph, are
+// not affected (the stream of the thread's last launch() is asked whether it is capturing).
 inline int debug_sync_level()
 {
     static const int level = [] { const char *e = getenv("GSAGE_DEBUG_SYNC"); return e ? atoi(e) : 0; }();
@@ -37,13 +38,18 @@ inline int debug_sync_level()
 }
 
 extern thread_local struct CmdList *t_recording;
+extern thread_local hipStream_t t_last_stream;      // stream of this thread's last launch() (debug sync only)
 
 inline int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && debug_sync_level() > 0 && !t_recording) {
-        if (debug_sync_level() > 1) { fprintf(stderr, "[gsage] %s\n", what); fflush(stderr); }
-        e = hipDeviceSynchronize();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(t_last_stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        if (cap == hipStreamCaptureStatusNone) {
+            if (debug_sync_level() > 1) { fprintf(stderr, "[gsage] %s\n", what); fflush(stderr); }
+            e = hipStreamSynchronize(t_last_stream);
+        }
     }
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));
@@ -134,6 +140,7 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
         });
         return;
     }
+    t_last_stream = stream;
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 

@@ -5,6 +5,10 @@
 // expression, models.py:71-104).  A train_step here is ~9 kernels of 5-40 us each, so how they are
 // issued decides the step time as much as the kernels do: see gsage_common.h launch().
 #include "gsage_common.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <cstring>
 
 #include <stdarg.h>
 #include <string.h>
@@ -15,6 +19,7 @@ namespace gsage {
 static thread_local char t_err[512] = "";
 std::atomic<uint64_t> g_launches{0};
 thread_local CmdList *t_recording = nullptr;
+thread_local hipStream_t t_last_stream = nullptr;
 thread_local const int32_t *t_head_n_valid = nullptr;
 thread_local const gsage_tail_gather_desc *t_gather_role = nullptr;
 thread_local int t_node_error = 0;      // set by a host-call node that failed during a replay
@@ -47,6 +52,42 @@ int gsage_gather_role_next(const gsage_tail_gather_desc *gather)
 }
 const char *gsage_last_error(void) { return t_err; }
 uint64_t gsage_launch_count(void) { return g_launches.load(); }
+
+static struct sigaction g_prev_abrt;
+static int g_abort_fd = 2;
+static void on_abort(int sig, siginfo_t *info, void *uc)
+{
+    static const char head[] = "\n[gsage] SIGABRT -- native backtrace of the aborting thread:\n";
+    (void)!write(g_abort_fd, head, sizeof(head) - 1);
+    void *frames[48];
+    const int n = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, n, g_abort_fd);
+    if (g_prev_abrt.sa_flags & SA_SIGINFO) {
+        if (g_prev_abrt.sa_sigaction) g_prev_abrt.sa_sigaction(sig, info, uc);
+    } else if (g_prev_abrt.sa_handler != SIG_DFL && g_prev_abrt.sa_handler != SIG_IGN) {
+        g_prev_abrt.sa_handler(sig);
+    } else {
+        signal(SIGABRT, SIG_DFL);
+        raise(SIGABRT);
+    }
+}
+
+int gsage_debug_abort_trace(int fd)
+{
+    static bool installed = false;
+    g_abort_fd = fd >= 0 ? fd : 2;
+    if (installed) return GSAGE_OK;
+    void *warm[2];
+    (void)backtrace(warm, 2);                  // (loads libgcc now, not inside the handler)
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = on_abort;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+    sigemptyset(&sa.sa_mask);
+    GSAGE_REQUIRE(sigaction(SIGABRT, &sa, &g_prev_abrt) == 0, "debug_abort_trace: sigaction failed");
+    installed = true;
+    return GSAGE_OK;
+}
 
 int gsage_device_info(char *arch, int arch_len, int *cu_count, int *wave_size)
 {

@@ -353,8 +353,34 @@ class FusedTrainStep(object):
         self.partial = torch.zeros(max(self.n_partial, self.partial.numel()), dtype=f32, device=dev)
         self.refresh_weights()
 
+    def _debug_addresses(self):
+        """GSAGE_DEBUG_ADDR=1: the address range of every device buffer the engine's kernels are handed, on stderr
+        -- what a 'Memory access fault ... on address' line of the runtime is matched against."""
+        seen = {}
+        def visit(name, v, depth=0):
+            if torch.is_tensor(v):
+                if v.is_cuda and v.numel():
+                    st = v.untyped_storage()
+                    seen.setdefault(st.data_ptr(), (name, st.nbytes()))
+            elif isinstance(v, (list, tuple)) and depth < 2:
+                for i, e in enumerate(v):
+                    visit("%s[%d]" % (name, i), e, depth + 1)
+            elif depth < 1 and hasattr(v, "__dict__") and not isinstance(v, torch.nn.Module):
+                for k, e in vars(v).items():
+                    visit("%s.%s" % (name, k), e, depth + 1)
+        for k, v in vars(self).items():
+            visit(k, v)
+        for k, v in self.model.state_dict().items():
+            visit("model." + k, v)
+        text = "[gsage addr] %s B=%d\n" % (type(self).__name__, self.B)
+        for ptr in sorted(seen):
+            text += "[gsage addr]   %#x .. %#x  %s\n" % (ptr, ptr + seen[ptr][1], seen[ptr][0])
+        os.write(2, text.encode())          # (fd 2, not sys.stderr: survives a test runner's sys-level capture)
+
     def _finish_init(self, capture, warmup):
         ddp = self.ddp
+        if os.environ.get("GSAGE_DEBUG_ADDR", "0") == "1":
+            self._debug_addresses()
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
         saved_opt = (self.flat_m.clone(), self.flat_v.clone(), self.step.clone())     # (zeros, or an imported state)
@@ -368,7 +394,8 @@ class FusedTrainStep(object):
         self.flat_p.copy_(saved)
         for t, v in zip((self.flat_m, self.flat_v, self.step), saved_opt):
             t.copy_(v)
-        for t in (self.counter,) + tuple(getattr(self, "_warm_reset", ())):
+        slots = getattr(self, "_norm_slots", None)     # (tags of the warm-up's update numbers must not meet the run's)
+        for t in (self.counter,) + tuple(getattr(self, "_warm_reset", ())) + ((slots,) if slots is not None else ()):
             t.zero_()
         if self.lazy_rows and int(self.step.item()) > 0:      # deferred table rows: every row is current at that count
             self.row_last.fill_(int(self.step.item()))
