@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSAGE_ABI_VERSION 4
+#define GSAGE_ABI_VERSION 5
 
 enum { GSAGE_F32 = 0, GSAGE_BF16 = 1 };
 enum {
@@ -387,6 +387,12 @@ typedef struct gsage_wgrad_desc {
                                  * read A + g * a_gstride row by row, like gsage_linear_nt's a_rows_group0_only) */
 } gsage_wgrad_desc;
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
+/* Device counters for the NEXT gsage_wgrad_multi launch of the calling thread to advance when it starts (consumed by
+ * it, also while a command list is being recorded): *tick += 1, *tick1 += inc1, *tick2 += inc2 (any may be NULL).
+ * For steps without a finalisation launch (gsage_adam_desc.reduce_descs): the Adam step count, the Philox call
+ * counter and the batch-queue index must move AFTER the seed level read them and BEFORE the launch that carries the
+ * update and the next frontier's sampling -- K5b sits exactly there and reads none of them. */
+int gsage_wgrad_ticks_next(int64_t *tick, int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2);
 /* dtype (both entry points) = type of dC and A: GSAGE_BF16 (the MFMA kernel described above) or
  * GSAGE_F32 (plain fp32 FMAs, same decomposition and slab layout: the exact-arithmetic parity mode in
  * which the golden fixtures generated from the reference are replayed through the fused engines). */
@@ -636,7 +642,24 @@ typedef struct gsage_adam_desc {
      * the data-parallel step: the norm of the AVERAGED gradient exists only after the exchange, and a launch of its
      * own for it sat on the critical path behind the collective.  norm_slots: >= 1 024 x 8 bytes, zero-initialised. */
     uint64_t *norm_slots;
+    /* ABI 5 (with norm_slots, n_partial_ready == 0): NO finalisation launch ran -- g does not exist yet.  reduce_descs:
+     * DEVICE array of n_reduce (<= 16) gsage_reduce_desc (below) that together cover [0, n): every update workgroup
+     * sums the partial buffers of the 1 024 elements it is about to update (buffer order 0 .. S-1: the bits
+     * gsage_finalize_grads would produce), stores them to g (then the clipped values, when the clip is active) and
+     * goes on as above.  Replaces the finalisation launch of the single-GPU step (~6.5 us between K5b and the update,
+     * reading the same partial buffers); a data-parallel step keeps it (the exchange needs the flat bucket).  The
+     * step's ticks then ride in the K5b launch (gsage_wgrad_ticks_next).  NULL: g holds the gradient. */
+    const void *reduce_descs;
+    int32_t n_reduce;
 } gsage_adam_desc;
+/* The update of a gsage_adam_desc with norm_slots as a launch of its own (per-call steps: nothing to ride with):
+ * one workgroup per 1 024 elements, all resident (<= 1 024 and <= gsage_gather_adam_capacity of an LDS-free launch). */
+int gsage_clip_adam_meet(const gsage_adam_desc *adam, void *stream);
+/* Workgroups of gsage_gather_mean_multi_adam's launch that are resident at once on the current device when the
+ * sampler role needs lds_bytes of dynamic LDS (one per CU kept as margin): the in-launch norm is admitted only when
+ * the update's workgroups -- ceil(n / 1024) -- all fit; callers fall back to norm partials otherwise.  dtype: of the
+ * gathered table.  0 on failure. */
+int gsage_gather_adam_capacity(int dtype, int64_t lds_bytes);
 /* tick1 / tick2 (may be NULL): *tick1 += inc1, *tick2 += inc2 when the kernel starts (e.g. the
  * Philox call index and batch-queue index, when nothing in the same launch reads them). */
 /* Live rows for the NEXT head launch of the calling thread (gsage_head_ce, gsage_mean_tail_ce, gsage_head_l1),

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
 F32, BF16 = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -94,6 +94,9 @@ SIGNATURES = {
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
     "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _int, _i64, _vp]),
     "gsage_wgrad_multi": (_int, [_i32, _vp, _int, _vp]),
+    "gsage_wgrad_ticks_next": (_int, [_vp, _vp, _i64, _vp, _i64]),
+    "gsage_clip_adam_meet": (_int, [_vp, _vp]),
+    "gsage_gather_adam_capacity": (_int, [_int, _i64]),
     "gsage_head_ce": (_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _int, _i64, _vp, _vp,
                              _vp, _vp, _vp, _i64, _vp]),
     "gsage_head_ce_scratch": (_i64, [_i32, _i32, _i32]),
@@ -211,7 +214,7 @@ class AdamDesc(ctypes.Structure):             # mirrors gsage_adam_desc (include
                 ("weight_decay", _f32), ("max_norm", _f32), ("norm_out", _vp),
                 ("step_is_current", _i32), ("n_partial_ready", _i32), ("prep_descs", _vp),
                 ("n_prep", _i32), ("tick1", _vp), ("inc1", _i64), ("tick2", _vp), ("inc2", _i64),
-                ("norm_slots", _vp)]
+                ("norm_slots", _vp), ("reduce_descs", _vp), ("n_reduce", _i32)]
 
 
 class RowAdamDesc(ctypes.Structure):          # mirrors gsage_row_adam (include/gsage.h)
@@ -315,10 +318,17 @@ class NativeComm(object):
         process group torch.distributed already has)."""
         self.load()
         buf = ctypes.create_string_buffer(128)
+        err = None
         if rank == 0:
-            check(lib().gsage_comm_unique_id(buf), "comm_unique_id")
-        raw = exchange_id(bytes(buf.raw) if rank == 0 else None)
-        assert len(raw) == 128
+            try:
+                check(lib().gsage_comm_unique_id(buf), "comm_unique_id")
+            except Exception as e:             # (raised AFTER the exchange below: every rank must enter it, or the
+                err = e                        #  others block in the broadcast while rank 0 moves on to the next collective)
+        raw = exchange_id((b"\0" * 128 if err is not None else bytes(buf.raw)) if rank == 0 else None)
+        if err is not None:
+            raise err
+        if len(raw) != 128 or raw == b"\0" * 128:
+            raise NativeLibraryError("gsage_comm_unique_id failed on rank 0: no RCCL id to join")
         h = _vp()
         check(lib().gsage_comm_create(ctypes.create_string_buffer(raw, 128), rank, world, ctypes.byref(h)), "comm_create")
         self._h, self.rank, self.world = h.value, rank, world

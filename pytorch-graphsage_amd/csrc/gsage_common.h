@@ -84,8 +84,17 @@ struct CmdList {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<Node> &target() { return side_open ? *side_open : nodes; }
+    // stream of the last replay: the destructor waits for it (and for the side stream) before it lets go of the
+    // list's events and side stream -- a list may be dropped by Python's cyclic collector at ANY allocation, e.g.
+    // in the middle of another engine's warm-up, while its last replay is still queued on the device
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool replayed = false;
     ~CmdList()
     {
+        if (replayed) {
+            if (hipStreamSynchronize(last_stream) != hipSuccess) (void)hipGetLastError();
+            if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) (void)hipGetLastError();
+        }
         for (int i = 0; i < CMDLIST_MARKS; ++i)
             if (marks[i]) (void)hipEventDestroy(marks[i]);
         delete side_open;

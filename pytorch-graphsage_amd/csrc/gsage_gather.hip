@@ -475,6 +475,36 @@ int gsage_gather_mean_multi(int32_t n_seg, const void *const *tables, const int6
     return check_launch("gather_mean_multi");
 }
 
+// Workgroups of k_gather_multi_adam that can be RESIDENT at once with `lds_bytes` of dynamic LDS (the sampler role's
+// frontier buffers): what bounds the in-launch gradient norm, a meeting of the update's workgroups (every one of
+// them polls the slots of all the others: one that is not resident yet would be waited for forever).  The occupancy
+// API's answer can be one workgroup per CU too high (MI355X_MICROARCH.md, "Correctness boundaries"), and a workgroup
+// of another role may hold a slot when the update's are dispatched: one per CU is kept as margin.
+static int gather_adam_capacity(int dtype, size_t lds_bytes)
+{
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    hipError_t e = dtype == GSAGE_F32
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gather_multi_adam<float, float, 4>, 256, lds_bytes)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gather_multi_adam<uint16_t, uint16_t, 8>, 256, lds_bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (per_cu > 8) per_cu = 8;
+    return (per_cu - 1) * prop.multiProcessorCount;
+}
+
+int gsage_gather_adam_capacity(int dtype, int64_t lds_bytes)
+{
+    GSAGE_REQUIRE((dtype == GSAGE_BF16 || dtype == GSAGE_F32) && lds_bytes >= 0, "gather_adam_capacity: bad arguments");
+    return gather_adam_capacity(dtype, (size_t)lds_bytes);
+}
+
 int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const int64_t *const *ids,
                                  void *const *outs, const int64_t *M, const int32_t *n, int dtype,
                                  int64_t ld, int64_t D, int out_dtype, int64_t out_ld,
@@ -510,6 +540,12 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
         rc = fill_hops(h, lds, *hops);
         if (rc != GSAGE_OK) return rc;
         n_smp = (int)ceil_div(hops->B, h.spw);
+    }
+    if (a.norm_slots) {
+        const int cap = gather_adam_capacity(dtype, lds);
+        GSAGE_REQUIRE(n_adam <= cap, "gather_mean_multi_adam: the in-launch norm is a meeting of the %d update workgroups, but "
+                      "only %d workgroups of this launch (%zu bytes of LDS) are resident at once on this device; pass norm "
+                      "partials instead (gsage_gather_adam_capacity)", n_adam, cap, lds);
     }
     // where the side roles sit in the grid (fraction of the gather workgroups dispatched before them).
     // Measured in-step at config 2 (tools/role_sweep.sh): 0.0 -> 33.1 us, 0.5 -> 34.8 us, 1.0 -> 37.2 us:

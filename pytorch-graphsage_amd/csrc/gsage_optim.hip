@@ -79,13 +79,17 @@ k_adam_clip(const AdamParams a)
     adam_workgroup(a, blockIdx.x, gridDim.x, red);
 }
 
+// the update with the norm formed by its own workgroups (and, given reduce descriptors, the gradient summed by them):
+// the body that rides in k_gather_multi_adam, as a launch of its own -- same slots, same partial order, same bits
+__global__ void __launch_bounds__(256)
+k_adam_meet(const AdamParams a)
+{
+    __shared__ float red[4];
+    adam_workgroup<false>(a, blockIdx.x, gridDim.x, red);
+}
+
 // ---- gradient finalisation: sum partial buffers into the flat bucket + squared-norm partials ------
-struct ReduceDesc {
-    const float *src;       // S partial buffers, `stride` floats apart, each [rows, ld]
-    int64_t stride;
-    int64_t out_off;        // destination offset in the flat gradient bucket ([rows, cols] contiguous)
-    int32_t S, rows, cols, ld;
-};
+// (struct ReduceDesc: gsage_optim_dev.h)
 
 // one workgroup of the finalisation: descriptor `by`, grid-stride slice bx of gx
 __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
@@ -773,7 +777,7 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
     d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay; d.max_norm = max_norm;
     d.norm_out = norm_out; d.step_is_current = step_is_current; d.n_partial_ready = n_partial_ready;
     d.prep_descs = prep_descs; d.n_prep = n_prep; d.tick1 = tick1; d.inc1 = inc1; d.tick2 = tick2;
-    d.inc2 = inc2; d.norm_slots = nullptr;
+    d.inc2 = inc2; d.norm_slots = nullptr; d.reduce_descs = nullptr; d.n_reduce = 0;
     GSAGE_REQUIRE(p && g && m && v && partial && lr && step, "clip_adam_step: null pointer");
     GSAGE_REQUIRE(n > 0 && n_partial_ready >= 0 && n_prep >= 0, "clip_adam_step: bad sizes");
     hipStream_t s = (hipStream_t)stream;
@@ -797,6 +801,28 @@ int gsage_clip_adam_step(float *p, float *g, float *m, float *v, int64_t n, floa
         rc = check_launch("step_inc");
     }
     return rc;
+}
+
+int gsage_clip_adam_meet(const gsage_adam_desc *adam, void *stream)
+{
+    GSAGE_REQUIRE(adam && adam->norm_slots && adam->n_partial_ready == 0 && adam->step_is_current,
+                  "clip_adam_meet: needs norm_slots, n_partial_ready == 0 and step_is_current");
+    AdamParams a;
+    int rc = fill_adam(a, *adam);
+    if (rc != GSAGE_OK) return rc;
+    const int n_adam = adam_grid(ceil_div(adam->n, 4), 2048);
+    int dev = 0, per_cu = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_adam_meet, 256, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = cus = 0;
+    }
+    per_cu = per_cu > 8 ? 8 : per_cu;
+    GSAGE_REQUIRE(a.n_prep > 0 && n_adam <= 1024 && (int64_t)n_adam * 1024 >= adam->n && n_adam <= (per_cu - 1) * cus,
+                  "clip_adam_meet: the in-launch norm needs one resident workgroup per 1 024 elements (%d asked, "
+                  "%d resident); pass norm partials to gsage_clip_adam_step instead", n_adam, (per_cu - 1) * cus);
+    launch(k_adam_meet, dim3(n_adam), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("adam_meet");
 }
 
 int gsage_grad_sqnorm(const float *g, int64_t n, float *partial, int32_t n_partial, void *stream)

@@ -50,6 +50,15 @@ __device__ __forceinline__ void prep_store(const PrepDesc &q, int r, int c, floa
     if (q.dst_p) q.dst_p[packed_offset(r, c, q.kc_p)] = b;
 }
 
+// ---- gradient sources: partial buffers whose sum is a slice of the flat gradient bucket ---------------
+// (gsage_reduce_desc: summed by gsage_finalize_grads -- or, ABI 5, by the update's own workgroups)
+struct ReduceDesc {
+    const float *src;       // S partial buffers, `stride` floats apart, each [rows, ld]
+    int64_t stride;
+    int64_t out_off;        // destination offset in the flat gradient bucket ([rows, cols] contiguous)
+    int32_t S, rows, cols, ld;
+};
+
 struct AdamParams {
     float *p, *g, *m, *v;
     const float *partial;       // per-block squared-norm partials of g
@@ -67,7 +76,50 @@ struct AdamParams {
     int32_t replay_math;           // != 0: the deferred-row arithmetic (adam_update<true>), for a table whose rows
                                    // may also be updated by gsage_rows_*: both must produce the same bits
     unsigned long long *norm_slots;   // != null: the workgroups form the squared norm themselves (slot = update << 32 | partial)
+    const ReduceDesc *rdesc;          // != null (with norm_slots): g does not exist yet -- element i of the bucket is the
+    int32_t n_rdesc;                  // sum of its descriptor's S partial buffers (what gsage_finalize_grads would store)
 };
+
+// g[i] for four elements of the flat bucket (i[u] < 0: none) out of the partial buffers of their descriptors.
+// Partials are added in buffer order 0 .. S-1 (gsage_finalize_grads' order: the same bits), four buffers of each of
+// the four elements in flight together (16 loads per lane and round: the register budget of k_gather_multi_adam).
+__device__ __forceinline__ void reduce_partials4(const ReduceDesc *__restrict__ rd, int n_rd, const int64_t (&i)[4],
+                                                 float (&g)[4])
+{
+    const float *src[4];
+    int64_t stride[4];
+    int S[4], Smax = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        src[u] = rd[0].src; stride[u] = 0; S[u] = 0; g[u] = 0.f;     // (no source: a valid address, nothing added)
+        for (int d = 0; d < n_rd; ++d) {
+            const int64_t o = i[u] - rd[d].out_off;
+            if (i[u] >= 0 && o >= 0 && o < (int64_t)rd[d].rows * rd[d].cols) {
+                const int64_t r = o / rd[d].cols;
+                src[u] = rd[d].src + r * rd[d].ld + (o - r * rd[d].cols);
+                stride[u] = rd[d].stride;
+                S[u] = rd[d].S;
+            }
+        }
+        Smax = S[u] > Smax ? S[u] : Smax;
+    }
+    for (int s0 = 0; s0 < Smax; s0 += 4) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sk = s0 + k;                       // (past the element's last buffer: its buffer 0 again,
+                v[u][k] = src[u][(int64_t)(sk < S[u] ? sk : 0) * stride[u]];                  // dropped below:
+                //                                                              the loads stay unconditional)
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k < S[u]) g[u] += v[u][k];
+    }
+}
 
 // The per-step constants and the per-element update of Adam (torch.optim.Adam's formulas), shared by the dense
 // kernels and the deferred row updates of a trainable embedding table (gsage_rows_*): the latter replay the
@@ -128,11 +180,24 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         // FENCE at device scope writes back / invalidates the XCD's whole L2 beside a gather role that is filling
         // it (measured: 32 us per launch) -- and no counter: the tag makes a slot's value self-describing.
         float q = 0.f;
+        if (a.rdesc) {
+            // no finalisation launch ran: this workgroup sums the partial buffers of the elements it updates (K5b's
+            // slabs, the head's per-workgroup partials) and leaves the result in the flat bucket for whoever reads
+            // p.grad -- the clipped value, as always, when the clip is active (below)
+            int64_t iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) iv[u] = i_first + u * stride < a.n ? i_first + u * stride : -1;
+            reduce_partials4(a.rdesc, a.n_rdesc, iv, gv0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (iv[u] >= 0) a.g[iv[u]] = gv0[u];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = i_first + u * stride;
             const int64_t ic = i < a.n ? i : i_first < a.n ? i_first : 0;
-            gv0[u] = a.g[ic]; pv0[u] = a.p[ic]; mv0[u] = a.m[ic]; vv0[u] = a.v[ic];
+            if (!a.rdesc) gv0[u] = a.g[ic];
+            pv0[u] = a.p[ic]; mv0[u] = a.m[ic]; vv0[u] = a.v[ic];
             if (i < a.n) q += gv0[u] * gv0[u];
         }
         const float mine = block_sum_256(q, red);
@@ -256,6 +321,11 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
     a.replay_math = 0;
     const bool inside = d.n_partial_ready == 0 && d.norm_slots;
     a.norm_slots = inside ? (unsigned long long *)d.norm_slots : nullptr;
+    GSAGE_REQUIRE(!d.reduce_descs || (inside && d.n_reduce > 0 && d.n_reduce <= 16),
+                  "clip_adam_step: reduce_descs (the update sums the partial buffers itself) needs norm_slots, "
+                  "n_partial_ready == 0 and 1..16 descriptors");
+    a.rdesc = (const ReduceDesc *)d.reduce_descs;
+    a.n_rdesc = d.reduce_descs ? d.n_reduce : 0;
     return GSAGE_OK;
 }
 

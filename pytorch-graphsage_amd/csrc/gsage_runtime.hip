@@ -141,6 +141,8 @@ int gsage_cmdlist_replay(const void *list, void *stream)
     const CmdList *l = (const CmdList *)list;
     if (l->nodes.empty()) return GSAGE_OK;
     t_node_error = 0;
+    l->last_stream = (hipStream_t)stream;
+    l->replayed = true;
     for (const auto &node : l->nodes) node((hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -368,11 +368,24 @@ struct WgradMulti {
     int32_t first[WGRAD_MAX_PROBLEMS + 1];     // workgroups [first[s], first[s+1]) belong to problem s
     int32_t S[WGRAD_MAX_PROBLEMS], ny[WGRAD_MAX_PROBLEMS];
     int32_t n_prob;
+    // gsage_wgrad_ticks_next: counters workgroup 0 advances when it starts (nothing in this launch reads them)
+    int64_t *tick, *tick1, *tick2;
+    int64_t inc1, inc2;
 };
+
+__device__ __forceinline__ void wgrad_ticks(const WgradMulti &q)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (q.tick) *q.tick += 1;
+        if (q.tick1) *q.tick1 += q.inc1;
+        if (q.tick2) *q.tick2 += q.inc2;
+    }
+}
 
 __global__ void __launch_bounds__(256, 1)
 k_wgrad_multi(const WgradMulti q)
 {
+    wgrad_ticks(q);
     int s = 0;
 #pragma unroll
     for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
@@ -449,6 +462,7 @@ k_wgrad_f32(const WgradParams p)
 __global__ void __launch_bounds__(256)
 k_wgrad_multi_f32(const WgradMulti q)
 {
+    wgrad_ticks(q);
     int s = 0;
 #pragma unroll
     for (int j = 1; j < WGRAD_MAX_PROBLEMS; ++j)
@@ -536,14 +550,28 @@ static int wgrad_fill(WgradParams &p, int dtype, const void *dC, int64_t ldc, co
     return GSAGE_OK;
 }
 
+namespace gsage {
+struct WgradTicks { int64_t *tick, *tick1, *tick2; int64_t inc1, inc2; };
+static thread_local WgradTicks t_wgrad_ticks = {nullptr, nullptr, nullptr, 0, 0};
+}
+
 extern "C" {
+
+int gsage_wgrad_ticks_next(int64_t *tick, int64_t *tick1, int64_t inc1, int64_t *tick2, int64_t inc2)
+{
+    t_wgrad_ticks = WgradTicks{tick, tick1, tick2, inc1, inc2};
+    return GSAGE_OK;
+}
 
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream)
 {
+    const WgradTicks ticks = t_wgrad_ticks;           // (consumed before any return path: never left for a later launch)
+    t_wgrad_ticks = WgradTicks{nullptr, nullptr, nullptr, 0, 0};
     GSAGE_REQUIRE(probs && n_prob >= 1 && n_prob <= WGRAD_MAX_PROBLEMS, "wgrad_multi: 1..%d problems",
                   WGRAD_MAX_PROBLEMS);
     WgradMulti q;
     q.n_prob = n_prob;
+    q.tick = ticks.tick; q.tick1 = ticks.tick1; q.tick2 = ticks.tick2; q.inc1 = ticks.inc1; q.inc2 = ticks.inc2;
     q.first[0] = 0;
     for (int s = 0; s < WGRAD_MAX_PROBLEMS; ++s) {
         if (s < n_prob) {

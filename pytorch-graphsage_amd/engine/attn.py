@@ -38,7 +38,7 @@ class FusedAttnTrainStep(FusedTrainStep):
     @classmethod
     def why_not(cls, model, feats, ddp=None):
         why = cls._why_not_common(model, feats, (AttentionAggregator,), "attention") or \
-            cls._why_not_input(model, feats)
+            cls._why_not_input(model, feats, ddp)
         if why:
             return why
         layers = list(model.agg_layers.children())
@@ -263,5 +263,7 @@ class FusedAttnTrainStep(FusedTrainStep):
             for i, ((dC, A, lda, M, ntot, K, prm, rows), slab) in enumerate(zip(self._wg_problems(l, s), self.slabs[l])):
                 probs.append((dC, A, lda, 0, M, ntot, K, ntot, slab, self.wg_target[(l, i)], rows))
         for i in range(0, len(probs), 8):
+            if i == 0:
+                self._wgrad_ticks()
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)

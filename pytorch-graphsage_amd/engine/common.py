@@ -77,7 +77,7 @@ class FusedTrainStep(object):
         return cls.why_not(model, feats, ddp) is None
 
     @classmethod
-    def head_why_not(cls, model, loss_fn, example_targets, batch, padded):
+    def head_why_not(cls, model, loss_fn, example_targets, batch, padded, world=1):
         """What the head of (model, loss_fn) costs a caller BEFORE an engine is built (train.py decides between the
         engine and the module path with it): None when a fused head applies (cross-entropy with <= 64 classes and an
         fc input of <= 1024, or the L1 regression head with <= 2048 seeds), else a sentence.  Without a fused head an
@@ -93,6 +93,9 @@ class FusedTrainStep(object):
             return None
         if loss_fn is ProblemLosses.regression_mae and ident and C == 1 and 1 < batch <= 2048 and \
                 example_targets.dtype == torch.float32:
+            if world * batch > 8192:       # gsage_head_l1_sharded keeps the GLOBAL batch's targets in LDS
+                return ("the sharded L1 head pairs every prediction with every target of the global batch, which it "
+                        "holds in LDS: world x batch = %d x %d exceeds 8192" % (world, batch))
             return None
         if not padded:
             return None
@@ -123,7 +126,7 @@ class FusedTrainStep(object):
         return None
 
     @staticmethod
-    def _why_not_input(model, feats):
+    def _why_not_input(model, feats, ddp=None):
         """Level-0 rows: an identity prep over a FeatureStore in HBM, or the trainable node-embedding prep without
         features (BASELINE configs[3] / utils/pokec.sh: nn_modules.py:126-155)."""
         if isinstance(model.prep, NodeEmbeddingPrep):
@@ -131,6 +134,11 @@ class FusedTrainStep(object):
                 return "a node-embedding prep concatenated with features"
             if model.prep.embedding_dim % 8 != 0 or not model.prep.embedding.weight.is_cuda:
                 return "an embedding width that is not a multiple of 8, or a table that is not in HBM"
+            if ddp is not None and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") == "1":
+                # the dense mode zeroes only the rows of THIS rank's frontier after the update; rows that another
+                # rank's frontier made non-zero (through the all-reduce of the whole bucket) would be re-applied forever
+                return "GSAGE_DENSE_TABLE_ADAM=1 (the dense table update) in a data-parallel run: only the deferred row " \
+                       "updates exchange and clear every rank's touched rows"
             return None
         if not isinstance(model.prep, IdentityPrep):
             return "a prep class other than identity / node_embedding (%s)" % type(model.prep).__name__
@@ -348,6 +356,7 @@ class FusedTrainStep(object):
         self.rdescs = torch.frombuffer(bytearray(bytes((_ReduceDesc * len(rdesc))(*rdesc))),
                                        dtype=torch.uint8).to(dev)
         self.n_rdesc = len(rdesc)
+        self._rdesc_max_S = max(int(d.S) for d in rdesc)
         self.r_max = max(d.rows * d.cols for d in rdesc)
         self.n_partial = nat.lib().gsage_finalize_partials(self.n_rdesc, self.r_max)
         self.partial = torch.zeros(max(self.n_partial, self.partial.numel()), dtype=f32, device=dev)
@@ -652,21 +661,70 @@ class FusedTrainStep(object):
         d.norm_out, d.step_is_current = self.gnorm.data_ptr(), 1
         d.n_partial_ready = 0 if self.ddp is not None else self.n_partial
         d.prep_descs, d.n_prep = self.descs.data_ptr(), self.n_desc
-        d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation ticks the counters
+        d.tick1, d.inc1, d.tick2, d.inc2 = None, 0, None, 0     # the finalisation (or K5b) ticks the counters
+        if self._fold_finalize():
+            # no finalisation launch: the update's workgroups sum the partial buffers of their own elements, form the
+            # norm among themselves and store the (clipped) gradient (gsage_adam_desc.reduce_descs)
+            d.n_partial_ready = 0
+            d.norm_slots = self._slots().data_ptr()
+            d.reduce_descs, d.n_reduce = self.rdescs.data_ptr(), self.n_rdesc
+            return d
         if self.ddp is not None and self._norm_in_launch():
             # data-parallel: the norm of the AVERAGED gradient is formed by the update's own workgroups inside the
             # launch that carries Adam (gsage_adam_desc.norm_slots) -- no norm launch behind the collective
-            if getattr(self, "_norm_slots", None) is None:
-                self._norm_slots = torch.zeros(1024, dtype=torch.int64, device=self.dev)
-            d.norm_slots = self._norm_slots.data_ptr()
+            d.norm_slots = self._slots().data_ptr()
         return d
 
+    def _slots(self):
+        if getattr(self, "_norm_slots", None) is None:
+            self._norm_slots = torch.zeros(1024, dtype=torch.int64, device=self.dev)
+        return self._norm_slots
+
+    def _meet_fits(self):
+        """The in-launch norm is a meeting of the update's workgroups (one per 1 024 parameters): every one of them
+        must be RESIDENT at once in the launch that carries them -- asked of the device (occupancy of the gather
+        launch with the sampler role's LDS, times the CU count, one workgroup per CU kept as margin), not assumed."""
+        if getattr(self, "_meet_ok", None) is None:
+            n_wg = -(-(-(-self.flat_p.numel() // 4)) // 256)
+            widest, width = 1, 1
+            for k in range(1, self.L + 1):
+                width *= self.fan[k]
+                widest = max(widest, width)
+            spw = int(os.environ.get("GSAGE_HOPS_SPW", "1"))
+            lds = 16 * (spw if 1 <= spw <= 16 else 1) * widest
+            cap = int(nat.lib().gsage_gather_adam_capacity(self.code, lds))
+            self._meet_ok = bool(n_wg <= 1024 and n_wg <= cap)
+        return self._meet_ok
+
     def _norm_in_launch(self):
-        """can the launch that carries Adam form the gradient norm itself?  (the mean engine's gather launch; its
-        update workgroups -- one per 1 024 parameters -- must all be resident at once: <= 1 024 of them)"""
-        n_wg = -(-(-(-self.flat_p.numel() // 4)) // 256)
-        return bool(self.MEAN_ENGINE and not self.emb and n_wg <= 1024 and
+        """can the launch that carries Adam form the gradient norm itself?  (the mean engine's gather launch)"""
+        return bool(self.MEAN_ENGINE and not self.emb and self._meet_fits() and
                     os.environ.get("GSAGE_DDP_NORM_IN_LAUNCH", "1") == "1")
+
+    def _fold_finalize(self):
+        """Single GPU: no finalisation launch -- the update's workgroups sum K5b's partial tiles and the head's
+        partial rows for the 1 024 elements each is about to update (gsage_adam_desc.reduce_descs), the norm is
+        formed among them (norm_slots), and the step's ticks ride in the K5b launch (gsage_wgrad_ticks_next).
+        Four launches per step instead of five at BASELINE configs[1].  Not with a process group (the exchange
+        wants the flat bucket), a trainable table (its gradient is scatter-added), the two-stream modes, or more
+        partial buffers per element than the update can sum inside its launch without becoming its longest role.
+        GSAGE_FOLD_FINALIZE: 0 = never, 1 (default) = the mean engine, all = every engine that qualifies."""
+        if getattr(self, "_fold", None) is None:
+            mode = os.environ.get("GSAGE_FOLD_FINALIZE", "1")
+            ok = (mode in ("1", "all") and (self.MEAN_ENGINE or mode == "all") and self.ddp is None and not self.emb
+                  and not self.pipelined and not getattr(self, "gather_cus", 0)
+                  and (self.fused_head or self.fused_l1) and getattr(self, "n_rdesc", 99) <= 16
+                  and getattr(self, "_rdesc_max_S", 1 << 30) <= 32 and self._meet_fits())
+            self._fold = bool(ok)
+        return self._fold
+
+    def _wgrad_ticks(self):
+        """(before the step's K5b launch) without a finalisation launch the step's ticks ride in K5b"""
+        if self._fold_finalize():
+            nat.check(nat.lib().gsage_wgrad_ticks_next(
+                self.step.data_ptr(), None if self.pipelined else self.counter.data_ptr(), self.L,
+                self.batch_idx.data_ptr() if self.queue else None, 1), "wgrad_ticks_next")
+            self._ticks_issued = True
 
     def _head_live_rows(self):
         """tell the next head launch how many seeds of the batch are live (padded chunks, see _pad_batch)"""
@@ -759,6 +817,10 @@ class FusedTrainStep(object):
         """Every partial buffer -> flat gradient bucket, + squared-norm partials, + the step's ticks:
         Adam step, Philox call counter, batch-queue index (nothing else in this launch reads them)."""
         L, lib, stream = self.L, nat.lib(), ops._stream()
+        if self._fold_finalize():
+            assert getattr(self, "_ticks_issued", False), "no finalisation launch: _wgrad_ticks() must precede K5b"
+            self._ticks_issued = False
+            return
         nat.check(lib.gsage_finalize_grads(self.rdescs.data_ptr(), self.n_rdesc, self.r_max,
                                            self.flat_g.data_ptr(), self.partial.data_ptr(),
                                            self.step.data_ptr(),
@@ -845,6 +907,9 @@ class FusedTrainStep(object):
         if self.emb:
             return self._stage_opt_emb()
         d = self._adam_desc()
+        if d.reduce_descs:               # (no finalisation launch ran: the update sums the partial buffers itself)
+            nat.check(nat.lib().gsage_clip_adam_meet(ctypes.addressof(d), ops._stream()), "clip_adam_meet")
+            return
         nat.check(nat.lib().gsage_clip_adam_step(d.p, d.g, d.m, d.v, d.n, d.partial, d.lr, d.step, d.beta1,
                                                  d.beta2, d.eps, d.weight_decay, d.max_norm, d.norm_out,
                                                  d.step_is_current, d.n_partial_ready, d.prep_descs,

@@ -49,7 +49,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         # bf16 storage = the production path; fp32 storage = the exact-arithmetic parity mode (same engine, same
         # kernel sources instantiated on fp32: golden fixtures replay at 2e-4).  With the node-embedding prep
         # (utils/pokec.sh:5-13) the level-0 rows are weights: computed per step, nothing is gathered ahead.
-        why = cls._why_not_common(model, feats, (MeanAggregator,), "mean") or cls._why_not_input(model, feats)
+        why = cls._why_not_common(model, feats, (MeanAggregator,), "mean") or cls._why_not_input(model, feats, ddp)
         if why:
             return why
         if not all(l.output_dim_ % 8 == 0 for l in model.agg_layers.children()):
@@ -363,6 +363,7 @@ class FusedMeanTrainStep(FusedTrainStep):
                                   self.slabs[l][g], self.wg_target[(l, g)], rows if g == 0 else None))
         for i in range(0, len(probs), 8):
             if i == 0:
+                self._wgrad_ticks()
                 self._time_next(6, 7)
             ops.wgrad_multi(probs[i:i + 8])
         self._side_join("k5b")

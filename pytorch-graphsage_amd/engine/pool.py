@@ -41,7 +41,7 @@ class FusedPoolTrainStep(FusedTrainStep):
             return why
         if not isinstance(model.prep, IdentityPrep):
             return "a prep class other than identity (%s)" % type(model.prep).__name__
-        why = cls._why_not_input(model, feats)
+        why = cls._why_not_input(model, feats, ddp)
         if why:
             return why
         layers = list(model.agg_layers.children())
@@ -276,6 +276,7 @@ class FusedPoolTrainStep(FusedTrainStep):
             probs.append((self.ghc[l], nb, ldnb, 0, NR, Hm, din, Hm, self.slabs[l]["m"], T[(l, "m")], nrows))
         for i in range(0, len(probs), 8):
             if i == 0:
+                self._wgrad_ticks()
                 self._time_next(6, 7)
             ops.wgrad_multi(probs[i:i + 8])
         self._stage_finalize(s)

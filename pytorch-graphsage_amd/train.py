@@ -237,7 +237,7 @@ def choose_engine(args, problem, model, ddp):
         if nodes.shape[0] // n_batches < 2:           # the smallest of the reference's array_split chunks
             return give_up('chunks of fewer than two training nodes')
     example = torch.zeros(1, dtype=torch.int64 if problem.task == 'classification' else torch.float32)
-    why = cls.head_why_not(model, problem.loss_fn, example, B, padded)
+    why = cls.head_why_not(model, problem.loss_fn, example, B, padded, world)
     if why is not None:
         return give_up(why)
     return cls
@@ -301,7 +301,9 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right behind
     # its step into a small device ring (problem.MetricRing), and the ring is read back -- one copy -- every 32 batches
     # and at the end of every epoch: same lines, same order, same values, printed 32 at a time.
-    ring = gs.problem.MetricRing(problem.task, dev)
+    # (the `time` of a line is taken when its batch is SUBMITTED, not when the ring is read back; GSAGE_METRIC_RING=1
+    # makes the ring one slot deep: the reference's per-batch flush, one host sync per batch)
+    ring = gs.problem.MetricRing(problem.task, dev, capacity=max(1, int(os.environ.get("GSAGE_METRIC_RING", "32"))))
     pending = []
     # (class ids outside [0, C) are scored the reference's way, on the host: the synchronous route)
     tg_ok = problem.task != 'classification' or (int(np.min(problem.targets)) >= 0 and
@@ -309,10 +311,10 @@ def train_fused(args, problem, model, ddp, start_time, cls):
 
     def flush():
         nonlocal train_metric
-        for prog, metric in zip(pending, ring.results()):
+        for (prog, stamp), metric in zip(pending, ring.results()):
             train_metric = metric
             print(dumps({"epoch": epoch, "epoch_progress": prog, "train_metric": train_metric,
-                         "val_metric": val_metric, "time": time() - start_time}))
+                         "val_metric": val_metric, "time": stamp}))
         del pending[:]
         sys.stdout.flush()
     # GSAGE_TRAIN_TIMING=1 (bench.py's CLI measurement): wall seconds of every epoch's batch loop, bracketed by device
@@ -330,25 +332,27 @@ def train_fused(args, problem, model, ddp, start_time, cls):
         if timing:
             torch.cuda.synchronize()
         t_loop = time()
-        for b in range(n_batches):
-            nb = live[b] if live is not None else B
-            step.set_progress((epoch + b / n_batches) / args.epochs)
-            preds = step.step_queue() if queued else step(ids[b, :nb], tgs[b, :nb])
-            if (b % every == 0 or b == n_batches - 1) and rank == 0:
-                if tg_ok and preds.dtype == torch.float32 and preds.is_contiguous():
-                    # (a full batch costs one indexing op here: the loop's host time per batch is what bounds the CLI)
-                    full = nb == B
-                    ring.score(tgs[b] if full else tgs[b, :nb], preds if full else preds[:nb])
-                    pending.append(b / n_batches)
-                    if ring.pending == ring.capacity:
+        try:
+            for b in range(n_batches):
+                nb = live[b] if live is not None else B
+                step.set_progress((epoch + b / n_batches) / args.epochs)
+                preds = step.step_queue() if queued else step(ids[b, :nb], tgs[b, :nb])
+                if (b % every == 0 or b == n_batches - 1) and rank == 0:
+                    if tg_ok and preds.dtype == torch.float32 and preds.is_contiguous():
+                        # (a full batch costs one indexing op here: the loop's host time per batch is what bounds the CLI)
+                        full = nb == B
+                        ring.score(tgs[b] if full else tgs[b, :nb], preds if full else preds[:nb])
+                        pending.append((b / n_batches, time() - start_time))
+                        if ring.pending == ring.capacity:
+                            flush()
+                    else:
                         flush()
-                else:
-                    flush()
-                    train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
-                    print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
-                                 "val_metric": val_metric, "time": time() - start_time}))
-                    sys.stdout.flush()
-        flush()
+                        train_metric = batch_metric(problem.task, tgs[b, :nb].view(nb, -1), preds[:nb])
+                        print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
+                                     "val_metric": val_metric, "time": time() - start_time}))
+                        sys.stdout.flush()
+        finally:
+            flush()                       # (a run that dies mid-epoch still prints the batches it scored)
         if timing:
             torch.cuda.synchronize()
             step.timing.append({"epoch": epoch, "batches": n_batches, "seeds": int(sum(live)) if live is not None

@@ -123,6 +123,17 @@ def pytest_runtestloop(session):
             recs, rc, tail = _run_file_in_child(session, path, tmpdir)
             for i, item in enumerate(items):
                 mine = recs.get(item.nodeid)
+                if i == len(items) - 1 and mine and any(r["when"] == "teardown" for r in mine) and \
+                        rc not in (0, 1, 5):
+                    # Every report arrived and the child STILL ended abnormally (return codes: 0 = passed, 1 = tests
+                    # failed, 5 = nothing selected): it died after the last test's teardown -- interpreter exit, i.e.
+                    # the teardown of whatever the file's tests left alive (engines, command lists, streams).  That
+                    # is a failure of this file; it is charged to its last test, with the child's last words.
+                    mine = [r for r in mine if r["when"] != "teardown"] + [{
+                        "when": "teardown", "outcome": "failed", "duration": 0.0, "sections": [],
+                        "longrepr": "every test of %s reported, but its pytest process then ended with return code %s "
+                                    "(a crash at interpreter exit); the end of its output:\n%s"
+                                    % (os.path.basename(path), rc, tail)}]
                 if not mine or not any(r["when"] == "teardown" for r in mine):
                     # the child never finished this test: it died in it.  The test fails with the child's last
                     # words; the rest of the file gets a fresh process.

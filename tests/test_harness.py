@@ -12,6 +12,11 @@ def test_before(): pass
 def test_dies(): ctypes.CDLL(None).abort()
 def test_after(): pass
 """
+EXIT = """
+import atexit, ctypes
+def test_leaves_a_bomb():
+    atexit.register(lambda: ctypes.CDLL(None).abort())
+"""
 FINE = """
 import pytest
 def test_fine(): pass
@@ -45,3 +50,19 @@ def test_a_dead_test_process_fails_one_test_and_the_run_goes_on(tmp_path):
 def test_stop_at_first_failure_still_stops(tmp_path):
     rc, out = _run(tmp_path, "-x")
     assert rc == 1 and "1 failed, 1 passed" in out and "stopping after 1 failures" in out, out
+
+
+def test_a_crash_at_interpreter_exit_fails_the_last_test_of_the_file(tmp_path):
+    """all reports arrived, then the child aborted while exiting (where engines are torn down): not green"""
+    (tmp_path / "test_c_exit.py").write_text(EXIT)
+    (tmp_path / "test_d_fine.py").write_text("def test_ok(): pass\n")
+    env = dict(os.environ, GSAGE_TEST_ISOLATE="1", PYTEST_PLUGINS="conftest", GSAGE_DEBUG_ABORT_TRACE="0",
+               PYTHONPATH=HERE + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("GSAGE_PYTEST_CHILD", None)
+    env.pop("GSAGE_PYTEST_REPORT", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--rootdir", str(tmp_path),
+                        str(tmp_path / "test_c_exit.py"), str(tmp_path / "test_d_fine.py")], cwd=str(tmp_path), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 1 and "crash at interpreter exit" in out, out
+    assert "2 passed, 1 error" in out, out                  # (the test itself passed; its file's exit did not)
