@@ -275,7 +275,9 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
         out = hbm_roofline("k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
                            rows_g * st.dim * elem, us["gather"], pmc_key, n_steps, rows_per_launch=rows_g)
         if rows_t and "seed_level" in us:
-            out["seed_level_launch"] = {"kernel": "k_mean_tail_ce (seed level + gather role on its idle CUs)",
+            out["seed_level_launch"] = {"kernel": ("k_mean_tail_mfma (16 seeds per workgroup on the matrix cores"
+                                                   if eng._tail_on_mfma() else "k_mean_tail_ce (seed level") +
+                                        " + gather role on its idle CUs)",
                                         "gather_rows": rows_t, "alg_bytes_per_launch": rows_t * st.dim * elem,
                                         "avg_launch_us": us["seed_level"]}
         # MFMA utilisation of the step's two contractions (north_star: "MFMA utilisation on the GEMM"): K5 = the
@@ -596,6 +598,25 @@ def extra_ddp_1rank(args):
     return out
 
 
+def extra_b4096(args):
+    """The headline step at B = 4 096 seeds per GPU ("512/GPU (also sweep 4096)"): the same engine, eight
+    times the work per launch -- fixed launch costs amortised, the seed level 256 workgroups wide.  A child process
+    (its own seed queue and engine)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--extra", "",
+           "--min-time", "0.3", "--batch-size", "4096", "--precision", args.precision]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"config": "BASELINE configs[1] at B = 4096 seeds per GPU", "ms_per_step": line["ms_per_step"],
+                "value": line["value"], "unit": "seed-nodes/sec",
+                "frac_of_hbm_gather_roofline": line["frac_of_hbm_gather_roofline"],
+                "kernel_launches_per_step": line["config"].get("kernel_launches_per_step"),
+                "gather_launch": {k: line["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_us",
+                                                                       "alg_bytes_per_launch")}}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def _free_port():
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
@@ -647,7 +668,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank,cli",
+    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank,cli,b4096",
                     help="comma-separated additional configurations measured after the main line (N=1 only) and "
                          "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
                          "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
@@ -811,7 +832,7 @@ def main():
             del res, step_fn, model
             torch.cuda.empty_cache()
             names = [a for a in args.extra.split(",") if a and a != args.aggregator]
-            for agg in [a for a in names if a not in ("papers", "pokec", "ddp_1rank", "cli")]:
+            for agg in [a for a in names if a not in ("papers", "pokec", "ddp_1rank", "cli", "b4096")]:
                 r2 = measure(agg, min(args.min_time, 0.3))
                 e2 = r2["elapsed"]
                 rec = {"config": {"max_pool": "BASELINE configs[2] shape on one GPU",
@@ -845,6 +866,8 @@ def main():
                     torch.cuda.empty_cache()
             if "ddp_1rank" in names and ddp is None:
                 extra["ddp_1rank"] = extra_ddp_1rank(args)
+            if "b4096" in names and args.batch_size != 4096:
+                extra["b4096"] = extra_b4096(args)
         line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)

@@ -589,6 +589,19 @@ int gsage_gather_role_next(const gsage_tail_gather_desc *gather);
  * instantiated on fp32 storage (every bf16 rounding point becomes a no-op; no gather role), used to
  * replay the reference-generated golden fixtures through this kernel at fp32 tolerance. */
 int64_t gsage_mean_tail_ce_scratch(int32_t B, int32_t C);
+/* The same seed level on the matrix cores (ABI 5; bf16 storage only): 16 seeds per 512-thread workgroup -- one MFMA
+ * row tile -- instead of 4 per 256-thread workgroup on the VALU.  ceil(B / 16) workgroups stream the projection
+ * weights (32 instead of 128 times at B = 512), both projections and the input gradients run on
+ * v_mfma_f32_16x16x32_bf16, the head (logits, d z, d fc.weight) on v_mfma_f32_16x16x4_f32 (exact fp32 products, as
+ * on the VALU).  Same arguments, same outputs and rounding points as gsage_mean_tail_ce with dtype = GSAGE_BF16
+ * (sums run in a different order: results agree to fp32 round-off, agg / dE / dH to one bf16 rounding); the partials
+ * are ceil(B / 16) rows (gsage_mean_tail_mfma_scratch).  gather: the role's workgroups are 512 threads here. */
+int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, int64_t ldw2,
+                         const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
+                         const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
+                         void *dE, float *preds, void *dH, float *partial,
+                         const gsage_tail_gather_desc *gather, void *stream);
+int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C);
 
 /* ------------------------------------------------------------------------------------------
  * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86

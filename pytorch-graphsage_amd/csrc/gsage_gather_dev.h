@@ -27,12 +27,13 @@ struct TailGather {
 
 // bx: index of this workgroup among the n_wg that play the role; U work items (16-byte chunks of an output row) per
 // lane and trip = U * N row requests in flight (U = 4 where the launch leaves the registers, 2 inside K5)
-template <int N, int U>
+// THREADS: workgroup size of the launch that plays the role (the matrix-core seed level runs 512-thread workgroups)
+template <int N, int U, int THREADS = 256>
 __device__ __forceinline__ void gather_role(const TailGather &g, int bx)
 {
     const int64_t total = (int64_t)g.rows * g.chunks;
-    const int64_t S = (int64_t)g.n_wg * 256;
-    for (int64_t t0 = (int64_t)bx * 256 + threadIdx.x; t0 < total; t0 += U * S) {
+    const int64_t S = (int64_t)g.n_wg * THREADS;
+    for (int64_t t0 = (int64_t)bx * THREADS + threadIdx.x; t0 < total; t0 += U * S) {
         int64_t row[U];
         int32_t c0[U];
         bool ok[U];

@@ -311,8 +311,10 @@ class FusedTrainStep(object):
         if self.fused_head:
             assert nat.lib().gsage_head_ce_scratch(B, C, D2) == nat.lib().gsage_mean_tail_ce_scratch(B, C) \
                 or not self.fused_tail
-            self.head_scratch = torch.zeros(nat.lib().gsage_head_ce_scratch(B, C, D2),
-                                            dtype=torch.float32, device=dev)
+            n_scr = nat.lib().gsage_head_ce_scratch(B, C, D2)
+            if self.fused_tail and self._tail_on_mfma():       # one partial row per 16 seeds instead of per 4
+                n_scr = nat.lib().gsage_mean_tail_mfma_scratch(B, C)
+            self.head_scratch = torch.zeros(n_scr, dtype=torch.float32, device=dev)
             self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
             self.preds = torch.zeros(B, C, dtype=torch.float32, device=dev)
         # the regression head of the Pokec problem (F.l1_loss with the reference's [B,1]-vs-[B] broadcast) as one kernel
@@ -706,13 +708,13 @@ class FusedTrainStep(object):
         partial rows for the 1 024 elements each is about to update (gsage_adam_desc.reduce_descs), the norm is
         formed among them (norm_slots), and the step's ticks ride in the K5b launch (gsage_wgrad_ticks_next).
         Four launches per step instead of five at BASELINE configs[1].  Not with a process group (the exchange
-        wants the flat bucket), a trainable table (its gradient is scatter-added), the two-stream modes, or more
-        partial buffers per element than the update can sum inside its launch without becoming its longest role.
+        wants the flat bucket), a trainable table (its gradient is scatter-added), or more partial buffers per
+        element than the update can sum inside its launch without becoming its longest role.  Every launch mode of
+        an engine takes the same path (per call, queue, pipelined, split): their results stay bit-identical.
         GSAGE_FOLD_FINALIZE: 0 = never, 1 (default) = the mean engine, all = every engine that qualifies."""
         if getattr(self, "_fold", None) is None:
             mode = os.environ.get("GSAGE_FOLD_FINALIZE", "1")
             ok = (mode in ("1", "all") and (self.MEAN_ENGINE or mode == "all") and self.ddp is None and not self.emb
-                  and not self.pipelined and not getattr(self, "gather_cus", 0)
                   and (self.fused_head or self.fused_l1) and getattr(self, "n_rdesc", 99) <= 16
                   and getattr(self, "_rdesc_max_S", 1 << 30) <= 32 and self._meet_fits())
             self._fold = bool(ok)
@@ -775,6 +777,9 @@ class FusedTrainStep(object):
             self._torch_head(s)
 
     def _will_fuse_tail(self, example_targets):
+        return False
+
+    def _tail_on_mfma(self):
         return False
 
     def _wg_target(self):

@@ -145,6 +145,11 @@ class FusedMeanTrainStep(FusedTrainStep):
                     2 * hs[L - 2] == 256 and 2 * hs[L - 1] == 256 and self.fan[1] <= 32 and
                     os.environ.get("GSAGE_NO_FUSED_TAIL", "0") != "1")
 
+    def _tail_on_mfma(self):
+        """... and on the matrix cores (gsage_mean_tail_mfma: 16 seeds per 512-thread workgroup; bf16 storage)?
+        GSAGE_TAIL_MFMA=0: the 4-seeds-per-workgroup VALU kernel (gsage_mean_tail_ce; the fp32 parity mode's)."""
+        return self.code == nat.BF16 and os.environ.get("GSAGE_TAIL_MFMA", "1") == "1"
+
 
     def _init_reduce(self):
         """Gradient partial buffers + the descriptor table gsage_finalize_grads sums them with."""
@@ -294,15 +299,17 @@ class FusedMeanTrainStep(FusedTrainStep):
                 self._side_section(side)
             self._time_next(2, 3)
             self._head_live_rows()
-            nat.check(lib.gsage_mean_tail_ce(
-                self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
-                self.w2[L - 1].shape[2], self.w2t[L - 1].data_ptr(), self.w2t[L - 1].shape[2],
-                m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), C, tg.data_ptr(),
-                self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
-                self.agg[L - 1].data_ptr(), self.dc[L - 1].data_ptr(), self.preds.data_ptr(),
-                self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
-                ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None, self.code,
-                stream), "mean_tail_ce")
+            args = (self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
+                    self.w2[L - 1].shape[2], self.w2t[L - 1].data_ptr(), self.w2t[L - 1].shape[2],
+                    m.fc.weight.data_ptr(), m.fc.bias.data_ptr(), C, tg.data_ptr(),
+                    self.batch_idx.data_ptr() if self.queue else None, self.queue[2] if self.queue else 0,
+                    self.agg[L - 1].data_ptr(), self.dc[L - 1].data_ptr(), self.preds.data_ptr(),
+                    self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
+                    ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None)
+            if self._tail_on_mfma():
+                nat.check(lib.gsage_mean_tail_mfma(*args, stream), "mean_tail_mfma")
+            else:
+                nat.check(lib.gsage_mean_tail_ce(*args, self.code, stream), "mean_tail_ce")
             self._side_join("tail")
         else:
             self._stage_head(s)
@@ -456,13 +463,15 @@ class FusedMeanTrainStep(FusedTrainStep):
         if not self.fused_tail or self.emb or self.fan[self.L] not in (5, 10, 15) or self.code != nat.BF16:
             return 0
         n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
-        n_idle = n_cu - (self.B + 3) // 4                 # one seed-level workgroup per CU
+        mfma = self._tail_on_mfma()
+        n_idle = n_cu - (self.B + 15) // 16 if mfma else n_cu - (self.B + 3) // 4    # one seed-level workgroup per CU
         if n_idle < 32:
             return 0
-        # what an idle CU moves while the ~27 us launch lasts does not depend on B: ~480 KB, i.e. ~40
-        # means of ten 1.2 KB rows (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs);
-        # other row sizes / fan-outs get the same bytes per idle CU
-        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.4"))
+        # what an idle CU moves while the launch lasts does not depend on B: ~480 KB in the VALU kernel's ~27 us,
+        # i.e. ~40 means of ten 1.2 KB rows (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs);
+        # the matrix-core kernel is about half as long and leaves 224 CUs: ~22 means per CU.  Other row sizes /
+        # fan-outs get the same bytes per idle CU
+        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.22" if mfma else "0.4"))
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))

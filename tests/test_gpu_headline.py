@@ -65,7 +65,7 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
                                                    capture="cmdlist")
     assert eng.capture_mode == "cmdlist" and eng.fused_head
     if agg == "mean":
-        assert eng.fused_tail and eng.B == B and eng.fan[1:] == [25, 10]        # k_mean_tail_ce<16, 10> at B = 512
+        assert eng.fused_tail and eng.B == B and eng.fan[1:] == [25, 10]        # the seed-level kernel (k_mean_tail_mfma<25, 10> at B = 512, bf16)
     eng.load_epoch(ids, tg)
     preds, norms = [], []
     before = nat.launch_count()
@@ -79,7 +79,7 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
                 hops = _frontier(csr, ids[b], b)
                 assert torch.equal(buf[B:B + B * 25], hops[0]) and torch.equal(buf[B + B * 25:], hops[1]), b
     torch.cuda.synchronize()
-    assert nat.launch_count() - before >= 5 * n_steps
+    assert nat.launch_count() - before >= 4 * n_steps         # (mean: K5 | seed level | K5b | gather + Adam + K1)
     csr.check()
     if agg == "mean" and prec == "bf16":
         assert eng._tail_rows > 0                         # the seed-level launch's gather role is part of the step
@@ -95,10 +95,10 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
         parts = np.split(inv, np.cumsum([B, hops[0].shape[0]]))
         r = tref.train_step(w, opt, 0.01, "classification", parts[0], small, tg[s].cpu(), None, None, FAN, None, agg,
                             "identity", 232966, rounding="bf16" if bf else None, frontier=parts[1:])
-        close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *((3e-3, 3e-3) if bf else (2e-4, 2e-4)))
-        assert abs(norms[s] - r["gradnorm"]) <= (5e-3 if bf else 2e-4) * max(1.0, r["gradnorm"]), (s, norms[s], r["gradnorm"])
+        close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *((1e-3, 1e-3) if bf else (2e-4, 2e-4)))
+        assert abs(norms[s] - r["gradnorm"]) <= (1e-3 if bf else 2e-4) * max(1.0, r["gradnorm"]), (s, norms[s], r["gradnorm"])
     for k, v in model.named_parameters():
         if bf:
-            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k), 5e-2)
+            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k), 5e-3)
         else:
             close_update(v.detach().cpu().numpy(), w[k].numpy(), w0[k].numpy(), ("weights after 2 steps", k))

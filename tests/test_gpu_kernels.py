@@ -667,12 +667,16 @@ def test_wgrad_reads_its_operand_rows_in_place_through_a_row_list(dtype):
             assert not torch.isnan(pr[8][:, :, :K]).any()
 
 
-@pytest.mark.parametrize("B,n,C", [(512, 25, 41), (13, 7, 5), (6, 32, 64), (4, 1, 2), (33, 16, 41), (35, 17, 3)])
-def test_seed_level_kernel_vs_fp64(B, n, C):
-    """gsage_mean_tail_ce = segment mean + both projections + normalize/fc/CE + every gradient down to
-    the previous level, against fp64 torch autograd on the same bf16-rounded operands (ragged last
-    workgroup, both neighbour-register variants, 1..64 classes)."""
+@pytest.mark.parametrize("variant", ["valu", "mfma"])
+@pytest.mark.parametrize("B,n,C", [(512, 25, 41), (13, 7, 5), (6, 32, 64), (4, 1, 2), (33, 16, 41), (35, 17, 3),
+                                   (16, 25, 17), (50, 25, 48)])
+def test_seed_level_kernel_vs_fp64(B, n, C, variant):
+    """gsage_mean_tail_ce / gsage_mean_tail_mfma = segment mean + both projections + normalize/fc/CE + every
+    gradient down to the previous level, against fp64 torch autograd on the same bf16-rounded operands (ragged last
+    workgroup, both neighbour-register variants, 1..64 classes) -- the VALU kernel (4 seeds per workgroup) and the
+    matrix-core kernel (16 seeds per workgroup; its fan-out-25 specialisation and the generic one)."""
     import torch.nn.functional as F
+    mfma = variant == "mfma"
     rng = np.random.RandomState(B * 131 + n * 7 + C)
     L = nat.lib()
     Hf = np.maximum(rng.normal(size=(B * (1 + n), 256)), 0).astype(np.float32)       # post-ReLU rows
@@ -686,13 +690,18 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
     dE = torch.full((B, 256), 7.0, device=DEV, dtype=torch.bfloat16)
     preds = torch.empty(B, C, device=DEV)
     dH = torch.full_like(H, 7.0)
-    n_wg = (B + 3) // 4
-    part = torch.empty(L.gsage_mean_tail_ce_scratch(B, C), device=DEV)
+    n_wg = (B + 15) // 16 if mfma else (B + 3) // 4
+    part = torch.empty((L.gsage_mean_tail_mfma_scratch if mfma else L.gsage_mean_tail_ce_scratch)(B, C), device=DEV)
     assert part.numel() == n_wg * (C * 256 + C + 1)
-    nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
-                                   Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
-                                   agg.data_ptr(), dE.data_ptr(), preds.data_ptr(), dH.data_ptr(),
-                                   part.data_ptr(), None, nat.BF16, None), "mean_tail_ce")
+
+    def run(outs, gather):
+        args = (H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128, Wfc.data_ptr(), bfc.data_ptr(), C,
+                tg.data_ptr(), None, 0, *[t.data_ptr() for t in outs], gather)
+        if mfma:
+            nat.check(L.gsage_mean_tail_mfma(*args, None), "mean_tail_mfma")
+        else:
+            nat.check(L.gsage_mean_tail_ce(*args, nat.BF16, None), "mean_tail_ce")
+    run((agg, dE, preds, dH, part), None)
     torch.cuda.synchronize()
     if B == 512:
         # the same launch carrying a gather role on the CUs it leaves idle: every output of the seed
@@ -708,11 +717,9 @@ def test_seed_level_kernel_vs_fp64(B, n, C):
         out = torch.zeros(rows + 3, 640, dtype=torch.bfloat16, device=DEV)
         d = nat.TailGatherDesc()
         d.table, d.ids, d.out = table.data_ptr(), gids.data_ptr(), out.data_ptr()
-        d.ld, d.out_ld, d.D, d.rows, d.n, d.n_workgroups = 640, 640, 602, rows, 10, 128
+        d.ld, d.out_ld, d.D, d.rows, d.n, d.n_workgroups = 640, 640, 602, rows, 10, (224 if mfma else 128)
         outs = [torch.zeros_like(t) for t in (agg, dE, preds, dH, part)]
-        nat.check(L.gsage_mean_tail_ce(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128,
-                                       Wfc.data_ptr(), bfc.data_ptr(), C, tg.data_ptr(), None, 0,
-                                       *[t.data_ptr() for t in outs], ctypes.addressof(d), nat.BF16, None), "mean_tail_ce")
+        run(outs, ctypes.addressof(d))
         torch.cuda.synchronize()
         for a, b_ in zip((agg, dE, preds, dH, part), outs):
             assert torch.equal(a, b_)

@@ -1,0 +1,95 @@
+"""-m gpu, round 5: the step without a finalisation launch (the update's workgroups sum the partial buffers
+themselves, gsage_adam_desc.reduce_descs; ticks in the K5b launch) and the seed level on the matrix cores
+(gsage_mean_tail_mfma) -- through the engines, against the launches they replace."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_gpu_engine import _model, _problem
+from util import close, close_fro
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+nat = gs._native
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    yield
+    ops.set_compute_dtype("bf16")
+
+
+def _run(monkeypatch, env, dims, fans, B, mode, n_steps=5, C=5, clip_scale=1.0):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    adj, feats, rng = _problem(n=900, D=40, seed=4)
+    store = gs.FeatureStore.from_array(feats * clip_scale, torch.device(DEV), dtype="bf16")
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(n_steps + 2, B))).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(n_steps + 2, B))).to(DEV)
+    m = _model(adj, feats.shape[1], C, dims, fans)
+    eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1),
+                                       capture=mode if mode != "queue" else "cmdlist")
+    before = nat.launch_count()
+    if mode == "queue":
+        eng.load_epoch(ids, tg)
+        before = nat.launch_count()
+        preds = torch.stack([eng.step_queue().clone() for _ in range(n_steps)])
+    else:
+        preds = torch.stack([eng(ids[k], tg[k].view(B, 1)).clone() for k in range(n_steps)])
+    torch.cuda.synchronize()
+    return {"preds": preds.float().cpu().numpy(), "p": eng.flat_p.clone().cpu().numpy(),
+            "g": eng.flat_g.clone().cpu().numpy(), "norm": float(eng.gnorm.item()), "fold": eng._fold_finalize(),
+            "launches": nat.launch_count() - before, "step": int(eng.step.item()), "ctr": int(eng.counter.item()),
+            "mfma": eng.fused_tail and eng._tail_on_mfma()}
+
+
+@pytest.mark.parametrize("mode", ["queue", "cmdlist", False])
+@pytest.mark.parametrize("dims,fans,B,scale", [((128, 128), (25, 10), 64, 1.0), ((128, 128), (25, 10), 64, 30.0),
+                                               ((16, 8), (5, 3), 33, 1.0), ((32, 16, 8), (4, 3, 2), 20, 1.0)])
+def test_update_that_sums_the_partial_buffers_equals_the_finalisation_launch(monkeypatch, mode, dims, fans, B, scale):
+    """GSAGE_FOLD_FINALIZE=1 (default): no gsage_finalize_grads launch -- every update workgroup sums the partial
+    buffers of its own 1 024 elements in the finalisation's order (the SAME gradient bits), forms the norm with the
+    others inside the launch and ticks ride in K5b.  Against GSAGE_FOLD_FINALIZE=0: identical gradients and
+    counters; weights equal unless the clip is active (the norm's terms are added in another order: scale = 30
+    makes it active), one launch fewer per step."""
+    a = _run(monkeypatch, {"GSAGE_FOLD_FINALIZE": "0"}, dims, fans, B, mode, clip_scale=scale)
+    b = _run(monkeypatch, {"GSAGE_FOLD_FINALIZE": "1"}, dims, fans, B, mode, clip_scale=scale)
+    assert not a["fold"] and b["fold"]
+    assert a["step"] == b["step"] == 5 and a["ctr"] == b["ctr"]
+    assert b["launches"] == a["launches"] - 5, (a["launches"], b["launches"])
+    assert abs(a["norm"] - b["norm"]) <= 2e-6 * max(1.0, a["norm"])
+    if a["norm"] < 4.9 and scale == 1.0:
+        assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["g"], b["g"]) and np.array_equal(a["preds"], b["preds"])
+    else:
+        close(b["preds"], a["preds"], "preds", 1e-4, 1e-5)
+        close_fro(b["p"], a["p"], "weights", 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["queue", "cmdlist"])
+@pytest.mark.parametrize("B,C", [(64, 5), (50, 41), (512, 41)])
+def test_matrix_core_seed_level_through_the_engine(monkeypatch, mode, B, C):
+    """FusedMeanTrainStep with the seed level on the matrix cores (16 seeds per workgroup) against the same engine on
+    the VALU seed-level kernel: five steps, width-256 levels, fan-out 25 / 10 (the gather role rides along in queue
+    mode): predictions and weights agree to fp32 round-off plus the bf16 roundings whose inputs moved by it."""
+    a = _run(monkeypatch, {"GSAGE_TAIL_MFMA": "0"}, (128, 128), (25, 10), B, mode, C=C)
+    b = _run(monkeypatch, {"GSAGE_TAIL_MFMA": "1"}, (128, 128), (25, 10), B, mode, C=C)
+    assert b["mfma"] and not a["mfma"]
+    close(b["preds"], a["preds"], "preds", 2e-3, 2e-4)
+    close_fro(b["p"], a["p"], "weights after five steps", 2e-4)
+    assert abs(a["norm"] - b["norm"]) <= 2e-3 * max(1.0, a["norm"])
+
+
+def test_in_launch_norm_is_admitted_by_the_device_not_by_a_constant():
+    """gsage_gather_adam_capacity: resident workgroups of the gather launch for a given sampler-role LDS footprint
+    (occupancy x CUs, one per CU kept as margin) -- what bounds the meeting of the update's workgroups."""
+    L = nat.lib()
+    small, big = L.gsage_gather_adam_capacity(nat.BF16, 4000), L.gsage_gather_adam_capacity(nat.BF16, 150 * 1024)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert small >= 3 * cus and small % cus == 0
+    assert big == 0                                       # one workgroup per CU fits: nothing left after the margin
+    assert L.gsage_gather_adam_capacity(nat.F32, 4000) >= 3 * cus
