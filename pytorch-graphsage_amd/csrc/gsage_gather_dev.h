@@ -45,17 +45,20 @@ __device__ __forceinline__ void gather_role(const TailGather &g, int bx)
             row[u] = t / g.chunks;
             c0[u] = (int32_t)(t - row[u] * g.chunks) * 8;
         }
-        int64_t id[U][N];
+        // (node ids are < 2^31 -- the adjacency's neighbour array is int32 --: the low dword of each int64, as in
+        // gather_mean_chunk; half the id registers, which is what lets a 512-thread launch keep U = 4 items in flight)
+        int32_t id[U][N];
+        const int32_t *ids32 = reinterpret_cast<const int32_t *>(g.ids);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < N; ++j) id[u][j] = g.ids[row[u] * N + j];
+            for (int j = 0; j < N; ++j) id[u][j] = ids32[2 * (row[u] * N + j)];
         vec16 v[U][N];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                v[u][j] = *reinterpret_cast<const vec16 *>(g.table + id[u][j] * g.ld + c0[u]);
+                v[u][j] = *reinterpret_cast<const vec16 *>(g.table + (int64_t)id[u][j] * g.ld + c0[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float acc[8];

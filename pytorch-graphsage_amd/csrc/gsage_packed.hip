@@ -25,7 +25,15 @@ namespace gsage {
 // Wave w owns columns [32w, 32w+32) of the 64 x 128 tile and all 64 rows (two 32 x 32 accumulators);
 // the four waves read the same A fragments.
 // -------------------------------------------------------------------------------------------------
-constexpr int WP_R = 4;                       // tiles in flight per workgroup
+#ifndef GSAGE_WP_R
+#define GSAGE_WP_R 4
+#endif
+constexpr int WP_R = GSAGE_WP_R;              // tiles in flight per workgroup (4, 6 or 8: WP_UNROLL is a multiple)
+// s_waitcnt vmcnt(6 * (WP_R - 1)): "this tile landed" = at most the WP_R - 1 later tiles' requests outstanding
+//     simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+constexpr int WP_WAIT = ((6 * (WP_R - 1)) & 15) | (7 << 4) | (15 << 8) | (((6 * (WP_R - 1)) >> 4) << 14);
+static_assert(WP_R == 4 || WP_R == 6 || WP_R == 8, "WP_R");
+static_assert(WP_R != 4 || WP_WAIT == 0x4F72, "vmcnt(18)");
 constexpr int WP_NBUF = WP_R + 1;             // A ring: the tile being read + WP_R in flight
 constexpr int WP_UNROLL = 24;                 // k-tiles of straight-line code (multiple of WP_R and PK_R)
 
@@ -145,7 +153,7 @@ k_linear_nt_packed(const PackedParams p, const TailGather tg)
 #pragma unroll
         for (int u = 0; u < WP_UNROLL; ++u) {
             if (kt + WP_R >= nk) { phase = u % WP_R; goto drain; }
-            __builtin_amdgcn_s_waitcnt(0x4F72);          // vmcnt(18)
+            __builtin_amdgcn_s_waitcnt(WP_WAIT);         // vmcnt(6 (WP_R - 1))
             __builtin_amdgcn_s_barrier();                // everybody's part of A(kt) landed; A(kt-1) is free
             compute_tile(kt, wr[u % WP_R]);
             issue_tile(kt + WP_R, (kt + WP_R) % WP_NBUF, wr[u % WP_R]);
@@ -155,7 +163,7 @@ k_linear_nt_packed(const PackedParams p, const TailGather tg)
 #pragma unroll
             for (int s = 0; s < WP_R; ++s) {
                 if (kt + WP_R >= nk) { phase = s; goto drain; }
-                __builtin_amdgcn_s_waitcnt(0x4F72);
+                __builtin_amdgcn_s_waitcnt(WP_WAIT);
                 __builtin_amdgcn_s_barrier();
                 compute_tile(kt, wr[s]);
                 issue_tile(kt + WP_R, (kt + WP_R) % WP_NBUF, wr[s]);

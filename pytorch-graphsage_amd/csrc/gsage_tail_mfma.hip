@@ -55,6 +55,7 @@ struct TailMfmaParams {
     float *partial;          // out: [grid, C*256 + C + 1] fc.weight / fc.bias / loss partials
     int64_t ldw2, ldw2t;
     int32_t B, n, C;
+    int32_t stop;            // measurement only (GSAGE_TAIL_STOP = 1 .. 5): leave after that phase; 0 = the whole kernel
 };
 
 constexpr size_t tm_lds_bytes()
@@ -125,6 +126,9 @@ __device__ __forceinline__ tm_f32x4 tm_mma_f32(const float a, const float b, con
 // N = the fan-out when the host knows a specialisation for it (every neighbour row a load slot of its own: nothing
 // clamped, nothing predicated), 0 = any n <= 32 (32 slots, the index clamped to n - 1; the weight fragments are then
 // requested after the rows have been consumed: the registers do not hold both).  GN = fan-out of the gather role.
+#ifndef GSAGE_TM_ROLE_U
+#define GSAGE_TM_ROLE_U 2
+#endif
 template <int N, int GN>
 __global__ void __launch_bounds__(TM_T)
 k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
@@ -132,7 +136,7 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
     if (GN > 0) {
         const int n_tail = (p.B + TM_S - 1) / TM_S;
         if ((int)blockIdx.x >= n_tail) {
-            gather_role<(GN > 0 ? GN : 1), 2, TM_T>(tg, (int)blockIdx.x - n_tail);
+            gather_role<(GN > 0 ? GN : 1), (GN > 10 ? 2 : GSAGE_TM_ROLE_U), TM_T>(tg, (int)blockIdx.x - n_tail);
             return;
         }
     }
@@ -168,6 +172,14 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
     const int64_t iw = row0 + sr;
     const bool live = iw < B;
     const int64_t iwc = live ? iw : B - 1;
+    // fc.weight first (rows >= C: past the buffer's end = zeros): it lands before the rows do and is parked in LDS
+    // while they are in flight (C <= 64 rows x 64 float4 = 8 per thread)
+    vec16 wf[8];
+    {
+        const __amdgpu_buffer_rsrc_t rF = tm_rsrc(p.Wfc, (uint32_t)(C * TM_D * 4));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wf[u] = tm_bload(rF, (uint32_t)t * 16u, (uint32_t)u * TM_T * 16u);
+    }
     const __amdgpu_buffer_rsrc_t rH = tm_rsrc(p.H, (uint32_t)(B * (1 + n) * TM_D * 2));
     vec16 xraw = tm_bload(rH, (uint32_t)(iwc * TM_D + cg * 8) * 2u, 0u);
     vec16 nb[NB];
@@ -196,6 +208,13 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
     // (scheduling barriers: every request above is issued before the first row is consumed, and the rows are consumed
     // one at a time in arrival order -- left alone, the scheduler unpacks all 8 x n bf16 of a lane to fp32 as they
     // land and sums afterwards: 200 live registers on top of the 42 requests' targets, i.e. spills)
+    __builtin_amdgcn_sched_barrier(0);
+    // fc.weight -> LDS, all 64 rows (zeros from row C on)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = t + u * TM_T;
+        *reinterpret_cast<vec16 *>(Ws + (q >> 6) * TM_LDF + (q & 63) * 4) = wf[u];
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 1. neighbour mean + ReLU masks of the rows this lane loaded ------------------------------------------
@@ -242,6 +261,7 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
     const int64_t tg0 = (row0 + 2 * wave < B) ? tgt[row0 + 2 * wave] : -1;          // softmax phase: this wave's
     const int64_t tg1 = (row0 + 2 * wave + 1 < B) ? tgt[row0 + 2 * wave + 1] : -1;  // two seeds
     lds_barrier();
+    if (p.stop == 1) return;
 
     // ---- 2. emb = [x Wx^T | agg Wn^T] on the matrix cores; row norms; z ----------------------------------------
     tm_f32x4 acc[2];
@@ -261,14 +281,6 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
     for (int r = 0; r < 4; ++r) {
         const float q = tm_sum16(acc[0][r] * acc[0][r] + acc[1][r] * acc[1][r]);
         if (li == 0) red[wave * TM_S + 4 * lg + r] = q;
-    }
-    // fc.weight: requested now (the forward fragments' registers are free), parked in LDS once the norms are formed
-    // (C <= 64 rows x 64 float4 = at most 8 per thread)
-    vec16 wf[8];                                                   // (rows >= C: past the buffer's end = zeros)
-    {
-        const __amdgpu_buffer_rsrc_t rF = tm_rsrc(p.Wfc, (uint32_t)(C * TM_D * 4));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wf[u] = tm_bload(rF, (uint32_t)t * 16u, (uint32_t)u * TM_T * 16u);
     }
     // backward weight fragments (both groups, this wave's 32 INPUT columns): B[k = j][i] = W_g[j][i] = w2t[g][i][j]
     vec16 bb[2][2][4];
@@ -297,13 +309,8 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
             zs[(4 * lg + r) * TM_LDF + col0 + 16 * ct] = z[ct][r];
         }
     }
-    // fc.weight -> LDS, all 64 rows (zeros from row C on)
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int q = t + u * TM_T;
-        *reinterpret_cast<vec16 *>(Ws + (q >> 6) * TM_LDF + (q & 63) * 4) = wf[u];
-    }
     lds_barrier();
+    if (p.stop == 2) return;
 
     // ---- 3. logits = z Wfc^T (fp32 matrix cores; this wave: 32 of the 256 k), softmax cross-entropy ------------
     {
@@ -345,6 +352,7 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
         if (lane == 0) lss[s] = (i < Bv && my_target >= 0 && my_target < C) ? -(lt - mx - logf(den)) : 0.f;
     }
     lds_barrier();
+    if (p.stop == 3) return;
 
     // ---- 4. d z = d logits Wfc (this wave's 32 columns), d emb; d fc.weight = d logits^T z ----------------------
     {
@@ -415,6 +423,7 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
         }
     }
     lds_barrier();                                                 // des complete; part (-> gxs | gns) free
+    if (p.stop == 4) return;
 
     // ---- 5. d emb rows to HBM; input gradients dX = dE[:, :128] Wx, dA = dE[:, 128:] Wn --------------------------
     if (live) *reinterpret_cast<vec16 *>(p.dE + iw * TM_D + cg * 8) = *reinterpret_cast<const vec16 *>(des + sr * TM_LDH + cg * 8);
@@ -442,6 +451,7 @@ k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
             }
     }
     lds_barrier();
+    if (p.stop == 5) return;
 
     // ---- 6. previous level's gradient rows of this half-wave's seed, ReLU masks applied ------------------------
     if (live) {
@@ -511,6 +521,10 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
     p.n_valid = n_valid;
     p.agg = (uint16_t *)agg; p.dE = (uint16_t *)dE; p.preds = preds; p.dH = (uint16_t *)dH;
     p.partial = partial; p.ldw2 = ldw2; p.ldw2t = ldw2t; p.B = B; p.n = n; p.C = C;
+    {
+        const char *e = getenv("GSAGE_TAIL_STOP");        // (phase timing, tools/kbench.py tailm: results are partial)
+        p.stop = e ? atoi(e) : 0;
+    }
     TailGather tg = {};
     const bool fused = gather && gather->rows > 0;
     if (fused) {

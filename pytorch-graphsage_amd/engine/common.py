@@ -711,9 +711,13 @@ class FusedTrainStep(object):
         wants the flat bucket), a trainable table (its gradient is scatter-added), or more partial buffers per
         element than the update can sum inside its launch without becoming its longest role.  Every launch mode of
         an engine takes the same path (per call, queue, pipelined, split): their results stay bit-identical.
-        GSAGE_FOLD_FINALIZE: 0 = never, 1 (default) = the mean engine, all = every engine that qualifies."""
+        GSAGE_FOLD_FINALIZE: 0 (default) = never, 1 = the mean engine, all = every engine that qualifies.
+        OPT-IN, because it measured slower on the MI355X: inside the launch that also
+        gathers, an update workgroup's six to eight dependent rounds of partial loads (16 in flight per lane is what
+        the launch's 72-register cap leaves) take ~28 us against 6.5 + 16 for the finalisation launch and the
+        update without them -- 0.0916 against 0.0836 ms/step at configs[1]."""
         if getattr(self, "_fold", None) is None:
-            mode = os.environ.get("GSAGE_FOLD_FINALIZE", "1")
+            mode = os.environ.get("GSAGE_FOLD_FINALIZE", "0")
             ok = (mode in ("1", "all") and (self.MEAN_ENGINE or mode == "all") and self.ddp is None and not self.emb
                   and (self.fused_head or self.fused_l1) and getattr(self, "n_rdesc", 99) <= 16
                   and getattr(self, "_rdesc_max_S", 1 << 30) <= 32 and self._meet_fits())

@@ -468,10 +468,12 @@ class FusedMeanTrainStep(FusedTrainStep):
         if n_idle < 32:
             return 0
         # what an idle CU moves while the launch lasts does not depend on B: ~480 KB in the VALU kernel's ~27 us,
-        # i.e. ~40 means of ten 1.2 KB rows (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs);
-        # the matrix-core kernel is about half as long and leaves 224 CUs: ~22 means per CU.  Other row sizes /
-        # fan-outs get the same bytes per idle CU
-        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.22" if mfma else "0.4"))
+        # i.e. ~40 means of ten 1.2 KB rows (sweep at B = 512, DESIGN.md section 3: 40 % of 12 800 rows on 128 CUs).
+        # The matrix-core kernel's 32 workgroups take as long in the step (~28 us: each moves 770 KB through one CU)
+        # but leave 224 CUs: ~60 means per CU, i.e. the WHOLE last hop at B = 512 (round-5 sweep, DESIGN.md section 5:
+        # 0.0905 / 0.0883 / 0.0842 / 0.0837 ms/step at 30 / 40 / 50 / >= 60 per CU; the gather launch then carries only
+        # the hop-1 means, Adam and the sampler).  Other row sizes / fan-outs get the same bytes per idle CU
+        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.6" if mfma else "0.4"))
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))

@@ -52,7 +52,7 @@ def _run(monkeypatch, env, dims, fans, B, mode, n_steps=5, C=5, clip_scale=1.0):
 @pytest.mark.parametrize("dims,fans,B,scale", [((128, 128), (25, 10), 64, 1.0), ((128, 128), (25, 10), 64, 30.0),
                                                ((16, 8), (5, 3), 33, 1.0), ((32, 16, 8), (4, 3, 2), 20, 1.0)])
 def test_update_that_sums_the_partial_buffers_equals_the_finalisation_launch(monkeypatch, mode, dims, fans, B, scale):
-    """GSAGE_FOLD_FINALIZE=1 (default): no gsage_finalize_grads launch -- every update workgroup sums the partial
+    """GSAGE_FOLD_FINALIZE=1 (opt-in: it measured slower): no gsage_finalize_grads launch -- every update workgroup sums the partial
     buffers of its own 1 024 elements in the finalisation's order (the SAME gradient bits), forms the norm with the
     others inside the launch and ticks ride in K5b.  Against GSAGE_FOLD_FINALIZE=0: identical gradients and
     counters; weights equal unless the clip is active (the norm's terms are added in another order: scale = 30
@@ -80,7 +80,7 @@ def test_matrix_core_seed_level_through_the_engine(monkeypatch, mode, B, C):
     b = _run(monkeypatch, {"GSAGE_TAIL_MFMA": "1"}, (128, 128), (25, 10), B, mode, C=C)
     assert b["mfma"] and not a["mfma"]
     close(b["preds"], a["preds"], "preds", 2e-3, 2e-4)
-    close_fro(b["p"], a["p"], "weights after five steps", 2e-4)
+    close_fro(b["p"], a["p"], "weights after five steps", 3e-3)      # (Adam: ~1e-2 of the UPDATES)
     assert abs(a["norm"] - b["norm"]) <= 2e-3 * max(1.0, a["norm"])
 
 

@@ -113,6 +113,26 @@ if 'tail' in which:
                                          preds.data_ptr(), dH.data_ptr(), part.data_ptr(), None, nat.BF16, ops._stream()))
       print('tail (B=%d n=%d): %.1f us' % (B, n, timeit(f)))
 
+if 'tailm' in which:
+  import os
+  for B in (512,):
+      n, C = 25, 41
+      H = torch.randn(B * (1 + n), 256, device=dev).bfloat16()
+      w2 = (torch.randn(2, 128, 256, device=dev) * 0.05).bfloat16(); w2t = w2.transpose(1, 2).contiguous()
+      Wfc = torch.randn(C, 256, device=dev) * 0.05; bfc = torch.zeros(C, device=dev)
+      tg = torch.randint(0, C, (B,), device=dev)
+      agg = torch.empty(B, 256, device=dev, dtype=torch.bfloat16); dE = torch.empty_like(agg)
+      preds = torch.empty(B, C, device=dev); dH = torch.empty_like(H)
+      part = torch.empty(L.gsage_mean_tail_mfma_scratch(B, C), device=dev)
+      def f():
+          nat.check(L.gsage_mean_tail_mfma(H.data_ptr(), B, n, w2.data_ptr(), 256, w2t.data_ptr(), 128, Wfc.data_ptr(),
+                                           bfc.data_ptr(), C, tg.data_ptr(), None, 0, agg.data_ptr(), dE.data_ptr(),
+                                           preds.data_ptr(), dH.data_ptr(), part.data_ptr(), None, ops._stream()))
+      for stop in (1, 2, 3, 4, 5, 0):
+          os.environ["GSAGE_TAIL_STOP"] = str(stop)
+          print('tailm B=%d stop after phase %d: %.1f us' % (B, stop, timeit(f)))
+      os.environ["GSAGE_TAIL_STOP"] = "0"
+
 if 'gmulti' in which:
     # the level-0 gathers of one step (x rows of 13 312 nodes | 512 means of 25 | 12 800 means of 10)
     # in one launch, for several segment orders
