@@ -278,6 +278,27 @@ int gsage_mt_choice_device(uint32_t *state, int64_t high, int64_t count, int32_t
  * nothing for a range of one value). */
 int gsage_mt_choice_segments(uint32_t *state, int64_t high, int64_t n_seg, const int64_t *seg_off,
                              const int64_t *seg_cnt, int32_t *out, void *stream);
+
+/* The same requests served by MANY workgroups (ABI 5; csrc/gsage_mtjump.hip): MT19937 is linear over GF(2), so the
+ * state n refills ahead is a convolution of a seed-independent polynomial's bits with the stream's raw words -- a
+ * workgroup jumps to its chunk with two table look-ups, pass A counts every chunk's accepted words, a scan turns the
+ * counts into offsets, pass B regenerates the chunks and stores value #n of the request at its slot; state and
+ * position are left exactly where numpy would leave them (same contract as gsage_mt_choice_segments).
+ *   seg_cum [n_seg + 1] (DEVICE): prefix sums of the requests' counts; seg_off [n_seg] (DEVICE); n_total = seg_cum[n_seg]
+ *   table (DEVICE): gsage_mt_jump_table()'s 128 x 312 words;  scratch: gsage_mt_choice_par_scratch(n_wg) bytes, 16-byte aligned
+ *   n_wg chunks of units_per_wg x 64 refills each (n_wg x units_per_wg <= 4096): choose them to cover
+ *   n_total / (624 x acceptance rate) refills with a margin; a serial finisher serves what an unlucky stretch left. */
+int gsage_mt_choice_par(uint32_t *state, int64_t high, int64_t n_seg, const int64_t *seg_cum, const int64_t *seg_off,
+                        int64_t n_total, int32_t *out, const uint64_t *table, void *scratch, int64_t scratch_bytes,
+                        int32_t n_wg, int32_t units_per_wg, void *stream);
+int64_t gsage_mt_choice_par_scratch(int32_t n_wg);
+/* HOST: the jump polynomials x^(b * 64 * 624) and x^(a * 64 * 64 * 624) mod phi(x), a, b < 64 (phi: MT19937's
+ * characteristic polynomial, found by Berlekamp-Massey on the generator's own output bits; ~1 s the first time in a
+ * process, callers cache the words).  out: gsage_mt_jump_table_words() x 8 bytes: [b = 0..63 | a = 0..63][312]. */
+int gsage_mt_jump_table(uint64_t *out, int64_t words);
+int64_t gsage_mt_jump_table_words(void);
+/* HOST (tests): out[624] = the state `poly` steps ahead of state[624] (word 0's low 31 bits are not part of the state) */
+int gsage_mt_jump_host(const uint32_t *state, const uint64_t *poly, uint32_t *out);
 /* np.random.permutation(n) -> int64 out[n]. */
 void gsage_mt_permutation(void *mt, int64_t n, int64_t *out);
 

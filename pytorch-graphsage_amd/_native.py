@@ -75,6 +75,11 @@ SIGNATURES = {
     "gsage_mt_permutation": (None, [_vp, _i64, _vp]),
     "gsage_mt_choice_device": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "gsage_mt_choice_segments": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gsage_mt_choice_par": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gsage_mt_choice_par_scratch": (_i64, [_i32]),
+    "gsage_mt_jump_table": (_int, [_vp, _i64]),
+    "gsage_mt_jump_table_words": (_i64, []),
+    "gsage_mt_jump_host": (_int, [_vp, _vp, _vp]),
     "gsage_head_n_valid_next": (_int, [_vp]),
     "gsage_gather_role_next": (_int, [_vp]),
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),

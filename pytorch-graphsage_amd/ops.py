@@ -12,6 +12,7 @@ done by the HIP kernels behind include/gsage.h.  Dispatch rule (no silent fallba
 Reference call sites each operator replaces are cited per function.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -128,10 +129,76 @@ def _philox_host(seed, call, g0, count, max_deg):
     return ((words * np.uint64(max_deg)) >> np.uint64(32)).astype(np.int64)
 
 
+_JUMP_TABLE = {}
+MT_PAR_MIN = 400000          # requests below this many values stay on the one-workgroup kernel (~1 ms)
+MT_PAR_MAX = 80000000        # values per parallel call: 4096 jump units of 64 refills reach 1.6e8 raw words
+
+
+def mt_jump_table(device):
+    """The seed-independent jump polynomials of numpy's MT19937 (gsage_mt_jump_table: 128 x 312 words) on `device`.
+    Computed by the library (~1 s: Berlekamp-Massey + square-and-multiply) the first time ever, then read from
+    mt19937_jump_table.bin next to the library (written by __graft_entry__.build(), or here when missing)."""
+    key = str(device)
+    if key not in _JUMP_TABLE:
+        import numpy as np
+        L = nat.lib()
+        words = int(L.gsage_mt_jump_table_words())
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937_jump_table.bin")
+        tab = None
+        if os.path.exists(path) and os.path.getsize(path) == 8 * words:
+            tab = np.fromfile(path, dtype=np.uint64)
+        if tab is None:
+            tab = np.zeros(words, dtype=np.uint64)
+            nat.check(L.gsage_mt_jump_table(tab.ctypes.data, words), "mt_jump_table")
+            try:
+                tab.tofile(path + ".tmp")
+                os.replace(path + ".tmp", path)
+            except OSError:
+                pass
+        _JUMP_TABLE[key] = torch.from_numpy(tab.view(np.int64)).to(device)
+    return _JUMP_TABLE[key]
+
+
+def _mt_choice_par(state, high, segs, flat):
+    """the requests served by up to 256 workgroups at once (gsage_mt_choice_par); segs as in mt_choice_segments"""
+    L = nat.lib()
+    top = high - 1
+    mask = (1 << top.bit_length()) - 1
+    rate = (top + 1) / (mask + 1)
+    table = mt_jump_table(flat.device)
+    i = 0
+    while i < len(segs):                          # (pieces of <= MT_PAR_MAX values: the jump table's reach)
+        j, total = i, 0
+        while j < len(segs) and (j == i or total + segs[j][1] <= MT_PAR_MAX):
+            total += segs[j][1]
+            j += 1
+        part = segs[i:j]
+        if total > MT_PAR_MAX:                    # one request larger than the reach: cut it
+            o, c = part[0]
+            part, segs = [(o, MT_PAR_MAX)], segs[:i] + [(o, MT_PAR_MAX), (o + MT_PAR_MAX, c - MT_PAR_MAX)] + segs[i + 1:]
+            total, j = MT_PAR_MAX, i + 1
+        units = int(total / (624.0 * rate) * 1.015 / 64) + 2
+        per = -(-units // 256)
+        n_wg = -(-units // per)
+        cum = [0]
+        for _, c in part:
+            cum.append(cum[-1] + c)
+        host = torch.tensor([cum, [o for o, _ in part] + [0]], dtype=torch.int64)
+        dev = host.to(flat.device)
+        scratch = torch.empty(int(L.gsage_mt_choice_par_scratch(n_wg)), dtype=torch.uint8, device=flat.device)
+        nat.check(L.gsage_mt_choice_par(_ptr(state), int(high), len(part), _ptr(dev[0]), _ptr(dev[1]), total, _ptr(flat),
+                                        _ptr(table), _ptr(scratch), scratch.numel(), n_wg, per, _stream()),
+                  "mt_choice_par")
+        i = j
+    return flat
+
+
 def mt_choice_segments(state, high, segs, out):
     """numpy's legacy stream on the device (`state`: helpers.legacy_stream.acquire), many np.random.choice(high, .)
-    requests in ONE launch: segs = [(offset into out, count)], served in order; out: int32 CUDA tensor (any shape,
-    offsets address its flat view)."""
+    requests in ONE call: segs = [(offset into out, count)], served in order; out: int32 CUDA tensor (any shape,
+    offsets address its flat view).  Large requests (an epoch's sampler draws) are served by many workgroups at
+    once (gsage_mt_choice_par: jump-ahead), small ones by the one-workgroup kernel; values, state and position are
+    numpy's either way."""
     segs = [(int(o), int(c)) for o, c in segs if c > 0]
     if not segs:
         return out
@@ -140,6 +207,9 @@ def mt_choice_segments(state, high, segs, out):
     if high < 2:                                   # a range of one value: numpy draws nothing
         for o, c in segs:
             flat[o:o + c].zero_()
+        return out
+    if sum(c for _, c in segs) >= MT_PAR_MIN and os.environ.get("GSAGE_MT_PARALLEL", "1") == "1":
+        _mt_choice_par(state, int(high), segs, flat)
         return out
     host = torch.tensor([[o for o, _ in segs], [c for _, c in segs]], dtype=torch.int64)
     dev = host.to(flat.device)

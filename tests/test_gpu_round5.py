@@ -93,3 +93,71 @@ def test_in_launch_norm_is_admitted_by_the_device_not_by_a_constant():
     assert small >= 3 * cus and small % cus == 0
     assert big == 0                                       # one workgroup per CU fits: nothing left after the margin
     assert L.gsage_gather_adam_capacity(nat.F32, 4000) >= 3 * cus
+
+
+def _np_draw(high, counts):
+    return [np.random.choice(high, c).astype(np.int32) for c in counts]
+
+
+@pytest.mark.parametrize("high,counts,gaps", [(21657, [140800 * 3, 512 * 25, 999999, 7, 2000000], True),
+                                             (4096, [450000, 450000], False), (3, [1500000], False),
+                                             (2 ** 31 + 5, [600000, 1], True)])
+def test_many_workgroups_consume_numpys_stream_like_numpy(high, counts, gaps):
+    """gsage_mt_choice_par through ops.mt_choice_segments: np.random.choice(high, .) requests served by up to 256
+    workgroups (jump-ahead) -- every value, the state and the position equal numpy's; the stream continues on the
+    device (one-workgroup kernel) and on the host."""
+    from importlib import import_module
+    helpers = import_module("pytorch-graphsage_amd.helpers")
+    ls = helpers.LegacyStreamOnDevice()
+    np.random.seed(99)
+    np.random.choice(1000, 333)                            # (somewhere inside a block)
+    state0 = np.random.get_state()
+    want = _np_draw(high, counts)
+    tail_want = np.random.choice(high, 5000).astype(np.int32)
+    after = np.random.get_state()
+    np.random.set_state(state0)
+    st = ls.acquire(torch.device(DEV))
+    offs, o = [], 0
+    for c in counts:
+        offs.append(o)
+        o += c + (13 if gaps else 0)
+    out = torch.full((o + 5,), -7, dtype=torch.int32, device=DEV)
+    before = nat.launch_count()
+    ops.mt_choice_segments(st, high, list(zip(offs, counts)), out)
+    assert nat.launch_count() - before == 5                # stream | count | scan | write | finisher
+    tail = torch.zeros(5000, dtype=torch.int32, device=DEV)
+    ops.mt_choice_segments(st, high, [(0, 5000)], tail)     # small request: the one-workgroup kernel continues
+    got = out.cpu().numpy()
+    for off, c, w in zip(offs, counts, want):
+        assert np.array_equal(got[off:off + c], w), (high, c)
+        if gaps:
+            assert (got[off + c:off + c + 13] == -7).all()
+    assert np.array_equal(tail.cpu().numpy(), tail_want)
+    ls.release()
+    s1 = np.random.get_state()
+    assert s1[2] == after[2] and np.array_equal(s1[1], after[1])
+
+
+def test_parallel_stream_finisher_and_block_zero():
+    """The C entry point directly: (a) chunks sized BELOW the request (an unlucky acceptance estimate): the serial
+    finisher completes it; (b) a request that ends inside the block the stream already stands in."""
+    L = nat.lib()
+    table = ops.mt_jump_table(torch.device(DEV))
+    for seed, count, n_wg, per in ((5, 700000, 3, 4), (6, 100, 2, 1), (7, 1300000, 16, 2)):
+        np.random.seed(seed)
+        np.random.choice(50, 17)
+        name, key, pos, *_ = np.random.get_state()
+        want = np.random.choice(21657, count).astype(np.int32)
+        a_key, a_pos = np.random.get_state()[1:3]
+        host = np.concatenate([np.asarray(key, dtype=np.uint32), np.array([pos], dtype=np.uint32)])
+        st = torch.from_numpy(host.view(np.int32).copy()).to(DEV)
+        cum = torch.tensor([0, count], dtype=torch.int64, device=DEV)
+        off = torch.tensor([3], dtype=torch.int64, device=DEV)
+        out = torch.full((count + 8,), -1, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(int(L.gsage_mt_choice_par_scratch(n_wg)), dtype=torch.uint8, device=DEV)
+        nat.check(L.gsage_mt_choice_par(st.data_ptr(), 21657, 1, cum.data_ptr(), off.data_ptr(), count, out.data_ptr(),
+                                        table.data_ptr(), scratch.data_ptr(), scratch.numel(), n_wg, per, None), "par")
+        got = out.cpu().numpy()
+        assert np.array_equal(got[3:3 + count], want) and (got[:3] == -1).all() and (got[3 + count:] == -1).all()
+        s = st.cpu().numpy().view(np.uint32)
+        assert int(s[624]) == int(a_pos) and np.array_equal(s[:624], np.asarray(a_key, dtype=np.uint32)), (seed, count)
