@@ -537,6 +537,9 @@ def extra_cli(gs, dev, data, store):
                          "batches_per_epoch": len([ln for ln in lines if ln.get("epoch") == 0 and "epoch_progress" in ln]),
                          "cli_seeds_per_s": rates[-1] if rates else None, "cli_seeds_per_s_by_epoch": rates,
                          "cli_seeds_per_s_incl_epoch_draws": rates_draws,
+                         # the headline of this entry: seeds of every epoch / wall seconds of the WHOLE command (engine
+                         # construction, every epoch's sampler draws, the per-batch log, the validation passes)
+                         "end_to_end_seeds_per_s": epochs * n_train / wall,
                          "wall_s": wall, "val_metric": lines[-1].get("val_metric") if lines else None}
     except Exception as e:
         out["reddit"] = {"error": repr(e)}
@@ -558,6 +561,7 @@ def extra_cli(gs, dev, data, store):
         out["pokec"] = {"command": "utils/pokec.sh:11-13 (--aggregator-class mean --prep-class node_embedding --epochs 3; "
                                    "DEFAULT dense sampler), defaults otherwise",
                         "engine": eng[-1] if eng else None, "train_nodes": n_train, "wall_s": wall,
+                        "end_to_end_seeds_per_s": 3 * n_train / wall,
                         "cli_seeds_per_s_by_epoch": rates, "final": lines[-1] if lines else None,
                         "reference_published_wall_s": 147.32675504684448,
                         "reference_note": "utils/pokec.sh:15, the reference's only published figure: unknown hardware, "

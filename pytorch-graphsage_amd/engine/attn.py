@@ -217,6 +217,8 @@ class FusedAttnTrainStep(FusedTrainStep):
             self._gemm(self.aggc[l].data_ptr(), ld, self.wn[l], out.data_ptr() + h * out.element_size(), code, 2 * h,
                        R, h, D, act)
         self._stage_head(s)
+        if self.eval_only:
+            return                                    # (forward only: train.evaluate's folds)
         self._backward_levels(s)
 
     def _backward_levels(self, s):

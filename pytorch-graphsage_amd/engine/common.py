@@ -149,7 +149,7 @@ class FusedTrainStep(object):
         return None
 
     def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
-                 warmup=2, pipelined=False, gather_cus=None):
+                 warmup=2, pipelined=False, gather_cus=None, eval_only=False):
         """gather_cus (queue mode, single GPU, command lists): run the weight-independent half of the step
         -- sampling of batch i+2 and the level-0 gathers of batch i+1 -- on a stream restricted to that many
         compute units while the forward / backward / update chain of batch i runs on a stream restricted
@@ -165,11 +165,26 @@ class FusedTrainStep(object):
             raise ValueError("example_targets must be a CUDA tensor with one row per seed")
         if gather_cus is None:
             gather_cus = int(os.environ.get("GSAGE_GATHER_CUS", "0"))
-        self.gather_cus = int(gather_cus) if (ddp is None and not pipelined and self.MEAN_ENGINE) else 0
+        # eval_only: the engine's FORWARD launches over the model's VALIDATION sampler (models.py:41-44: the full
+        # graph, n_val_samples), for train.evaluate's folds (evaluate_fold below).  The Parameters stay where they are
+        # (a training engine's bucket, FlatAdam's, or their own storage): only the operand copies are this engine's.
+        self.eval_only = bool(eval_only)
+        assert not (self.eval_only and (ddp is not None or pipelined)), "eval_only: single process, sequential"
+        self.gather_cus = int(gather_cus) if (ddp is None and not pipelined and self.MEAN_ENGINE and not eval_only) else 0
         self._init_common(model, feats, loss_fn, example_ids, example_targets, ddp, pipelined)
         self._init_levels(example_ids, example_targets)
         self._init_head(loss_fn, example_targets)
-        self._init_reduce()
+        if self.eval_only:
+            Cc, D2c = model.fc.weight.shape
+            if self.fused_l1:                      # (what _install_reduce gives the training engines' heads)
+                self.l1_scratch = torch.zeros(nat.lib().gsage_head_l1_scratch(self.B, D2c), dtype=torch.float32,
+                                              device=self.dev)
+            elif not self.fused_head:
+                self.head_stage = torch.zeros(Cc * D2c + Cc, dtype=torch.float32, device=self.dev)
+            self._param_ptrs = self._current_param_ptrs()
+            self.refresh_weights()
+        else:
+            self._init_reduce()
         self._finish_init(capture, warmup)
 
     # ---- construction, in five steps (subclasses override the aggregator-specific ones) -----------
@@ -184,7 +199,7 @@ class FusedTrainStep(object):
         self.nset = 2 if self.pipelined else 1
         # trainable node-embedding prep: the level-0 rows are weights (computed per step from the current table)
         self.emb = isinstance(model.prep, NodeEmbeddingPrep)
-        self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1"
+        self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1" and not self.eval_only
         # the step's collectives: issued by the library (RCCL through gsage_comm_*, a node of the step's list) when the
         # handle carries a native communicator, else torch.distributed (gloo in the tests) through a host-call node
         self.world = int(ddp.world) if ddp is not None else 1
@@ -215,11 +230,13 @@ class FusedTrainStep(object):
         self.layers = list(model.agg_layers.children())
         L = self.L = len(self.layers)
         self.post = _split_activation(self.layers[-1].activation)[1]
-        self.fan = [1] + [fn.keywords["n_samples"] for fn in model.train_sample_fns]
-        if isinstance(model.train_sampler, UniformNeighborSampler):
+        the_sampler = model.val_sampler if self.eval_only else model.train_sampler
+        self.fan = [1] + [fn.keywords["n_samples"] for fn in (model.val_sample_fns if self.eval_only
+                                                              else model.train_sample_fns)]
+        if isinstance(the_sampler, UniformNeighborSampler):
             # the dense sampler keeps `perm[:n_samples]` of the adjacency's K columns (nn_modules.py:43-49): asking for
             # more than K yields K -- the frontier's real geometry (run.sh:8-10's defaults 25 / 10 on a K = 16 file)
-            K = int(model.train_sampler.adj.size(1))
+            K = int(the_sampler.adj.size(1))
             self.fan = [1] + [min(int(n), K) for n in self.fan[1:]]
         B = self.B = int(example_ids.shape[0])
         self.size = [B]
@@ -228,7 +245,7 @@ class FusedTrainStep(object):
         self.off = [0]
         for k in range(L + 1):
             self.off.append(self.off[-1] + self.size[k])          # off[k] = first row of hop k
-        self.sampler = model.train_sampler
+        self.sampler = the_sampler
         self.csr = self.sampler.csr(dev)          # store.DeviceCSR, or store.DenseAdj for the dense sampler
         # where the sampler's draws come from:
         #   philox  in-kernel counter RNG (throughput runs)
@@ -265,22 +282,25 @@ class FusedTrainStep(object):
         for n in sizes:
             self.poff.append(self.poff[-1] + n)
         total = self.poff[-1]
-        self.flat_p = torch.cat([p.detach().reshape(-1).float() for p in self.params]).contiguous()
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros_like(self.flat_g)
-        self.flat_v = torch.zeros_like(self.flat_g)
-        for p, o, n in zip(self.params, self.poff, sizes):
-            p.data = self.flat_p[o:o + n].view_as(p)
-            p.grad = self.flat_g[o:o + n].view_as(p)
         self.pidx = {id(p): i for i, p in enumerate(self.params)}
-        import weakref
-        model._engine = weakref.ref(self)          # models.py hands the Adam state back through this
         self.step = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.lr = torch.tensor([float(model.lr)], dtype=torch.float32, device=dev)
-        self.wd = float(model.optimizer.param_groups[0].get("weight_decay", 0.0))
-        self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
-        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._import_optimizer_state()
+        if self.eval_only:
+            self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        else:
+            self.flat_p = torch.cat([p.detach().reshape(-1).float() for p in self.params]).contiguous()
+            self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.flat_m = torch.zeros_like(self.flat_g)
+            self.flat_v = torch.zeros_like(self.flat_g)
+            for p, o, n in zip(self.params, self.poff, sizes):
+                p.data = self.flat_p[o:o + n].view_as(p)
+                p.grad = self.flat_g[o:o + n].view_as(p)
+            import weakref
+            model._engine = weakref.ref(self)          # models.py hands the Adam state back through this
+            self.lr = torch.tensor([float(model.lr)], dtype=torch.float32, device=dev)
+            self.wd = float(model.optimizer.param_groups[0].get("weight_decay", 0.0))
+            self.partial = torch.zeros(nat.lib().gsage_adam_partials(total), dtype=torch.float32, device=dev)
+            self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._import_optimizer_state()
 
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.preds = None
@@ -392,6 +412,8 @@ class FusedTrainStep(object):
         ddp = self.ddp
         if os.environ.get("GSAGE_DEBUG_ADDR", "0") == "1":
             self._debug_addresses()
+        if self.eval_only:
+            return self._finish_init_eval(capture, warmup)
         # warm-up (library handles, allocator) with state restored afterwards, then capture
         saved = self.flat_p.clone()
         saved_opt = (self.flat_m.clone(), self.flat_v.clone(), self.step.clone())     # (zeros, or an imported state)
@@ -592,7 +614,8 @@ class FusedTrainStep(object):
             d.fan[k] = int(self.fan[k + 1]) if k < L else 1
         d.max_deg, d.seed = self.csr.max_deg, int(getattr(self.sampler, "seed", 0))
         d.call_ctr, d.call_base = ctr.data_ptr(), (L if ahead else 0)
-        d.rank = getattr(self.sampler, "shard", (0, 1))[0]
+        # (evaluation: every rank scores the WHOLE fold with the samples a single process would draw)
+        d.rank = 0 if self.eval_only else getattr(self.sampler, "shard", (0, 1))[0]
         d.seed_queue = self.queue[0].data_ptr() if self.queue else None
         d.batch_idx = bidx.data_ptr() if self.queue else None
         d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
@@ -1154,6 +1177,83 @@ class FusedTrainStep(object):
                 self.sync_rows()
             self._rows_dirty = True
             self._rows_since += 1
+
+    # ---- forward only: train.evaluate's folds on the engine's launches (eval_only=True) ----------------------
+    EVAL_BATCHES = 64          # batches per replay of the evaluation queue's buffers (longer folds run in pieces)
+
+    def _current_param_ptrs(self):
+        return tuple(int(p.data_ptr()) for p in self.params)
+
+    def _finish_init_eval(self, capture, warmup):
+        dev, B, nb = self.dev, self.B, self.EVAL_BATCHES
+        self.capture_mode = {True: "cmdlist", False: None, None: None}.get(capture, capture)
+        if self.capture_mode == "cmdlist" and not (self.fused_head or self.fused_l1):
+            self.capture_mode = None               # (the stock-torch head cannot be recorded: eager launches)
+        assert self.capture_mode in (None, "cmdlist"), "eval_only records command lists (or launches eagerly)"
+        # the fold's batches as a device-resident queue (ids, draws): one recorded list serves every batch
+        self.q_ids = torch.zeros(nb, B, dtype=torch.int64, device=dev)
+        tdt = torch.int64 if self.fused_head else torch.float32
+        self.q_tg = torch.zeros(nb, B, dtype=tdt, device=dev)             # (the heads want targets: zeros)
+        self.queue = (self.q_ids, self.q_tg, nb)
+        self.nv_queue = torch.full((nb,), B, dtype=torch.int32, device=dev)
+        self.sel_queue = None
+        if self.draws != "philox":
+            self.sel_queue = torch.zeros(nb, self.n_sel, dtype=torch.int32, device=dev)
+        self.tg_set[0].zero_()
+        self.q_ids[:] = self.ids_set[0][:B]
+        for _ in range(max(1, warmup)):
+            self._eval_step()
+        torch.cuda.synchronize()
+        self.batch_idx.zero_()
+        self.counter.zero_()
+        self.g_eval = self._record(self._eval_step) if self.capture_mode else None
+        torch.cuda.synchronize()
+
+    def _eval_step(self):
+        """sample (the queue's next batch, its recorded draws) -> gather -> forward -> tick"""
+        lib, st = nat.lib(), ops._stream()
+        if self.emb:
+            self._cur_ids = self.ids_set[0]
+        self._stage_sample(0)
+        self._stage_gather(0)
+        self._stage_compute(0)
+        nat.check(lib.gsage_counter_add(self.batch_idx.data_ptr(), 1, st), "counter_add")
+        nat.check(lib.gsage_counter_add(self.counter.data_ptr(), self.L, st), "counter_add")
+
+    def evaluate_fold(self, ids, live):
+        """Predictions of a fold cut into batches the way problem.iterate(mode, shuffle=False) cuts it
+        (reference train.py:29-36 + problem.py:141-153): ids int64 [n_batches, B] (short chunks padded with their
+        first id), live = the chunks' sizes.  The frontier of every batch is the validation sampler's -- drawn from
+        the generator the reference's evaluation would draw from, in its order (compat: numpy's legacy stream,
+        padded seeds draw nothing) -- and the forward is the engine's (no autograd, no per-op launches).
+        -> float32 [sum(live), n_outputs] on the device, the fold's rows in order."""
+        assert self.eval_only and ids.dim() == 2 and int(ids.shape[1]) == self.B and len(live) == int(ids.shape[0])
+        settle = getattr(self.model, "_settle_rows", None)
+        if settle is not None:                      # a training engine's deferred table rows
+            settle()
+        if self._current_param_ptrs() != self._param_ptrs:
+            raise RuntimeError("the model's Parameters moved (another engine or optimizer re-pointed them) after this "
+                               "evaluation engine was built: build a new one")
+        self.refresh_weights()                      # operand copies of the CURRENT weights (one launch)
+        nb, B, nbuf = int(ids.shape[0]), self.B, self.EVAL_BATCHES
+        C = int(self.preds.shape[1])
+        out = torch.empty(nb, B, C, dtype=torch.float32, device=self.dev)
+        for b0 in range(0, nb, nbuf):
+            n = min(nbuf, nb - b0)
+            self.q_ids[:n].copy_(ids[b0:b0 + n])
+            if self.draws != "philox":
+                self.sel_queue[:n].copy_(self._draw_epoch(live[b0:b0 + n]))
+            self.batch_idx.zero_()
+            for b in range(n):
+                if self.g_eval is not None:
+                    self.g_eval.replay()
+                else:
+                    self._eval_step()
+                out[b0 + b].copy_(self.preds)
+        if all(int(v) == B for v in live):
+            return out.view(nb * B, C)
+        keep = torch.cat([torch.arange(b * B, b * B + int(v)) for b, v in enumerate(live)]).to(self.dev)
+        return out.view(nb * B, C)[keep]
 
     # ---- per-batch entry --------------------------------------------------------------------------
     def set_progress(self, progress):

@@ -313,6 +313,8 @@ class FusedMeanTrainStep(FusedTrainStep):
             self._side_join("tail")
         else:
             self._stage_head(s)
+        if self.eval_only:
+            return                                    # (forward only: train.evaluate's folds)
         self._backward_levels(s)
 
     def _backward_levels(self, s):

@@ -223,6 +223,8 @@ class FusedPoolTrainStep(FusedTrainStep):
             self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
                        out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act, self.wn_p[l])
         self._stage_head_ce(s)
+        if self.eval_only:
+            return                                    # (forward only: train.evaluate's folds)
         self._backward_levels(s)
 
     def _backward_levels(self, s):

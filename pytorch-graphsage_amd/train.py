@@ -90,6 +90,52 @@ def evaluate(model, problem, mode='val'):
     return problem.metric_fn(np.vstack([to_numpy(a) for a in acts]), np.vstack([to_numpy(p) for p in preds]))
 
 
+class FusedEvaluator(object):
+    """evaluate() on a fused engine's FORWARD launches (engine.FusedTrainStep(eval_only=True).evaluate_fold): the
+    fold cut into the reference's chunks (problem.py:141-153 with shuffle=False, batch_size 512 as train.py:32 calls
+    it), the validation sampler's frontier drawn from the generator -- and in the order -- the reference's evaluation
+    would draw from, no autograd, no per-op launches, the metric on the device.  One engine per fold (their chunk
+    sizes differ), built on first use; a model / store no engine covers keeps the module path (said once)."""
+
+    def __init__(self, cls, model, problem):
+        self.cls, self.model, self.problem = cls, model, problem
+        self.engines, self.off = {}, False
+
+    def _fold(self, mode, batch_size=512):
+        nodes = self.problem.nodes[mode]
+        chunks = np.array_split(np.arange(nodes.shape[0]), nodes.shape[0] // batch_size + 1)
+        B = max(int(c.shape[0]) for c in chunks)
+        mids = np.stack([np.concatenate([nodes[c], np.repeat(nodes[c[:1]], B - c.shape[0])]) for c in chunks])
+        return torch.from_numpy(mids).cuda(), [int(c.shape[0]) for c in chunks]
+
+    def __call__(self, mode='val'):
+        assert mode in ['test', 'val']
+        model, problem = self.model, self.problem
+        if self.off or problem.nodes[mode].shape[0] < 2:
+            return evaluate(model, problem, mode=mode)
+        ids, live = self._fold(mode)
+        if min(live) < 2:
+            return evaluate(model, problem, mode=mode)
+        eng = self.engines.get(mode)
+        if eng is None:
+            try:
+                tg = torch.zeros(ids.shape[1], 1, dtype=torch.int64, device=ids.device) \
+                    if problem.task == 'classification' else \
+                    torch.zeros((ids.shape[1],) + tuple(np.asarray(problem.targets[:1]).shape[1:]), dtype=torch.float32,
+                                device=ids.device)
+                eng = self.engines[mode] = self.cls(model, problem.feats, problem.loss_fn, ids[0], tg, eval_only=True)
+            except Exception as e:
+                self.off = True
+                print('gsage: evaluation stays on the module path (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+                return evaluate(model, problem, mode=mode)
+        preds = eng.evaluate_fold(ids, live)
+        nodes = problem.nodes[mode]
+        _, acts = problem._batch(nodes, problem.targets[nodes])
+        check_samplers(model)
+        eng.csr.check()
+        return batch_metric(problem.task, acts.reshape(acts.shape[0], -1), preds)
+
+
 def parse_args(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--problem-path', type=str, required=True)
@@ -298,6 +344,8 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     assert live is None or step.fused_head or step.fused_l1 or min(live) == B
     val_metric = train_metric = None
     epoch = 0
+    fold_eval = FusedEvaluator(cls, model, problem) if os.environ.get("GSAGE_FUSED_EVAL", "1") == "1" else \
+        (lambda mode='val': evaluate(model, problem, mode=mode))
     # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right behind
     # its step into a small device ring (problem.MetricRing), and the ring is read back -- one copy -- every 32 batches
     # and at the end of every epoch: same lines, same order, same values, printed 32 at a time.
@@ -358,7 +406,9 @@ def train_fused(args, problem, model, ddp, start_time, cls):
             step.timing.append({"epoch": epoch, "batches": n_batches, "seeds": int(sum(live)) if live is not None
                                 else n_batches * B * world, "loop_s": time() - t_loop, "with_draws_s": time() - t_epoch})
         model.eval()
-        val_metric = evaluate(model, problem, mode='val')
+        val_metric = fold_eval('val')
+    if rank == 0 and args.show_test:
+        test_metric = fold_eval('test')
     gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host
     print('-- done --', file=sys.stderr)
     if rank == 0:
@@ -366,7 +416,7 @@ def train_fused(args, problem, model, ddp, start_time, cls):
                      "time": time() - start_time}))
         sys.stdout.flush()
         if args.show_test:
-            print(dumps({"test_f1": evaluate(model, problem, mode='test')}))
+            print(dumps({"test_f1": test_metric}))
     if ddp is not None:
         ddp.close()
     return step
