@@ -214,6 +214,17 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             s += __uint_as_float((uint32_t)v);
         }
     } else {
+        // (the first trip's operands do not depend on the norm either: requested BEFORE its partials are summed, one
+        // dependent round trip less in a chain that is the floor of the launch it rides in -- not for the big plain
+        // buckets of the 16-byte path below, which read their operands themselves)
+        if (a.n_prep > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i_first + u * stride;
+                const int64_t ic = i < a.n ? i : i_first < a.n ? i_first : 0;
+                gv0[u] = a.g[ic]; pv0[u] = a.p[ic]; mv0[u] = a.m[ic]; vv0[u] = a.v[ic];
+            }
+        }
         for (int i = threadIdx.x; i < a.n_partial; i += 256) s += a.partial[i];
     }
     const float sq = block_sum_256(s, red);
@@ -261,8 +272,8 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         float gv[4], pv[4], mv[4], vv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (meet) {      // (one trip: the host admits the in-launch norm only when gx * 1 024 covers the bucket)
-                gv[u] = gv0[u]; pv[u] = pv0[u]; mv[u] = mv0[u]; vv[u] = vv0[u];
+            if (meet || (a.n_prep > 0 && i0 == i_first)) {      // (the in-launch norm is one trip: the host admits it
+                gv[u] = gv0[u]; pv[u] = pv0[u]; mv[u] = mv0[u]; vv[u] = vv0[u];   // only when gx * 1 024 covers the bucket)
                 continue;
             }
             const int64_t i = i0 + u * stride;

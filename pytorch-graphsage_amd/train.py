@@ -406,7 +406,12 @@ def train_fused(args, problem, model, ddp, start_time, cls):
             step.timing.append({"epoch": epoch, "batches": n_batches, "seeds": int(sum(live)) if live is not None
                                 else n_batches * B * world, "loop_s": time() - t_loop, "with_draws_s": time() - t_epoch})
         model.eval()
+        t_val = time()
         val_metric = fold_eval('val')
+        if timing:
+            torch.cuda.synchronize()
+            step.timing[-1]["val_s"] = time() - t_val
+            step.timing[-1]["epoch_s"] = time() - t_epoch            # draws + batch loop + validation
     if rank == 0 and args.show_test:
         test_metric = fold_eval('test')
     gs.helpers.legacy_stream.release()                 # hand numpy's stream back to the host

@@ -18,8 +18,9 @@ try:
     d = json.loads([l for l in open(path) if l.startswith("{")][-1])
     r = d["roofline"]
     print("%-22s ms/step %.4f  seeds/s %.3fM  launches %.1f  gather %.1f us  seed %.1f us  k5 %.1f  k5b %.1f" % (
-        name, d["ms_per_step"], d["value"] / 1e6, d["config"]["kernel_launches_per_step"], r["avg_launch_us"],
-        r.get("seed_level_launch", {}).get("avg_launch_us", -1), r.get("k5_launch", {}).get("avg_launch_us", -1),
+        name, d["ms_per_step"], d["value"] / 1e6, d["config"]["kernel_launches_per_step"],
+        r.get("gather_launch", r)["avg_launch_us"],
+        r.get("seed_level_launch", r).get("avg_launch_us", -1), r.get("k5_launch", {}).get("avg_launch_us", -1),
         r.get("k5b_launch", {}).get("avg_launch_us", -1)))
 except Exception as e:
     print(name, "FAILED", e); print(open(path).read()[-1500:])

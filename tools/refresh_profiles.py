@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def json_line(path):
@@ -58,11 +58,11 @@ if len(per) == 2:
     }, open(os.path.join(PROF, tag + "_pmc_gather_launch.json"), "w"), indent=1)
 
 # per-configuration PMC passes (tools/gpu_round.sh pmcx): the launch each `extra` roofline names
-PICK = {"reddit": ("reddit_gather", "k_gather_multi_adam"), "max_pool": ("maxpool_k3", "k_pool_mlp_packed"),
-        "attention": ("attention_k4", "k_attn_aggregate_grp"), "papers": ("papers_gather", "k_gather_multi_adam"),
-        "pokec": ("pokec_k4", "k_attn_aggregate_grp")}
+PICK = [("reddit", "reddit_gather", "k_gather_multi_adam"), ("reddit", "reddit_seed_level", "k_mean_tail_mfma"),
+        ("max_pool", "maxpool_k3", "k_pool_mlp_packed"), ("attention", "attention_k4", "k_attn_aggregate_grp"),
+        ("papers", "papers_gather", "k_gather_multi_adam"), ("pokec", "pokec_k4", "k_attn_aggregate_grp")]
 launches = {}
-for cfg, (key, kname) in PICK.items():
+for cfg, key, kname in PICK:
     rec = {}
     for c, field in (("FETCH_SIZE", "hbm_read_bytes_per_launch"), ("WRITE_SIZE", "hbm_write_bytes_per_launch")):
         pth = os.path.join(OUT, "pmcx_%s_%s.json" % (cfg, c))
