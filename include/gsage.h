@@ -606,6 +606,13 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
  * Only with act = ReLU and fan-out 5 or 10 (the level-0 projection of the mean engine: 416 workgroups where 768
  * fit, streaming at half of what a CU keeps in flight); n_workgroups is ignored.  NULL: no role. */
 int gsage_gather_role_next(const gsage_tail_gather_desc *gather);
+/* A SAMPLER role for the NEXT gsage_linear_nt_packed launch of the calling thread (ABI 5; consumed by it; HOST
+ * descriptor, read before that launch call returns): one more z-slice of the projection's grid runs the fused
+ * multi-hop sampler (gsage_sample_hops) for a LATER batch -- address it through call_base / batch_base, the counters
+ * are not touched -- ceil(B / slice size) seeds per workgroup.  K1 is ~9 us of dependent loads that move almost
+ * nothing: in the projection's free workgroup slots it is off every critical path.  Only with act = ReLU, a CSR
+ * adjacency and no gather role; same frontier as gsage_sample_hops (sampling reads no weights).  NULL: no role. */
+int gsage_hops_role_next(const gsage_hops_desc *hops);
 /* dtype = storage type of H, w2, w2t, agg, dE, dH: GSAGE_BF16, or GSAGE_F32 -- the same kernel source
  * instantiated on fp32 storage (every bf16 rounding point becomes a no-op; no gather role), used to
  * replay the reference-generated golden fixtures through this kernel at fp32 tolerance. */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gsage_mt_jump_host": (_int, [_vp, _vp, _vp]),
     "gsage_head_n_valid_next": (_int, [_vp]),
     "gsage_gather_role_next": (_int, [_vp]),
+    "gsage_hops_role_next": (_int, [_vp]),
     "gsage_gather_mean": (_int, [_vp, _int, _i64, _vp, _i64, _i32, _i64, _vp, _int, _i64, _vp]),
     "gsage_gather_mean_multi": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64, _vp]),
     "gsage_gather_mean_multi_adam": (_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _int, _i64,

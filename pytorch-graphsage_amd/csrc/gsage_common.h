@@ -109,6 +109,8 @@ extern thread_local int t_node_error;
 extern thread_local const int32_t *t_head_n_valid;
 // gsage_gather_role_next(): gather-role descriptor for the NEXT gsage_linear_nt_packed launch of this thread
 extern thread_local const gsage_tail_gather_desc *t_gather_role;
+// gsage_hops_role_next(): sampler descriptor for the NEXT gsage_linear_nt_packed launch of this thread
+extern thread_local const gsage_hops_desc *t_hops_role;
 inline const gsage_tail_gather_desc *take_gather_role()
 {
     const gsage_tail_gather_desc *p = t_gather_role;

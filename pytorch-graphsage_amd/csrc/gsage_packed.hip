@@ -8,6 +8,7 @@
 #include "gsage_common.h"
 #include "gsage_gather_dev.h"
 #include "gsage_mma_dev.h"
+#include "gsage_sample_dev.h"
 
 namespace gsage {
 
@@ -54,17 +55,28 @@ struct PackedParams {
 // GN > 0: gridDim.z is one more than the number of groups, and the workgroups of that last z-slice play the gather
 // role (gsage_gather_dev.h) on fan-out GN: the projection fills 416 of the 768 workgroup slots of the chip at
 // config 2's level 0 and streams its operands at half of what a CU can keep in flight.
-template <int ACT, int GN>
+// HOPS: gridDim.z is one more than the number of groups, and the workgroups of that last z-slice sample a LATER
+// batch's frontier (the fused multi-hop sampler, gsage_sample_dev.h; gsage_hops_role_next): K1 is a chain of six
+// dependent loads per seed (~9 us) that moves almost nothing -- inside the projection's launch, whose 416 workgroups
+// leave 352 slots free and wait on their own operand stream, it costs nothing, where in the launch that carries the
+// update it was the longer of that launch's two chains (round 5: 15.8 -> ~12 us for that launch).
+constexpr int WP_SMEM_VEC = (BM * (BN + 4) * 4) / 16 > WP_NBUF * (BM * CH) ? (BM * (BN + 4) * 4) / 16 : WP_NBUF * (BM * CH);
+
+template <int ACT, int GN, bool HOPS>
 __global__ void __launch_bounds__(256)
-k_linear_nt_packed(const PackedParams p, const TailGather tg)
+k_linear_nt_packed(const PackedParams p, const TailGather tg, const HopsParams hp)
 {
+    constexpr int EPC = 8;
+    constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
+    __shared__ vec16 smem[WP_SMEM_VEC];
+    if (HOPS && blockIdx.z + 1 == gridDim.z) {
+        sample_hops_workgroup<false>(hp, (int)(blockIdx.y * gridDim.x + blockIdx.x), reinterpret_cast<int64_t *>(smem));
+        return;
+    }
     if (GN > 0 && blockIdx.z + 1 == gridDim.z) {
         gather_role<(GN > 0 ? GN : 1), 2>(tg, (int)(blockIdx.y * gridDim.x + blockIdx.x));
         return;
     }
-    constexpr int EPC = 8;
-    constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
-    __shared__ vec16 smem[(BM * (BN + 4) * 4) / 16 > WP_NBUF * ATILE ? (BM * (BN + 4) * 4) / 16 : WP_NBUF * ATILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -546,8 +558,10 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
                            int64_t M, int64_t N, int64_t K, int act, int groups, int64_t a_gstride,
                            int64_t c_gstride, void *stream)
 {
-    // gsage_gather_role_next(): consumed before any return path, so that it is never left for a later launch
+    // gsage_gather_role_next() / gsage_hops_role_next(): consumed before any return path, never left for a later launch
     const gsage_tail_gather_desc *gd = take_gather_role();
+    const gsage_hops_desc *hd = t_hops_role;
+    t_hops_role = nullptr;
     GSAGE_REQUIRE(A && Wp && C, "linear_nt_packed: null pointer");
     GSAGE_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_nt_packed: bad sizes");
     GSAGE_REQUIRE(c_dtype == GSAGE_BF16 || c_dtype == GSAGE_F32, "linear_nt_packed: bad c_dtype");
@@ -568,6 +582,26 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
     hipStream_t s = (hipStream_t)stream;
     // gsage_gather_role_next(): one more z-slice of workgroups gathers part of the next batch's level-0 rows
     TailGather tg = {};
+    HopsParams hp = {};
+    if (hd) {
+        // gsage_hops_role_next(): one more z-slice of workgroups samples a later batch's frontier
+        GSAGE_REQUIRE(!(gd && gd->rows > 0) && act == ACT_RELU && !hd->dense_adj,
+                      "linear_nt_packed: the sampler role rides with the ReLU projection, walks a CSR, and excludes the "
+                      "gather role");
+        size_t lds = 0;
+        const int rc = fill_hops(hp, lds, *hd);
+        if (rc != GSAGE_OK) return rc;
+        const int64_t slots = (int64_t)grid.x * grid.y;
+        hp.spw = (int32_t)ceil_div(hd->B > 0 ? hd->B : 1, slots);     // seeds per workgroup: the slice serves the batch
+        int64_t widest = 1, width = 1;
+        for (int k = 1; k <= hp.n_hops; ++k) { width *= hp.fan[k]; widest = width > widest ? width : widest; }
+        GSAGE_REQUIRE(sizeof(int64_t) * 2 * (size_t)hp.spw * (size_t)widest <= sizeof(vec16) * WP_SMEM_VEC,
+                      "linear_nt_packed: the sampler role's frontier (%d seeds x %lld ids, twice) does not fit the "
+                      "projection's LDS", hp.spw, (long long)widest);
+        grid.z += 1;
+        launch(k_linear_nt_packed<ACT_RELU, 0, true>, grid, dim3(256), 0, s, p, tg, hp);
+        return check_launch("linear_nt_packed");
+    }
     if (gd && gd->rows > 0) {
         const int rc = fill_gather_role(tg, *gd, "linear_nt_packed (gather role)");
         if (rc != GSAGE_OK) return rc;
@@ -575,16 +609,16 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
                       "linear_nt_packed: the gather role rides with the ReLU projection, fan-out 5 or 10");
         tg.n_wg = (int32_t)(grid.x * grid.y);
         grid.z += 1;
-        if (gd->n == 10) launch(k_linear_nt_packed<ACT_RELU, 10>, grid, dim3(256), 0, s, p, tg);
-        else launch(k_linear_nt_packed<ACT_RELU, 5>, grid, dim3(256), 0, s, p, tg);
+        if (gd->n == 10) launch(k_linear_nt_packed<ACT_RELU, 10, false>, grid, dim3(256), 0, s, p, tg, hp);
+        else launch(k_linear_nt_packed<ACT_RELU, 5, false>, grid, dim3(256), 0, s, p, tg, hp);
         return check_launch("linear_nt_packed");
     }
     if (act == ACT_RELU)
-        launch(k_linear_nt_packed<ACT_RELU, 0>, grid, dim3(256), 0, s, p, tg);
+        launch(k_linear_nt_packed<ACT_RELU, 0, false>, grid, dim3(256), 0, s, p, tg, hp);
     else if (act == ACT_TANH)
-        launch(k_linear_nt_packed<ACT_TANH, 0>, grid, dim3(256), 0, s, p, tg);
+        launch(k_linear_nt_packed<ACT_TANH, 0, false>, grid, dim3(256), 0, s, p, tg, hp);
     else
-        launch(k_linear_nt_packed<ACT_NONE, 0>, grid, dim3(256), 0, s, p, tg);
+        launch(k_linear_nt_packed<ACT_NONE, 0, false>, grid, dim3(256), 0, s, p, tg, hp);
     return check_launch("linear_nt_packed");
 }
 

@@ -22,6 +22,7 @@ thread_local CmdList *t_recording = nullptr;
 thread_local hipStream_t t_last_stream = nullptr;
 thread_local const int32_t *t_head_n_valid = nullptr;
 thread_local const gsage_tail_gather_desc *t_gather_role = nullptr;
+thread_local const gsage_hops_desc *t_hops_role = nullptr;
 thread_local int t_node_error = 0;      // set by a host-call node that failed during a replay
 
 void set_error(const char *fmt, ...)
@@ -48,6 +49,11 @@ int gsage_head_n_valid_next(const int32_t *n_valid)
 int gsage_gather_role_next(const gsage_tail_gather_desc *gather)
 {
     t_gather_role = gather;
+    return GSAGE_OK;
+}
+int gsage_hops_role_next(const gsage_hops_desc *hops)
+{
+    t_hops_role = hops;
     return GSAGE_OK;
 }
 const char *gsage_last_error(void) { return t_err; }

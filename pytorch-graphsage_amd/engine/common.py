@@ -613,12 +613,12 @@ class FusedTrainStep(object):
         for k in range(5):
             d.fan[k] = int(self.fan[k + 1]) if k < L else 1
         d.max_deg, d.seed = self.csr.max_deg, int(getattr(self.sampler, "seed", 0))
-        d.call_ctr, d.call_base = ctr.data_ptr(), (L if ahead else 0)
+        d.call_ctr, d.call_base = ctr.data_ptr(), L * int(ahead)       # (ahead: how many batches past the counters)
         # (evaluation: every rank scores the WHOLE fold with the samples a single process would draw)
         d.rank = 0 if self.eval_only else getattr(self.sampler, "shard", (0, 1))[0]
         d.seed_queue = self.queue[0].data_ptr() if self.queue else None
         d.batch_idx = bidx.data_ptr() if self.queue else None
-        d.batch_base, d.n_batches = (1 if ahead else 0), (self.queue[2] if self.queue else 0)
+        d.batch_base, d.n_batches = int(ahead), (self.queue[2] if self.queue else 0)
         d.err_flag = self.csr.err_flag.data_ptr()
         if self.queue and self.sel_queue is not None:
             d.sel, d.sel_stride = self.sel_queue.data_ptr(), int(self.sel_queue.shape[1])
@@ -1332,6 +1332,11 @@ class FusedTrainStep(object):
         # From here on the step is software-pipelined (see step_queue): two frontier buffers, batch
         # i+2 is sampled while batch i+1 is gathered and batch i is updated.
         self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
+        # K1 inside the level-0 projection's launch (mean engine, _k1_in_k5): batch i+2 is sampled at the START of
+        # step i, while K5(i) and K5b(i) still read batch i's frontier as their row list -- a ring of THREE
+        self.P = 3 if self._k1_in_k5() else 2
+        if self.P == 3:
+            self.ids_q.append(torch.zeros_like(self.ids_set[0]))
         # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
         # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
@@ -1341,6 +1346,8 @@ class FusedTrainStep(object):
         self._side_rows = self._side_gather_rows() if self._tail_rows else 0
         if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
             self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
+        while (self._tail_rows or self.split) and len(self.xa0_set) < self.P:
+            self.xa0_set.append(torch.zeros_like(self.xa0_set[0]))
         self._front_ready, self._qstep = False, 0
         if self.split:
             self._split_setup()
@@ -1364,7 +1371,7 @@ class FusedTrainStep(object):
             torch.cuda.synchronize()
             self.g_prime = self._record(self._queue_prime)
             if self.ddp is None:
-                self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(2)]
+                self.g_queue = [self._record(lambda par=par: self._queue_step(par)) for par in range(self.P)]
             else:
                 if self._one_list_ddp():
                     # ONE list per step, the exchange a node of it (on the side stream when it overlaps the gathers)
@@ -1405,7 +1412,7 @@ class FusedTrainStep(object):
 
     def last_launch_ms(self):
         if self.queue is not None:
-            par = (self._qstep - 1) % 2
+            par = (self._qstep - 1) % getattr(self, "P", 2)
             cl = self.g_queue[par].cl
             front = self.g_qfront[par].cl if getattr(self, "split", False) else cl
         else:
@@ -1428,6 +1435,17 @@ class FusedTrainStep(object):
     def _qset(self, par):
         return par if self._tail_rows else 0
 
+    def _k1_in_k5(self):
+        return False
+
+    def _nx(self, par):
+        """ring position of the NEXT batch (gathered during this step)"""
+        return (par + 1) % getattr(self, "P", 2)
+
+    def _nx2(self, par):
+        """ring position the batch AFTER the next is sampled into"""
+        return (par + 2) % getattr(self, "P", 2)
+
     def _queue_prime(self):
         self._stage_sample(0, ids=self.ids_q[0])
         self._stage_sample(0, ids=self.ids_q[1], ahead=True)
@@ -1442,13 +1460,15 @@ class FusedTrainStep(object):
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)      # batch i+2 (batch i's frontier is done with)
             return
         self._time_next(0, 1)
+        nx = self._nx(par)
         if self.dense:           # (the gather launch's sampler role walks a CSR: the dense frontier is a launch of its own)
-            self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
+            self._stage_gather(self._qset(nx), with_adam=with_adam, ids=self.ids_q[nx],
                                skip_rows=self._ahead_rows())
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)
             return
-        self._stage_gather(self._qset(1 - par), with_adam=with_adam, ids=self.ids_q[1 - par],
-                           hops=self._hops_desc(self.ids_q[par], True),
+        # (P == 3: batch i+2 was sampled by the projection's launch of this step: nothing to sample here)
+        self._stage_gather(self._qset(nx), with_adam=with_adam, ids=self.ids_q[nx],
+                           hops=self._hops_desc(self.ids_q[self._nx2(par)], True) if self.P == 2 else None,
                            skip_rows=self._ahead_rows())
 
     def _queue_compute(self, par):
@@ -1520,7 +1540,7 @@ class FusedTrainStep(object):
             else:
                 self._queue_prime()
             self._front_ready = True
-        par = self._qstep % 2
+        par = self._qstep % self.P
         self._qstep += 1
         if self.ddp is None:
             if rec:

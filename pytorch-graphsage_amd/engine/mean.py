@@ -278,6 +278,9 @@ class FusedMeanTrainStep(FusedTrainStep):
                 if l == 0 and getattr(self, "_k5_gather", None) is not None:
                     # the projection's spare workgroup slots gather part of the NEXT batch's last-hop means
                     nat.check(lib.gsage_gather_role_next(ctypes.addressof(self._k5_gather)), "gather_role_next")
+                elif l == 0 and getattr(self, "_k5_hops", None) is not None:
+                    # ... or sample the frontier of the batch after the next
+                    nat.check(lib.gsage_hops_role_next(ctypes.addressof(self._k5_hops)), "hops_role_next")
                 if l == 0:
                     self._time_next(4, 5)
                 ops._linear_packed_launch(xbuf.data_ptr(), lda, rows, int(rows is not None), self.wp[l].data_ptr(), None,
@@ -523,12 +526,27 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.dense:
             self._stage_sample(0, ids=self.ids_q[par], ahead=True)
 
+    def _k1_in_k5(self):
+        """Sample batch i+2 inside the launch of the level-0 projection of step i (gsage_hops_role_next) instead of
+        in the launch that carries the update?  OPT-IN (GSAGE_K1_IN_K5=1): measured on the MI355X (round 5, DESIGN.md
+        section 5) the launch that carries the update gets 1.6 us shorter (16.2 -> 14.6: what is left is the update's
+        own chain) and the projection 2.8 us longer (14.0 -> 16.8: the sampler's 171 workgroups hold slots its 416
+        want) -- 0.0846 against 0.0835 ms/step.  Needs the packed ReLU projection at level 0, a CSR sampler, one GPU,
+        no split mode; a ring of three frontier buffers (K5 / K5b of step i still read batch i's as their row list)."""
+        return bool(self.wp and self.wp[0] is not None and self.L >= 2 and not self.dense and not self.emb and
+                    self.ddp is None and not getattr(self, "split", False) and not self.gather_cus and
+                    float(os.environ.get("GSAGE_K5_GATHER_FRAC", "0.0")) == 0.0 and      # (one role per launch)
+                    os.environ.get("GSAGE_K1_IN_K5", "0") == "1")
+
     def _queue_compute_body(self, par):
+        nx = self._nx(par)
+        if self.P == 3:
+            self._k5_hops = self._hops_desc(self.ids_q[self._nx2(par)], 2)
         if self._tail_rows:
-            L, st, nxt = self.L, self.store, self.ids_q[1 - par]
+            L, st, nxt = self.L, self.store, self.ids_q[nx]
             d = nat.TailGatherDesc()
             d.table, d.ids = st.data.data_ptr(), nxt[self.off[L]:].data_ptr()
-            d.out = self.xa0_set[1 - par][1][self.off[L - 1]:].data_ptr()
+            d.out = self.xa0_set[nx][1][self.off[L - 1]:].data_ptr()
             d.ld, d.out_ld, d.D, d.rows = st.ld, st.ld, st.dim, self._tail_rows
             d.n, d.n_workgroups = self.fan[L], self._tail_wgs
             self._tail_gather = d
@@ -536,23 +554,24 @@ class FusedMeanTrainStep(FusedTrainStep):
             if self._k5_rows:
                 k = nat.TailGatherDesc()
                 k.table, k.ids = st.data.data_ptr(), nxt[self.off[L] + t0 * self.fan[L]:].data_ptr()
-                k.out = self.xa0_set[1 - par][1][self.off[L - 1] + t0:].data_ptr()
+                k.out = self.xa0_set[nx][1][self.off[L - 1] + t0:].data_ptr()
                 k.ld, k.out_ld, k.D, k.rows = st.ld, st.ld, st.dim, self._k5_rows
                 k.n, k.n_workgroups = self.fan[L], 1
                 self._k5_gather = k
                 t0 += self._k5_rows
             if self._side_rows:
-                self._side_job = (1 - par, nxt, t0, t0 + self._side_rows)
+                self._side_job = (nx, nxt, t0, t0 + self._side_rows)
         try:
             self._stage_compute(self._qset(par))
             if self._side_rows and not self._in_list:      # (eager launching: the same rows, on the main stream)
                 t1 = self._tail_rows + self._k5_rows
-                self._stage_gather(1 - par, ids=self.ids_q[1 - par], part="means", skip_rows=t1,
+                self._stage_gather(nx, ids=self.ids_q[nx], part="means", skip_rows=t1,
                                    stop_rows=t1 + self._side_rows)
         finally:
             self._tail_gather = None
             self._k5_gather = None
             self._side_job = None
+            self._k5_hops = None
 
     def _step_queue_split(self):
         user = torch.cuda.current_stream()

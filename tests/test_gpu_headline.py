@@ -73,9 +73,9 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
         preds.append(eng.step_queue().detach().float().cpu().numpy().copy())
         norms.append(float(eng.gnorm.item()))
         if s == 0:
-            # the pipeline's buffers: batch 1 sampled by the prime launch, batch 2 by step 0's gather launch
+            # the pipeline's buffers: batch 1 sampled by the prime launch, batch 2 inside step 0 (its projection's launch)
             torch.cuda.synchronize()
-            for b, buf in ((1, eng.ids_q[1]), (2, eng.ids_q[0])):
+            for b, buf in ((1, eng.ids_q[1]), (2, eng.ids_q[2 % eng.P])):     # (a ring of eng.P frontier buffers)
                 hops = _frontier(csr, ids[b], b)
                 assert torch.equal(buf[B:B + B * 25], hops[0]) and torch.equal(buf[B + B * 25:], hops[1]), b
     torch.cuda.synchronize()

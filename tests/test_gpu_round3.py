@@ -109,8 +109,8 @@ def test_fused_sampler_consumes_numpys_stream_like_the_reference(mode):
             check(eng.ids_q[1], 1)
         for b in range(nb):
             eng.step_queue()
-            if b + 2 < nb:                                # step b sampled batch b + 2 into the buffer batch b left
-                check(eng.ids_q[b % 2], b + 2)
+            if b + 2 < nb:                                # step b sampled batch b + 2 (ring of eng.P buffers)
+                check(eng.ids_q[(b + 2) % eng.P], b + 2)     # (a ring of eng.P frontier buffers)
     torch.cuda.synchronize()
     assert nat.launch_count() > before
     model.train_sampler.csr(DEV).check()
@@ -164,7 +164,7 @@ def test_fused_dense_sampler_consumes_torchs_generator_like_the_reference(mode):
         for b in range(nb):
             eng.step_queue()
             if b + 2 < nb:
-                check(eng.ids_q[b % 2], b + 2)
+                check(eng.ids_q[(b + 2) % eng.P], b + 2)     # (a ring of eng.P frontier buffers)
     torch.cuda.synchronize()
     model.train_sampler.table(DEV).check()
     assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, size=4), g["k0_tail_np"])

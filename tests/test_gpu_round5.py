@@ -206,3 +206,14 @@ def test_fused_evaluation_equals_the_module_path(tmp_path, kind, extra):
     finally:
         helpers.legacy_stream.enabled = False
         helpers.legacy_stream.drop()
+
+
+@pytest.mark.parametrize("mode", ["queue", False])
+def test_sampler_role_of_the_projection_launch_changes_nothing(monkeypatch, mode):
+    """GSAGE_K1_IN_K5=1: batch i+2 is sampled by a z-slice of the level-0 projection's launch of step i
+    (gsage_hops_role_next; a ring of three frontier buffers) instead of in the launch that carries the update: the
+    same Philox words, the same frontier, the same weights bit for bit."""
+    a = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0"}, (128, 128), (25, 10), 64, mode, n_steps=7)
+    b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "1"}, (128, 128), (25, 10), 64, mode, n_steps=7)
+    assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["p"], b["p"])
+    assert a["ctr"] == b["ctr"] and a["step"] == b["step"] == 7
