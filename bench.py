@@ -280,10 +280,14 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
             # the whole last hop): it is the dominant kernel; the gather launch (hop-1 means | Adam | K1) is listed beside it
             out = hbm_roofline(seed_name, rows_t * st.dim * elem, us["seed_level"], "reddit_seed_level", n_steps,
                                rows_per_launch=rows_t)
+            # (the rows the gather launch reads for the hop-1 means are the hop-1 nodes' own rows, which K5 / K5b also
+            # read in place as x rows: the step's algorithmic bytes count them once, `rows_read` is what this launch moves)
+            rows_h1 = eng.size[1] if rows_g == 0 else rows_g
             out["gather_launch"] = {"kernel": "k_gather_multi_adam (in-step: rest of the gathers of batch i+1 | Adam(i) | K1(i+2))",
-                                    "gather_rows": rows_g, "alg_bytes_per_launch": rows_g * st.dim * elem,
-                                    "avg_launch_us": us["gather"],
-                                    "achieved": rows_g * st.dim * elem / (us["gather"] * 1e-6) / 1e9}
+                                    "gather_rows": rows_g, "rows_read": rows_h1,
+                                    "bytes_read_per_launch": rows_h1 * st.dim * elem, "avg_launch_us": us["gather"],
+                                    "read_rate_gbs": rows_h1 * st.dim * elem / (us["gather"] * 1e-6) / 1e9,
+                                    "note": "bounded by the update's and the sampler's dependent chains, not by its gathers"}
         else:
             out = hbm_roofline("k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
                                rows_g * st.dim * elem, us["gather"], pmc_key, n_steps, rows_per_launch=rows_g)

@@ -91,6 +91,10 @@ class GSSupervised(nn.Module):
         assert len(hops) == 1, "len(all_feats) != 1"
 
         out = F.normalize(hops[0].float(), dim=1)
+        if out.is_cuda:
+            # the head's projection on K5 in exact fp32 (models.py:91 is an nn.Linear: a library GEMM on the GPU
+            # otherwise -- the last one of the module path, forward and backward)
+            return ops.linear(out, self.fc.weight, self.fc.bias, compute_dtype="fp32")
         return self.fc(out)
 
     def __getstate__(self):

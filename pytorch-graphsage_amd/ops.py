@@ -26,7 +26,6 @@ _vp = ctypes.c_void_p
 
 class _Config(object):
     compute_dtype = "bf16"      # "bf16": MFMA bf16 in / fp32 accumulate;  "fp32": exact-fp32 MFMA
-    mm_out_f32 = None           # does torch.mm(bf16, bf16, out_dtype=fp32) work on this build?
 
 
 config = _Config()
@@ -58,24 +57,43 @@ def _stream():
 
 
 def warmup(device):
-    """Probe optional torch features once, outside any graph capture."""
-    if config.mm_out_f32 is None:
-        try:
-            a = torch.zeros(8, 8, dtype=torch.bfloat16, device=device)
-            r = torch.mm(a, a, out_dtype=torch.float32)
-            config.mm_out_f32 = (r.dtype == torch.float32)
-        except Exception:
-            config.mm_out_f32 = False
+    """Load the library (raises loudly when it is missing) before any graph capture."""
     nat.lib()
 
 
-def _mm_f32(a, b):
-    """a @ b with an fp32 result (plain library GEMM used for the backward contractions)."""
-    if a.dtype == torch.float32:
-        return torch.mm(a, b)
-    if config.mm_out_f32:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    return torch.mm(a.float(), b.float())
+def _dgrad(gc, wa, K):
+    """d input = gc @ W[:, :K] -- gc [M, N] in the compute type, wa [N, >= K] the weight's operand copy -- on K5
+    (gsage_linear_nt: the NT kernel against the TRANSPOSED operand copy), fp32 result [M, K].  The backward of the
+    module path (the literal aggregator_lookup[...] plug-in under autograd, reference nn_modules.py:196-204,
+    :223-232) runs no library GEMM: round 4 still called torch.mm here."""
+    cdt = gc.dtype
+    epc = 8 if cdt == torch.bfloat16 else 4
+    M, N = gc.shape
+    out = torch.empty(M, K, dtype=torch.float32, device=gc.device)
+    if M == 0:
+        return out
+    ga = _pad_cast(gc, cdt, 8 * epc)
+    wt = _pad_cast(wa[:, :K].t(), cdt, 8 * epc)              # [K, round_up(N)]: rows = this product's outputs
+    _linear_launch(_ptr(ga), ga.stride(0), None, 0, _ptr(wt), wt.stride(0), None, _ptr(out), K, M, K, N,
+                   nat.ACT_NONE, 1, 0, 0, 0, _code(cdt), nat.F32)
+    return out
+
+
+def _wgrad_any(gc, xa, K):
+    """d W = gc^T @ xa[:, :K] on K5b (gsage_wgrad: bf16 MFMA, or its fp32 twin in the parity mode) for ANY shape:
+    the columns of gc are padded to whole 16-byte chunks (zero columns: zero rows of the result, dropped), the rows of
+    xa taken as they are when they already are.  fp32 result [N, K]."""
+    cdt = gc.dtype
+    mult = 8 if cdt == torch.bfloat16 else 4
+    M, N = gc.shape
+    if M == 0:
+        return torch.zeros(N, K, dtype=torch.float32, device=gc.device)
+    g = _pad_cast(gc, cdt, mult)
+    ok = (xa.dtype == cdt and xa.stride(1) == 1 and xa.stride(0) % mult == 0 and xa.data_ptr() % 16 == 0 and
+          xa.stride(0) >= _round_up(K, 4))
+    x = xa if ok else _pad_cast(xa[:, :K], cdt, mult)
+    Np = g.shape[1]
+    return wgrad(g, x, x.stride(0), 0, M, Np, K, Np)[0][:N]
 
 
 def mark_zero_padded(view):
@@ -514,7 +532,8 @@ def wgrad_multi(problems):
 
 
 class _Linear(torch.autograd.Function):
-    """act(x @ W^T + b) on the matrix cores; backward contractions are plain library GEMMs."""
+    """act(x @ W^T + b) on the matrix cores; the backward contractions too (K5 against the transposed operand copy for the
+    input gradient, K5b for the weight gradient)."""
 
     @staticmethod
     def forward(ctx, x, W, b, act, cdt_name, out_dtype):
@@ -545,14 +564,10 @@ class _Linear(torch.autograd.Function):
         gc = g.to(xa.dtype)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _mm_f32(gc, wa)[:, :K].to(xdt)
+            dx = _dgrad(gc, wa, K).to(xdt)
         if ctx.needs_input_grad[1]:
-            N = gc.shape[1]
-            if xa.dtype == torch.bfloat16 and N % 8 == 0 and xa.stride(0) % 8 == 0 and gc.shape[0] >= 64:
-                # K5b: the library GEMM behind gc.t() @ xa ran at ~20 TF/s on these skinny shapes
-                dw = wgrad(gc.contiguous(), xa, xa.stride(0), 0, gc.shape[0], N, K, N)[0].to(wdt)
-            else:
-                dw = _mm_f32(gc.t(), xa)[:, :K].to(wdt)
+            # K5b (the library GEMM behind gc.t() @ xa ran at ~20 TF/s on these skinny shapes)
+            dw = _wgrad_any(gc, xa, K).to(wdt)
         if has_b and ctx.needs_input_grad[2]:
             db = g.sum(dim=0)
         return dx, dw, db, None, None, None
@@ -653,16 +668,16 @@ class _SageProject(torch.autograd.Function):
             if k5b_ok and xm.stride(0) % 8 == 0:
                 dwx = wgrad(gx, xm, xm.stride(0), 0, gc.shape[0], h, Dx, h)[0].to(wdt)
             else:
-                dwx = _mm_f32(gx.t(), xm)[:, :Dx].to(wdt)
+                dwx = _wgrad_any(gx, xm, Dx).to(wdt)
         if ctx.needs_input_grad[3] and not fused_w:
             if k5b_ok and an.stride(0) % 8 == 0:
                 dwn = wgrad(gn, an, an.stride(0), 0, gc.shape[0], h, Dn, h)[0].to(wdt)
             else:
-                dwn = _mm_f32(gn.t(), an)[:, :Dn].to(wdt)
+                dwn = _wgrad_any(gn, an, Dn).to(wdt)
         if ctx.needs_input_grad[0]:
-            dx = _mm_f32(gx, wxa)[:, :Dx].to(xdt)
+            dx = _dgrad(gx, wxa, Dx).to(xdt)
         if ctx.needs_input_grad[1]:
-            dagg = _mm_f32(gn, wna)[:, :Dn].to(adt)
+            dagg = _dgrad(gn, wna, Dn).to(adt)
         return dx, dagg, dwx, dwn, None, None, None, None, None, None
 
 
@@ -738,15 +753,19 @@ class _PoolMLP(torch.autograd.Function):
                 gh.scatter_(1, argmax.long().unsqueeze(1), (g * (pooled > 0)).unsqueeze(1))
                 gh = gh.view(M * n, H)
             else:
-                hid = torch.relu(_mm_f32(rows, wa.t()) + bf)             # recompute (mean pool only)
+                hid = torch.empty(M * n, H, dtype=torch.float32, device=g.device)     # recompute (mean pool only): K5
+                ra = _pad_cast(rows, cdt, 8 * epc, True) if rows.stride(0) % (8 * epc) == 0 else _pad_cast(rows[:, :K], cdt, 8 * epc)
+                wl = _pad_cast(wa[:, :K], cdt, 8 * epc)
+                _linear_launch(_ptr(ra), ra.stride(0), None, 0, _ptr(wl), wl.stride(0), _ptr(bf), _ptr(hid), H, M * n, H, K,
+                               nat.ACT_RELU, 1, 0, 0, 0, _code(cdt), nat.F32)
                 gh = (g / n).repeat_interleave(n, dim=0) * (hid > 0)
             ghc = gh.to(cdt)
             if ctx.needs_input_grad[1]:
-                dw = _mm_f32(ghc.t(), rows)[:, :K].to(wdt)
+                dw = _wgrad_any(ghc, rows, K).to(wdt)
             if ctx.needs_input_grad[2]:
                 db = gh.sum(dim=0)
         if ctx.needs_input_grad[0]:
-            dn = _mm_f32(ghc, wa)[:, :K].to(ndt)
+            dn = _dgrad(ghc, wa, K).to(ndt)
         return dn, dw, db, None, None, None, None, None, None, None
 
 

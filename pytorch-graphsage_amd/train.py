@@ -108,16 +108,18 @@ class FusedEvaluator(object):
         mids = np.stack([np.concatenate([nodes[c], np.repeat(nodes[c[:1]], B - c.shape[0])]) for c in chunks])
         return torch.from_numpy(mids).cuda(), [int(c.shape[0]) for c in chunks]
 
-    def __call__(self, mode='val'):
-        assert mode in ['test', 'val']
+    def prepare(self, mode='val'):
+        """build the fold's engine now (part of a run's set-up, not of its first epoch)"""
+        if not self.off and self.problem.nodes[mode].shape[0] >= 2:
+            ids, live = self._fold(mode)
+            if min(live) >= 2:
+                self._engine(mode, ids)
+        return self
+
+    def _engine(self, mode, ids):
         model, problem = self.model, self.problem
-        if self.off or problem.nodes[mode].shape[0] < 2:
-            return evaluate(model, problem, mode=mode)
-        ids, live = self._fold(mode)
-        if min(live) < 2:
-            return evaluate(model, problem, mode=mode)
         eng = self.engines.get(mode)
-        if eng is None:
+        if eng is None and not self.off:
             try:
                 tg = torch.zeros(ids.shape[1], 1, dtype=torch.int64, device=ids.device) \
                     if problem.task == 'classification' else \
@@ -127,7 +129,19 @@ class FusedEvaluator(object):
             except Exception as e:
                 self.off = True
                 print('gsage: evaluation stays on the module path (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
-                return evaluate(model, problem, mode=mode)
+        return eng
+
+    def __call__(self, mode='val'):
+        assert mode in ['test', 'val']
+        model, problem = self.model, self.problem
+        if self.off or problem.nodes[mode].shape[0] < 2:
+            return evaluate(model, problem, mode=mode)
+        ids, live = self._fold(mode)
+        if min(live) < 2:
+            return evaluate(model, problem, mode=mode)
+        eng = self._engine(mode, ids)
+        if eng is None:
+            return evaluate(model, problem, mode=mode)
         preds = eng.evaluate_fold(ids, live)
         nodes = problem.nodes[mode]
         _, acts = problem._batch(nodes, problem.targets[nodes])
@@ -344,7 +358,7 @@ def train_fused(args, problem, model, ddp, start_time, cls):
     assert live is None or step.fused_head or step.fused_l1 or min(live) == B
     val_metric = train_metric = None
     epoch = 0
-    fold_eval = FusedEvaluator(cls, model, problem) if os.environ.get("GSAGE_FUSED_EVAL", "1") == "1" else \
+    fold_eval = FusedEvaluator(cls, model, problem).prepare('val') if os.environ.get("GSAGE_FUSED_EVAL", "1") == "1" else \
         (lambda mode='val': evaluate(model, problem, mode=mode))
     # The per-batch line (train.py:150-158) without a host sync per step: batch b is scored on the device right behind
     # its step into a small device ring (problem.MetricRing), and the ring is read back -- one copy -- every 32 batches

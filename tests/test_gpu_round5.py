@@ -217,3 +217,30 @@ def test_sampler_role_of_the_projection_launch_changes_nothing(monkeypatch, mode
     b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "1"}, (128, 128), (25, 10), 64, mode, n_steps=7)
     assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["p"], b["p"])
     assert a["ctr"] == b["ctr"] and a["step"] == b["step"] == 7
+
+
+@pytest.mark.parametrize("agg", ["mean", "max_pool", "mean_pool", "attention"])
+def test_module_path_runs_no_library_gemm(monkeypatch, agg):
+    """GSSupervised.train_step -- the literal aggregator_lookup[...] plug-ins under autograd -- forward AND backward
+    on this library's kernels only: with every library-GEMM entry of torch poisoned the step still runs (round 4's
+    backward called torch.mm for the input gradients and the head was an nn.Linear)."""
+    import torch.nn.functional as F
+
+    def boom(*a, **k):
+        raise AssertionError("a library GEMM was called in the module path")
+    adj, feats, rng = _problem(n=500, D=24, seed=2)
+    B, C = 48, 5
+    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+    m = _model(adj, feats.shape[1], C, (16, 8), (5, 3), agg=agg)
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=B)).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(B, 1))).to(DEV)
+    w0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for name in ("mm", "matmul", "addmm", "bmm", "einsum"):
+        monkeypatch.setattr(torch, name, boom)
+    monkeypatch.setattr(F, "linear", boom)
+    for _ in range(2):
+        preds = m.train_step(ids=ids, feats=store, targets=tg, loss_fn=gs.ProblemLosses.classification)
+    torch.cuda.synchronize()
+    assert preds.shape == (B, C) and bool(torch.isfinite(preds).all())
+    moved = [k for k, v in m.state_dict().items() if not torch.equal(v, w0[k])]
+    assert len(moved) == len(w0), "every parameter received a gradient and moved"
