@@ -282,7 +282,7 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
                                rows_per_launch=rows_t)
             # (the rows the gather launch reads for the hop-1 means are the hop-1 nodes' own rows, which K5 / K5b also
             # read in place as x rows: the step's algorithmic bytes count them once, `rows_read` is what this launch moves)
-            rows_h1 = eng.size[1] if rows_g == 0 else rows_g
+            rows_h1 = sum(eng.size[1:L]) if rows_g == 0 else rows_g        # (children of every hop but the last)
             out["gather_launch"] = {"kernel": "k_gather_multi_adam (in-step: rest of the gathers of batch i+1 | Adam(i) | K1(i+2))",
                                     "gather_rows": rows_g, "rows_read": rows_h1,
                                     "bytes_read_per_launch": rows_h1 * st.dim * elem, "avg_launch_us": us["gather"],

@@ -532,15 +532,20 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
         if (rc != GSAGE_OK) return rc;
     }
     const int gn = fused ? gather->n : 0;
-    const bool exact = n == 25;
-    void (*kern)(const TailMfmaParams, const TailGather) =
-        gn == 10 ? (exact ? k_mean_tail_mfma<25, 10> : k_mean_tail_mfma<0, 10>)
-        : gn == 5 ? (exact ? k_mean_tail_mfma<25, 5> : k_mean_tail_mfma<0, 5>)
-        : gn == 15 ? (exact ? k_mean_tail_mfma<25, 15> : k_mean_tail_mfma<0, 15>)
-                   : (exact ? k_mean_tail_mfma<25, 0> : k_mean_tail_mfma<0, 0>);
+    // fan-outs with a specialisation of their own (one load slot per neighbour row): BASELINE's 25 (configs[1]) and
+    // 15 (configs[4]'s first hop), 10; everything else takes the 32-slot kernel
+    const int ex = n == 25 ? 1 : n == 15 ? 2 : n == 10 ? 3 : 0;
+    typedef void (*kern_t)(const TailMfmaParams, const TailGather);
+    static const kern_t table[4][4] = {
+        {k_mean_tail_mfma<0, 0>, k_mean_tail_mfma<0, 10>, k_mean_tail_mfma<0, 5>, k_mean_tail_mfma<0, 15>},
+        {k_mean_tail_mfma<25, 0>, k_mean_tail_mfma<25, 10>, k_mean_tail_mfma<25, 5>, k_mean_tail_mfma<25, 15>},
+        {k_mean_tail_mfma<15, 0>, k_mean_tail_mfma<15, 10>, k_mean_tail_mfma<15, 5>, k_mean_tail_mfma<15, 15>},
+        {k_mean_tail_mfma<10, 0>, k_mean_tail_mfma<10, 10>, k_mean_tail_mfma<10, 5>, k_mean_tail_mfma<10, 15>}};
+    const int gi = gn == 10 ? 1 : gn == 5 ? 2 : gn == 15 ? 3 : 0;
+    kern_t kern = table[ex][gi];
     {   // more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
-        static bool raised[8] = {false, false, false, false, false, false, false, false};
-        const int slot = (exact ? 1 : 0) + 2 * (gn == 10 ? 1 : gn == 5 ? 2 : gn == 15 ? 3 : 0);
+        static bool raised[16] = {};
+        const int slot = ex * 4 + gi;
         if (!raised[slot]) {
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tm_lds_bytes()) != hipSuccess) {

@@ -669,7 +669,7 @@ def test_wgrad_reads_its_operand_rows_in_place_through_a_row_list(dtype):
 
 @pytest.mark.parametrize("variant", ["valu", "mfma"])
 @pytest.mark.parametrize("B,n,C", [(512, 25, 41), (13, 7, 5), (6, 32, 64), (4, 1, 2), (33, 16, 41), (35, 17, 3),
-                                   (16, 25, 17), (50, 25, 48)])
+                                   (16, 25, 17), (50, 25, 48), (48, 15, 41), (20, 10, 7)])
 def test_seed_level_kernel_vs_fp64(B, n, C, variant):
     """gsage_mean_tail_ce / gsage_mean_tail_mfma = segment mean + both projections + normalize/fc/CE + every
     gradient down to the previous level, against fp64 torch autograd on the same bf16-rounded operands (ragged last
