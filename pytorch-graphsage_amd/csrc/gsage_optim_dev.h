@@ -280,9 +280,11 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             const int64_t ic = i < a.n ? i : i0;
             gv[u] = a.g[ic]; pv[u] = a.p[ic]; mv[u] = a.m[ic]; vv[u] = a.v[ic];
         }
+        float pnew[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + u * stride;
+            pnew[u] = 0.f;
             if (i >= a.n) continue;
             float g = gv[u] * coef;
             if (clipped) a.g[i] = g;                    // clipped gradient stays visible (p.grad)
@@ -293,14 +295,22 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             a.m[i] = m;
             a.v[i] = v;
             a.p[i] = pn;
-            // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch)
-            for (int d = 0; d < a.n_prep; ++d) {
-                const PrepDesc &q = a.prep[d];
-                const int64_t o = i - (q.src - a.p);
-                if (o >= 0 && o < (int64_t)q.rows * q.cols) {
+            pnew[u] = pn;
+        }
+        // operand copies for the next step's GEMMs (replaces a separate k_prep_weights launch).  Descriptor-major:
+        // a descriptor is fetched ONCE per trip (a wave-uniform address in a uniform loop: scalar loads) and tested
+        // against the trip's four elements -- element-major with an early exit it was up to 16 dependent descriptor
+        // fetches per thread at the END of the update's chain, which is the floor of the launch it rides in
+        for (int d = 0; d < a.n_prep; ++d) {
+            const PrepDesc q = a.prep[d];
+            const int64_t base = q.src - a.p, span = (int64_t)q.rows * q.cols;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * stride;
+                const int64_t o = i - base;
+                if (i < a.n && o >= 0 && o < span) {    // (descriptors cover disjoint slices: at most one matches)
                     const int r = (int)(o / q.cols), c = (int)(o - (int64_t)r * q.cols);
-                    prep_store(q, r, c, pn);
-                    break;
+                    prep_store(q, r, c, pnew[u]);
                 }
             }
         }

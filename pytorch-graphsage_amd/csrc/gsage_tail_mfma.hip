@@ -515,6 +515,9 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
     GSAGE_REQUIRE((((uintptr_t)H | (uintptr_t)w2 | (uintptr_t)w2t | (uintptr_t)Wfc | (uintptr_t)agg | (uintptr_t)dE |
                     (uintptr_t)dH) & 15) == 0, "mean_tail_mfma: buffers must be 16-byte aligned");
     GSAGE_REQUIRE(!batch_idx || n_batches > 0, "mean_tail_mfma: bad target queue");
+    GSAGE_REQUIRE((int64_t)B * (1 + n) * TM_D * 2 < ((int64_t)1 << 31) && 2 * 128 * ldw2 * 2 < ((int64_t)1 << 31) &&
+                  2 * TM_D * ldw2t * 2 < ((int64_t)1 << 31),
+                  "mean_tail_mfma: H and the operand copies are addressed with 32-bit buffer offsets (< 2 GiB each)");
     TailMfmaParams p;
     p.H = (const uint16_t *)H; p.w2 = (const uint16_t *)w2; p.w2t = (const uint16_t *)w2t;
     p.Wfc = Wfc; p.bfc = bfc; p.targets = targets; p.batch_idx = batch_idx; p.n_batches = n_batches;
