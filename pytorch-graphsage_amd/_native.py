@@ -361,23 +361,6 @@ class NativeComm(object):
         self._h = None
 
 
-def masked_stream(cu_bits):
-    """HIP stream restricted to the CUs whose indices are in cu_bits -> raw stream handle (int)."""
-    words = (max(cu_bits) + 32) // 32
-    mask = (_u32 * words)()
-    for b in cu_bits:
-        mask[b // 32] |= 1 << (b % 32)
-    h = _vp()
-    check(lib().gsage_stream_create_masked(mask, words, ctypes.byref(h)), "stream_create_masked")
-    return h.value
-
-
-def new_event():
-    h = _vp()
-    check(lib().gsage_event_create(ctypes.byref(h)), "event_create")
-    return h.value
-
-
 def device_info():
     arch = ctypes.create_string_buffer(64)
     cu, ws = _int(0), _int(0)

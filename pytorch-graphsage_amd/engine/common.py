@@ -62,7 +62,7 @@ class FusedTrainStep(object):
     checkpointing keep working.  `__call__(ids, targets)` has the contract of train_step;
     `load_epoch()` + `step_queue()` walk a device-resident queue of seed batches with no host copies."""
 
-    MEAN_ENGINE = False       # FusedMeanTrainStep only: seed-level kernel, split mode, gathers split around the exchange
+    MEAN_ENGINE = False       # FusedMeanTrainStep only: seed-level kernel, gathers cut around the exchange
     ROW_HIST = 1 << 15        # updates whose constants are kept for deferred table rows (sync_rows() before it wraps)
 
     # ---- which (model, feature store) pairs an engine covers ----------------------------------------
@@ -149,11 +149,9 @@ class FusedTrainStep(object):
         return None
 
     def __init__(self, model, feats, loss_fn, example_ids, example_targets, ddp=None, capture=True,
-                 warmup=2, pipelined=False, gather_cus=None, eval_only=False):
-        """gather_cus (queue mode, single GPU, command lists): run the weight-independent half of the step
-        -- sampling of batch i+2 and the level-0 gathers of batch i+1 -- on a stream restricted to that many
-        compute units while the forward / backward / update chain of batch i runs on a stream restricted
-        to the others (see _split_* below).  None: GSAGE_GATHER_CUS from the environment, else off."""
+                 warmup=2, pipelined=False, eval_only=False):
+        """capture: "cmdlist" (or True) / "graph" / False; pipelined: two batches in flight on two streams (Philox
+        sampler only); eval_only: the forward launches over the validation sampler (evaluate_fold)."""
         if not type(self).supports(model, feats, ddp):
             raise ValueError("%s does not cover this (model, feature store): %s"
                              % (type(self).__name__, type(self).why_not(model, feats, ddp)))
@@ -163,14 +161,11 @@ class FusedTrainStep(object):
         if not (torch.is_tensor(example_targets) and example_targets.is_cuda
                 and int(example_targets.shape[0]) == int(example_ids.shape[0])):
             raise ValueError("example_targets must be a CUDA tensor with one row per seed")
-        if gather_cus is None:
-            gather_cus = int(os.environ.get("GSAGE_GATHER_CUS", "0"))
         # eval_only: the engine's FORWARD launches over the model's VALIDATION sampler (models.py:41-44: the full
         # graph, n_val_samples), for train.evaluate's folds (evaluate_fold below).  The Parameters stay where they are
         # (a training engine's bucket, FlatAdam's, or their own storage): only the operand copies are this engine's.
         self.eval_only = bool(eval_only)
         assert not (self.eval_only and (ddp is not None or pipelined)), "eval_only: single process, sequential"
-        self.gather_cus = int(gather_cus) if (ddp is None and not pipelined and self.MEAN_ENGINE and not eval_only) else 0
         self._init_common(model, feats, loss_fn, example_ids, example_targets, ddp, pipelined)
         self._init_levels(example_ids, example_targets)
         self._init_head(loss_fn, example_targets)
@@ -733,7 +728,7 @@ class FusedTrainStep(object):
         Four launches per step instead of five at BASELINE configs[1].  Not with a process group (the exchange
         wants the flat bucket), a trainable table (its gradient is scatter-added), or more partial buffers per
         element than the update can sum inside its launch without becoming its longest role.  Every launch mode of
-        an engine takes the same path (per call, queue, pipelined, split): their results stay bit-identical.
+        an engine takes the same path (per call, queue, pipelined): their results stay bit-identical.
         GSAGE_FOLD_FINALIZE: 0 (default) = never, 1 = the mean engine, all = every engine that qualifies.
         OPT-IN, because it measured slower on the MI355X: inside the launch that also
         gathers, an update workgroup's six to eight dependent rounds of partial loads (16 in flight per lane is what
@@ -815,16 +810,10 @@ class FusedTrainStep(object):
     def _tail_gather_rows(self):
         return 0
 
-    def _side_gather_rows(self):
-        return 0
-
-    def _k5_gather_rows(self):
-        return 0
-
     def _ahead_rows(self):
         """rows of the next batch's last-hop means that launches of the CURRENT step gather (the seed-level launch's
         and the level-0 projection's gather roles, the side section): the gather launch skips them"""
-        return self._tail_rows + getattr(self, "_k5_rows", 0) + getattr(self, "_side_rows", 0)
+        return self._tail_rows
 
     def _queue_compute_body(self, par):
         self._stage_compute(self._qset(par))
@@ -1262,7 +1251,6 @@ class FusedTrainStep(object):
         if lr != getattr(self, "_lr_host", None):      # (a constant schedule costs no launch per batch)
             self._lr_host = lr
             self.lr.fill_(lr)
-            self._user_dirty = True       # split mode: the chain stream must see this write
 
     def set_sel(self, sels):
         """Replace the Philox draws of the sampler by caller-supplied ones for the following steps
@@ -1314,8 +1302,7 @@ class FusedTrainStep(object):
                              % (self.B, targets_epoch.dtype, tuple(targets_epoch.shape)))
         if not (ids_epoch.is_cuda and targets_epoch.is_cuda):
             raise ValueError("the epoch queue lives in HBM: pass CUDA tensors")
-        # the previous epoch's last launches (in split mode: on the CU-masked gather stream, which the caller's
-        # stream never waits for) still tick the sampler counters and write the frontier buffers zeroed below
+        # the previous epoch's last launches still tick the sampler counters and write the frontier buffers zeroed below
         torch.cuda.synchronize()
         tq = targets_epoch.reshape(n_batches, self.B).contiguous()
         self.queue = (ids_epoch.contiguous(), tq, n_batches)
@@ -1340,17 +1327,10 @@ class FusedTrainStep(object):
         # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
         # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
-        self.split = bool(self.gather_cus and self.capture_mode == "cmdlist" and self.ddp is None)
-        self._tail_rows = 0 if self.split else self._tail_gather_rows()
-        self._k5_rows = self._k5_gather_rows() if self._tail_rows else 0
-        self._side_rows = self._side_gather_rows() if self._tail_rows else 0
-        if (self._tail_rows or self.split) and len(self.xa0_set) == 1:
-            self.xa0_set = [self.xa0_set[0], torch.zeros_like(self.xa0_set[0])]
-        while (self._tail_rows or self.split) and len(self.xa0_set) < self.P:
+        self._tail_rows = self._tail_gather_rows()
+        while self._tail_rows and len(self.xa0_set) < self.P:
             self.xa0_set.append(torch.zeros_like(self.xa0_set[0]))
         self._front_ready, self._qstep = False, 0
-        if self.split:
-            self._split_setup()
         self._record_queue()
         return self
 
@@ -1361,12 +1341,6 @@ class FusedTrainStep(object):
         self._ddp_split = bool(self.ddp is not None and self.MEAN_ENGINE and not self.emb and
                                self.size[self.L - 1] > self._tail_rows and
                                os.environ.get("GSAGE_DDP_SPLIT", "1") == "1")
-        if getattr(self, "split", False):
-            torch.cuda.synchronize()
-            self.g_prime = self._record(self._split_prime)
-            self.g_qfront = [self._record(lambda par=par: self._split_front(par)) for par in range(2)]
-            self.g_queue = [self._record(lambda par=par: self._split_chain(par)) for par in range(2)]
-            return
         if self.g_main is not None:
             torch.cuda.synchronize()
             self.g_prime = self._record(self._queue_prime)
@@ -1414,7 +1388,7 @@ class FusedTrainStep(object):
         if self.queue is not None:
             par = (self._qstep - 1) % getattr(self, "P", 2)
             cl = self.g_queue[par].cl
-            front = self.g_qfront[par].cl if getattr(self, "split", False) else cl
+            front = cl
         else:
             cl = front = self.g_main[0].cl
         out = {}
@@ -1531,8 +1505,6 @@ class FusedTrainStep(object):
         gathers batch 0."""
         assert self.queue is not None, "call load_epoch() first"
         self._rows_tick()
-        if getattr(self, "split", False):
-            return self._step_queue_split()
         rec = self.g_queue is not None
         if not self._front_ready:
             if rec:

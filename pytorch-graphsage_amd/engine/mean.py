@@ -122,9 +122,8 @@ class FusedMeanTrainStep(FusedTrainStep):
         # K5 and K5b read the x rows of level 0 in place through the frontier's row list (gsage_linear_nt_packed
         # a_rows / gsage_wgrad_desc.a_rows) instead of from xa0[0]: no row copies in the gather launch (28.5 vs
         # 32.9 us in-step, 0.092 vs 0.095 ms/step at config 2; GSAGE_MEAN_INPLACE_X=0 brings the copies back)
-        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.L >= 2 and not self.emb and
-                          not getattr(self, "gather_cus", 0))         # (split mode keeps frontier rings of its own;
-        #                                                                one level: the copies ARE the "rest" launch
+        self.inplace_x = (os.environ.get("GSAGE_MEAN_INPLACE_X", "1") == "1" and self.L >= 2 and not self.emb)
+        #                                                               (one level: the copies ARE the "rest" launch
         #                                                                that carries Adam in data-parallel runs)
         self.agg, self.hout, self.dc, self.dg = [], [], [], []
         for l in range(L):
@@ -174,7 +173,7 @@ class FusedMeanTrainStep(FusedTrainStep):
             return sum((ops.wgrad_plan(m, nt, k, t)[1]) * ((nt + 127) // 128) * ((k + 127) // 128)
                        for (m, nt, k), t in zip(shapes, targets))
         cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
-        balanced = n_wg(plain) > cus and not self.gather_cus
+        balanced = n_wg(plain) > cus
         self.wg_target = dict(zip(order, ops.wgrad_balance(shapes, budget=cus - 8) if balanced else plain))
         for l in range(L):
             h, din, R = self.h[l], self.din[l], self.rows[l]
@@ -198,11 +197,8 @@ class FusedMeanTrainStep(FusedTrainStep):
             self._init_emb_optimizer()
 
     def _wg_target(self):
-        """K5b workgroups to plan for: the chip, or the chain's share of it in split mode."""
-        if not self.gather_cus:
-            return 240
-        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
-        return max(32, n_cu - self.gather_cus - 8)
+        """K5b workgroups to plan for: the chip (one workgroup fits per CU)"""
+        return 240
 
     def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0, part=None, adam=None, stop_rows=None):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
@@ -248,10 +244,6 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.emb:
             self._cur_ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
             self._prep_forward(s)
-        side_at = os.environ.get("GSAGE_SIDE_AT", "tail")
-        side = self._side_job if (self._in_list and getattr(self, "_side_job", None)) else None
-        if side is not None and side_at == "k5":
-            self._side_section(side)
         for l in range(L - 1 if self.fused_tail else L):
             R, h, din = self.rows[l], self.h[l], self.din[l]
             rows = None
@@ -275,11 +267,8 @@ class FusedMeanTrainStep(FusedTrainStep):
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
             if self.wp[l] is not None:
-                if l == 0 and getattr(self, "_k5_gather", None) is not None:
-                    # the projection's spare workgroup slots gather part of the NEXT batch's last-hop means
-                    nat.check(lib.gsage_gather_role_next(ctypes.addressof(self._k5_gather)), "gather_role_next")
-                elif l == 0 and getattr(self, "_k5_hops", None) is not None:
-                    # ... or sample the frontier of the batch after the next
+                if l == 0 and getattr(self, "_k5_hops", None) is not None:
+                    # the projection's spare workgroup slots sample the frontier of the batch after the next
                     nat.check(lib.gsage_hops_role_next(ctypes.addressof(self._k5_hops)), "hops_role_next")
                 if l == 0:
                     self._time_next(4, 5)
@@ -297,9 +286,6 @@ class FusedMeanTrainStep(FusedTrainStep):
         if self.fused_tail:
             C = m.fc.weight.shape[0]
             tg = self.queue[1] if self.queue else self.tg_set[s].view(-1)
-            self._side_join("k5")
-            if side is not None and side_at == "tail":
-                self._side_section(side)
             self._time_next(2, 3)
             self._head_live_rows()
             args = (self.hout[L - 2].data_ptr(), B, self.fan[1], self.w2[L - 1].data_ptr(),
@@ -313,7 +299,6 @@ class FusedMeanTrainStep(FusedTrainStep):
                 nat.check(lib.gsage_mean_tail_mfma(*args, stream), "mean_tail_mfma")
             else:
                 nat.check(lib.gsage_mean_tail_ce(*args, self.code, stream), "mean_tail_ce")
-            self._side_join("tail")
         else:
             self._stage_head(s)
         if self.eval_only:
@@ -378,89 +363,16 @@ class FusedMeanTrainStep(FusedTrainStep):
                 self._wgrad_ticks()
                 self._time_next(6, 7)
             ops.wgrad_multi(probs[i:i + 8])
-        self._side_join("k5b")
         self._stage_finalize(s)
-        self._side_join("fin")
-
-    def _side_section(self, side):
-        """A second gather of the NEXT batch's last-hop means as a kernel of its own on the command list's side
-        stream, concurrent with the main-stream launches that follow until _side_join: GSAGE_SIDE_AT = "k5" (beside
-        the level-0 projection, whose LDS-DMA rings tolerate latency) or "tail" (beside the seed-level launch, whose
-        workgroups hold one 384-register wave per SIMD and leave their CU's memory pipes idle -- but whose chain of
-        dependent loads then queues behind the gather's requests: measured SLOWER)."""
-        lib = nat.lib()
-        nat.check(lib.gsage_cmdlist_side_begin(), "cmdlist_side_begin")
-        self._stage_gather(side[0], ids=side[1], part="means", skip_rows=side[2], stop_rows=side[3])
-        nat.check(lib.gsage_cmdlist_side_end(), "cmdlist_side_end")
-        self._side_pending = True
-
-    def _side_join(self, point):
-        """the main stream waits for the side section (see _stage_compute) at the point GSAGE_SIDE_JOIN names:
-        after the seed-level launch (default), after K5b, or after the finalisation"""
-        if getattr(self, "_side_pending", False) and os.environ.get("GSAGE_SIDE_JOIN", "tail") == point:
-            nat.check(nat.lib().gsage_cmdlist_join(), "cmdlist_join")
-            self._side_pending = False
-
-    # ---- split mode: gathers and chain side by side on disjoint halves of the chip ------------------
-    # The level-0 gathers of batch i+1 (170 MB of HBM reads, no weights involved) and the chain of batch i
-    # (K5 -> seed level -> K5b -> finalise -> Adam: ~65 us of latency-bound launches that move little)
-    # want different things from the chip, and on one stream they can only take turns.  Two streams
-    # alone do not help (tools/overlap2_check.py, round 1): the chain's kernels own their CUs through
-    # registers / LDS and a gather squeezed in beside them runs at a fraction of its bandwidth.  So each
-    # gets CUs of its own (hipExtStreamCreateWithCUMask): `gather_cus` for the gathers (they need ~96
-    # to finish inside the chain's time), the rest for the chain.  Per step: the gather stream waits
-    # for chain(i-1) (whose K5 / K5b read the operand buffers it is about to overwrite), gathers batch
-    # i+1 and samples batch i+2; the chain stream waits for the gathers of batch i.  The sampler reads
-    # counters of its own, advanced on the gather stream (the chain's finalisation ticks the step's).
-    def _split_setup(self):
-        assert not self.dense, "split mode samples inside the gather launch (CSR sampler only)"
-        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)
-        assert 16 <= self.gather_cus <= n_cu - 32, "gather_cus out of range"
-        if getattr(self, "_sG", None) is None:
-            self._sG = nat.masked_stream(range(self.gather_cus))
-            self._sC = nat.masked_stream(range(self.gather_cus, n_cu))
-            self._evG = [nat.new_event() for _ in range(2)]
-            self._evC = [nat.new_event() for _ in range(2)]
-            self.g_ctr = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            self.g_bidx = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.g_ctr.zero_()
-        self.g_bidx.zero_()
-        self._user_dirty = True
-
-    def _split_prime(self):
-        c = (self.g_ctr, self.g_bidx)
-        self._stage_sample(0, ids=self.ids_q[0], counters=c)
-        self._stage_sample(0, ids=self.ids_q[1], ahead=True, counters=c)
-        self._stage_gather(0, ids=self.ids_q[0])
-        self._split_tick(2)
-
-    def _split_tick(self, n):
-        lib, st = nat.lib(), ops._stream()
-        nat.check(lib.gsage_counter_add(self.g_ctr.data_ptr(), n * self.L, st), "counter_add")
-        nat.check(lib.gsage_counter_add(self.g_bidx.data_ptr(), n, st), "counter_add")
-
-    def _split_front(self, par):
-        """gather stream, step i (par = i % 2): gathers of batch i+1 || sampling of batch i+2."""
-        self._time_next(0, 1)
-        self._stage_gather(1 - par, ids=self.ids_q[1 - par],
-                           hops=self._hops_desc(self.ids_q[par], False, (self.g_ctr, self.g_bidx)))
-        self._split_tick(1)
-
-    def _split_chain(self, par):
-        """chain stream, step i: everything that needs the current weights, then the update."""
-        self._tail_gather = None
-        self._stage_compute(par)
-        self._stage_opt()
 
     def gather_launch_rows(self):
         """(rows the queue-mode gather launch reads, rows the seed-level launch's gather role reads) per
         step: every sampled frontier row is read exactly once, by one of the two."""
         total = self.off[self.L + 1]
         tail = self._tail_rows * self.fan[self.L]
-        side = (getattr(self, "_side_rows", 0) + getattr(self, "_k5_rows", 0)) * self.fan[self.L]
         if getattr(self, "inplace_x", False):          # K5 / K5b read the x rows themselves
             total -= self.rows[0]
-        return total - tail - side, tail
+        return total - tail, tail
 
     def _tail_gather_rows(self):
         """Rows of the last hop's neighbour means that the seed-level launch of the previous step
@@ -482,24 +394,6 @@ class FusedMeanTrainStep(FusedTrainStep):
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
-
-    def _k5_gather_rows(self):
-        """Rows of the last hop's neighbour means that the gather role of the level-0 projection's launch takes
-        (0: none): GSAGE_K5_GATHER_FRAC of the hop (the packed K5 with the ReLU epilogue, fan-out 5 or 10)."""
-        if self.wp[0] is None or self.L < 2 or self.fan[self.L] not in (5, 10) or self.emb:
-            return 0
-        frac = float(os.environ.get("GSAGE_K5_GATHER_FRAC", "0.0"))
-        left = int(self.size[self.L - 1]) - self._tail_rows
-        return max(0, min(left, int(frac * self.size[self.L - 1])))
-
-    def _side_gather_rows(self):
-        """Rows of the last hop's neighbour means gathered by the side section that runs beside the seed-level
-        launch (0: none): GSAGE_SIDE_GATHER_FRAC of the hop, single-GPU queue mode on command lists."""
-        if self.ddp is not None or self.capture_mode != "cmdlist" or self.split:
-            return 0
-        frac = float(os.environ.get("GSAGE_SIDE_GATHER_FRAC", "0.0"))
-        left = int(self.size[self.L - 1]) - self._tail_rows - self._k5_rows
-        return max(0, min(left, int(frac * self.size[self.L - 1])))
 
     def _k1_early(self):
         """data-parallel order: K1(i+2) rides in the launch that gathers the bulk of batch i+1 WHILE the exchange is in
@@ -531,12 +425,10 @@ class FusedMeanTrainStep(FusedTrainStep):
         in the launch that carries the update?  OPT-IN (GSAGE_K1_IN_K5=1): measured on the MI355X (round 5, DESIGN.md
         section 5) the launch that carries the update gets 1.6 us shorter (16.2 -> 14.6: what is left is the update's
         own chain) and the projection 2.8 us longer (14.0 -> 16.8: the sampler's 171 workgroups hold slots its 416
-        want) -- 0.0846 against 0.0835 ms/step.  Needs the packed ReLU projection at level 0, a CSR sampler, one GPU,
-        no split mode; a ring of three frontier buffers (K5 / K5b of step i still read batch i's as their row list)."""
+        want) -- 0.0846 against 0.0835 ms/step.  Needs the packed ReLU projection at level 0, a CSR sampler, one GPU;
+        a ring of three frontier buffers (K5 / K5b of step i still read batch i's as their row list)."""
         return bool(self.wp and self.wp[0] is not None and self.L >= 2 and not self.dense and not self.emb and
-                    self.ddp is None and not getattr(self, "split", False) and not self.gather_cus and
-                    float(os.environ.get("GSAGE_K5_GATHER_FRAC", "0.0")) == 0.0 and      # (one role per launch)
-                    os.environ.get("GSAGE_K1_IN_K5", "0") == "1")
+                    self.ddp is None and os.environ.get("GSAGE_K1_IN_K5", "0") == "1")
 
     def _queue_compute_body(self, par):
         nx = self._nx(par)
@@ -550,47 +442,9 @@ class FusedMeanTrainStep(FusedTrainStep):
             d.ld, d.out_ld, d.D, d.rows = st.ld, st.ld, st.dim, self._tail_rows
             d.n, d.n_workgroups = self.fan[L], self._tail_wgs
             self._tail_gather = d
-            t0 = self._tail_rows
-            if self._k5_rows:
-                k = nat.TailGatherDesc()
-                k.table, k.ids = st.data.data_ptr(), nxt[self.off[L] + t0 * self.fan[L]:].data_ptr()
-                k.out = self.xa0_set[nx][1][self.off[L - 1] + t0:].data_ptr()
-                k.ld, k.out_ld, k.D, k.rows = st.ld, st.ld, st.dim, self._k5_rows
-                k.n, k.n_workgroups = self.fan[L], 1
-                self._k5_gather = k
-                t0 += self._k5_rows
-            if self._side_rows:
-                self._side_job = (nx, nxt, t0, t0 + self._side_rows)
         try:
             self._stage_compute(self._qset(par))
-            if self._side_rows and not self._in_list:      # (eager launching: the same rows, on the main stream)
-                t1 = self._tail_rows + self._k5_rows
-                self._stage_gather(nx, ids=self.ids_q[nx], part="means", skip_rows=t1,
-                                   stop_rows=t1 + self._side_rows)
         finally:
             self._tail_gather = None
-            self._k5_gather = None
-            self._side_job = None
             self._k5_hops = None
 
-    def _step_queue_split(self):
-        user = torch.cuda.current_stream()
-        if not self._front_ready:
-            self.g_prime.replay()                       # on the caller's stream, once per epoch
-            torch.cuda.synchronize()
-            self._front_ready = True
-        i = self._qstep
-        par = i % 2
-        self._qstep += 1
-        if self._user_dirty:                            # e.g. set_progress wrote the learning rate
-            ev = torch.cuda.Event()
-            ev.record(user)
-            for h in (self._sC, self._sG):
-                torch.cuda.ExternalStream(h).wait_event(ev)
-            self._user_dirty = False
-        vp = ctypes.c_void_p
-        nat.check(nat.lib().gsage_cmdlist_replay_pair(
-            self.g_qfront[par].cl._h, vp(self._sG), vp(self._evC[1 - par]) if i > 0 else None, vp(self._evG[par]),
-            self.g_queue[par].cl._h, vp(self._sC), vp(self._evG[1 - par]) if i > 0 else None, vp(self._evC[par]),
-            vp(user.cuda_stream), 1), "cmdlist_replay_pair")
-        return self.preds

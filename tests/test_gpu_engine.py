@@ -285,41 +285,6 @@ def test_captured_autograd_engine_runs_and_advances_samples():
     assert int(eng.counter.item()) == 4
 
 
-@pytest.mark.parametrize("B,fans", [(40, (25, 10)), (24, (4, 3, 5))])
-def test_split_mode_equals_single_stream(B, fans):
-    """gather_cus: the gathers of batch i+1 / sampling of batch i+2 on a CU-masked stream, the chain of batch
-    i on the complementary one (engine._split_*).  Same kernels on the same data in the same order per
-    stream, so the results are those of the plain per-call engine built with the same K5b plan, bit for bit,
-    across the queue's wrap-around."""
-    adj, feats, rng = _problem(seed=8)
-    D, C, dims = feats.shape[1], 5, (128,) * len(fans)
-    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
-    ids_all = torch.from_numpy(rng.randint(1, adj.shape[0], size=(3, B))).to(DEV)
-    tg_all = torch.from_numpy(rng.randint(0, C, size=(3, B, 1))).to(DEV)
-    res = []
-    for queued in (False, True):
-        model = _model(adj, D, C, dims, fans)
-        eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids_all[0], tg_all[0],
-                                           capture="cmdlist", gather_cus=96)
-        preds = []
-        if queued:
-            eng.load_epoch(ids_all, tg_all)
-            assert eng.split
-            for k in range(7):
-                if k == 3:
-                    eng.set_progress(0.5)            # a write from the caller's stream between steps
-                preds.append(eng.step_queue().clone())
-        else:
-            for k in range(7):
-                if k == 3:
-                    eng.set_progress(0.5)
-                preds.append(eng(ids_all[k % 3], tg_all[k % 3]).clone())
-        torch.cuda.synchronize()
-        res.append((torch.stack(preds), eng.flat_p.clone()))
-        model.train_sampler.csr(DEV).check()
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
 def test_engine_hands_its_adam_state_back_to_train_step_and_checkpoints():
     """An engine trains three steps, then GSSupervised.train_step takes the Parameters back: FlatAdam must continue
     from the engine's exp_avg / exp_avg_sq / step count (the moments used to restart from zero), and
@@ -355,54 +320,3 @@ def test_engine_hands_its_adam_state_back_to_train_step_and_checkpoints():
     pickle.dumps(model.state_dict())
 
 
-@pytest.mark.parametrize("mode", [False, "cmdlist"])
-def test_projection_launch_gather_role_equals_the_plain_step(monkeypatch, mode):
-    """Queue mode with part of the next batch's last-hop means gathered by the spare workgroup slots of the level-0
-    projection's launch (gsage_gather_role_next, GSAGE_K5_GATHER_FRAC): the same rows, the same arithmetic, in
-    another launch -- predictions and weights after eight steps are bit-identical to the plain step."""
-    adj, feats, rng = _problem(n=900, D=64)
-    D, C, B = feats.shape[1], 5, 64
-    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
-    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(10, B))).to(DEV)
-    tg = torch.from_numpy(rng.randint(0, C, size=(10, B))).to(DEV)
-    outs = []
-    monkeypatch.setenv("GSAGE_TAIL_GATHER_FRAC", "0.005")         # (so that the seed-level launch leaves rows over)
-    for frac in ("0", "0.4"):
-        monkeypatch.setenv("GSAGE_K5_GATHER_FRAC", frac)
-        m = _model(adj, D, C, (128, 128), (25, 10))
-        eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1),
-                                           capture=mode)
-        eng.load_epoch(ids, tg)
-        assert eng._tail_rows > 0 and (eng._k5_rows > 0) == (frac != "0") and eng.wp[0] is not None
-        preds = torch.stack([eng.step_queue().clone() for _ in range(8)])
-        torch.cuda.synchronize()
-        outs.append((preds, eng.flat_p.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
-@pytest.mark.parametrize("join", ["tail", "fin"])
-def test_side_section_gather_equals_the_single_stream_step(monkeypatch, join):
-    """Queue mode with part of the next batch's last-hop means gathered by a kernel of its own on the command
-    list's side stream, beside the seed-level launch (GSAGE_SIDE_GATHER_FRAC; cmdlist side sections): the same
-    rows, the same arithmetic, another stream -- predictions and weights after eight steps are bit-identical to the
-    single-stream step, and the launch count says the side kernel ran."""
-    adj, feats, rng = _problem(n=900, D=40)
-    D, C, B = feats.shape[1], 5, 64
-    store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
-    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(10, B))).to(DEV)
-    tg = torch.from_numpy(rng.randint(0, C, size=(10, B))).to(DEV)
-    outs = []
-    for frac in ("0", "0.3"):
-        monkeypatch.setenv("GSAGE_SIDE_GATHER_FRAC", frac)
-        monkeypatch.setenv("GSAGE_SIDE_JOIN", join)
-        monkeypatch.setenv("GSAGE_TAIL_GATHER_FRAC", "0.005")      # (so that the seed-level launch leaves rows over)
-        m = _model(adj, D, C, (128, 128), (25, 10))
-        eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1))
-        eng.load_epoch(ids, tg)
-        assert eng._tail_rows > 0 and (eng._side_rows > 0) == (frac != "0")
-        before = gs._native.launch_count()
-        preds = torch.stack([eng.step_queue().clone() for _ in range(8)])
-        torch.cuda.synchronize()
-        outs.append((preds, eng.flat_p.clone(), gs._native.launch_count() - before))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert outs[1][2] == outs[0][2] + 8                       # one more kernel per step
