@@ -126,12 +126,19 @@ class FusedTrainStep(object):
         return None
 
     @staticmethod
-    def _why_not_input(model, feats, ddp=None):
-        """Level-0 rows: an identity prep over a FeatureStore in HBM, or the trainable node-embedding prep without
-        features (BASELINE configs[3] / utils/pokec.sh: nn_modules.py:126-155)."""
+    def _why_not_input(model, feats, ddp=None, concat_ok=False):
+        """Level-0 rows: an identity prep over a FeatureStore in HBM, or the trainable node-embedding prep
+        (nn_modules.py:126-155) -- without features (BASELINE configs[3] / utils/pokec.sh) or, where the engine says
+        concat_ok, concatenated behind them (nn_modules.py:152-153: [feats | fc(embedding)])."""
         if isinstance(model.prep, NodeEmbeddingPrep):
-            if feats is not None or model.prep.input_dim:
-                return "a node-embedding prep concatenated with features"
+            if (feats is None) != (not model.prep.input_dim):
+                return "a node-embedding prep whose input_dim disagrees with the features it is given"
+            if feats is not None:
+                if not concat_ok:
+                    return "a node-embedding prep concatenated with features"
+                if not isinstance(feats, FeatureStore) or not feats.is_cuda or feats.dim != int(model.prep.input_dim) \
+                        or feats.dtype not in (torch.bfloat16, torch.float32):
+                    return "features beside the node embedding that are not a bf16 / fp32 FeatureStore in HBM"
             if model.prep.embedding_dim % 8 != 0 or not model.prep.embedding.weight.is_cuda:
                 return "an embedding width that is not a multiple of 8, or a table that is not in HBM"
             if ddp is not None and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") == "1":
@@ -194,6 +201,9 @@ class FusedTrainStep(object):
         self.nset = 2 if self.pipelined else 1
         # trainable node-embedding prep: the level-0 rows are weights (computed per step from the current table)
         self.emb = isinstance(model.prep, NodeEmbeddingPrep)
+        # ... E columns wide, behind the D0 feature columns of the row when the problem has features too
+        self.E = int(model.prep.embedding_dim) if self.emb else 0
+        self.D0 = int(feats.dim) if (self.emb and feats is not None) else 0
         self.lazy_rows = self.emb and os.environ.get("GSAGE_DENSE_TABLE_ADAM", "0") != "1" and not self.eval_only
         # the step's collectives: issued by the library (RCCL through gsage_comm_*, a node of the step's list) when the
         # handle carries a native communicator, else torch.distributed (gloo in the tests) through a host-call node
@@ -949,15 +959,20 @@ class FusedTrainStep(object):
     # =================================================================================================
     # Trainable node-embedding prep (reference nn_modules.py:126-155; BASELINE configs[3], utils/pokec.sh).
     # The level-0 rows are prep.fc(embedding[ids]) -- computed at the start of the step from the CURRENT table,
-    # their gradient scattered back into the table's (dense) gradient at the end.  Shared by the mean and the
+    # their gradient scattered back into the table's (dense) gradient at the end.  A problem WITH features
+    # (nn_modules.py:152-153) has rows [features (D0 columns) | prep.fc(embedding) (E columns)]: the feature columns
+    # are copied beside the prep's output each step, and only columns [D0, D0 + E) of the level-0 input gradient
+    # are formed (the features take none).  Shared by the mean and the
     # attention engines; a subclass calls _init_emb() from _init_levels, adds _emb_wgrad_problem() to its K5b
     # problems of level 0, forms the level-0 input gradient (din0f / din0) and hands over to _prep_backward().
     # =================================================================================================
     def _init_emb(self, copies):
         """copies(parameter, need_transposed) -> (operand copy, transposed copy): the subclass's operand-copy factory
-        (it also records the refresh descriptor).  Allocates the prep's work buffers; ld0 = self.ldin[0]."""
+        (it also records the refresh descriptor).  Allocates the prep's work buffers."""
         prep, dev, T, f32 = self.model.prep, self.dev, self.tdt, torch.float32
-        RA0, E, ld0 = self.off[self.L + 1], int(prep.embedding_dim), self.ldin[0]
+        RA0, E = self.off[self.L + 1], self.E
+        ld0 = self.ldE = -(-E // 8) * 8 if T == torch.bfloat16 else E          # (the prep's own operands: E wide)
+        assert self.din[0] == self.D0 + E and tuple(prep.fc.weight.shape) == (E, E)
         self.wprep, self.wprepT = copies(prep.fc.weight, True)   # (operand copies of prep.fc.weight)
         self.table = prep.embedding.weight                 # a view of the flat parameter bucket
         assert self.pidx[id(self.table)] == 0 and self.table.shape[1] == E and self.table.numel() % 4 == 0
@@ -973,12 +988,12 @@ class FusedTrainStep(object):
 
     def _emb_wgrad_problem(self):
         """(dC, A, lda, M, Ntot, K, parameter, row list) of the prep's affine: d out^T x embedding rows"""
-        E = self.din[0]
+        E = self.E
         return (self.din0, self.eraw, self.eraw.stride(0), self.off[self.L + 1], E, E, self.model.prep.fc.weight, None)
 
     def _emb_reduce_desc(self):
         """finalisation source of prep.fc.bias (column sums of the level-0 input gradient)"""
-        E = self.din[0]
+        E = self.E
         ib = self.pidx[id(self.model.prep.fc.bias)]
         return _ReduceDesc(self.bpart.data_ptr(), E, self.poff[ib], self.bpart.shape[0], 1, E, E)
 
@@ -994,7 +1009,7 @@ class FusedTrainStep(object):
             return
         # a step touches its frontier's rows, everything else is replayed -- bit for bit -- when it is next read
         # (sync_rows: GSSupervised.forward, state_dict, another optimizer / engine taking the Parameters)
-        n_rows, E = int(self.table.shape[0]), self.din[0]
+        n_rows, E = int(self.table.shape[0]), self.E
         i32 = torch.int32
         self.row_last = torch.zeros(n_rows, dtype=i32, device=dev)
         self.row_seen = torch.zeros(n_rows, dtype=i32, device=dev)
@@ -1039,7 +1054,7 @@ class FusedTrainStep(object):
 
     def _prep_forward(self, s):
         lib, stream, prep = nat.lib(), ops._stream(), self.model.prep
-        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.din[0]
+        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.E
         tab = self.table
         if self.lazy_rows:       # the rows this step reads, brought up to the last update
             nat.check(lib.gsage_rows_catch_up(ctypes.byref(self.row_desc), self.seed_rows.data_ptr(), 1,
@@ -1047,15 +1062,19 @@ class FusedTrainStep(object):
         # fp32 table rows -> the operand type in the gather itself (seeds read the spare row n_nodes)
         segs = [(tab, self.seed_rows, self.eraw[:B], B, 1), (tab, ids[B:RA0], self.eraw[B:], RA0 - B, 1)]
         ops.gather_mean_multi(segs, E, E, self.eraw.stride(0))
+        g0 = self.g0_set[s]
+        if self.D0:              # [features | ...]: the frontier's feature rows (whole 16-byte chunks: before the affine)
+            st = self.store
+            ops.gather_mean_multi([(st.data, ids[:RA0], g0, RA0, 1)], st.ld, st.dim, self.ldin[0])
         ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wprep.data_ptr(), self.wprep.shape[1],
-                           prep.fc.bias.data_ptr(), self.g0_set[s].data_ptr(), self.ldin[0], RA0, E, E, nat.ACT_NONE, 1,
-                           0, 0, 0, self.code, self.code)
+                           prep.fc.bias.data_ptr(), g0.data_ptr() + self.D0 * self.esz, self.ldin[0], RA0, E, E,
+                           nat.ACT_NONE, 1, 0, 0, 0, self.code, self.code)
 
     def _prep_backward(self, s):
         """level 0's input gradient (din0f fp32, din0 = its operand copy; formed by the subclass) -> prep.fc (weight:
         a K5b problem of level 0; bias: column sums) -> the table's gradient."""
         lib, stream = nat.lib(), ops._stream()
-        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.din[0]
+        ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.E
         nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
                                             self.bpart.shape[0], stream), "colsum_partials")
         ops._linear_launch(self.din0.data_ptr(), self.din0.stride(0), None, 0, self.wprepT.data_ptr(), self.wprepT.shape[1],
@@ -1074,7 +1093,7 @@ class FusedTrainStep(object):
     def _stage_opt_emb(self):
         lib, stream = nat.lib(), ops._stream()
         d = self._adam_desc()
-        nt, B, RA0, E = self.n_tab, self.B, self.off[self.L + 1], self.din[0]
+        nt, B, RA0, E = self.n_tab, self.B, self.off[self.L + 1], self.E
         g = self._grad_slice(self.table)
         n_all = self.n_partial + self.n_tab_partial
         if self.lazy_rows:

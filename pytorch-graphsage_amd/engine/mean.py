@@ -49,7 +49,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         # bf16 storage = the production path; fp32 storage = the exact-arithmetic parity mode (same engine, same
         # kernel sources instantiated on fp32: golden fixtures replay at 2e-4).  With the node-embedding prep
         # (utils/pokec.sh:5-13) the level-0 rows are weights: computed per step, nothing is gathered ahead.
-        why = cls._why_not_common(model, feats, (MeanAggregator,), "mean") or cls._why_not_input(model, feats, ddp)
+        why = cls._why_not_common(model, feats, (MeanAggregator,), "mean") or cls._why_not_input(model, feats, ddp, concat_ok=True)
         if why:
             return why
         if not all(l.output_dim_ % 8 == 0 for l in model.agg_layers.children()):
@@ -62,9 +62,9 @@ class FusedMeanTrainStep(FusedTrainStep):
         model, feats, dev, L, B = self.model, self.store, self.dev, self.L, self.B
         # ---- per-level shapes, operand copies and work buffers ------------------------------
         self.h = [l.output_dim_ for l in self.layers]
-        if self.emb:                                              # level-0 rows = prep.fc(embedding[ids])
-            E = int(model.prep.embedding_dim)
-            d0, ld0 = E, (_r8(E) if self.tdt == torch.bfloat16 else E)
+        if self.emb:                                 # level-0 rows = [features |] prep.fc(embedding[ids])
+            d0 = self.D0 + self.E
+            ld0 = _r8(d0) if (self.tdt == torch.bfloat16 or self.D0) else d0
         else:
             d0, ld0 = feats.dim, feats.ld
         self.din = [d0] + [2 * h for h in self.h[:-1]]
@@ -134,7 +134,9 @@ class FusedMeanTrainStep(FusedTrainStep):
             last = l == L - 1
             self.hout.append(torch.zeros(R, 2 * self.h[l], dtype=f32 if last else bf, device=dev))
             self.dc.append(torch.zeros(R, 2 * self.h[l], dtype=bf, device=dev))
-            self.dg.append(torch.zeros(R, 2 * self.din[l], dtype=f32, device=dev) if (l > 0 or self.emb) else None)
+            # (level 0 under the embedding prep: only the prep's E columns of the row have a gradient to pass on)
+            self.dg.append(torch.zeros(R, 2 * (self.din[l] if l > 0 else self.E), dtype=f32, device=dev)
+                           if (l > 0 or self.emb) else None)
 
     def _will_fuse_tail(self, example_targets):
         """The seed level (segment mean + GEMM + head + input gradients + mask/route) as ONE kernel?"""
@@ -327,11 +329,13 @@ class FusedMeanTrainStep(FusedTrainStep):
                       "bwd_merge")
         if self.emb:
             # level 0's input is the prep's output: (dX | dAgg) = dC[0] against the transposed copies, merged into
-            # one gradient row per frontier row (x rows: dX; children: dAgg of the parent / fan-out; no ReLU below)
-            R, h, E = self.rows[0], self.h[0], self.din[0]
+            # one gradient row per frontier row (x rows: dX; children: dAgg of the parent / fan-out; no ReLU below).
+            # With features in front ([features | prep output]) only rows [D0, D0 + E) of the transposed copies --
+            # the prep's columns -- are multiplied: the features are data, they take no gradient.
+            R, h, E, d0 = self.rows[0], self.h[0], self.E, self.din[0]
             w2t, dg = self.w2t[0], self.dg[0]
-            self._linear(self.dc[0].data_ptr(), 2 * h, None, 0, w2t.data_ptr(), w2t.shape[2], dg.data_ptr(), nat.F32,
-                         2 * E, R, E, h, nat.ACT_NONE, h, E * w2t.shape[2], E)
+            self._linear(self.dc[0].data_ptr(), 2 * h, None, 0, w2t.data_ptr() + self.D0 * w2t.shape[2] * esz,
+                         w2t.shape[2], dg.data_ptr(), nat.F32, 2 * E, R, E, h, nat.ACT_NONE, h, d0 * w2t.shape[2], E)
             lp = self.din0 is not self.din0f
             nat.check(lib.gsage_attn_merge_bwd2(
                 None, self.code, 0, None, 0, dg.data_ptr(), 2 * E, R, dg.data_ptr() + 4 * E, 2 * E, None,

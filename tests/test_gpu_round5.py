@@ -169,6 +169,8 @@ def test_parallel_stream_finisher_and_block_zero():
     ("pokec_dense", ["--aggregator-class", "mean", "--prep-class", "node_embedding"]),
     ("sparse", ["--aggregator-class", "max_pool", "--sampler-class", "sparse_uniform_neighbor_sampler"]),
     ("sparse", ["--aggregator-class", "attention", "--sampler-class", "sparse_uniform_neighbor_sampler"]),
+    ("sparse", ["--aggregator-class", "mean", "--prep-class", "node_embedding", "--sampler-class",
+                "sparse_uniform_neighbor_sampler"]),                       # [features | embedding] rows
 ])
 def test_fused_evaluation_equals_the_module_path(tmp_path, kind, extra):
     """train.FusedEvaluator (engine forward launches over the validation sampler, the fold's draws taken from the
@@ -244,3 +246,93 @@ def test_module_path_runs_no_library_gemm(monkeypatch, agg):
     assert preds.shape == (B, C) and bool(torch.isfinite(preds).all())
     moved = [k for k, v in m.state_dict().items() if not torch.equal(v, w0[k])]
     assert len(moved) == len(w0), "every parameter received a gradient and moved"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the node-embedding prep concatenated with features (nn_modules.py:152-153) in the mean engine
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,p", [("model_kat.npz", "c5_"), ("round5_kat.npz", "e0_"), ("round5_kat.npz", "e1_")])
+@pytest.mark.parametrize("table", ["deferred", "dense"])
+@pytest.mark.parametrize("capture", [False, "cmdlist"])
+def test_fp32_mean_engine_over_embedding_beside_features_replays_reference_train_steps(monkeypatch, src, p, table, capture):
+    """[features | prep.fc(embedding[ids])] rows (reference nn_modules.py:143-155) through FusedMeanTrainStep: two
+    train steps of the reference (model_kat c5: feature width 12, regression_mae; round5_kat e0: 24, classification;
+    e1: 40, regression_mae with weight decay) in fp32 with the recorded draws -- predictions, gradient norm, clipped
+    gradients, and every weight incl. every row of the embedding table after each step."""
+    from conftest import load_golden
+    from util import build_model, close_rel, close_update
+    if table == "dense":
+        monkeypatch.setenv("GSAGE_DENSE_TABLE_ADAM", "1")
+    g = load_golden(src)
+    ops.set_compute_dtype("fp32")
+    model, store, task = build_model(gs, g, p, device=DEV, feats_dtype="fp32")
+    assert store is not None and type(model.prep).__name__ == "NodeEmbeddingPrep" and model.prep.input_dim == store.dim
+    fan = [int(v) for v in g[p + "fanouts"]]
+    ids = torch.from_numpy(g[p + "ids"]).to(DEV)
+    tg = torch.from_numpy(g[p + "targets"]).to(DEV)
+    w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cls = gs.engine.fused_engine_for(model, store)
+    assert cls is gs.engine.FusedMeanTrainStep, gs.engine.FusedMeanTrainStep.why_not(model, store)
+    eng = cls(model, store, getattr(gs.ProblemLosses, task), ids, tg, capture=capture)
+    assert eng.emb and eng.D0 == store.dim and eng.din[0] == store.dim + eng.E and eng.tdt == torch.float32
+    assert eng.lazy_rows == (table == "deferred")
+    for step in range(2):
+        eng.set_progress(0.25 * step)
+        eng.set_sel([g[p + "s%d_sel%d" % (step, h)] for h in range(len(fan))])
+        preds = eng(ids, tg).detach().cpu().numpy()
+        close(preds, g[p + "s%d_preds" % step], (step, "preds"), 2e-4, 2e-5)
+        gn, want = float(eng.gnorm.item()), float(g[p + "s%d_gradnorm" % step])
+        assert abs(gn - want) <= 2e-4 * max(1.0, want), (gn, want)
+        if step == 0:
+            for k, v in model.named_parameters():
+                if k != "prep.embedding.weight":         # the table's gradient is consumed (zeroed) by the step
+                    close_rel(v.grad.cpu().numpy(), g[p + "s0_cg_%s" % k], (step, "clipped grad", k), 2e-4)
+        for k, v in model.state_dict().items():          # (state_dict settles the deferred rows)
+            close_update(v.detach().cpu().numpy(), g[p + "w%d_%s" % (step + 1, k)], w0[k].numpy(), (step, "weights", k))
+
+
+def _emb_feats_model(adj, D, C, dims, fans, task):
+    import torch.nn.functional as F
+    torch.manual_seed(9)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "philox"
+    specs = [{"n_train_samples": f, "n_val_samples": f, "output_dim": h,
+              "activation": (lambda x: x) if i == len(dims) - 1 else F.relu} for i, (h, f) in enumerate(zip(dims, fans))]
+    m = gs.GSSupervised(sampler_class=gs.sampler_lookup["sparse_uniform_neighbor_sampler"], adj=adj, train_adj=adj,
+                        prep_class=gs.prep_lookup["node_embedding"], aggregator_class=gs.aggregator_lookup["mean"],
+                        input_dim=D, n_nodes=adj.shape[0], n_classes=C, layer_specs=specs, lr_init=0.01, weight_decay=1e-4)
+    gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
+    m.train_sampler.seed = m.val_sampler.seed = 77
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("dims,fans,D", [((128, 128), (10, 5), 40), ((64, 32), (5, 3), 24)])
+def test_bf16_engine_over_embedding_beside_features_tracks_the_fp32_engine(dims, fans, D):
+    """The production precision of the same rows: bf16 storage ([features | prep output] operand rows, the seed level
+    in one launch at 128 / 128) against the fp32 instantiation on the same Philox-sampled batches through the device
+    queue -- same frontier, predictions and the weights after six steps within bf16's rounding; the features' columns
+    of the level-0 weights learn too (the fc_x / fc_neib gradients span D0 + E columns)."""
+    adj, feats, rng = _problem(n=700, D=D, seed=6)
+    B, C, steps = 64, 5, 6
+    ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(steps, B))).to(DEV)
+    tg = torch.from_numpy(rng.randint(0, C, size=(steps, B))).to(DEV)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        ops.set_compute_dtype(prec)
+        store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype=prec)
+        m = _emb_feats_model(adj, D, C, dims, fans, "classification")
+        w0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        eng = gs.engine.FusedMeanTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0].view(B, 1),
+                                           capture="cmdlist")
+        assert eng.emb and eng.D0 == D and eng.fused_tail == (dims == (128, 128))
+        eng.load_epoch(ids, tg)
+        preds = [eng.step_queue().detach().float().cpu().numpy().copy() for _ in range(steps)]
+        w = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+        moved = {k: float((m.state_dict()[k] - w0[k]).abs().max()) for k in w0}
+        assert all(v > 0 for v in moved.values()), moved
+        fx = m.state_dict()["agg_layers.0.fc_x.weight"] - w0["agg_layers.0.fc_x.weight"]
+        assert float(fx[:, :D].abs().max()) > 0 and float(fx[:, D:].abs().max()) > 0
+        res[prec] = (preds, w)
+    for s in range(steps):                  # (a trajectory: the bf16 run's rounding compounds over the updates)
+        close_fro(res["bf16"][0][s], res["fp32"][0][s], ("preds", s), 2e-2 if s == 0 else 8e-2)
+    for k in res["fp32"][1]:
+        close_fro(res["bf16"][1][k], res["fp32"][1][k], ("weights", k), 3e-2)
