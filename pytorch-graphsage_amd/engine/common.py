@@ -981,7 +981,7 @@ class FusedTrainStep(object):
         self.din0f = torch.zeros(RA0, E, dtype=f32, device=dev)             # d prep output
         self.din0 = self.din0f if T == f32 else torch.zeros(RA0, ld0, dtype=T, device=dev)
         self.deraw = torch.zeros(RA0, E, dtype=f32, device=dev)             # d embedding rows
-        self.bpart = torch.zeros(256, E, dtype=f32, device=dev)             # prep.fc.bias gradient partials
+        self.prep_bpart = torch.zeros(256, E, dtype=f32, device=dev)             # prep.fc.bias gradient partials
         self.seed_grad = torch.zeros(min(16, self.B), E, dtype=f32, device=dev)   # partial sums of the gradient of
         #                                                                             the spare row the seeds read
         self._cur_ids = self.ids_set[0]
@@ -995,7 +995,7 @@ class FusedTrainStep(object):
         """finalisation source of prep.fc.bias (column sums of the level-0 input gradient)"""
         E = self.E
         ib = self.pidx[id(self.model.prep.fc.bias)]
-        return _ReduceDesc(self.bpart.data_ptr(), E, self.poff[ib], self.bpart.shape[0], 1, E, E)
+        return _ReduceDesc(self.prep_bpart.data_ptr(), E, self.poff[ib], self.prep_bpart.shape[0], 1, E, E)
 
     def _init_emb_optimizer(self):
         """after _install_reduce: the table's gradient comes from scatter-adds, its squared norm from a pass of its
@@ -1075,8 +1075,8 @@ class FusedTrainStep(object):
         a K5b problem of level 0; bias: column sums) -> the table's gradient."""
         lib, stream = nat.lib(), ops._stream()
         ids, B, RA0, E = self._cur_ids, self.B, self.off[self.L + 1], self.E
-        nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.bpart.data_ptr(),
-                                            self.bpart.shape[0], stream), "colsum_partials")
+        nat.check(lib.gsage_colsum_partials(self.din0f.data_ptr(), E, RA0, E, self.prep_bpart.data_ptr(),
+                                            self.prep_bpart.shape[0], stream), "colsum_partials")
         ops._linear_launch(self.din0.data_ptr(), self.din0.stride(0), None, 0, self.wprepT.data_ptr(), self.wprepT.shape[1],
                            None, self.deraw.data_ptr(), E, RA0, E, E, nat.ACT_NONE, 1, 0, 0, 0, self.code, nat.F32)
         g = self._grad_slice(self.table)

@@ -8,8 +8,8 @@ import torch
 
 from .. import _native as nat
 from .. import ops
-from ..nn_modules import IdentityPrep, MaxPoolAggregator, MeanPoolAggregator
-from .common import FusedTrainStep, _PrepDesc, _ReduceDesc, _r64
+from ..nn_modules import IdentityPrep, MaxPoolAggregator, MeanPoolAggregator, NodeEmbeddingPrep
+from .common import FusedTrainStep, _PrepDesc, _ReduceDesc, _r8, _r64
 
 
 class FusedPoolTrainStep(FusedTrainStep):
@@ -29,6 +29,11 @@ class FusedPoolTrainStep(FusedTrainStep):
                  K5b  all weight gradients of all levels in one grouped launch (fc_x, fc_neib, mlp)
     Level 0 reads its operands from two row buffers gathered once per step (x rows, neighbour rows):
     K3, K5 and K5b all want plain row-major operands, and the gathers run one batch ahead beside Adam.
+    Under the trainable node-embedding prep (nn_modules.py:126-155; with or without features beside it) the level-0
+    rows of the whole frontier are the prep's output, computed per step into one buffer (common._prep_forward): x rows
+    = its first rows, neighbour rows = the rest; level 0 then passes a gradient down too (dX through fc_x, dN through
+    the pooling MLP, added row by row -- no ReLU below an affine prep) and common._prep_backward takes it to
+    prep.fc and the table.
     """
 
     NPART = 256          # partial rows per hop for the MLP bias gradient (summed by the finalisation)
@@ -39,16 +44,17 @@ class FusedPoolTrainStep(FusedTrainStep):
         why = cls._why_not_common(model, feats, (MaxPoolAggregator, MeanPoolAggregator), "max-pool / mean-pool")
         if why:
             return why
-        if not isinstance(model.prep, IdentityPrep):
-            return "a prep class other than identity (%s)" % type(model.prep).__name__
-        why = cls._why_not_input(model, feats, ddp)
+        if not isinstance(model.prep, (IdentityPrep, NodeEmbeddingPrep)):
+            return "a prep class other than identity / node_embedding (%s)" % type(model.prep).__name__
+        why = cls._why_not_input(model, feats, ddp, concat_ok=True)
         if why:
             return why
         layers = list(model.agg_layers.children())
-        if feats.ld % (64 if feats.dtype == torch.bfloat16 else 4) != 0:      # whole lines for the LDS-DMA kernels
+        # whole lines for the LDS-DMA kernels (the embedding prep's output rows are padded to them by the engine)
+        if isinstance(model.prep, IdentityPrep) and feats.ld % (64 if feats.dtype == torch.bfloat16 else 4) != 0:
             return "feature rows that are not whole 128-byte lines"
-        if any(fn.keywords["n_samples"] > 64 for fn in model.train_sample_fns) or len(layers) > 2:
-            return "a fan-out above 64 or more than two layers (K3 tiles hold whole segments up to 64 rows)"
+        if any(fn.keywords["n_samples"] > 64 for fn in model.train_sample_fns) or len(layers) > 3:
+            return "a fan-out above 64 (K3 tiles hold whole segments up to 64 rows) or more than three layers"
         if not all(l.output_dim_ % 64 == 0 and l.mlp[0].weight.shape[0] % 128 == 0 for l in layers):
             return "output dims that are not multiples of 64, or a pooling MLP whose width is not a multiple of 128"
         return None
@@ -61,7 +67,13 @@ class FusedPoolTrainStep(FusedTrainStep):
         self.pool_mode = nat.POOL_MAX if type(self.layers[0]) is MaxPoolAggregator else nat.POOL_MEAN
         self.h = [l.output_dim_ for l in self.layers]
         self.Hm = [int(l.mlp[0].weight.shape[0]) for l in self.layers]
-        self.din = [feats.dim] + [2 * h for h in self.h[:-1]]
+        if self.emb:                                 # level-0 rows = [features |] prep.fc(embedding[ids])
+            d0 = self.D0 + self.E
+            ld0 = _r64(d0) if is_bf else _r8(d0)
+        else:
+            d0, ld0 = feats.dim, feats.ld
+        self.din = [d0] + [2 * h for h in self.h[:-1]]
+        self.ldin = [ld0] + [2 * h for h in self.h[:-1]]
         self.rows = [self.off[L - l] for l in range(L)]                     # x rows of level l
         self.nrows = [self.off[L - l + 1] - self.off[1] for l in range(L)]  # neighbour rows of level l
         assert all(d % 64 == 0 for d in self.din[1:]), "hidden widths must be multiples of 32"
@@ -85,12 +97,15 @@ class FusedPoolTrainStep(FusedTrainStep):
             order = [self.pidx[id(p)] for p in (layer.mlp[0].weight, layer.mlp[0].bias, layer.fc_x.weight,
                                                 layer.fc_neib.weight)]
             assert order == list(range(order[0], order[0] + 4)), "unexpected parameter order"
-            wm, wmT, wm_p = copies(layer.mlp[0].weight, l > 0, True)
-            wx, wxT, wx_p = copies(layer.fc_x.weight, l > 0, True)
+            ing = l > 0 or self.emb                  # does this level's input need a gradient?
+            wm, wmT, wm_p = copies(layer.mlp[0].weight, ing, True)
+            wx, wxT, wx_p = copies(layer.fc_x.weight, ing, True)
             wn, wnT, wn_p = copies(layer.fc_neib.weight, True, True)
             self.wm.append(wm); self.wmT.append(wmT); self.wx.append(wx); self.wxT.append(wxT)
             self.wn.append(wn); self.wnT.append(wnT)
             self.wm_p.append(wm_p); self.wx_p.append(wx_p); self.wn_p.append(wn_p)
+        if self.emb:
+            self._init_emb(lambda prm, need_t: copies(prm, need_t))
         self.descs = torch.frombuffer(bytearray(bytes((_PrepDesc * len(descs))(*descs))), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
         self.max_elems = max(d.rows * d.cols for d in descs)
@@ -99,10 +114,15 @@ class FusedPoolTrainStep(FusedTrainStep):
         # 180 MB at Reddit's shape) are read IN PLACE through the frontier's row list by K3 and by K5b
         # (gsage_wgrad_desc.a_rows; its list starts at entry B of the frontier and must be 16-byte aligned: even B) --
         # GSAGE_POOL_COPY_ROWS=1 brings back the gathered copy
-        self.inplace0 = os.environ.get("GSAGE_POOL_COPY_ROWS", "0") != "1" and self.B % 2 == 0
-        self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
-        self.xn0_set = [None if self.inplace0 else torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev)
-                        for _ in range(self.nset)]
+        # (embedding prep: ONE buffer per batch in flight holds the prep's output for every row of the frontier)
+        self.inplace0 = os.environ.get("GSAGE_POOL_COPY_ROWS", "0") != "1" and self.B % 2 == 0 and not self.emb
+        if self.emb:
+            self.g0_set = [torch.zeros(self.off[L + 1], ld0, dtype=bf, device=dev) for _ in range(self.nset)]
+            self.x0_set = self.xn0_set = [None] * self.nset
+        else:
+            self.x0_set = [torch.zeros(self.rows[0], feats.ld, dtype=bf, device=dev) for _ in range(self.nset)]
+            self.xn0_set = [None if self.inplace0 else torch.zeros(self.nrows[0], feats.ld, dtype=bf, device=dev)
+                            for _ in range(self.nset)]
         self._q_ids = None
         self.pooled, self.pooled_b, self.argmax, self.hout, self.dc = [], [], [], [], []
         self.dpool, self.ghc, self.dxb, self.dnb, self.bpart = [], [], [], [], []
@@ -120,20 +140,27 @@ class FusedPoolTrainStep(FusedTrainStep):
             self.dc.append(torch.zeros(R, 2 * h, dtype=bf, device=dev))
             self.dpool.append(torch.zeros(R, Hm, dtype=f32, device=dev))
             self.ghc.append(torch.zeros(NR, Hm, dtype=bf, device=dev))
-            self.dxb.append(torch.zeros(R, din, dtype=f32, device=dev) if l > 0 else None)
-            self.dnb.append(torch.zeros(NR, din, dtype=f32, device=dev) if l > 0 else None)
+            if l == 0 and self.emb:      # the prep's E columns only (features take no gradient); the neighbour rows'
+                E = self.E                # gradient sits at its rows of the frontier, above zeros for the seeds
+                self.dn_all = torch.zeros(self.off[L + 1], E, dtype=f32, device=dev)
+                self.dzero = torch.zeros(R, E, dtype=f32, device=dev)
+                self.dxb.append(torch.zeros(R, E, dtype=f32, device=dev))
+                self.dnb.append(self.dn_all[self.off[1]:])
+            else:
+                self.dxb.append(torch.zeros(R, din, dtype=f32, device=dev) if l > 0 else None)
+                self.dnb.append(torch.zeros(NR, din, dtype=f32, device=dev) if l > 0 else None)
             self.bpart.append(torch.zeros((L - l) * self.NPART, Hm, dtype=f32, device=dev))
 
-    def _init_head(self, loss_fn, example_targets):
-        super(FusedPoolTrainStep, self)._init_head(loss_fn, example_targets)
-        assert self.fused_head, "FusedPoolTrainStep needs the fused classification head"
-
     def _x_operand(self, l, s):
+        if l == 0 and self.emb:
+            return self.g0_set[s], self.ldin[0]
         return (self.x0_set[s], self.store.ld) if l == 0 else (self.hout[l - 1], self.din[l])
 
     def _nb_operand(self, l, s):
         """neighbour rows of level l: (row block, leading dimension, row list or None).  With a row list, neighbour
         row i is block[list[i]] (level 0 read in place from the feature table)."""
+        if l == 0 and self.emb:
+            return self.g0_set[s][self.off[1]:], self.ldin[0], None
         if l == 0:
             if self.inplace0:       # the frontier of the batch being computed: the queue's, else the set's own
                 ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
@@ -168,11 +195,22 @@ class FusedPoolTrainStep(FusedTrainStep):
             ib = self.pidx[id(layer.mlp[0].bias)]
             rdesc.append(_ReduceDesc(self.bpart[l].data_ptr(), Hm, self.poff[ib], self.bpart[l].shape[0], 1, Hm, Hm))
             self.slabs.append(bufs)
+        if self.emb:                                  # prep.fc: weight through K5b, bias through column sums
+            dC, A, lda, M_, ntot, K, prm, _rows = self._emb_wgrad_problem()
+            self.wg_target[("prep", 0)] = 40
+            rps, S, ldk = ops.wgrad_plan(M_, ntot, K, 40)
+            self.slab_prep = torch.zeros(S, ntot, ldk, dtype=f32, device=dev)
+            rdesc.append(_ReduceDesc(self.slab_prep.data_ptr(), ntot * ldk, self.poff[self.pidx[id(prm)]], S, ntot, K, ldk))
+            rdesc.append(self._emb_reduce_desc())
         self._install_reduce(rdesc)
+        if self.emb:
+            self._init_emb_optimizer()
 
     # ---- stages ----------------------------------------------------------------------------------------
     def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0):
         L, st = self.L, self.store
+        if self.emb:
+            return               # nothing to gather ahead: the level-0 rows are weights (read after Adam)
         if ids is None:
             ids = self.ids_set[s]
         segs = [(st.data, ids[:self.rows[0]], self.x0_set[s], self.rows[0], 1)]
@@ -191,6 +229,9 @@ class FusedPoolTrainStep(FusedTrainStep):
 
     def _stage_compute(self, s):
         L, B, lib, stream, m = self.L, self.B, nat.lib(), ops._stream(), self.model
+        if self.emb:
+            self._cur_ids = self._q_ids if self._q_ids is not None else self.ids_set[s]
+            self._prep_forward(s)
         for l, layer in enumerate(self.layers):
             R, Hm, h, din = self.rows[l], self.Hm[l], self.h[l], self.din[l]
             nb, ldnb, nrows = self._nb_operand(l, s)
@@ -222,7 +263,7 @@ class FusedPoolTrainStep(FusedTrainStep):
             self._gemm(x.data_ptr(), ldx, self.wx[l], out.data_ptr(), code, 2 * h, R, h, din, act, self.wx_p[l])
             self._gemm(self.pooled_b[l].data_ptr(), self.pooled_b[l].shape[1], self.wn[l],
                        out.data_ptr() + h * out.element_size(), code, 2 * h, R, h, Hm, act, self.wn_p[l])
-        self._stage_head_ce(s)
+        self._stage_head(s)
         if self.eval_only:
             return                                    # (forward only: train.evaluate's folds)
         self._backward_levels(s)
@@ -265,7 +306,24 @@ class FusedPoolTrainStep(FusedTrainStep):
                                                    self.dnb[l].data_ptr(), din, self.off[1],
                                                    self.dc[l - 1].data_ptr(), self.dc[l - 1].stride(0),
                                                    self.rows[l - 1], din, stream), "pool_merge_bwd")
+            if l == 0 and self.emb:
+                # level 0's input is the prep's output: dX (x rows) + dN (neighbour rows, at their rows of the frontier),
+                # only through the prep's columns [D0, D0 + E) of the transposed copies, no ReLU below
+                E, D0, RA0 = self.E, self.D0, self.off[L + 1]
+                self._gemm(dc.data_ptr(), 2 * h, self.wxT[0][D0:D0 + E], self.dxb[0].data_ptr(), nat.F32, E, R, E, h,
+                           nat.ACT_NONE)
+                self._gemm(self.ghc[0].data_ptr(), Hm, self.wmT[0][D0:D0 + E], self.dnb[0].data_ptr(), nat.F32, E, NR, E,
+                           Hm, nat.ACT_NONE)
+                lp = self.din0 is not self.din0f
+                nat.check(lib.gsage_attn_merge_bwd2(
+                    None, self.code, 0, self.dn_all.data_ptr(), E, self.dxb[0].data_ptr(), E, R, self.dzero.data_ptr(), E,
+                    None, self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host, self.fan_host,
+                    self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0, stream), "merge_bwd (level 0)")
+                self._prep_backward(s)
         probs = []
+        if self.emb:
+            dC, A, lda, M_, ntot, K, _prm, _rows = self._emb_wgrad_problem()
+            probs.append((dC, A, lda, 0, M_, ntot, K, ntot, self.slab_prep, self.wg_target[("prep", 0)], None))
         for l in range(L - 1, -1, -1):
             R, NR, Hm, h, din = self.rows[l], self.nrows[l], self.Hm[l], self.h[l], self.din[l]
             x, ldx = self._x_operand(l, s)

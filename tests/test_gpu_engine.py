@@ -88,7 +88,8 @@ def test_fused_engine_matches_eager_autograd_path(dims, fans, B, capture):
     eng_model.train_sampler.csr(DEV).check()
 
 
-@pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((64, 64), (5, 3), 33), ((64,), (7,), 20)])
+@pytest.mark.parametrize("dims,fans,B", [((128, 128), (25, 10), 64), ((64, 64), (5, 3), 33), ((64,), (7,), 20),
+                                         ((64, 128, 64), (4, 3, 2), 20)])
 @pytest.mark.parametrize("capture", [False, "cmdlist"])
 @pytest.mark.parametrize("agg", ["max_pool", "mean_pool"])
 def test_fused_pool_engine_matches_eager_autograd_path(dims, fans, B, capture, agg):
