@@ -38,7 +38,7 @@ class FusedAttnTrainStep(FusedTrainStep):
     @classmethod
     def why_not(cls, model, feats, ddp=None):
         why = cls._why_not_common(model, feats, (AttentionAggregator,), "attention") or \
-            cls._why_not_input(model, feats, ddp)
+            cls._why_not_input(model, feats, ddp, concat_ok=True)
         if why:
             return why
         layers = list(model.agg_layers.children())
@@ -58,9 +58,9 @@ class FusedAttnTrainStep(FusedTrainStep):
         T, f32 = self.tdt, torch.float32
         self.Ha = 32
         self.h = [l.output_dim_ for l in self.layers]
-        if self.emb:
-            E = int(self.model.prep.embedding_dim)
-            d0, ld0 = E, _r64(E) if T == torch.bfloat16 else E
+        if self.emb:                                 # level-0 rows = [features |] prep.fc(embedding[ids])
+            d0 = self.D0 + self.E
+            ld0 = _r64(d0) if T == torch.bfloat16 else (-(-d0 // 8) * 8 if self.D0 else d0)
         else:
             d0, ld0 = feats.dim, feats.ld
         self.din = [d0] + [2 * h for h in self.h[:-1]]
@@ -169,12 +169,13 @@ class FusedAttnTrainStep(FusedTrainStep):
 
     def _input_grad0(self):
         """level 0's input gradient with an embedding prep: through att(.), through fc_x, ws * d agg of the parent
-        -- no ReLU below (the prep's output is affine) -> din0f (fp32) + din0 (operand copy)"""
-        ld, E, RA0, L = self.ldin[0], self.din[0], self.rall[0], self.L
+        -- no ReLU below (the prep's output is affine) -> din0f (fp32) + din0 (operand copy).  With features in front
+        of the prep's output only columns [D0, D0 + E) of the three sources are merged (the features take no gradient)"""
+        ld, E, RA0, L, o = self.ldin[0], self.E, self.rall[0], self.L, 4 * self.D0
         lp = self.din0 is not self.din0f          # fp32 for the bias gradient's column sums + the GEMMs' operand copy
         nat.check(nat.lib().gsage_attn_merge_bwd2(
-            None, self.code, 0, self.datt[0].data_ptr(), ld, self.dx[0].data_ptr(), ld, self.rows[0],
-            self.dagg[0].data_ptr(), ld, self.ws[0].data_ptr(), self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1,
+            None, self.code, 0, self.datt[0].data_ptr() + o, ld, self.dx[0].data_ptr() + o, ld, self.rows[0],
+            self.dagg[0].data_ptr() + o, ld, self.ws[0].data_ptr(), self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1,
             self.off_host, self.fan_host, self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0,
             ops._stream()), "attn_merge_bwd")
 

@@ -10,8 +10,9 @@ harness and shims as gen_golden.py, which imports the reference).
            on -- two train steps of the reference's GSSupervised.train_step (models.py:97-104) with the `sel` its
            sampler drew (nn_modules.py:88), predictions, clipped gradients, loss, gradient norm and every weight
            incl. the embedding table after each step.  (model_kat.npz c5 is the same model family at feature width 12.)
-  f0, f1   the pooling aggregators (nn_modules.py:207-256) over the same prep: f0 max_pool without features,
-           classification; f1 mean_pool beside 24 feature columns, regression_mae -- the same records.
+  f0 - f2  the other aggregators over the same prep: f0 max_pool (nn_modules.py:207-256) without features,
+           classification; f1 mean_pool beside 24 feature columns, regression_mae; f2 attention (nn_modules.py:279-317)
+           beside 24 feature columns, classification -- the same records.
 
     python -B tests/golden/gen_golden_round5.py      # writes tests/golden/round5_kat.npz
 """
@@ -93,9 +94,11 @@ def gen_embedding_beside_features(out):
 
 def gen_pool_over_embedding(out):
     """f0 / f1: the pooling aggregators (nn_modules.py:207-256) over the node-embedding prep -- f0 max_pool, no
-    features, classification; f1 mean_pool beside 24 feature columns, regression_mae, weight decay on."""
+    features, classification; f1 mean_pool beside 24 feature columns, regression_mae, weight decay on; f2: the
+    attention aggregator (nn_modules.py:279-317) beside 24 feature columns, classification."""
     cfgs = [("max_pool", "classification", 0, (5, 3), (64, 64), 0.0, 1.0),
-            ("mean_pool", "regression_mae", 24, (4, 2), (64, 64), 5e-4, 0.3)]
+            ("mean_pool", "regression_mae", 24, (4, 2), (64, 64), 5e-4, 0.3),
+            ("attention", "classification", 24, (4, 3), (16, 16), 5e-4, 1.0)]
     for case, (aggn, task, D, fan, odims, wd, fscale) in enumerate(cfgs):
         grng = np.random.RandomState(1700 + case)
         n = 150

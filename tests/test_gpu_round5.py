@@ -334,17 +334,18 @@ def test_bf16_engine_over_embedding_beside_features_tracks_the_fp32_engine(dims,
         res[prec] = (preds, w)
     for s in range(steps):                  # (a trajectory: the bf16 run's rounding compounds over the updates)
         close_fro(res["bf16"][0][s], res["fp32"][0][s], ("preds", s), 2e-2 if s == 0 else 8e-2)
-    for k in res["fp32"][1]:                # (Adam's first updates are sign-like: small weights move by O(lr) either way)
-        close_fro(res["bf16"][1][k], res["fp32"][1][k], ("weights", k), 0.15 if k.startswith("prep.fc") else 8e-2)
+    for k in res["fp32"][1]:                # (Adam's first updates are sign-like: entries whose gradient is noise move
+        close_fro(res["bf16"][1][k], res["fp32"][1][k], ("weights", k), 0.2)   # by O(lr) either way -- a loose bound)
 
 
-@pytest.mark.parametrize("p", ["f0_", "f1_"])
+@pytest.mark.parametrize("p", ["f0_", "f1_", "f2_"])
 @pytest.mark.parametrize("capture", [False, "cmdlist"])
-def test_fp32_pool_engine_over_node_embedding_replays_reference_train_steps(p, capture):
-    """max_pool / mean_pool aggregators (nn_modules.py:207-256) over the node-embedding prep through
-    FusedPoolTrainStep: round5_kat f0 (max_pool, no features, classification) and f1 (mean_pool beside 24 feature
-    columns, regression_mae: the L1 head under the pool engine) -- two train steps of the reference in fp32 with the
-    recorded draws; every weight incl. every row of the embedding table after each step."""
+def test_fp32_pool_and_attention_engines_over_node_embedding_replay_reference_train_steps(p, capture):
+    """The other aggregators over the node-embedding prep: max_pool / mean_pool (nn_modules.py:207-256) through
+    FusedPoolTrainStep -- round5_kat f0 (max_pool, no features, classification) and f1 (mean_pool beside 24 feature
+    columns, regression_mae: the L1 head under the pool engine) -- and attention (nn_modules.py:279-317) beside 24
+    feature columns through FusedAttnTrainStep (f2): two train steps of the reference in fp32 with the recorded
+    draws; every weight incl. every row of the embedding table after each step."""
     from conftest import load_golden
     from util import build_model, close_rel, close_update
     g = load_golden("round5_kat.npz")
@@ -355,7 +356,8 @@ def test_fp32_pool_engine_over_node_embedding_replays_reference_train_steps(p, c
     tg = torch.from_numpy(g[p + "targets"]).to(DEV)
     w0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     cls = gs.engine.fused_engine_for(model, store)
-    assert cls is gs.engine.FusedPoolTrainStep, gs.engine.FusedPoolTrainStep.why_not(model, store)
+    want_cls = gs.engine.FusedAttnTrainStep if p == "f2_" else gs.engine.FusedPoolTrainStep
+    assert cls is want_cls, want_cls.why_not(model, store)
     eng = cls(model, store, getattr(gs.ProblemLosses, task), ids, tg, capture=capture)
     assert eng.emb and eng.D0 == (store.dim if store is not None else 0) and eng.tdt == torch.float32
     assert eng.fused_l1 == (task == "regression_mae") and eng.fused_head == (task == "classification")
@@ -409,5 +411,5 @@ def test_bf16_pool_engine_over_node_embedding_tracks_the_fp32_engine(agg, D):
         res[prec] = (preds, {k: v.detach().float().cpu().numpy() for k, v in sd.items()})
     for s in range(steps):
         close_fro(res["bf16"][0][s], res["fp32"][0][s], ("preds", s), 2e-2 if s == 0 else 8e-2)
-    for k in res["fp32"][1]:                # (Adam's first updates are sign-like: small weights move by O(lr) either way)
-        close_fro(res["bf16"][1][k], res["fp32"][1][k], ("weights", k), 0.15 if k.startswith("prep.fc") else 8e-2)
+    for k in res["fp32"][1]:                # (Adam's first updates are sign-like: entries whose gradient is noise move
+        close_fro(res["bf16"][1][k], res["fp32"][1][k], ("weights", k), 0.2)   # by O(lr) either way -- a loose bound)
