@@ -606,8 +606,11 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
  * Only with act = ReLU and fan-out 5 or 10 (the level-0 projection of the mean engine: 416 workgroups where 768
  * fit, streaming at half of what a CU keeps in flight); n_workgroups is ignored.  NULL: no role. */
 int gsage_gather_role_next(const gsage_tail_gather_desc *gather);
-/* A SAMPLER role for the NEXT gsage_linear_nt_packed launch of the calling thread (ABI 5; consumed by it; HOST
- * descriptor, read before that launch call returns): one more z-slice of the projection's grid runs the fused
+/* A SAMPLER role for the NEXT gsage_linear_nt_packed OR gsage_mean_tail_mfma launch of the calling thread (ABI 5;
+ * consumed by whichever comes first; HOST descriptor, read before that launch call returns).  In the seed-level launch
+ * (which must carry a gather role): gsage_mean_tail_mfma_sampler_wgs(B) workgroups right behind the seed-level ones --
+ * every workgroup of that launch owns a CU, so the caller sizes the gather role for the CUs that are left.  In the
+ * projection: one more z-slice of the projection's grid runs the fused
  * multi-hop sampler (gsage_sample_hops) for a LATER batch -- address it through call_base / batch_base, the counters
  * are not touched -- ceil(B / slice size) seeds per workgroup.  K1 is ~9 us of dependent loads that move almost
  * nothing: in the projection's free workgroup slots it is off every critical path.  Only with act = ReLU, a CSR
@@ -630,6 +633,8 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
                          void *dE, float *preds, void *dH, float *partial,
                          const gsage_tail_gather_desc *gather, void *stream);
 int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C);
+/* workgroups a sampler role (gsage_hops_role_next) adds to that launch for a batch of B seeds */
+int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B);
 
 /* ------------------------------------------------------------------------------------------
  * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86

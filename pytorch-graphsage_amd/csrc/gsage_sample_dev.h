@@ -158,6 +158,90 @@ __device__ __forceinline__ void sample_hops_workgroup(const HopsParams &p, int w
 }
 
 
+// The same sub-trees walked by a WIDE workgroup (THREADS lanes, U samples per lane and trip, CSR only): the role of a
+// launch whose workgroups own a whole CU each (k_mean_tail_mfma, gsage_tail_mfma.hip) -- few workgroups, many seeds
+// each, so a hop is several trips of dependent (rowptr -> col) loads; the U samples of a trip have their loads issued
+// together instead of one chain after the other.  Same Philox words, same ids as sample_hops_workgroup.
+template <int THREADS, int U>
+__device__ __forceinline__ void sample_hops_wide(const HopsParams &p, int wg, int64_t *frontier)
+{
+    const int seed0 = wg * p.spw;
+    const int nseed = min(p.spw, p.B - seed0);
+    if (nseed <= 0) return;
+    int width = 1, widest = 1;
+    for (int k = 1; k <= p.n_hops; ++k) { width *= p.fan[k]; widest = max(widest, width); }
+    int64_t *cur = frontier, *nxt = frontier + (int64_t)p.spw * widest;
+    const int32_t *sel = p.sel;
+    if (p.seed_queue) {
+        const int64_t b = (int64_t)((uint64_t)(*p.batch_idx + p.batch_base) % (uint64_t)p.n_batches);
+        if (sel) sel += b * p.sel_stride;
+        for (int t = threadIdx.x; t < nseed; t += THREADS) {
+            const int64_t v = p.seed_queue[b * p.B + seed0 + t];
+            cur[t] = v;
+            p.ids[p.off[0] + seed0 + t] = v;
+        }
+    } else {
+        for (int t = threadIdx.x; t < nseed; t += THREADS) cur[t] = p.ids[p.off[0] + seed0 + t];
+    }
+    lds_barrier();
+    const uint64_t ctr = p.call_ctr ? *p.call_ctr : 0ull;
+    int64_t per_seed = 1;
+    for (int k = 1; k <= p.n_hops; ++k) {
+        const uint32_t n = (uint32_t)p.fan[k];
+        per_seed *= n;
+        const int64_t count = per_seed * nseed;
+        const uint64_t call = p.call_base + ctr + (uint64_t)(k - 1);
+        const int64_t local0 = (int64_t)seed0 * per_seed;
+        for (int64_t t0 = threadIdx.x; t0 < count; t0 += (int64_t)THREADS * U) {
+            uint32_t s[U];
+            int64_t parent[U], beg[U], deg[U], v[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = t0 + (int64_t)u * THREADS;
+                ok[u] = t < count;
+                const int64_t tt = ok[u] ? t : count - 1;
+                if (sel) {
+                    s[u] = (uint32_t)sel[p.off[k] - p.off[1] + local0 + tt];
+                } else {
+                    const uint64_t g = p.g0[k] + (uint64_t)(local0 + tt);
+                    const uint64_t blk = g >> 2;
+                    const philox4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)call,
+                                                    (uint32_t)(call >> 32), p.seed_lo, p.seed_hi);
+                    const uint32_t sel4 = (uint32_t)g & 3u;
+                    const uint32_t w = sel4 == 0 ? r.v[0] : sel4 == 1 ? r.v[1] : sel4 == 2 ? r.v[2] : r.v[3];
+                    s[u] = (uint32_t)(((uint64_t)w * (uint64_t)p.max_deg) >> 32);
+                }
+                parent[u] = cur[(uint32_t)tt / n];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = (uint64_t)parent[u] < (uint64_t)p.n_rows;
+                if (!in && ok[u] && p.err_flag) *p.err_flag = 1;              // the reference raises IndexError here
+                const int64_t id = in ? parent[u] : 0;
+                beg[u] = p.rowptr[id];
+                deg[u] = in ? p.rowptr[id + 1] - beg[u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t o = (deg[u] <= 0xffffffffLL) ? (uint64_t)(s[u] % (uint32_t)(deg[u] > 0 ? deg[u] : 1))
+                                                            : (uint64_t)s[u];
+                v[u] = deg[u] > 0 ? (int64_t)p.col[beg[u] + (int64_t)o] : 0;      // (numpy: x % 0 == 0 -> column 0)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = t0 + (int64_t)u * THREADS;
+                if (ok[u]) {
+                    nxt[t] = v[u];
+                    p.ids[p.off[k] + local0 + t] = v[u];
+                }
+            }
+        }
+        lds_barrier();
+        int64_t *tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
 // [host] validate a gsage_hops_desc and turn it into kernel parameters + dynamic LDS bytes
 inline int fill_hops(HopsParams &p, size_t &lds, const gsage_hops_desc &d)
 {

@@ -23,6 +23,7 @@
 // Everything that changes layout goes through LDS (padded so that the fragment reads are conflict-free).
 #include "gsage_common.h"
 #include "gsage_gather_dev.h"
+#include "gsage_sample_dev.h"
 
 namespace gsage {
 
@@ -56,6 +57,7 @@ struct TailMfmaParams {
     int64_t ldw2, ldw2t;
     int32_t B, n, C;
     int32_t stop;            // measurement only (GSAGE_TAIL_STOP = 1 .. 5): leave after that phase; 0 = the whole kernel
+    int32_t n_smp;           // workgroups of the sampler role (behind the seed-level ones, before the gather role's)
 };
 
 constexpr size_t tm_lds_bytes()
@@ -129,19 +131,28 @@ __device__ __forceinline__ tm_f32x4 tm_mma_f32(const float a, const float b, con
 #ifndef GSAGE_TM_ROLE_U
 #define GSAGE_TM_ROLE_U 2
 #endif
+// Beside the gather role the launch can carry a SAMPLER role (gsage_hops_role_next): p.n_smp workgroups right behind
+// the seed-level ones walk the sub-trees of a later batch's seeds (K1: dependent rowptr -> col loads that move almost
+// nothing).  In the launch that carries the update K1's chain was the longer of that launch's two; here it runs
+// under a launch that the gather role keeps busy for ~30 us anyway.
 template <int N, int GN>
 __global__ void __launch_bounds__(TM_T)
-k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg)
+k_mean_tail_mfma(const TailMfmaParams p, const TailGather tg, const HopsParams hp)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (GN > 0) {
         const int n_tail = (p.B + TM_S - 1) / TM_S;
         if ((int)blockIdx.x >= n_tail) {
-            gather_role<(GN > 0 ? GN : 1), (GN > 10 ? 2 : GSAGE_TM_ROLE_U), TM_T>(tg, (int)blockIdx.x - n_tail);
+            const int r = (int)blockIdx.x - n_tail;
+            if (r < p.n_smp) {
+                sample_hops_wide<TM_T, 4>(hp, r, reinterpret_cast<int64_t *>(lds_raw));
+                return;
+            }
+            gather_role<(GN > 0 ? GN : 1), (GN > 10 ? 2 : GSAGE_TM_ROLE_U), TM_T>(tg, r - p.n_smp);
             return;
         }
     }
     constexpr int NB = N > 0 ? N : 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *Ws = reinterpret_cast<float *>(lds_raw);               // [64][260] fc.weight, rows >= C zero
     float *zs = Ws + TM_CMAX * TM_LDF;                             // [16][260] emb, then z
     float *part = zs + TM_S * TM_LDF;                              // [8][16][68] logit partials per wave
@@ -499,6 +510,17 @@ int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C)
     return n_wg * ((int64_t)C * TM_D + C + 1);
 }
 
+// Workgroups the sampler role adds to the launch for a batch of B_hops seeds (GSAGE_TAIL_SMP_WGS, read once; default
+// 32: sixteen seeds each at B = 512): every workgroup of this launch owns a CU, so they come out of the gather role's.
+int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B_hops)
+{
+    static const int want = [] { const char *e = getenv("GSAGE_TAIL_SMP_WGS"); const int x = e ? atoi(e) : 32;
+                                 return x >= 1 && x <= 128 ? x : 32; }();
+    if (B_hops <= 0) return 0;
+    const int64_t spw = ceil_div(B_hops, (int64_t)want);
+    return (int32_t)ceil_div(B_hops, spw);
+}
+
 int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, int64_t ldw2,
                          const void *w2t, int64_t ldw2t, const float *Wfc, const float *bfc, int32_t C,
                          const int64_t *targets, const int64_t *batch_idx, int64_t n_batches, void *agg,
@@ -506,6 +528,8 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
                          void *stream)
 {
     const int32_t *n_valid = take_head_n_valid();     // (consumed before any return path: never left for a later launch)
+    const gsage_hops_desc *hd = t_hops_role;          // gsage_hops_role_next(): likewise
+    t_hops_role = nullptr;
     GSAGE_REQUIRE(H && w2 && w2t && Wfc && bfc && targets && agg && dE && preds && dH && partial,
                   "mean_tail_mfma: null pointer");
     GSAGE_REQUIRE(B > 0 && n >= 1 && n <= 32 && C >= 1 && C <= TM_CMAX,
@@ -534,11 +558,27 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
         const int rc = fill_gather_role(tg, *gather, "mean_tail_mfma");
         if (rc != GSAGE_OK) return rc;
     }
+    HopsParams hp = {};
+    p.n_smp = 0;
+    if (hd) {
+        // gsage_hops_role_next(): workgroups behind the seed-level ones sample a later batch's frontier
+        GSAGE_REQUIRE(fused && !hd->dense_adj, "mean_tail_mfma: the sampler role rides beside the gather role and walks a CSR");
+        size_t lds = 0;
+        const int rc = fill_hops(hp, lds, *hd);
+        if (rc != GSAGE_OK) return rc;
+        p.n_smp = gsage_mean_tail_mfma_sampler_wgs(hd->B);
+        hp.spw = (int32_t)ceil_div(hd->B > 0 ? hd->B : 1, (int64_t)(p.n_smp > 0 ? p.n_smp : 1));
+        int64_t widest = 1, width = 1;
+        for (int k = 1; k <= hp.n_hops; ++k) { width *= hp.fan[k]; widest = width > widest ? width : widest; }
+        GSAGE_REQUIRE(sizeof(int64_t) * 2 * (size_t)hp.spw * (size_t)widest <= tm_lds_bytes(),
+                      "mean_tail_mfma: the sampler role's frontier (%d seeds x %lld ids, twice) does not fit the launch's LDS",
+                      hp.spw, (long long)widest);
+    }
     const int gn = fused ? gather->n : 0;
     // fan-outs with a specialisation of their own (one load slot per neighbour row): BASELINE's 25 (configs[1]) and
     // 15 (configs[4]'s first hop), 10; everything else takes the 32-slot kernel
     const int ex = n == 25 ? 1 : n == 15 ? 2 : n == 10 ? 3 : 0;
-    typedef void (*kern_t)(const TailMfmaParams, const TailGather);
+    typedef void (*kern_t)(const TailMfmaParams, const TailGather, const HopsParams);
     static const kern_t table[4][4] = {
         {k_mean_tail_mfma<0, 0>, k_mean_tail_mfma<0, 10>, k_mean_tail_mfma<0, 5>, k_mean_tail_mfma<0, 15>},
         {k_mean_tail_mfma<25, 0>, k_mean_tail_mfma<25, 10>, k_mean_tail_mfma<25, 5>, k_mean_tail_mfma<25, 15>},
@@ -560,7 +600,8 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
         }
     }
     const unsigned n_tail = (unsigned)((B + TM_S - 1) / TM_S);
-    launch(kern, dim3(n_tail + (fused ? (unsigned)tg.n_wg : 0u)), dim3(TM_T), tm_lds_bytes(), (hipStream_t)stream, p, tg);
+    launch(kern, dim3(n_tail + (unsigned)p.n_smp + (fused ? (unsigned)tg.n_wg : 0u)), dim3(TM_T), tm_lds_bytes(),
+           (hipStream_t)stream, p, tg, hp);
     return check_launch("mean_tail_mfma");
 }
 

@@ -1340,7 +1340,7 @@ class FusedTrainStep(object):
         self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
         # K1 inside the level-0 projection's launch (mean engine, _k1_in_k5): batch i+2 is sampled at the START of
         # step i, while K5(i) and K5b(i) still read batch i's frontier as their row list -- a ring of THREE
-        self.P = 3 if self._k1_in_k5() else 2
+        self.P = 3 if (self._k1_in_k5() or self._k1_in_tail()) else 2
         if self.P == 3:
             self.ids_q.append(torch.zeros_like(self.ids_set[0]))
         # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
@@ -1429,6 +1429,9 @@ class FusedTrainStep(object):
         return par if self._tail_rows else 0
 
     def _k1_in_k5(self):
+        return False
+
+    def _k1_in_tail(self):
         return False
 
     def _nx(self, par):

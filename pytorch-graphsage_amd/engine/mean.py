@@ -269,7 +269,7 @@ class FusedMeanTrainStep(FusedTrainStep):
             assert delta % esz == 0 and agg.stride(0) == lda
             last = l == L - 1
             if self.wp[l] is not None:
-                if l == 0 and getattr(self, "_k5_hops", None) is not None:
+                if l == 0 and getattr(self, "_k5_hops", None) is not None and self._k1_in_k5():
                     # the projection's spare workgroup slots sample the frontier of the batch after the next
                     nat.check(lib.gsage_hops_role_next(ctypes.addressof(self._k5_hops)), "hops_role_next")
                 if l == 0:
@@ -298,6 +298,9 @@ class FusedMeanTrainStep(FusedTrainStep):
                     self.dc[L - 2].data_ptr(), self.head_scratch.data_ptr(),
                     ctypes.addressof(self._tail_gather) if self._tail_gather is not None else None)
             if self._tail_on_mfma():
+                if getattr(self, "_k5_hops", None) is not None and self._tail_gather is not None and self._k1_in_tail():
+                    # workgroups behind the seed-level ones sample the frontier of the batch after the next
+                    nat.check(lib.gsage_hops_role_next(ctypes.addressof(self._k5_hops)), "hops_role_next")
                 nat.check(lib.gsage_mean_tail_mfma(*args, stream), "mean_tail_mfma")
             else:
                 nat.check(lib.gsage_mean_tail_ce(*args, self.code, stream), "mean_tail_ce")
@@ -383,9 +386,8 @@ class FusedMeanTrainStep(FusedTrainStep):
         gathers (0: none)."""
         if not self.fused_tail or self.emb or self.fan[self.L] not in (5, 10, 15) or self.code != nat.BF16:
             return 0
-        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
         mfma = self._tail_on_mfma()
-        n_idle = n_cu - (self.B + 15) // 16 if mfma else n_cu - (self.B + 3) // 4    # one seed-level workgroup per CU
+        n_idle = self._tail_idle_cus(self._k1_in_tail())
         if n_idle < 32:
             return 0
         # what an idle CU moves while the launch lasts does not depend on B: ~480 KB in the VALU kernel's ~27 us,
@@ -398,6 +400,14 @@ class FusedMeanTrainStep(FusedTrainStep):
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
+
+    def _tail_idle_cus(self, with_sampler):
+        """CUs the seed-level launch leaves to its gather role: every workgroup of that launch owns a CU"""
+        n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
+        n_idle = n_cu - ((self.B + 15) // 16 if self._tail_on_mfma() else (self.B + 3) // 4)
+        if with_sampler:
+            n_idle -= int(nat.lib().gsage_mean_tail_mfma_sampler_wgs(self.B))
+        return n_idle
 
     def _k1_early(self):
         """data-parallel order: K1(i+2) rides in the launch that gathers the bulk of batch i+1 WHILE the exchange is in
@@ -433,6 +443,18 @@ class FusedMeanTrainStep(FusedTrainStep):
         a ring of three frontier buffers (K5 / K5b of step i still read batch i's as their row list)."""
         return bool(self.wp and self.wp[0] is not None and self.L >= 2 and not self.dense and not self.emb and
                     self.ddp is None and os.environ.get("GSAGE_K1_IN_K5", "0") == "1")
+
+    def _k1_in_tail(self):
+        """Sample batch i+2 inside the SEED-LEVEL launch of step i (a sampler role behind its seed-level workgroups,
+        gsage_hops_role_next) instead of in the launch that carries the update?  That launch lasts as long as its
+        gather role (~31 us at config 2) whatever else rides in it; K1's chain of dependent loads was the longer of the
+        last launch's two.  Needs the matrix-core seed level with a gather role, a CSR sampler, one GPU; a ring of three
+        frontier buffers as for _k1_in_k5.  GSAGE_K1_IN_TAIL=0: K1 stays in the launch that carries the update."""
+        return bool(self.fused_tail and self._tail_on_mfma() and self.L >= 2 and not self.dense and not self.emb and
+                    self.ddp is None and self.fan[self.L] in (5, 10, 15) and not self._k1_in_k5() and
+                    self._tail_idle_cus(True) >= 32 and
+                    float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.6")) > 0 and
+                    os.environ.get("GSAGE_K1_IN_TAIL", "1") == "1")
 
     def _queue_compute_body(self, par):
         nx = self._nx(par)
