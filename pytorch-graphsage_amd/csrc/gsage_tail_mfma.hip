@@ -510,12 +510,13 @@ int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C)
     return n_wg * ((int64_t)C * TM_D + C + 1);
 }
 
-// Workgroups the sampler role adds to the launch for a batch of B_hops seeds (GSAGE_TAIL_SMP_WGS, read once; default
-// 32: sixteen seeds each at B = 512): every workgroup of this launch owns a CU, so they come out of the gather role's.
+// Workgroups the sampler role adds to the launch for a batch of B_hops seeds (GSAGE_TAIL_SMP_WGS; default 32: sixteen
+// seeds each at B = 512): every workgroup of this launch owns a CU, so they come out of the gather role's.
 int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B_hops)
 {
-    static const int want = [] { const char *e = getenv("GSAGE_TAIL_SMP_WGS"); const int x = e ? atoi(e) : 32;
-                                 return x >= 1 && x <= 128 ? x : 32; }();
+    const char *e = getenv("GSAGE_TAIL_SMP_WGS");
+    const int x = e ? atoi(e) : 32;
+    const int want = x >= 1 && x <= 128 ? x : 32;
     if (B_hops <= 0) return 0;
     const int64_t spw = ceil_div(B_hops, (int64_t)want);
     return (int32_t)ceil_div(B_hops, spw);

@@ -396,7 +396,10 @@ class FusedMeanTrainStep(FusedTrainStep):
         # but leave 224 CUs: ~60 means per CU, i.e. the WHOLE last hop at B = 512 (round-5 sweep, DESIGN.md section 5:
         # 0.0905 / 0.0883 / 0.0842 / 0.0837 ms/step at 30 / 40 / 50 / >= 60 per CU; the gather launch then carries only
         # the hop-1 means, Adam and the sampler).  Other row sizes / fan-outs get the same bytes per idle CU
-        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.6" if mfma else "0.4"))
+        # (with the sampler role on 32 of those CUs the other 192 still take the whole last hop: 67 means each, the launch
+        #  31.4 instead of 30.3 us and the launch that carries the update 11.8 instead of 13.3)
+        frac = float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.7" if mfma else "0.4"))
+        n_idle = max(32, min(n_idle, int(os.environ.get("GSAGE_TAIL_GATHER_WGS", n_idle))))     # (a sweep knob)
         self._tail_wgs = n_idle
         per_cu = 100.0 * frac * (10.0 * 1204.0) / (self.fan[self.L] * max(self.store.dim * self.esz, 256))
         return min(int(self.size[self.L - 1]), max(int(per_cu * n_idle), 0))
@@ -453,7 +456,7 @@ class FusedMeanTrainStep(FusedTrainStep):
         return bool(self.fused_tail and self._tail_on_mfma() and self.L >= 2 and not self.dense and not self.emb and
                     self.ddp is None and self.fan[self.L] in (5, 10, 15) and not self._k1_in_k5() and
                     self._tail_idle_cus(True) >= 32 and
-                    float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.6")) > 0 and
+                    float(os.environ.get("GSAGE_TAIL_GATHER_FRAC", "0.7")) > 0 and
                     os.environ.get("GSAGE_K1_IN_TAIL", "1") == "1")
 
     def _queue_compute_body(self, par):

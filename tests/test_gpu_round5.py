@@ -45,7 +45,7 @@ def _run(monkeypatch, env, dims, fans, B, mode, n_steps=5, C=5, clip_scale=1.0):
     return {"preds": preds.float().cpu().numpy(), "p": eng.flat_p.clone().cpu().numpy(),
             "g": eng.flat_g.clone().cpu().numpy(), "norm": float(eng.gnorm.item()), "fold": eng._fold_finalize(),
             "launches": nat.launch_count() - before, "step": int(eng.step.item()), "ctr": int(eng.counter.item()),
-            "mfma": eng.fused_tail and eng._tail_on_mfma()}
+            "mfma": eng.fused_tail and eng._tail_on_mfma(), "k1_in_tail": eng._k1_in_tail()}
 
 
 @pytest.mark.parametrize("mode", ["queue", "cmdlist", False])
@@ -215,8 +215,22 @@ def test_sampler_role_of_the_projection_launch_changes_nothing(monkeypatch, mode
     """GSAGE_K1_IN_K5=1: batch i+2 is sampled by a z-slice of the level-0 projection's launch of step i
     (gsage_hops_role_next; a ring of three frontier buffers) instead of in the launch that carries the update: the
     same Philox words, the same frontier, the same weights bit for bit."""
-    a = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0"}, (128, 128), (25, 10), 64, mode, n_steps=7)
-    b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "1"}, (128, 128), (25, 10), 64, mode, n_steps=7)
+    a = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "0"}, (128, 128), (25, 10), 64, mode, n_steps=7)
+    b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "1", "GSAGE_K1_IN_TAIL": "0"}, (128, 128), (25, 10), 64, mode, n_steps=7)
+    assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["p"], b["p"])
+    assert a["ctr"] == b["ctr"] and a["step"] == b["step"] == 7
+
+
+@pytest.mark.parametrize("B,wgs", [(64, "32"), (200, "7"), (512, "32"), (512, "128")])
+def test_sampler_role_of_the_seed_level_launch_changes_nothing(monkeypatch, B, wgs):
+    """GSAGE_K1_IN_TAIL=1 (the default where it applies): batch i+2 is sampled by workgroups of the SEED-LEVEL launch
+    of step i (gsage_hops_role_next before gsage_mean_tail_mfma; sample_hops_wide: many seeds per 512-thread
+    workgroup, four samples per lane and trip) instead of in the launch that carries the update: the same Philox
+    words, the same frontier, the same weights bit for bit -- for whole and ragged seed groups."""
+    monkeypatch.setenv("GSAGE_TAIL_SMP_WGS", wgs)
+    a = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "0"}, (128, 128), (25, 10), B, "queue", n_steps=7)
+    b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "1"}, (128, 128), (25, 10), B, "queue", n_steps=7)
+    assert b["k1_in_tail"] and not a["k1_in_tail"]
     assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["p"], b["p"])
     assert a["ctr"] == b["ctr"] and a["step"] == b["step"] == 7
 

@@ -35,6 +35,9 @@ for cfg in ${R5_CFGS:-base mfma mfma_fold f15 f30 f40}; do
     s*)        b stop5_$cfg GSAGE_TAIL_STOP=5 GSAGE_TAIL_GATHER_FRAC=0.${cfg#s} ;;
     t*)        b stop3_$cfg GSAGE_TAIL_STOP=3 GSAGE_TAIL_GATHER_FRAC=0.${cfg#t} ;;
     p*)        b spw4_$cfg GSAGE_HOPS_SPW=4 GSAGE_TAIL_GATHER_FRAC=0.${cfg#p} ;;
+    w*)        b gather_wgs_$cfg GSAGE_TAIL_GATHER_WGS=${cfg#w} GSAGE_TAIL_GATHER_FRAC=1.5 ;;
+    q0)        b k1_in_gather_launch GSAGE_K1_IN_TAIL=0 ;;
+    q*)        b k1_in_tail_$cfg GSAGE_K1_IN_TAIL=1 GSAGE_TAIL_SMP_WGS=${cfg#q} ;;
     x0)        b x_rows_copied GSAGE_MEAN_INPLACE_X=0 ;;
     x1)        b x_rows_in_place GSAGE_MEAN_INPLACE_X=1 ;;
     k0)        b k1_in_gather GSAGE_K1_IN_K5=0 ;;
