@@ -60,7 +60,8 @@ struct chunk_io<float, VEC> {
 
 // One work item: 16-byte column chunk c0 of output row `row` = mean of n table rows.
 // TI = table element type, TO = output element type, VEC elements per chunk (both sides).
-template <typename TI, typename TO, int VEC>
+// BATCH = rows in flight per lane (8; 16 in k_gather_multi_adam_wide): the summation order j = 0 .. n-1 is the same.
+template <typename TI, typename TO, int VEC, int BATCH = 8>
 __device__ __forceinline__ void gather_mean_chunk(const TI *__restrict__ table, int64_t ld,
                                                   const int64_t *__restrict__ ids, int64_t row,
                                                   int32_t n, int32_t D, int32_t c0,
@@ -87,29 +88,29 @@ __device__ __forceinline__ void gather_mean_chunk(const TI *__restrict__ table, 
         // hits) and drops the repeats at the accumulation: loads stay unconditional, the order j = 0 .. n-1 and
         // with it every bit of the mean is unchanged.
         const int32_t *ids32 = reinterpret_cast<const int32_t *>(ids + base);
-        int32_t rc[8], rn[8];
+        int32_t rc[BATCH], rn[BATCH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rc[u] = ids32[2 * min(u, n - 1)];
-        for (int32_t j = 0; j < n; j += 8) {
-            const int32_t m = min(8, n - j);
-            if (j + 8 < n) {
-                const int32_t m2 = min(8, n - j - 8);
+        for (int u = 0; u < BATCH; ++u) rc[u] = ids32[2 * min(u, n - 1)];
+        for (int32_t j = 0; j < n; j += BATCH) {
+            const int32_t m = min(BATCH, n - j);
+            if (j + BATCH < n) {
+                const int32_t m2 = min(BATCH, n - j - BATCH);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rn[u] = ids32[2 * (j + 8 + min(u, m2 - 1))];
+                for (int u = 0; u < BATCH; ++u) rn[u] = ids32[2 * (j + BATCH + min(u, m2 - 1))];
             }
-            in_raw v[8];
+            in_raw v[BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + (int64_t)rc[u] * ld + c0);
-            if (m == 8) {
+            for (int u = 0; u < BATCH; ++u) v[u] = *reinterpret_cast<const in_raw *>(table + (int64_t)rc[u] * ld + c0);
+            if (m == BATCH) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) in_io::accumulate(v[u], acc);
+                for (int u = 0; u < BATCH; ++u) in_io::accumulate(v[u], acc);
             } else {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < BATCH; ++u)
                     if (u < m) in_io::accumulate(v[u], acc);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rc[u] = rn[u];
+            for (int u = 0; u < BATCH; ++u) rc[u] = rn[u];
         }
     } else {
         int32_t j = 0;
@@ -169,7 +170,7 @@ struct MultiSeg {
     int32_t all_single;     // every segment has n == 1 (plain row copies): 4 rows in flight per lane
 };
 
-template <typename TI, typename TO, int VEC>
+template <typename TI, typename TO, int VEC, int BATCH = 8>
 __device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_t ld, int32_t D,
                                                        int32_t chunks, int64_t out_ld, int bx, int gx)
 {
@@ -267,8 +268,8 @@ __device__ __forceinline__ void gather_multi_workgroup(const MultiSeg &q, int64_
             }
             continue;
         }
-        gather_mean_chunk<TI, TO, VEC>((const TI *)q.table[s], ld, q.ids[s], row, q.n[s], D, c0,
-                                       (TO *)q.out[s], out_ld);
+        gather_mean_chunk<TI, TO, VEC, BATCH>((const TI *)q.table[s], ld, q.ids[s], row, q.n[s], D, c0,
+                                              (TO *)q.out[s], out_ld);
     }
 }
 
@@ -305,6 +306,32 @@ k_gather_multi_adam(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int
         sample_hops_workgroup<false>(h, bx - first - n_adam, frontier);
     else
         gather_multi_workgroup<TI, TO, VEC>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_side, n_gather);
+}
+
+// The same launch when its gather role is LIGHT (a few hundred workgroups of means with fan-outs above 8, e.g. config 2's
+// hop-1 means once the seed-level launch has taken the whole last hop): the launch is then as long as a lane's chain of
+// dependent row trips -- fan-out 25 is four trips of eight rows under the 72-register cap above -- so this variant
+// trades occupancy it does not need (3-4 waves per SIMD) for 16 rows in flight per lane: two trips.  Same sums, bit
+// for bit (gather_mean_chunk's order does not depend on the batch).
+#ifndef GSAGE_WIDE_BATCH
+#define GSAGE_WIDE_BATCH 16
+#endif
+template <typename TI, typename TO, int VEC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSAGE_WIDE_BATCH > 16 ? 2 : 3, GSAGE_WIDE_BATCH > 16 ? 2 : 4)))
+k_gather_multi_adam_wide(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks, int64_t out_ld,
+                         int n_adam, const AdamParams a, int n_smp, const HopsParams h, int first)
+{
+    extern __shared__ int64_t frontier[];
+    __shared__ float red[4];
+    const int n_side = n_adam + n_smp;
+    const int n_gather = (int)gridDim.x - n_side;
+    const int bx = (int)blockIdx.x;
+    if (bx >= first && bx < first + n_adam)
+        adam_workgroup<false>(a, bx - first, n_adam, red);
+    else if (bx >= first + n_adam && bx < first + n_side)
+        sample_hops_workgroup<false>(h, bx - first - n_adam, frontier);
+    else
+        gather_multi_workgroup<TI, TO, VEC, GSAGE_WIDE_BATCH>(q, ld, D, chunks, out_ld, bx < first ? bx : bx - n_side, n_gather);
 }
 
 // dneibs[i*n+j, :] = dagg[i, :] / n     (fp32, 16-byte chunks when aligned)
@@ -554,8 +581,19 @@ int gsage_gather_mean_multi_adam(int32_t n_seg, const void *const *tables, const
     const int n_gather = grid_for(q.first[n_seg]);
     int first = (int)(n_gather * side_pos);
     first = first < 0 ? 0 : (first > n_gather ? n_gather : first);
+    // a LIGHT gather role whose means have more than eight rows: the variant with 16 rows in flight per lane (the
+    // launch is as long as a lane's chain of row trips; GSAGE_GATHER_WIDE=0: never).  Not with the in-launch norm:
+    // its capacity check above is the narrow kernel's.
+    static const bool wide_ok = [] { const char *e = getenv("GSAGE_GATHER_WIDE"); return !e || atoi(e) != 0; }();
+    int32_t max_n = 0;
+    for (int sidx = 0; sidx < n_seg; ++sidx)
+        if (q.ids[sidx] && q.n[sidx] > max_n) max_n = q.n[sidx];
+    const bool wide = wide_ok && dtype == GSAGE_BF16 && !a.norm_slots && max_n > 8 && q.first[n_seg] <= 256LL * 1024;
     if (dtype == GSAGE_F32)
         launch(k_gather_multi_adam<float, float, 4>, dim3(n_gather + n_adam + n_smp),
+               dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
+    else if (wide)
+        launch(k_gather_multi_adam_wide<uint16_t, uint16_t, 8>, dim3(n_gather + n_adam + n_smp),
                dim3(256), lds, (hipStream_t)stream, q, ld, (int32_t)D, chunks, out_ld, n_adam, a, n_smp, h, first);
     else
         launch(k_gather_multi_adam<uint16_t, uint16_t, 8>, dim3(n_gather + n_adam + n_smp),
