@@ -82,7 +82,9 @@ struct AdamParams {
 
 // g[i] for four elements of the flat bucket (i[u] < 0: none) out of the partial buffers of their descriptors.
 // Partials are added in buffer order 0 .. S-1 (gsage_finalize_grads' order: the same bits), four buffers of each of
-// the four elements in flight together (16 loads per lane and round: the register budget of k_gather_multi_adam).
+// the four elements in flight together (16 loads per lane and round: the register budget of k_gather_multi_adam;
+// R = 12 in k_gather_multi_adam_wide: 48 per round, K5b's 24 slabs in two rounds instead of six).
+template <int R = 4>
 __device__ __forceinline__ void reduce_partials4(const ReduceDesc *__restrict__ rd, int n_rd, const int64_t (&i)[4],
                                                  float (&g)[4])
 {
@@ -103,12 +105,12 @@ __device__ __forceinline__ void reduce_partials4(const ReduceDesc *__restrict__ 
         }
         Smax = S[u] > Smax ? S[u] : Smax;
     }
-    for (int s0 = 0; s0 < Smax; s0 += 4) {
-        float v[4][4];
+    for (int s0 = 0; s0 < Smax; s0 += R) {
+        float v[4][R];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < R; ++k) {
                 const int sk = s0 + k;                       // (past the element's last buffer: its buffer 0 again,
                 v[u][k] = src[u][(int64_t)(sk < S[u] ? sk : 0) * stride[u]];                  // dropped below:
                 //                                                              the loads stay unconditional)
@@ -116,7 +118,7 @@ __device__ __forceinline__ void reduce_partials4(const ReduceDesc *__restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < R; ++k)
                 if (s0 + k < S[u]) g[u] += v[u][k];
     }
 }
@@ -162,7 +164,8 @@ __device__ __forceinline__ float adam_update(float g, float p, float &m, float &
 
 // one workgroup of the clip + Adam update: grid-stride slice bx of gx.  REPLAY_OK = false: the caller never sets
 // a.replay_math (k_gather_multi_adam: only the exact arithmetic is compiled in, its registers are the gather role's)
-template <bool REPLAY_OK = true>
+// PR = partial buffers per element and round when the workgroup sums them itself (reduce_partials4)
+template <bool REPLAY_OK = true, int PR = 4>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
             int64_t iv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) iv[u] = i_first + u * stride < a.n ? i_first + u * stride : -1;
-            reduce_partials4(a.rdesc, a.n_rdesc, iv, gv0);
+            reduce_partials4<PR>(a.rdesc, a.n_rdesc, iv, gv0);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (iv[u] >= 0) a.g[iv[u]] = gv0[u];
