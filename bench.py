@@ -273,8 +273,10 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
         st = eng.store
         elem = st.data.element_size()
         rows_g, rows_t = eng.gather_launch_rows()
+        k1_tail = bool(eng._k1_in_tail())
         seed_name = ("k_mean_tail_mfma (seed level, 16 seeds per workgroup on the matrix cores" if eng._tail_on_mfma()
-                     else "k_mean_tail_ce (seed level") + " + gather role on the CUs it leaves idle: batch i+1's last-hop means)"
+                     else "k_mean_tail_ce (seed level") + " + gather role on the CUs it leaves idle: batch i+1's last-hop means" + \
+            (" + sampler role: K1 of batch i+2)" if k1_tail else ")")
         if rows_t > rows_g and "seed_level" in us:
             # the launch that reads most of the step's frontier rows is the seed-level launch's gather role (round 5:
             # the whole last hop): it is the dominant kernel; the gather launch (hop-1 means | Adam | K1) is listed beside it
@@ -283,11 +285,14 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
             # (the rows the gather launch reads for the hop-1 means are the hop-1 nodes' own rows, which K5 / K5b also
             # read in place as x rows: the step's algorithmic bytes count them once, `rows_read` is what this launch moves)
             rows_h1 = sum(eng.size[1:L]) if rows_g == 0 else rows_g        # (children of every hop but the last)
-            out["gather_launch"] = {"kernel": "k_gather_multi_adam (in-step: rest of the gathers of batch i+1 | Adam(i) | K1(i+2))",
+            out["gather_launch"] = {"kernel": "k_gather_multi_adam (in-step: rest of the gathers of batch i+1 | Adam(i)" +
+                                              ("" if k1_tail else " | K1(i+2)") + ")",
                                     "gather_rows": rows_g, "rows_read": rows_h1,
                                     "bytes_read_per_launch": rows_h1 * st.dim * elem, "avg_launch_us": us["gather"],
                                     "read_rate_gbs": rows_h1 * st.dim * elem / (us["gather"] * 1e-6) / 1e9,
-                                    "note": "bounded by the update's and the sampler's dependent chains, not by its gathers"}
+                                    "note": "bounded by the update's dependent chain and a lane's row trips of the hop-1 "
+                                            "means, not by its bytes" if k1_tail else
+                                            "bounded by the update's and the sampler's dependent chains, not by its gathers"}
         else:
             out = hbm_roofline("k_gather_multi_adam (in-step: gathers of batch i+1 | Adam(i) | K1(i+2))",
                                rows_g * st.dim * elem, us["gather"], pmc_key, n_steps, rows_per_launch=rows_g)

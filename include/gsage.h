@@ -608,7 +608,7 @@ int gsage_mean_tail_ce(const void *H, int32_t B, int32_t n, const void *w2, int6
 int gsage_gather_role_next(const gsage_tail_gather_desc *gather);
 /* A SAMPLER role for the NEXT gsage_linear_nt_packed OR gsage_mean_tail_mfma launch of the calling thread (ABI 5;
  * consumed by whichever comes first; HOST descriptor, read before that launch call returns).  In the seed-level launch
- * (which must carry a gather role): gsage_mean_tail_mfma_sampler_wgs(B) workgroups right behind the seed-level ones --
+ * (which must carry a gather role): gsage_mean_tail_mfma_sampler_wgs(B, widest) workgroups right behind the seed-level ones --
  * every workgroup of that launch owns a CU, so the caller sizes the gather role for the CUs that are left.  In the
  * projection: one more z-slice of the projection's grid runs the fused
  * multi-hop sampler (gsage_sample_hops) for a LATER batch -- address it through call_base / batch_base, the counters
@@ -633,8 +633,9 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
                          void *dE, float *preds, void *dH, float *partial,
                          const gsage_tail_gather_desc *gather, void *stream);
 int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C);
-/* workgroups a sampler role (gsage_hops_role_next) adds to that launch for a batch of B seeds */
-int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B);
+/* workgroups a sampler role (gsage_hops_role_next) adds to that launch for a batch of B seeds whose widest hop holds
+ * `widest` ids per seed (the product of the fan-outs so far); 0: the role's frontier does not fit the launch's LDS */
+int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B, int64_t widest);
 
 /* ------------------------------------------------------------------------------------------
  * Fused tail of train_step (models.py:101-102) and inter-layer backward routing (models.py:85-86

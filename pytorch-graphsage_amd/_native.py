@@ -112,7 +112,7 @@ SIGNATURES = {
     "gsage_mean_tail_mfma": (_int, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i64,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsage_mean_tail_mfma_scratch": (_i64, [_i32, _i32]),
-    "gsage_mean_tail_mfma_sampler_wgs": (_i32, [_i64]),
+    "gsage_mean_tail_mfma_sampler_wgs": (_i32, [_i64, _i64]),
     "gsage_clip_adam_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _f32, _f32,
                                     _f32, _vp, _int, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "gsage_finalize_grads": (_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -510,15 +510,17 @@ int64_t gsage_mean_tail_mfma_scratch(int32_t B, int32_t C)
     return n_wg * ((int64_t)C * TM_D + C + 1);
 }
 
-// Workgroups the sampler role adds to the launch for a batch of B_hops seeds (GSAGE_TAIL_SMP_WGS; default 32: sixteen
-// seeds each at B = 512): every workgroup of this launch owns a CU, so they come out of the gather role's.
-int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B_hops)
+// Workgroups the sampler role adds to the launch for a batch of B_hops seeds whose widest hop holds `widest` ids per
+// seed (GSAGE_TAIL_SMP_WGS; default 32: sixteen seeds each at B = 512): every workgroup of this launch owns a CU, so
+// they come out of the gather role's.  0: a workgroup's two frontier buffers would not fit the launch's LDS.
+int32_t gsage_mean_tail_mfma_sampler_wgs(int64_t B_hops, int64_t widest)
 {
     const char *e = getenv("GSAGE_TAIL_SMP_WGS");
     const int x = e ? atoi(e) : 32;
     const int want = x >= 1 && x <= 128 ? x : 32;
-    if (B_hops <= 0) return 0;
+    if (B_hops <= 0 || widest <= 0) return 0;
     const int64_t spw = ceil_div(B_hops, (int64_t)want);
+    if (sizeof(int64_t) * 2 * (size_t)spw * (size_t)widest > tm_lds_bytes()) return 0;
     return (int32_t)ceil_div(B_hops, spw);
 }
 
@@ -567,13 +569,12 @@ int gsage_mean_tail_mfma(const void *H, int32_t B, int32_t n, const void *w2, in
         size_t lds = 0;
         const int rc = fill_hops(hp, lds, *hd);
         if (rc != GSAGE_OK) return rc;
-        p.n_smp = gsage_mean_tail_mfma_sampler_wgs(hd->B);
-        hp.spw = (int32_t)ceil_div(hd->B > 0 ? hd->B : 1, (int64_t)(p.n_smp > 0 ? p.n_smp : 1));
         int64_t widest = 1, width = 1;
         for (int k = 1; k <= hp.n_hops; ++k) { width *= hp.fan[k]; widest = width > widest ? width : widest; }
-        GSAGE_REQUIRE(sizeof(int64_t) * 2 * (size_t)hp.spw * (size_t)widest <= tm_lds_bytes(),
-                      "mean_tail_mfma: the sampler role's frontier (%d seeds x %lld ids, twice) does not fit the launch's LDS",
-                      hp.spw, (long long)widest);
+        p.n_smp = gsage_mean_tail_mfma_sampler_wgs(hd->B, widest);
+        GSAGE_REQUIRE(p.n_smp > 0, "mean_tail_mfma: the sampler role's frontier (%lld ids per seed, twice) does not fit the "
+                      "launch's LDS (gsage_mean_tail_mfma_sampler_wgs)", (long long)widest);
+        hp.spw = (int32_t)ceil_div(hd->B, (int64_t)p.n_smp);
     }
     const int gn = fused ? gather->n : 0;
     // fan-outs with a specialisation of their own (one load slot per neighbour row): BASELINE's 25 (configs[1]) and

@@ -409,8 +409,16 @@ class FusedMeanTrainStep(FusedTrainStep):
         n_cu = int(torch.cuda.get_device_properties(self.dev).multi_processor_count)      # MI355X: 256
         n_idle = n_cu - ((self.B + 15) // 16 if self._tail_on_mfma() else (self.B + 3) // 4)
         if with_sampler:
-            n_idle -= int(nat.lib().gsage_mean_tail_mfma_sampler_wgs(self.B))
+            n_smp = self._tail_sampler_wgs()
+            n_idle = n_idle - n_smp if n_smp > 0 else -1           # (0: the role does not fit -- no sampler role)
         return n_idle
+
+    def _tail_sampler_wgs(self):
+        widest, width = 1, 1
+        for k in range(1, self.L + 1):
+            width *= int(self.fan[k])
+            widest = max(widest, width)
+        return int(nat.lib().gsage_mean_tail_mfma_sampler_wgs(self.B, widest))
 
     def _k1_early(self):
         """data-parallel order: K1(i+2) rides in the launch that gathers the bulk of batch i+1 WHILE the exchange is in
