@@ -427,3 +427,18 @@ def test_bf16_pool_engine_over_node_embedding_tracks_the_fp32_engine(agg, D):
         close_fro(res["bf16"][0][s], res["fp32"][0][s], ("preds", s), 2e-2 if s == 0 else 8e-2)   # bf16 reroutes a whole
     #                                          gradient row, and Adam's first updates are sign-like)
     assert all(np.isfinite(v).all() for v in res["bf16"][1].values())
+
+
+def test_sampler_role_with_three_hops_and_when_it_does_not_fit(monkeypatch):
+    """BASELINE configs[4]'s geometry (three layers, fan-outs 15 / 10 / 5: 750 ids per seed at the widest hop): with
+    two seeds per sampler workgroup the role runs and changes nothing; at B = 512 sixteen seeds' frontiers (twice 96 KB)
+    do not fit the launch's LDS -- gsage_mean_tail_mfma_sampler_wgs says 0 and K1 stays in the launch that carries
+    the update."""
+    dims, fans = (128, 128, 128), (15, 10, 5)
+    a = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "0"}, dims, fans, 64, "queue", n_steps=5)
+    b = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "1"}, dims, fans, 64, "queue", n_steps=5)
+    assert b["k1_in_tail"] and not a["k1_in_tail"] and b["mfma"]
+    assert np.array_equal(a["preds"], b["preds"]) and np.array_equal(a["p"], b["p"]) and a["ctr"] == b["ctr"]
+    assert nat.lib().gsage_mean_tail_mfma_sampler_wgs(512, 750) == 0 and nat.lib().gsage_mean_tail_mfma_sampler_wgs(512, 250) == 32
+    c = _run(monkeypatch, {"GSAGE_K1_IN_K5": "0", "GSAGE_K1_IN_TAIL": "1"}, dims, fans, 512, "queue", n_steps=3)
+    assert not c["k1_in_tail"] and c["step"] == 3 and np.isfinite(c["preds"]).all()
