@@ -63,14 +63,25 @@ class DeviceCSR(object):
         if not adj.has_sorted_indices:
             adj = adj.sorted_indices()
         indptr = np.asarray(adj.indptr, dtype=np.int64)
-        if not np.array_equal(np.asarray(adj.indices), row_positions(indptr)):
+        # columns 0..deg-1 in every row: strictly increasing columns (scipy's canonical-format flag: one C pass over the
+        # indices, cached on the matrix) whose LAST one is deg - 1 -- an O(rows) look instead of building and comparing
+        # an nnz-long position array (0.36 of the 0.47 s the reference's Reddit command line took, two adjacencies)
+        deg = np.diff(indptr)
+        rows = np.flatnonzero(deg > 0)
+        indices = np.asarray(adj.indices)
+        ok = bool(adj.has_canonical_format) and (rows.size == 0 or (
+            np.array_equal(indices[indptr[rows + 1] - 1], deg[rows] - 1) and bool((indices[indptr[rows]] == 0).all())))
+        if not ok:
             raise ValueError("adjacency is not in the reference's sparse convention "
                              "(row i must hold its neighbours in columns 0..deg_i-1)")
         data = np.asarray(adj.data)
-        if data.size and (data.min() <= 0 or data.max() >= 2 ** 31):
+        if data.size and data.dtype.itemsize > 4 and data.max() >= 2 ** 31:
             raise ValueError("neighbour ids must be 1-based positive int32 values")
         rowptr = torch.from_numpy(indptr).to(device)
-        col = torch.from_numpy(data.astype(np.int32)).to(device)
+        col = torch.from_numpy(data.astype(np.int32, copy=False)).to(device)
+        # (the lower bound is looked at where the narrowed ids already are: one pass on the device, not on the host)
+        if data.size and int(col.min()) <= 0:
+            raise ValueError("neighbour ids must be 1-based positive int32 values")
         return DeviceCSR(rowptr, col, adj.shape[0], adj.shape[1])
 
     def check(self):
