@@ -327,7 +327,7 @@ k_gather_multi_adam_wide(const MultiSeg q, int64_t ld, int32_t D, int32_t chunks
     const int n_gather = (int)gridDim.x - n_side;
     const int bx = (int)blockIdx.x;
     if (bx >= first && bx < first + n_adam)
-        adam_workgroup<false>(a, bx - first, n_adam, red);
+        adam_workgroup<false, 4, true>(a, bx - first, n_adam, red);
     else if (bx >= first + n_adam && bx < first + n_side)
         sample_hops_workgroup<false>(h, bx - first - n_adam, frontier);
     else

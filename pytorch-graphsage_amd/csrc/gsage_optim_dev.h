@@ -78,6 +78,7 @@ struct AdamParams {
     unsigned long long *norm_slots;   // != null: the workgroups form the squared norm themselves (slot = update << 32 | partial)
     const ReduceDesc *rdesc;          // != null (with norm_slots): g does not exist yet -- element i of the bucket is the
     int32_t n_rdesc;                  // sum of its descriptor's S partial buffers (what gsage_finalize_grads would store)
+    int32_t stage_prep;               // != 0: kernels that can (adam_workgroup<.., STAGE>) stage the descriptors in LDS
 };
 
 // g[i] for four elements of the flat bucket (i[u] < 0: none) out of the partial buffers of their descriptors.
@@ -165,10 +166,19 @@ __device__ __forceinline__ float adam_update(float g, float p, float &m, float &
 // one workgroup of the clip + Adam update: grid-stride slice bx of gx.  REPLAY_OK = false: the caller never sets
 // a.replay_math (k_gather_multi_adam: only the exact arithmetic is compiled in, its registers are the gather role's)
 // PR = partial buffers per element and round when the workgroup sums them itself (reduce_partials4)
-template <bool REPLAY_OK = true, int PR = 4>
+// STAGE: the operand-copy descriptors travel through LDS (for kernels with registers to spare: k_gather_multi_adam_wide)
+template <bool REPLAY_OK = true, int PR = 4, bool STAGE = false>
 __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int gx, float *red)
 {
     float s = 0.f;
+    // The operand-copy descriptors are read at the END of the update's chain, one scalar load after the other (each a
+    // dependent round trip of its own): they are fetched into LDS here, beside the first operands, and read back from
+    // there (the barriers of the norm's block sum order the two).
+    static_assert(sizeof(PrepDesc) == 64, "PrepDesc is staged as four 16-byte words");
+    __shared__ PrepDesc sh_prep[16];
+    const bool staged = STAGE && a.stage_prep && a.n_prep > 0 && a.n_prep <= 16;
+    if (staged && (int)threadIdx.x < 4 * a.n_prep)
+        reinterpret_cast<vec16 *>(sh_prep)[threadIdx.x] = reinterpret_cast<const vec16 *>(a.prep)[threadIdx.x];
     // the first (with the in-launch norm: the only) trip's operands, requested before anything else
     const int64_t stride = (int64_t)gx * 256;
     const int64_t i_first = (int64_t)bx * 256 + threadIdx.x;
@@ -305,7 +315,7 @@ __device__ __forceinline__ void adam_workgroup(const AdamParams &a, int bx, int 
         // against the trip's four elements -- element-major with an early exit it was up to 16 dependent descriptor
         // fetches per thread at the END of the update's chain, which is the floor of the launch it rides in
         for (int d = 0; d < a.n_prep; ++d) {
-            const PrepDesc q = a.prep[d];
+            const PrepDesc q = staged ? sh_prep[d] : a.prep[d];
             const int64_t base = q.src - a.p, span = (int64_t)q.rows * q.cols;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -350,6 +360,8 @@ inline int fill_adam(AdamParams &a, const gsage_adam_desc &d)
                   "n_partial_ready == 0 and 1..16 descriptors");
     a.rdesc = (const ReduceDesc *)d.reduce_descs;
     a.n_rdesc = d.reduce_descs ? d.n_reduce : 0;
+    static const int stage = [] { const char *e = getenv("GSAGE_ADAM_STAGE"); return e ? atoi(e) : 1; }();
+    a.stage_prep = stage;
     return GSAGE_OK;
 }
 

@@ -38,6 +38,8 @@ for cfg in ${R5_CFGS:-base mfma mfma_fold f15 f30 f40}; do
     w*)        b gather_wgs_$cfg GSAGE_TAIL_GATHER_WGS=${cfg#w} GSAGE_TAIL_GATHER_FRAC=1.5 ;;
     z0)        b finalize_launch GSAGE_FOLD_FINALIZE=0 ;;
     z1)        b folded_wide GSAGE_FOLD_FINALIZE=1 ;;
+    a0)        b adam_descs_global GSAGE_ADAM_STAGE=0 ;;
+    a1)        b adam_descs_staged GSAGE_ADAM_STAGE=1 ;;
     v0)        b gather_narrow GSAGE_GATHER_WIDE=0 ;;
     v1)        b gather_wide GSAGE_GATHER_WIDE=1 ;;
     q0)        b k1_in_gather_launch GSAGE_K1_IN_TAIL=0 ;;
