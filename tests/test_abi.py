@@ -141,3 +141,22 @@ def test_ctypes_structs_mirror_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_sampler_role_workgroup_count_is_host_arithmetic(monkeypatch):
+    """gsage_mean_tail_mfma_sampler_wgs: how many workgroups the sampler role adds to the seed-level launch, or 0 when
+    a workgroup's two frontier buffers (16 bytes per id of the widest hop and seed) would not fit the launch's LDS --
+    what the engines size the gather role with (engine/mean.py:_tail_idle_cus)."""
+    L = pkg()._native.lib()
+    monkeypatch.delenv("GSAGE_TAIL_SMP_WGS", raising=False)
+    assert L.gsage_mean_tail_mfma_sampler_wgs(512, 250) == 32          # BASELINE configs[1]: sixteen seeds each
+    assert L.gsage_mean_tail_mfma_sampler_wgs(64, 250) == 32           # two seeds each
+    assert L.gsage_mean_tail_mfma_sampler_wgs(20, 250) == 20           # never more workgroups than seeds
+    assert L.gsage_mean_tail_mfma_sampler_wgs(512, 750) == 0           # configs[4]: 16 x 750 ids twice is 192 KB
+    assert L.gsage_mean_tail_mfma_sampler_wgs(0, 250) == 0 and L.gsage_mean_tail_mfma_sampler_wgs(512, 0) == 0
+    monkeypatch.setenv("GSAGE_TAIL_SMP_WGS", "7")
+    assert L.gsage_mean_tail_mfma_sampler_wgs(200, 250) == 7           # ceil(200 / ceil(200 / 7))
+    monkeypatch.setenv("GSAGE_TAIL_SMP_WGS", "64")
+    assert L.gsage_mean_tail_mfma_sampler_wgs(512, 750) == 64          # eight seeds each: 96 KB fits
+    monkeypatch.setenv("GSAGE_TAIL_SMP_WGS", "100000")                 # out of range: the default
+    assert L.gsage_mean_tail_mfma_sampler_wgs(512, 250) == 32
