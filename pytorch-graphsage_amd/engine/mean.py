@@ -22,17 +22,20 @@ class FusedMeanTrainStep(FusedTrainStep):
 
         K5            level 0: ONE grouped MFMA GEMM (x | agg against Wx | Wn), bf16 out
         seed level    segment mean + both projections + normalize/fc/CE + all gradients down to the
-                      level-0 activations in one kernel (gsage_mean_tail_ce; generic models use K2 + K5
-                      + gsage_head_ce + K5/merge per level instead); in queue mode the CUs its B / 4
-                      workgroups leave idle gather the first part of the NEXT batch's last-hop means
+                      level-0 activations in one kernel (gsage_mean_tail_mfma: 16 seeds per workgroup on
+                      the matrix cores; gsage_mean_tail_ce for fp32 storage; generic models use K2 + K5
+                      + gsage_head_ce + K5/merge per level instead); in queue mode the CUs its B / 16
+                      workgroups leave idle gather the NEXT batch's last-hop means (at B = 512: all of
+                      them) and, where it fits, sample the batch after that (K1: _k1_in_tail)
         K5b           every level's weight gradient in one grouped launch (partial tiles -> slabs)
         finalise      partial tiles + head partials -> flat gradient bucket + norm partials; ticks the
                       step's device counters
         [RCCL]        one all-reduce of the flat gradient bucket (data-parallel runs only)
-        Adam          clip + Adam + refresh of the bf16 operand copies, side by side with the level-0
-                      gathers (x rows | neighbour means of every hop) of the NEXT batch and with K1
-                      (all hops) for the batch after that (queue mode; otherwise K1 and the gathers
-                      open the step as launches of their own)
+        Adam          clip + Adam + refresh of the bf16 operand copies, side by side with what is left of
+                      the level-0 gathers of the NEXT batch (the neighbour means of the other hops; the x
+                      rows are read in place by K5 / K5b) and -- unless the seed-level launch carried it --
+                      with K1 (all hops) for the batch after that (queue mode; otherwise K1 and the
+                      gathers open the step as launches of their own)
 
     The arithmetic is that of GSSupervised.train_step.  Parameters and gradients live in flat fp32
     buckets; the model's Parameters become views of them, so `model.state_dict()`, evaluation and
