@@ -19,9 +19,6 @@ for w in $WHAT; do
         rc=$?; [ $rc -ne 0 ] && [ $rc -ne 5 ] && { rc_all=$rc; echo "!! $f rc=$rc" >> $OUT/tests.log; }
       done
       echo "== tests rc=$rc_all"; grep -E "passed|failed|^FAILED|^ERROR|!! |Error|error:|assert " $OUT/tests.log | grep -v "^  File" | cut -c1-260 | tail -70 ;;
-    dbg)
-      timeout 600 python tools/debug_r3.py > $OUT/dbg.log 2>&1
-      echo "== dbg rc=$?"; tail -60 $OUT/dbg.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
       echo "== smoke rc=$?"; tail -5 $OUT/smoke.log ;;
