@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgsage_hip.so")
 F32, BF16 = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -139,6 +139,11 @@ SIGNATURES = {
                                     _i64, _vp, _i64, _vp, _vp]),
     "gsage_attn_aggregate_lp": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _i32, _i64,
                                        _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "gsage_attn_fused_ok": (_int, [_int, _i64, _i64, _i32, _i64]),
+    "gsage_attn_fused_fwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i64, _vp,
+                                    _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "gsage_attn_fused_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
+                                    _i64, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "gsage_attn_mlp2_fwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_mlp2_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32,
                                    _vp]),

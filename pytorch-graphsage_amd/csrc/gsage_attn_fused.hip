@@ -1,0 +1,572 @@
+// gsage_attn_fused.hip -- K4 / K4' with the attention MLP inside: one pass over a hop's child rows per direction.
+//
+// Replaces, for the LAST hop of an attention level (the bulk of its rows: Reddit's 128 000 of 141 312), what
+// engine.FusedAttnTrainStep issued as separate launches over the same rows (reference nn_modules.py:305-321):
+//
+//   forward    hid = tanh(rows W0^T)   (a GEMM launch that streamed every row)      nn_modules.py:293-295
+//              a   = hid W2^T          (k_attn_mlp2_fwd)                            nn_modules.py:296
+//              s   = <a_child, a_parent>, w = softmax over the fan-out, agg = sum w * row   (K4, the rows again)
+//   backward   dws = <row, d agg>, softmax backward, d a_parent, d a_child          (K4', the rows a third time)
+//              da  = bf16(d a_child),  dhid = bf16((da W2) (1 - hid^2))              (k_attn_mlp2_bwd)
+//
+// A child row is fetched ONCE per direction: global -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 16 bytes per lane,
+// whole row pieces of up to 1 KiB per instruction), the hidden layer of the attention MLP comes off the matrix cores
+// from that LDS tile (v_mfma_f32_16x16x32_bf16, W0 resident in LDS for the whole launch), and the weighted sum /
+// the dot products with d agg read the same tile with 16-byte lane reads.
+//
+// Decomposition: a wavefront owns a whole parent (its n <= 16 children are one 16-row MFMA tile) and a private LDS
+// tile; there is no workgroup barrier after W0 has been staged, so the waves of a CU drift apart and one wave's
+// loads cover another's arithmetic.  hid^T = W0 X^T is computed (A = W0 rows, B = child rows: both operands are read
+// as "16 contiguous bytes of one row", no transposition), which leaves lane (row, q) with eight hidden units of ITS
+// row -- exactly the B fragment of a^T = W2 hid^T under a fixed permutation of the reduction index (applied to W2's
+// fragment once per launch), so the second layer needs no LDS round trip either.
+//
+// LDS image of a row tile: row-major [n][CH] 16-byte chunks, chunk c of row r at slot r * CH + (c ^ swz(r)),
+// swz(r) = (4 - (r >> 2)) & 3: the DMA writes LDS linearly (wave-uniform base + lane * 16), so the permutation is
+// applied to the SOURCE chunk each lane fetches; with it the four 16-lane groups of a fragment's ds_read_b128
+// (lanes = 16 rows x chunks 4 ks + {0..3}) touch 16 distinct 16-byte slots of the 256-byte bank row.
+#include "gsage_common.h"
+#include "gsage_mma_dev.h"
+
+namespace gsage {
+
+typedef float af_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t af_u32x2 __attribute__((ext_vector_type(2)));
+
+struct AttnFusedFwd {
+    const uint16_t *table;      // child rows: table[(ids ? ids[pos] : row0 + pos) * ld], pos = parent * n + j
+    int64_t ld;
+    const int64_t *ids;
+    int64_t row0;
+    const uint16_t *W0;         // att.0 operand copy [32][ldw0], zero beyond D
+    int64_t ldw0;
+    const uint16_t *W2;         // att.2 operand copy [32][ldw2]
+    int64_t ldw2;
+    const float *xa;            // a of the parents [M][xa_ld]
+    int64_t xa_ld;
+    int64_t M;
+    int32_t n, D;
+    uint16_t *hid;              // out: hidden layer of the children [M n][hid_ld]
+    int64_t hid_ld;
+    float *a;                   // out: a of the children [M n][a_ld]
+    int64_t a_ld;
+    float *ws;                  // out: softmax weights [M n]
+    float *agg;                 // out (optional): fp32 aggregate [M][agg_ld]
+    int64_t agg_ld;
+    uint16_t *agg_lp;           // out (optional): bf16 operand copy [M][lp_ld]
+    int64_t lp_ld;
+};
+
+struct AttnFusedBwd {
+    const uint16_t *table;
+    int64_t ld;
+    const int64_t *ids;
+    int64_t row0;
+    const uint16_t *W2T;        // transposed operand copy of att.2: W2T[k][h] = W2[h][k], [32][ldw2t]
+    int64_t ldw2t;
+    const float *g;             // d agg of the parents [M][g_ld]
+    int64_t g_ld;
+    const float *ws;            // [M n]
+    const float *na;            // a of the children [M n][na_ld]
+    int64_t na_ld;
+    const float *xa;            // a of the parents [M][xa_ld]
+    int64_t xa_ld;
+    const uint16_t *hid;        // hidden layer of the children [M n][hid_ld]
+    int64_t hid_ld;
+    int64_t M;
+    int32_t n, D;
+    uint16_t *da;               // out: bf16(d a) of the children [M n][da_ld]
+    int64_t da_ld;
+    uint16_t *dhid;             // out: bf16((da W2)(1 - hid^2)) [M n][dhid_ld]
+    int64_t dhid_ld;
+    float *dxa;                 // out: d a of the parents through this hop [M][dxa_ld]
+    int64_t dxa_ld;
+};
+
+constexpr int AF_NMAX = 16;          // children per parent (one 16-row MFMA tile)
+constexpr int AF_MAX_WAVES = 8;      // per workgroup (512 threads: the register allocator may use up to 256 VGPRs)
+
+__device__ __forceinline__ int af_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+__device__ __forceinline__ af_f32x4 af_mfma(const vec16 &a, const vec16 &b, const af_f32x4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0,
+                                                   0);
+}
+
+__device__ __forceinline__ void af_unpack(const vec16 &raw, float (&f)[8])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w = raw[e >> 1];
+        f[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+}
+
+// the n row ids of parent p: lane j < n keeps the (low dword of the) table row of child j
+__device__ __forceinline__ uint32_t af_load_id(const int64_t *ids, int64_t row0, int64_t p, int n, int lane)
+{
+    const int64_t pos = p * n + (lane < n ? lane : n - 1);
+    if (ids) return reinterpret_cast<const uint32_t *>(ids + pos)[0];      // (row ids are < 2^31)
+    return (uint32_t)(row0 + pos);
+}
+
+__device__ __forceinline__ float af_readlane(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// rows of one parent -> the wave's LDS tile: instruction i fills slots 64 i .. 64 i + 63 (1 KiB, row-major).
+// Rows of >= 64 chunks: an instruction covers pieces of at most two rows, whose ids come from v_readlane (scalar
+// index); shorter rows take the id of each lane's row from a ds_bpermute.
+template <int KS>
+__device__ __forceinline__ void af_issue_tile(const uint16_t *table, int64_t ld, uint32_t idreg, int n, vec16 *xb, int lane)
+{
+    constexpr int CH = 4 * KS;
+    const int n_instr = (n * CH + 63) >> 6;                     // wave-uniform
+    for (int i = 0; i < n_instr; ++i) {
+        const int s = 64 * i + lane;
+        const int row = s / CH;                                  // (constant divisor)
+        const int cp = s - row * CH;
+        const int c = cp ^ af_swz(row);
+        uint32_t id;
+        if constexpr (CH >= 64) {
+            const int rf = (64 * i) / CH;                        // scalar: the row of the instruction's first slot
+            const uint32_t ida = (uint32_t)__builtin_amdgcn_readlane((int)idreg, rf < n ? rf : n - 1);
+            const uint32_t idb = (uint32_t)__builtin_amdgcn_readlane((int)idreg, rf + 1 < n ? rf + 1 : n - 1);
+            id = row == rf ? ida : idb;
+        } else {
+            id = (uint32_t)__shfl((int)idreg, row < n ? row : n - 1, 64);
+        }
+        if (row < n)
+            __builtin_amdgcn_global_load_lds((global_void_t *)(table + (int64_t)id * ld + c * 8), (lds_void_t *)(xb + 64 * i), 16,
+                                             0, 0);
+    }
+}
+
+__device__ __forceinline__ float af_group16_max(float v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float af_group16_sum(float v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int KS>
+__global__ void __launch_bounds__(AF_MAX_WAVES * 64)
+k_attn_fused_fwd(const AttnFusedFwd p)
+{
+    constexpr int CH = 4 * KS;
+    extern __shared__ __attribute__((aligned(16))) char af_smem[];
+    vec16 *w0s = reinterpret_cast<vec16 *>(af_smem);            // [32][CH], swizzled like a row tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const int n = p.n;
+    for (int s = tid; s < 32 * CH; s += blockDim.x) {
+        const int row = s / CH, cp = s - row * CH;
+        w0s[s] = *reinterpret_cast<const vec16 *>(p.W0 + row * p.ldw0 + (cp ^ af_swz(row)) * 8);
+    }
+    __syncthreads();
+    vec16 *xb = w0s + 32 * CH + wave * (n * CH);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int sw = af_swz(r16);
+    const bool valid = r16 < n;
+
+    // att.2 as the A operand of a^T = W2 hid^T: reduction slot (q, e) is hidden unit (e < 4 ? 4 q + e : 16 + 4 q + e - 4)
+    vec16 w2a[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint16_t *wr = p.W2 + (16 * t + r16) * p.ldw2;
+        const af_u32x2 lo = *reinterpret_cast<const af_u32x2 *>(wr + 4 * q);
+        const af_u32x2 hi = *reinterpret_cast<const af_u32x2 *>(wr + 16 + 4 * q);
+        w2a[t] = vec16{lo[0], lo[1], hi[0], hi[1]};
+    }
+
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    int64_t par = (int64_t)blockIdx.x * n_waves + wave;
+    uint32_t id_next = par < p.M ? af_load_id(p.ids, p.row0, par, n, lane) : 0u;
+    while (par < p.M) {
+        const af_f32x4 x0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 4 * q);
+        const af_f32x4 x1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 16 + 4 * q);
+        af_issue_tile<KS>(p.table, p.ld, id_next, n, xb, lane);
+        const int64_t nxt = par + stride;
+        // (unconditional: a load inside a branch makes the compiler drain every outstanding request at the join)
+        id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile has landed (this wave's own DMAs)
+        __builtin_amdgcn_sched_barrier(0);
+
+        // hid^T [32 x 16 rows] = W0 [32 x D] X^T; the fragments of step ks + 1 are requested before the MFMAs of step ks
+        af_f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+        vec16 fb[2], fa0[2], fa1[2];
+        {
+            const int c = q ^ sw;
+            fb[0] = xb[r16 * CH + c];
+            fa0[0] = w0s[r16 * CH + c];
+            fa1[0] = w0s[(16 + r16) * CH + c];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                const int c = (4 * (ks + 1) + q) ^ sw;
+                fb[(ks + 1) & 1] = xb[r16 * CH + c];
+                fa0[(ks + 1) & 1] = w0s[r16 * CH + c];
+                fa1[(ks + 1) & 1] = w0s[(16 + r16) * CH + c];
+            }
+            h0 = af_mfma(fa0[ks & 1], fb[ks & 1], h0);
+            h1 = af_mfma(fa1[ks & 1], fb[ks & 1], h1);
+        }
+        vec16 hb;
+        hb[0] = pack_bf16x2(apply_act(h0[0], ACT_TANH), apply_act(h0[1], ACT_TANH));
+        hb[1] = pack_bf16x2(apply_act(h0[2], ACT_TANH), apply_act(h0[3], ACT_TANH));
+        hb[2] = pack_bf16x2(apply_act(h1[0], ACT_TANH), apply_act(h1[1], ACT_TANH));
+        hb[3] = pack_bf16x2(apply_act(h1[2], ACT_TANH), apply_act(h1[3], ACT_TANH));
+        const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const af_f32x4 a0v = af_mfma(w2a[0], hb, zero);          // a[row][4 q + reg]
+        const af_f32x4 a1v = af_mfma(w2a[1], hb, zero);          // a[row][16 + 4 q + reg]
+        const int64_t child = par * n + r16;
+        if (valid) {
+            uint16_t *hr = p.hid + child * p.hid_ld;
+            *reinterpret_cast<af_u32x2 *>(hr + 4 * q) = af_u32x2{hb[0], hb[1]};
+            *reinterpret_cast<af_u32x2 *>(hr + 16 + 4 * q) = af_u32x2{hb[2], hb[3]};
+            float *ar = p.a + child * p.a_ld;
+            *reinterpret_cast<af_f32x4 *>(ar + 4 * q) = a0v;
+            *reinterpret_cast<af_f32x4 *>(ar + 16 + 4 * q) = a1v;
+        }
+        // score of this lane's row, softmax over the rows of the 16-lane group
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += a0v[e] * x0[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += a1v[e] * x1[e];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mx = af_group16_max(valid ? s : -INFINITY);
+        const float ex = valid ? expf(s - mx) : 0.f;
+        const float w = ex / af_group16_sum(ex);
+        if (valid && q == 0) p.ws[child] = w;
+
+        // agg = sum_j w_j row_j: lane = 16-byte column chunk
+#pragma unroll
+        for (int c0 = 0; c0 < CH; c0 += 64) {
+            const int c = c0 + lane;
+            const bool live = c < CH;
+            const int cc = live ? c : CH - 1;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < AF_NMAX; ++j)
+                if (j < n) {                                    // wave-uniform: the reads of a round go out together
+                    const float wj = af_readlane(w, j);
+                    float f[8];
+                    af_unpack(xb[j * CH + (cc ^ af_swz(j))], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += wj * f[e];
+                }
+            if (live) {
+                if (p.agg) {
+                    float *o = p.agg + par * p.agg_ld + 8 * c;
+                    *reinterpret_cast<af_f32x4 *>(o) = af_f32x4{acc[0], acc[1], acc[2], acc[3]};
+                    *reinterpret_cast<af_f32x4 *>(o + 4) = af_f32x4{acc[4], acc[5], acc[6], acc[7]};
+                }
+                if (p.agg_lp) {
+                    vec16 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+                    *reinterpret_cast<vec16 *>(p.agg_lp + par * p.lp_ld + 8 * c) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        par = nxt;
+    }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(AF_MAX_WAVES * 64)
+k_attn_fused_bwd(const AttnFusedBwd p)
+{
+    constexpr int CH = 4 * KS;
+    constexpr int ROUNDS = (CH + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char af_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const int n = p.n;
+    vec16 *xb = reinterpret_cast<vec16 *>(af_smem) + wave * (n * CH);
+    const int r16 = lane & 15, q = lane >> 4;
+    const bool valid = r16 < n;
+    const int h32 = lane & 31, half = lane >> 5;
+
+    // att.2 as the A operand of dhg^T = W2^T da^T: A[m = k][h] = W2[h][k] = W2T[k][h]
+    vec16 w2ta[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w2ta[t] = *reinterpret_cast<const vec16 *>(p.W2T + (16 * t + r16) * p.ldw2t + 8 * q);
+
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    int64_t par = (int64_t)blockIdx.x * n_waves + wave;
+    uint32_t id_next = par < p.M ? af_load_id(p.ids, p.row0, par, n, lane) : 0u;
+    while (par < p.M) {
+        const int64_t child = par * n + (valid ? r16 : n - 1);
+        // everything else this parent needs, requested ahead of the rows
+        af_f32x4 gv[ROUNDS][2];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int c = 64 * r + lane;
+            const int cc = c < CH ? c : CH - 1;
+            gv[r][0] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc);
+            gv[r][1] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc + 4);
+            if (c >= CH) { gv[r][0] = af_f32x4{0.f, 0.f, 0.f, 0.f}; gv[r][1] = gv[r][0]; }
+        }
+        const float wgt = valid ? p.ws[child] : 0.f;
+        const af_f32x4 xq0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q);
+        const af_f32x4 xq1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q + 4);
+        const af_u32x2 hlo = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 4 * q);
+        const af_u32x2 hhi = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 16 + 4 * q);
+        float nav[AF_NMAX / 2];
+#pragma unroll
+        for (int i = 0; i < AF_NMAX / 2; ++i) {
+            const int j = 2 * i + half;
+            nav[i] = p.na[(par * n + (j < n ? j : n - 1)) * p.na_ld + h32];
+        }
+        af_issue_tile<KS>(p.table, p.ld, id_next, n, xb, lane);
+        const int64_t nxt = par + stride;
+        id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // dws[j] = <row_j, d agg>: per-lane partial sums over its column chunks, then across the wave
+        float pj[AF_NMAX];
+#pragma unroll
+        for (int j = 0; j < AF_NMAX; ++j) pj[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int c = 64 * r + lane;
+            const int cc = c < CH ? c : CH - 1;
+#pragma unroll
+            for (int j = 0; j < AF_NMAX; ++j)
+                if (j < n) {                                    // wave-uniform
+                    float f[8];
+                    af_unpack(xb[j * CH + (cc ^ af_swz(j))], f);
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d += f[e] * gv[r][0][e];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d += f[4 + e] * gv[r][1][e];
+                    pj[j] += d;
+                }
+        }
+        float dws = 0.f;
+#pragma unroll
+        for (int j = 0; j < AF_NMAX; ++j)
+            if (j < n) {
+                float t = pj[j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                if (r16 == j) dws = t;
+            }
+        // softmax backward (rows of the 16-lane group)
+        const float dot = af_group16_sum(dws * wgt);
+        const float ds = wgt * (dws - dot);
+
+        // d a of the parent through this hop: dxa[h] = sum_j ds_j a_child[j][h]
+        float dx = 0.f;
+#pragma unroll
+        for (int i = 0; i < AF_NMAX / 2; ++i)
+            if (2 * i < n) {
+                const float d0 = af_readlane(ds, 2 * i), d1 = af_readlane(ds, 2 * i + 1 < n ? 2 * i + 1 : 0);
+                const float dj = half ? (2 * i + 1 < n ? d1 : 0.f) : d0;
+                dx += dj * nav[i];
+            }
+        dx += __shfl_xor(dx, 32, 64);
+        if (lane < 32) p.dxa[par * p.dxa_ld + h32] = dx;
+
+        // d a of this lane's row, its hidden units 8 q .. 8 q + 7 (no gradient reaches a last-hop row as a parent)
+        vec16 dav;
+        dav[0] = pack_bf16x2(ds * xq0[0], ds * xq0[1]);
+        dav[1] = pack_bf16x2(ds * xq0[2], ds * xq0[3]);
+        dav[2] = pack_bf16x2(ds * xq1[0], ds * xq1[1]);
+        dav[3] = pack_bf16x2(ds * xq1[2], ds * xq1[3]);
+        if (valid) *reinterpret_cast<vec16 *>(p.da + child * p.da_ld + 8 * q) = dav;
+        // dhg^T [k][row] = sum_h W2[h][k] da[row][h]; lane (row, q) gets k = 4 q + reg and 16 + 4 q + reg
+        const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const af_f32x4 g0 = af_mfma(w2ta[0], dav, zero);
+        const af_f32x4 g1 = af_mfma(w2ta[1], dav, zero);
+        float hl[4], hh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t wl = hlo[e >> 1], wh = hhi[e >> 1];
+            hl[e] = __uint_as_float((e & 1) ? (wl & 0xffff0000u) : (wl << 16));
+            hh[e] = __uint_as_float((e & 1) ? (wh & 0xffff0000u) : (wh << 16));
+        }
+        if (valid) {
+            uint16_t *dr = p.dhid + child * p.dhid_ld;
+            *reinterpret_cast<af_u32x2 *>(dr + 4 * q) =
+                af_u32x2{pack_bf16x2(g0[0] * (1.f - hl[0] * hl[0]), g0[1] * (1.f - hl[1] * hl[1])),
+                         pack_bf16x2(g0[2] * (1.f - hl[2] * hl[2]), g0[3] * (1.f - hl[3] * hl[3]))};
+            *reinterpret_cast<af_u32x2 *>(dr + 16 + 4 * q) =
+                af_u32x2{pack_bf16x2(g1[0] * (1.f - hh[0] * hh[0]), g1[1] * (1.f - hh[1] * hh[1])),
+                         pack_bf16x2(g1[2] * (1.f - hh[2] * hh[2]), g1[3] * (1.f - hh[3] * hh[3]))};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        par = nxt;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+constexpr int AF_LDS_BYTES = 160 * 1024;
+
+static int af_ksteps(int64_t D)
+{
+    const int64_t ks = ceil_div(D, 32);
+    for (int k : {1, 2, 4, 8, 19, 20})
+        if (ks <= k) return k;
+    return 0;
+}
+
+// Waves per workgroup and workgroups per CU: one LDS tile per wave, W0 once per workgroup.  The kernels need 104-128
+// registers (four waves per SIMD: at most 16 waves per CU), so the pair (waves, workgroups per CU) with the most
+// waves per CU that the 160 KiB hold wins; ties go to fewer, larger workgroups (fewer copies of W0).
+static bool af_geometry(int ks, int n, bool with_w0, int64_t M, int *waves, int *grid, size_t *lds)
+{
+    const int64_t ch = 4 * ks, tile = (int64_t)n * ch * 16, fixed = (with_w0 ? 32 * ch * 16 : 0) + (16 - n) * ch * 16;
+    int best_nw = 0, best_pc = 0;
+    for (int nw = 1; nw <= AF_MAX_WAVES; ++nw)
+        for (int pc = 1; pc <= 16; ++pc) {
+            if (pc * (fixed + nw * tile) > AF_LDS_BYTES || nw * pc > 16) break;
+            if (nw * pc > best_nw * best_pc || (nw * pc == best_nw * best_pc && nw > best_nw)) { best_nw = nw; best_pc = pc; }
+        }
+    if (!best_nw) return false;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else (void)hipGetLastError();
+    } else (void)hipGetLastError();
+    int64_t g = ceil_div(M, best_nw);
+    if (g > (int64_t)cus * best_pc) g = (int64_t)cus * best_pc;
+    *waves = best_nw;
+    *grid = (int)(g < 1 ? 1 : g);
+    *lds = (size_t)(fixed + best_nw * tile);
+    return true;
+}
+
+// more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU): raised once per kernel
+template <typename K>
+static int af_raise_lds(K kernel, bool &done)
+{
+    if (done) return GSAGE_OK;
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("attn_fused: cannot raise the dynamic LDS limit");
+        return GSAGE_ELAUNCH;
+    }
+    done = true;
+    return GSAGE_OK;
+}
+
+}  // namespace gsage
+
+using namespace gsage;
+
+extern "C" int gsage_attn_fused_ok(int dtype, int64_t ld, int64_t D, int32_t n, int64_t Ha)
+{
+    if (dtype != GSAGE_BF16 || Ha != 32 || n < 2 || n > AF_NMAX || D < 1 || ld % 8 != 0) return 0;
+    const int ks = af_ksteps(D);
+    return ks > 0 && 32 * (int64_t)ks <= ld ? 1 : 0;
+}
+
+#define GSAGE_AF_DISPATCH(ks, KERNEL, ...)                                       \
+    do {                                                                         \
+        switch (ks) {                                                            \
+        case 1: KERNEL(1, __VA_ARGS__); break;                                   \
+        case 2: KERNEL(2, __VA_ARGS__); break;                                   \
+        case 4: KERNEL(4, __VA_ARGS__); break;                                   \
+        case 8: KERNEL(8, __VA_ARGS__); break;                                   \
+        case 19: KERNEL(19, __VA_ARGS__); break;                                 \
+        default: KERNEL(20, __VA_ARGS__); break;                                 \
+        }                                                                        \
+    } while (0)
+
+extern "C" int gsage_attn_fused_fwd(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t row0,
+                                    const void *W0, int64_t ldw0, const void *W2, int64_t ldw2, const float *xa,
+                                    int64_t xa_ld, int64_t M, int32_t n, int64_t D, void *hid, int64_t hid_ld, float *a,
+                                    int64_t a_ld, float *ws, float *agg, int64_t agg_ld, void *agg_lp, int64_t lp_ld,
+                                    void *stream)
+{
+    GSAGE_REQUIRE(gsage_attn_fused_ok(dtype, ld, D, n, 32), "attn_fused_fwd: shape not covered (bf16 rows of whole 16-byte "
+                  "chunks, D <= 640, fan-out 2..16)");
+    const int ks = af_ksteps(D);
+    const int64_t cols = 32 * (int64_t)ks;
+    GSAGE_REQUIRE(M >= 0 && ldw0 >= cols && ldw0 % 8 == 0 && ldw2 >= 32 && ldw2 % 4 == 0 && xa_ld >= 32 && xa_ld % 4 == 0 &&
+                  hid_ld >= 32 && hid_ld % 4 == 0 && a_ld >= 32 && a_ld % 4 == 0, "attn_fused_fwd: bad leading dimension");
+    GSAGE_REQUIRE(agg || agg_lp, "attn_fused_fwd: no output");
+    GSAGE_REQUIRE((!agg || (agg_ld >= cols && agg_ld % 4 == 0)) && (!agg_lp || (lp_ld >= cols && lp_ld % 8 == 0)),
+                  "attn_fused_fwd: output rows must hold whole 16-byte chunks up to the 32-column step");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(table && W0 && W2 && xa && hid && a && ws, "attn_fused_fwd: null pointer");
+    GSAGE_REQUIRE((((uintptr_t)table | (uintptr_t)W0 | (uintptr_t)xa | (uintptr_t)a | (uintptr_t)agg | (uintptr_t)agg_lp) & 15) == 0 &&
+                  (((uintptr_t)W2 | (uintptr_t)hid) & 7) == 0, "attn_fused_fwd: misaligned pointer");
+    int waves, grid;
+    size_t lds;
+    GSAGE_REQUIRE(af_geometry(ks, n, true, M, &waves, &grid, &lds), "attn_fused_fwd: a row tile does not fit the LDS");
+    AttnFusedFwd p;
+    p.table = (const uint16_t *)table; p.ld = ld; p.ids = ids; p.row0 = row0; p.W0 = (const uint16_t *)W0; p.ldw0 = ldw0;
+    p.W2 = (const uint16_t *)W2; p.ldw2 = ldw2; p.xa = xa; p.xa_ld = xa_ld; p.M = M; p.n = n; p.D = (int32_t)D;
+    p.hid = (uint16_t *)hid; p.hid_ld = hid_ld; p.a = a; p.a_ld = a_ld; p.ws = ws; p.agg = agg; p.agg_ld = agg_ld;
+    p.agg_lp = (uint16_t *)agg_lp; p.lp_ld = lp_ld;
+#define GSAGE_AF_FWD(KSV, P)                                                                                              \
+    do {                                                                                                                  \
+        static bool raised = false;                                                                                       \
+        rc = af_raise_lds(k_attn_fused_fwd<KSV>, raised);                                                                 \
+        if (rc == GSAGE_OK) launch(k_attn_fused_fwd<KSV>, dim3(grid), dim3(waves * 64), lds, (hipStream_t)stream, P);     \
+    } while (0)
+    int rc = GSAGE_OK;
+    GSAGE_AF_DISPATCH(ks, GSAGE_AF_FWD, p);
+#undef GSAGE_AF_FWD
+    if (rc != GSAGE_OK) return rc;
+    return check_launch("attn_fused_fwd");
+}
+
+extern "C" int gsage_attn_fused_bwd(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t row0,
+                                    const void *W2T, int64_t ldw2t, const float *g, int64_t g_ld, const float *ws,
+                                    const float *na, int64_t na_ld, const float *xa, int64_t xa_ld, const void *hid,
+                                    int64_t hid_ld, int64_t M, int32_t n, int64_t D, void *da, int64_t da_ld, void *dhid,
+                                    int64_t dhid_ld, float *dxa, int64_t dxa_ld, void *stream)
+{
+    GSAGE_REQUIRE(gsage_attn_fused_ok(dtype, ld, D, n, 32), "attn_fused_bwd: shape not covered (bf16 rows of whole 16-byte "
+                  "chunks, D <= 640, fan-out 2..16)");
+    const int ks = af_ksteps(D);
+    const int64_t cols = 32 * (int64_t)ks;
+    GSAGE_REQUIRE(M >= 0 && ldw2t >= 32 && ldw2t % 8 == 0 && g_ld >= cols && g_ld % 4 == 0 && na_ld >= 32 && xa_ld >= 32 &&
+                  xa_ld % 4 == 0 && hid_ld >= 32 && hid_ld % 4 == 0 && da_ld >= 32 && da_ld % 8 == 0 && dhid_ld >= 32 &&
+                  dhid_ld % 4 == 0 && dxa_ld >= 32, "attn_fused_bwd: bad leading dimension");
+    if (M == 0) return GSAGE_OK;
+    GSAGE_REQUIRE(table && W2T && g && ws && na && xa && hid && da && dhid && dxa, "attn_fused_bwd: null pointer");
+    GSAGE_REQUIRE((((uintptr_t)table | (uintptr_t)W2T | (uintptr_t)g | (uintptr_t)xa | (uintptr_t)da) & 15) == 0 &&
+                  (((uintptr_t)hid | (uintptr_t)dhid) & 7) == 0, "attn_fused_bwd: misaligned pointer");
+    int waves, grid;
+    size_t lds;
+    GSAGE_REQUIRE(af_geometry(ks, n, false, M, &waves, &grid, &lds), "attn_fused_bwd: a row tile does not fit the LDS");
+    AttnFusedBwd p;
+    p.table = (const uint16_t *)table; p.ld = ld; p.ids = ids; p.row0 = row0; p.W2T = (const uint16_t *)W2T; p.ldw2t = ldw2t;
+    p.g = g; p.g_ld = g_ld; p.ws = ws; p.na = na; p.na_ld = na_ld; p.xa = xa; p.xa_ld = xa_ld; p.hid = (const uint16_t *)hid;
+    p.hid_ld = hid_ld; p.M = M; p.n = n; p.D = (int32_t)D; p.da = (uint16_t *)da; p.da_ld = da_ld; p.dhid = (uint16_t *)dhid;
+    p.dhid_ld = dhid_ld; p.dxa = dxa; p.dxa_ld = dxa_ld;
+#define GSAGE_AF_BWD(KSV, P)                                                                                              \
+    do {                                                                                                                  \
+        static bool raised = false;                                                                                       \
+        rc = af_raise_lds(k_attn_fused_bwd<KSV>, raised);                                                                 \
+        if (rc == GSAGE_OK) launch(k_attn_fused_bwd<KSV>, dim3(grid), dim3(waves * 64), lds, (hipStream_t)stream, P);     \
+    } while (0)
+    int rc = GSAGE_OK;
+    GSAGE_AF_DISPATCH(ks, GSAGE_AF_BWD, p);
+#undef GSAGE_AF_BWD
+    if (rc != GSAGE_OK) return rc;
+    return check_launch("attn_fused_bwd");
+}

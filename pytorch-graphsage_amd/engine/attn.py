@@ -111,6 +111,11 @@ class FusedAttnTrainStep(FusedTrainStep):
             self.da.append(z(RA, HL, dt=T)); self.dhid.append(z(RA, HL, dt=T))
             ing = l > 0 or self.emb
             self.datt.append(z(RA, ld) if ing else None); self.dx.append(z(R, ld) if ing else None)
+        # the LAST hop of a level (most of its rows) through K4 / K4' with the attention MLP inside
+        # (csrc/gsage_attn_fused.hip: the rows are read once per direction); GSAGE_ATTN_FUSED=0: the separate launches
+        on = os.environ.get("GSAGE_ATTN_FUSED", "1") != "0"
+        self.fuse = [bool(on and nat.lib().gsage_attn_fused_ok(self.code, self.ldin[l], self.din[l], self.fan[L - l], Ha))
+                     for l in range(L)]
 
     def _in(self, l, s):
         """input rows of level l (all hops it reads): (row block, leading dimension, row list or None) -- with a
@@ -199,14 +204,23 @@ class FusedAttnTrainStep(FusedTrainStep):
         for l in range(L):
             R, RA, h, D = self.rows[l], self.rall[l], self.h[l], self.din[l]
             inp, ld, rows = self._in(l, s)
-            self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RA, Ha, D, nat.ACT_TANH, rows)
+            RM = R if self.fuse[l] else RA            # rows whose att(.) is a launch of its own (fused: all but the last hop)
+            self._gemm(inp.data_ptr(), ld, self.w0[l], self.hid[l].data_ptr(), self.code, HL, RM, Ha, D, nat.ACT_TANH, rows)
             nat.check(lib.gsage_attn_mlp2_fwd(self.hid[l].data_ptr(), self.code, HL, self.w2[l].data_ptr(),
-                                              self.w2[l].shape[1], self.a[l].data_ptr(), Ha, RA, Ha, stream), "attn_mlp2_fwd")
+                                              self.w2[l].shape[1], self.a[l].data_ptr(), Ha, RM, Ha, stream), "attn_mlp2_fwd")
             for k in range(L - l):                   # K4 writes the aggregate as fp32 and as the next GEMMs' operand
                 r0, c0 = self.off[k], self.off[k + 1]
                 tab, idp = self._child_rows(inp, rows, c0)
                 if l == 0 and k == L - 1:
                     self._time_next(4, 5)
+                if self.fuse[l] and k == L - l - 1:  # the last hop: att(children), the weights and the sum in one pass
+                    nat.check(lib.gsage_attn_fused_fwd(
+                        tab, self.code, ld, idp, 0, self.w0[l].data_ptr(), self.w0[l].shape[1], self.w2[l].data_ptr(),
+                        self.w2[l].shape[1], self.a[l][r0:].data_ptr(), Ha, self.size[k], self.fan[k + 1], D,
+                        self.hid[l][c0:].data_ptr(), HL, self.a[l][c0:].data_ptr(), Ha,
+                        self.ws[l][c0 - self.off[1]:].data_ptr(), self.agg[l][r0:].data_ptr(), ld,
+                        self.aggc[l][r0:].data_ptr(), ld, stream), "attn_fused_fwd")
+                    continue
                 nat.check(lib.gsage_attn_aggregate_lp(
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
                     idp, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
@@ -232,11 +246,19 @@ class FusedAttnTrainStep(FusedTrainStep):
             # d agg = dC[:, h:] Wn
             self._gemm(dc.data_ptr() + h * esz, 2 * h, self.wnT[l], self.dagg[l].data_ptr(), nat.F32, ld, R, D, h,
                        nat.ACT_NONE)
-            for k in range(L - l):
+            for k in range(L - l - 1, -1, -1):       # (the last hop first: it leaves d a of its PARENTS, hop k's rows)
                 r0, c0 = self.off[k], self.off[k + 1]
                 tab, idp = self._child_rows(inp, rows, c0)
                 if l == 0 and k == L - 1:
                     self._time_next(6, 7)
+                if self.fuse[l] and k == L - l - 1:
+                    nat.check(lib.gsage_attn_fused_bwd(
+                        tab, self.code, ld, idp, 0, self.w2T[l].data_ptr(), self.w2T[l].shape[1],
+                        self.dagg[l][r0:].data_ptr(), ld, self.ws[l][c0 - self.off[1]:].data_ptr(),
+                        self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, self.hid[l][c0:].data_ptr(), HL,
+                        self.size[k], self.fan[k + 1], D, self.da[l][c0:].data_ptr(), HL, self.dhid[l][c0:].data_ptr(), HL,
+                        self.dax[l][r0:].data_ptr(), Ha, stream), "attn_fused_bwd")
+                    continue
                 nat.check(lib.gsage_attn_bwd(
                     self.dagg[l][r0:].data_ptr(), ld, self.ws[l][c0 - self.off[1]:].data_ptr(),
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
@@ -247,7 +269,7 @@ class FusedAttnTrainStep(FusedTrainStep):
             nat.check(lib.gsage_attn_mlp2_bwd(self.dan[l].data_ptr(), Ha, self.dax[l].data_ptr(), Ha,
                                               self.hid[l].data_ptr(), self.code, HL, self.w2T[l].data_ptr(),
                                               self.w2T[l].shape[1], self.da[l].data_ptr(), HL, self.dhid[l].data_ptr(), HL,
-                                              RA, Ha, stream), "attn_mlp2_bwd")
+                                              R if self.fuse[l] else RA, Ha, stream), "attn_mlp2_bwd")
             if l > 0 or self.emb:
                 self._gemm(self.dhid[l].data_ptr(), HL, self.w0T[l], self.datt[l].data_ptr(), nat.F32, ld, RA, D, Ha,
                            nat.ACT_NONE)

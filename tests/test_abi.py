@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), "libgsage_hip.so does not export %s" % n
         assert n in gs._native.SIGNATURES, "ctypes binding lacks %s" % n
     assert set(gs._native.SIGNATURES) == set(names)
-    assert gs._native.lib().gsage_abi_version() == gs._native.ABI_VERSION == 5
+    assert gs._native.lib().gsage_abi_version() == gs._native.ABI_VERSION == 6
 
 
 def test_missing_library_fails_loudly(monkeypatch):

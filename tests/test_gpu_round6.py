@@ -1,0 +1,221 @@
+"""-m gpu, round 6: K4 / K4' with the attention MLP inside (csrc/gsage_attn_fused.hip) against the launches they
+replace (att.0 GEMM + tanh, gsage_attn_mlp2_fwd, gsage_attn_aggregate_lp; gsage_attn_bwd, gsage_attn_mlp2_bwd) and against
+the definition in plain torch with the engine's rounding points (reference nn_modules.py:293-296, 309-315)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+gs = pkg()
+ops = gs.ops
+nat = gs._native
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(autouse=True)
+def _setup():
+    ops.set_compute_dtype("bf16")
+    ops.warmup(torch.device(DEV))
+    yield
+    ops.set_compute_dtype("bf16")
+
+
+def _r64(v):
+    return -(-v // 64) * 64
+
+
+def _case(D, n, M, N, with_ids, seed=3):
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    ld = _r64(D)
+    rows = M * n
+    table = torch.zeros(N if with_ids else rows, ld, dtype=BF, device=DEV)
+    table[:, :D] = (torch.randn(table.shape[0], D, generator=g) * 0.7).to(DEV).to(BF)
+    ids = torch.randint(0, N, (rows,), generator=g).to(DEV) if with_ids else None
+    w0 = torch.zeros(32, ld, dtype=BF, device=DEV)
+    w0[:, :D] = (torch.randn(32, D, generator=g) / np.sqrt(D)).to(DEV).to(BF)
+    w2 = torch.zeros(32, 64, dtype=BF, device=DEV)
+    w2[:, :32] = (torch.randn(32, 32, generator=g) / np.sqrt(32)).to(DEV).to(BF)
+    w2t = torch.zeros(32, 64, dtype=BF, device=DEV)
+    w2t[:, :32] = w2[:, :32].t()
+    xa = torch.randn(M, 32, generator=g).to(DEV)
+    gout = torch.zeros(M, ld, device=DEV)
+    gout[:, :D] = torch.randn(M, D, generator=g).to(DEV)
+    return dict(D=D, n=n, M=M, ld=ld, table=table, ids=ids, w0=w0, w2=w2, w2t=w2t, xa=xa, gout=gout)
+
+
+def _fused(c):
+    L, st = nat.lib(), ops._stream()
+    D, n, M, ld = c["D"], c["n"], c["M"], c["ld"]
+    rows = M * n
+    hid = torch.zeros(rows, 64, dtype=BF, device=DEV); a = torch.zeros(rows, 32, device=DEV)
+    ws = torch.zeros(rows, device=DEV); agg = torch.full((M, ld), 7.0, device=DEV)
+    aggc = torch.full((M, ld), 7.0, dtype=BF, device=DEV)
+    idp = c["ids"].data_ptr() if c["ids"] is not None else None
+    assert L.gsage_attn_fused_ok(nat.BF16, ld, D, n, 32) == 1
+    nat.check(L.gsage_attn_fused_fwd(c["table"].data_ptr(), nat.BF16, ld, idp, 0, c["w0"].data_ptr(), ld, c["w2"].data_ptr(),
+                                     64, c["xa"].data_ptr(), 32, M, n, D, hid.data_ptr(), 64, a.data_ptr(), 32, ws.data_ptr(),
+                                     agg.data_ptr(), ld, aggc.data_ptr(), ld, st), "fused_fwd")
+    da = torch.zeros(rows, 64, dtype=BF, device=DEV); dhid = torch.zeros(rows, 64, dtype=BF, device=DEV)
+    dxa = torch.zeros(M, 32, device=DEV)
+    nat.check(L.gsage_attn_fused_bwd(c["table"].data_ptr(), nat.BF16, ld, idp, 0, c["w2t"].data_ptr(), 64,
+                                     c["gout"].data_ptr(), ld, ws.data_ptr(), a.data_ptr(), 32, c["xa"].data_ptr(), 32,
+                                     hid.data_ptr(), 64, M, n, D, da.data_ptr(), 64, dhid.data_ptr(), 64, dxa.data_ptr(), 32,
+                                     st), "fused_bwd")
+    torch.cuda.synchronize()
+    return dict(hid=hid, a=a, ws=ws, agg=agg, aggc=aggc, da=da, dhid=dhid, dxa=dxa)
+
+
+def _separate(c):
+    """the launches engine.FusedAttnTrainStep issued before round 6, on the same operands"""
+    L, st = nat.lib(), ops._stream()
+    D, n, M, ld = c["D"], c["n"], c["M"], c["ld"]
+    rows = M * n
+    hid = torch.zeros(rows, 64, dtype=BF, device=DEV); a = torch.zeros(rows, 32, device=DEV)
+    idp = c["ids"].data_ptr() if c["ids"] is not None else None
+    ops._linear_launch(c["table"].data_ptr(), ld, idp, 0, c["w0"].data_ptr(), ld, None, hid.data_ptr(), 64, rows, 32, D,
+                       nat.ACT_TANH, 1, 0, 0, 0, nat.BF16, nat.BF16)
+    nat.check(L.gsage_attn_mlp2_fwd(hid.data_ptr(), nat.BF16, 64, c["w2"].data_ptr(), 64, a.data_ptr(), 32, rows, 32, st), "mlp2")
+    ws = torch.zeros(rows, device=DEV); agg = torch.zeros(M, ld, device=DEV); aggc = torch.zeros(M, ld, dtype=BF, device=DEV)
+    nat.check(L.gsage_attn_aggregate_lp(a.data_ptr(), 32, c["xa"].data_ptr(), 32, c["table"].data_ptr(), nat.BF16, ld, idp, M,
+                                        n, 32, D, agg.data_ptr(), ld, ws.data_ptr(), aggc.data_ptr(), ld, st), "k4")
+    dan = torch.zeros(rows, 32, device=DEV); dax = torch.zeros(M, 32, device=DEV)
+    nat.check(L.gsage_attn_bwd(c["gout"].data_ptr(), ld, ws.data_ptr(), a.data_ptr(), 32, c["xa"].data_ptr(), 32,
+                               c["table"].data_ptr(), nat.BF16, ld, idp, M, n, 32, D, dan.data_ptr(), 32, dax.data_ptr(), 32,
+                               st), "k4'")
+    zero = torch.zeros(rows, 32, device=DEV)
+    da = torch.zeros(rows, 64, dtype=BF, device=DEV); dhid = torch.zeros(rows, 64, dtype=BF, device=DEV)
+    nat.check(L.gsage_attn_mlp2_bwd(dan.data_ptr(), 32, zero.data_ptr(), 32, hid.data_ptr(), nat.BF16, 64, c["w2t"].data_ptr(),
+                                    64, da.data_ptr(), 64, dhid.data_ptr(), 64, rows, 32, st), "mlp2'")
+    torch.cuda.synchronize()
+    return dict(hid=hid, a=a, ws=ws, agg=agg, aggc=aggc, da=da, dhid=dhid, dxa=dax)
+
+
+def _definition(c):
+    """nn_modules.py:293-296, 309-315 and their autograd in fp64 with the engine's rounding points (hid, d a, d hid in
+    bf16; operands bf16)"""
+    D, n, M = c["D"], c["n"], c["M"]
+    X = (c["table"][c["ids"]] if c["ids"] is not None else c["table"])[:, :D].double()
+    W0, W2 = c["w0"][:, :D].double(), c["w2"][:, :32].double()
+    rb = lambda t: t.to(torch.float32).to(BF).double()
+    hid = rb(torch.tanh(X @ W0.t()))
+    a = hid @ W2.t()
+    xa = c["xa"].double()
+    s = torch.bmm(a.view(M, n, 32), xa.unsqueeze(2)).squeeze(2)
+    ws = torch.softmax(s, dim=1)
+    agg = (X.view(M, n, D) * ws.unsqueeze(2)).sum(1)
+    g = c["gout"][:, :D].double()
+    dws = torch.bmm(X.view(M, n, D), g.unsqueeze(2)).squeeze(2)
+    ds = ws * (dws - (dws * ws).sum(1, keepdim=True))
+    dxa = (ds.unsqueeze(2) * a.view(M, n, 32)).sum(1)
+    da = rb((ds.unsqueeze(2) * xa.unsqueeze(1)).reshape(M * n, 32))
+    dhid = rb((da @ W2) * (1 - hid * hid))
+    return dict(hid=hid, a=a, ws=ws.reshape(-1), agg=agg, da=da, dhid=dhid, dxa=dxa)
+
+
+SHAPES = [(602, 10, 300, True), (602, 10, 37, False), (64, 15, 500, False), (64, 15, 129, True), (12, 3, 55, True),
+          (40, 2, 64, True), (128, 16, 70, True), (256, 5, 33, False), (640, 7, 19, True), (100, 4, 21, True)]
+
+
+@pytest.mark.parametrize("D,n,M,with_ids", SHAPES)
+def test_fused_attention_hop_against_the_separate_launches_and_the_definition(D, n, M, with_ids):
+    c = _case(D, n, M, 5000, with_ids)
+    f, s, d = _fused(c), _separate(c), _definition(c)
+    ld = c["ld"]
+    # --- against the definition (fp64, the same rounding points)
+    tol = dict(rtol=2e-3, atol=2e-3)
+    # hid is a bf16 value: one ulp (2^-8 relative) where the pre-activation rounds differently
+    torch.testing.assert_close(f["hid"][:, :32].double(), d["hid"], rtol=0, atol=1.0 / 128)
+    torch.testing.assert_close(f["a"].double(), d["a"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(f["ws"].double(), d["ws"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(f["agg"][:, :D].double(), d["agg"], rtol=0, atol=3e-2)
+    torch.testing.assert_close(f["dxa"].double(), d["dxa"], rtol=5e-2, atol=5e-2 * float(d["dxa"].abs().max()))
+    # --- against the separate launches: the same operands through the same rounding points; sums in another order
+    assert torch.equal(f["hid"][:, 32:], torch.zeros_like(f["hid"][:, 32:]))
+    dh = (f["hid"][:, :32].float() - s["hid"][:, :32].float()).abs()
+    assert float(dh.max()) <= 1.0 / 128 and float((dh > 0).float().mean()) < 0.02, (float(dh.max()), float((dh > 0).float().mean()))
+    torch.testing.assert_close(f["a"], s["a"], rtol=0, atol=2e-2)
+    same = (dh.max(dim=1).values == 0)                      # rows whose hidden layer came out bit-identical
+    assert float(same.float().mean()) > 0.5
+    torch.testing.assert_close(f["a"][same], s["a"][same], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(f["ws"], s["ws"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(f["agg"][:, :D], s["agg"][:, :D], rtol=0, atol=3e-2)
+    # pad columns: zeros up to the 32-column step, untouched beyond it
+    cols = -(-D // 32) * 32
+    assert float(f["agg"][:, D:cols].abs().max() if cols > D else 0.0) == 0.0
+    assert float(f["aggc"][:, D:cols].float().abs().max() if cols > D else 0.0) == 0.0
+    if ld > cols:
+        assert torch.all(f["agg"][:, cols:] == 7.0) and torch.all(f["aggc"][:, cols:].float() == 7.0)
+    torch.testing.assert_close(f["aggc"][:, :D].float(), f["agg"][:, :D].to(BF).float(), rtol=0, atol=0)
+    # backward: fed the fused forward's own ws / a / hid, the definition fed the exact ones -- compare in norm
+    for k in ("da", "dhid"):
+        x, y = f[k][:, :32].double(), d[k]
+        assert float((x - y).norm() / (y.norm() + 1e-30)) < 3e-2, (k, float((x - y).norm() / y.norm()))
+        x2 = s[k][:, :32].double()
+        assert float((x - x2).norm() / (x2.norm() + 1e-30)) < 3e-2, (k, "separate")
+    assert float((f["dxa"] - s["dxa"]).norm() / s["dxa"].norm()) < 3e-2
+
+
+def test_fused_attention_backward_on_identical_inputs_equals_the_separate_launches():
+    """K4' + the second layer's backward fed the SAME ws / a / hid: d a and d hid are products of the same factors
+    rounded at the same points -- equal up to the order of the fp32 sums inside dws."""
+    c = _case(602, 10, 200, 5000, True)
+    L, st = nat.lib(), ops._stream()
+    s = _separate(c)
+    D, n, M, ld = c["D"], c["n"], c["M"], c["ld"]
+    rows = M * n
+    da = torch.zeros(rows, 64, dtype=BF, device=DEV); dhid = torch.zeros(rows, 64, dtype=BF, device=DEV)
+    dxa = torch.zeros(M, 32, device=DEV)
+    nat.check(L.gsage_attn_fused_bwd(c["table"].data_ptr(), nat.BF16, ld, c["ids"].data_ptr(), 0, c["w2t"].data_ptr(), 64,
+                                     c["gout"].data_ptr(), ld, s["ws"].data_ptr(), s["a"].data_ptr(), 32, c["xa"].data_ptr(), 32,
+                                     s["hid"].data_ptr(), 64, M, n, D, da.data_ptr(), 64, dhid.data_ptr(), 64, dxa.data_ptr(), 32,
+                                     st), "fused_bwd")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dxa, s["dxa"], rtol=1e-4, atol=1e-4 * float(s["dxa"].abs().max()))
+    for got, want in ((da, s["da"]), (dhid, s["dhid"])):
+        diff = (got.float() - want.float()).abs()
+        # a bf16 ulp where the fp32 value sat on a rounding boundary
+        assert float((diff > 0).float().mean()) < 0.02
+        assert float(diff.max()) <= float(want.float().abs().max()) / 64
+
+
+def test_fused_attention_refuses_what_it_does_not_cover():
+    L = nat.lib()
+    assert L.gsage_attn_fused_ok(nat.F32, 640, 602, 10, 32) == 0          # fp32 rows: the separate launches
+    assert L.gsage_attn_fused_ok(nat.BF16, 640, 602, 25, 32) == 0         # a fan-out beyond one 16-row tile
+    assert L.gsage_attn_fused_ok(nat.BF16, 640, 602, 1, 32) == 0
+    assert L.gsage_attn_fused_ok(nat.BF16, 1280, 1200, 10, 32) == 0       # rows beyond 640 columns
+    assert L.gsage_attn_fused_ok(nat.BF16, 600, 600, 10, 32) == 0         # ld below the 32-column step
+    assert L.gsage_attn_fused_ok(nat.BF16, 640, 602, 10, 64) == 0
+    rc = L.gsage_attn_fused_fwd(None, nat.F32, 640, None, 0, None, 640, None, 64, None, 32, 4, 10, 602, None, 64, None, 32,
+                                None, None, 640, None, 640, None)
+    assert rc == -1 and b"not covered" in L.gsage_last_error()
+
+
+@pytest.mark.parametrize("capture", ["cmdlist", False])
+def test_attention_engine_with_the_fused_hop_tracks_the_separate_launches(monkeypatch, capture):
+    """engine.FusedAttnTrainStep over bf16 features, four steps: the last hop through the fused kernels (default) against
+    GSAGE_ATTN_FUSED=0 -- predictions, gradient norm and weights within the bf16 engines' bounds."""
+    from test_gpu_engine import _model, _problem
+    from util import close_fro
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GSAGE_ATTN_FUSED", flag)
+        adj, feats, rng = _problem(n=900, D=40, seed=4)
+        store = gs.FeatureStore.from_array(feats, torch.device(DEV), dtype="bf16")
+        B, C = 48, 5
+        ids = torch.from_numpy(rng.randint(1, adj.shape[0], size=(6, B))).to(DEV)
+        tg = torch.from_numpy(rng.randint(0, C, size=(6, B, 1))).to(DEV)
+        m = _model(adj, feats.shape[1], C, (32, 16), (5, 3), agg="attention")
+        eng = gs.engine.FusedAttnTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0], capture=capture)
+        assert eng.fuse == [flag == "1", False]
+        preds = torch.stack([eng(ids[k], tg[k]).clone() for k in range(4)])
+        torch.cuda.synchronize()
+        outs[flag] = (preds.float().cpu().numpy(), eng.flat_p.clone().cpu().numpy(), float(eng.gnorm.item()))
+    a, b = outs["0"], outs["1"]
+    assert np.abs(a[0] - b[0]).max() < 3e-3 * max(1.0, np.abs(a[0]).max())
+    assert abs(a[2] - b[2]) < 5e-3 * a[2]
+    # (weights: Adam moves every entry by ~lr per step whatever the gradient's size, so compare the UPDATES)
+    close_fro(b[1], a[1], "weights", 2e-3)
