@@ -55,6 +55,7 @@ struct AttnFusedFwd {
     int64_t agg_ld;
     uint16_t *agg_lp;           // out (optional): bf16 operand copy [M][lp_ld]
     int64_t lp_ld;
+    int32_t stop;               // diagnostic (GSAGE_AF_STOP): leave a parent after phase `stop` (0 = run everything)
 };
 
 struct AttnFusedBwd {
@@ -81,10 +82,17 @@ struct AttnFusedBwd {
     int64_t dhid_ld;
     float *dxa;                 // out: d a of the parents through this hop [M][dxa_ld]
     int64_t dxa_ld;
+    int32_t stop;
 };
 
 constexpr int AF_NMAX = 16;          // children per parent (one 16-row MFMA tile)
 constexpr int AF_MAX_WAVES = 8;      // per workgroup (512 threads: the register allocator may use up to 256 VGPRs)
+constexpr int AF_SCRATCH = 4;        // 16-byte slots of per-wave scratch behind a wave's row tile (16 floats)
+
+typedef __attribute__((ext_vector_type(4))) short af_s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 af_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float af_f32x2;
+typedef __attribute__((address_space(3))) af_s16x4 af_lds_s16x4;
 
 __device__ __forceinline__ int af_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
@@ -94,13 +102,31 @@ __device__ __forceinline__ af_f32x4 af_mfma(const vec16 &a, const vec16 &b, cons
                                                    0);
 }
 
+// two floats -> two bf16 in one dword, round to nearest even (v_cvt_pk_bf16_f32: the values f32_to_bf16 gives)
+__device__ __forceinline__ uint32_t af_pack2(float lo, float hi)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(af_f32x2{lo, hi}, af_bf16x2));
+}
+
+__device__ __forceinline__ float af_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float af_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
 __device__ __forceinline__ void af_unpack(const vec16 &raw, float (&f)[8])
 {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t w = raw[e >> 1];
-        f[e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = af_lo(raw[e]);
+        f[2 * e + 1] = af_hi(raw[e]);
     }
+}
+
+// tanh(v) = sign(v) (1 - 2 / (exp(2 |v|) + 1)) on v_exp_f32 / v_rcp_f32 (~1 ulp each): |error| ~ 2e-7, far below the
+// bf16 rounding that follows (the GEMM epilogue of the separate launches uses expf and a true division: ~1e-7)
+__device__ __forceinline__ float af_tanh(float v)
+{
+    const float e = __expf(2.f * fabsf(v));
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return copysignf(t, v);
 }
 
 // the n row ids of parent p: lane j < n keeps the (low dword of the) table row of child j
@@ -158,11 +184,16 @@ __device__ __forceinline__ float af_group16_sum(float v)
     return v;
 }
 
+// Forward.  Nothing below the tile issue depends on the fan-out except clamped row numbers: rows n .. 15 of the
+// 16-row tile are whatever lies behind the wave's tile in LDS (any bits), they only reach MFMA outputs of their own
+// rows / carry zero weight, and every lane that owns such a row is masked where it matters.
 template <int KS>
 __global__ void __launch_bounds__(AF_MAX_WAVES * 64)
 k_attn_fused_fwd(const AttnFusedFwd p)
 {
     constexpr int CH = 4 * KS;
+    constexpr int NT = CH / 2;                  // 16-column tiles of a row
+    constexpr int NACC = (NT + 7) / 8;          // eight column tiles share an accumulator (one per pair of MFMA columns)
     extern __shared__ __attribute__((aligned(16))) char af_smem[];
     vec16 *w0s = reinterpret_cast<vec16 *>(af_smem);            // [32][CH], swizzled like a row tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,7 +204,8 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         w0s[s] = *reinterpret_cast<const vec16 *>(p.W0 + row * p.ldw0 + (cp ^ af_swz(row)) * 8);
     }
     __syncthreads();
-    vec16 *xb = w0s + 32 * CH + wave * (n * CH);
+    vec16 *xb = w0s + 32 * CH + wave * (n * CH + AF_SCRATCH);
+    float *scr = reinterpret_cast<float *>(xb + n * CH);
     const int r16 = lane & 15, q = lane >> 4;
     const int sw = af_swz(r16);
     const bool valid = r16 < n;
@@ -187,6 +219,14 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         const af_u32x2 hi = *reinterpret_cast<const af_u32x2 *>(wr + 16 + 4 * q);
         w2a[t] = vec16{lo[0], lo[1], hi[0], hi[1]};
     }
+    // the weighted sum on the matrix cores: agg^T [16 columns][.] = X^T [16 columns x 16 rows] w, the column tile's
+    // X^T fragment read TRANSPOSED from the row-major tile (ds_read_b64_tr_b16: lane i of a 16-lane group supplies
+    // the four columns 4 (i & 3).. of row i >> 2 and receives column i of the group's four rows).  Row (clamped to a
+    // fetched one: its weight is zero) and byte address of this lane's piece for even / odd column tiles:
+    const int trow = 4 * q + (r16 >> 2) < n ? 4 * q + (r16 >> 2) : n - 1;
+    const int tsw = af_swz(trow), tb = (r16 & 3) >> 1;
+    const char *t_even = reinterpret_cast<const char *>(xb) + (trow * CH + (tb ^ tsw)) * 16 + (r16 & 1) * 8;
+    const char *t_odd = reinterpret_cast<const char *>(xb) + (trow * CH + ((2 + tb) ^ tsw)) * 16 + (r16 & 1) * 8;
 
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     int64_t par = (int64_t)blockIdx.x * n_waves + wave;
@@ -200,6 +240,7 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile has landed (this wave's own DMAs)
         __builtin_amdgcn_sched_barrier(0);
+        if (p.stop == 1) { par = nxt; continue; }
 
         // hid^T [32 x 16 rows] = W0 [32 x D] X^T; the fragments of step ks + 1 are requested before the MFMAs of step ks
         af_f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
@@ -221,11 +262,16 @@ k_attn_fused_fwd(const AttnFusedFwd p)
             h0 = af_mfma(fa0[ks & 1], fb[ks & 1], h0);
             h1 = af_mfma(fa1[ks & 1], fb[ks & 1], h1);
         }
+        if (p.stop == 2) {
+            if (valid && q == 0) p.ws[par * n + r16] = h0[0] + h1[0];
+            par = nxt;
+            continue;
+        }
         vec16 hb;
-        hb[0] = pack_bf16x2(apply_act(h0[0], ACT_TANH), apply_act(h0[1], ACT_TANH));
-        hb[1] = pack_bf16x2(apply_act(h0[2], ACT_TANH), apply_act(h0[3], ACT_TANH));
-        hb[2] = pack_bf16x2(apply_act(h1[0], ACT_TANH), apply_act(h1[1], ACT_TANH));
-        hb[3] = pack_bf16x2(apply_act(h1[2], ACT_TANH), apply_act(h1[3], ACT_TANH));
+        hb[0] = af_pack2(af_tanh(h0[0]), af_tanh(h0[1]));
+        hb[1] = af_pack2(af_tanh(h0[2]), af_tanh(h0[3]));
+        hb[2] = af_pack2(af_tanh(h1[0]), af_tanh(h1[1]));
+        hb[3] = af_pack2(af_tanh(h1[2]), af_tanh(h1[3]));
         const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const af_f32x4 a0v = af_mfma(w2a[0], hb, zero);          // a[row][4 q + reg]
         const af_f32x4 a1v = af_mfma(w2a[1], hb, zero);          // a[row][16 + 4 q + reg]
@@ -248,39 +294,41 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         s += __shfl_xor(s, 32, 64);
         const float mx = af_group16_max(valid ? s : -INFINITY);
         const float ex = valid ? expf(s - mx) : 0.f;
-        const float w = ex / af_group16_sum(ex);
+        const float w = ex / af_group16_sum(ex);                 // (0 for the rows beyond the fan-out)
         if (valid && q == 0) p.ws[child] = w;
+        if (p.stop == 3) { par = nxt; continue; }
 
-        // agg = sum_j w_j row_j: lane = 16-byte column chunk
+        // the weights as the B operand: rows 4 q .. 4 q + 3, split into bf16 high and low parts (w = hi + lo to 2^-17:
+        // the sum keeps fp32-grade weights); even MFMA columns carry the high parts, odd ones the low parts
+        if (q == 0) scr[r16] = w;
+        const af_f32x4 w4 = *reinterpret_cast<const af_f32x4 *>(scr + 4 * q);
+        const uint32_t wh0 = af_pack2(w4[0], w4[1]), wh1 = af_pack2(w4[2], w4[3]);
+        const uint32_t wl0 = af_pack2(w4[0] - af_lo(wh0), w4[1] - af_hi(wh0));
+        const uint32_t wl1 = af_pack2(w4[2] - af_lo(wh1), w4[3] - af_hi(wh1));
+        const uint32_t ws0 = (r16 & 1) ? wl0 : wh0, ws1 = (r16 & 1) ? wl1 : wh1;
+        af_f32x4 acc[NACC];
 #pragma unroll
-        for (int c0 = 0; c0 < CH; c0 += 64) {
-            const int c = c0 + lane;
-            const bool live = c < CH;
-            const int cc = live ? c : CH - 1;
-            float acc[8];
+        for (int r = 0; r < NACC; ++r) acc[r] = zero;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const char *src = ((t & 1) ? t_odd : t_even) + (t >> 1) * 64;
+            const af_s16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((af_lds_s16x4 *)src);
+            const bool mine = (r16 >> 1) == (t & 7);             // column pair (t & 7) of the accumulator takes tile t
+            const af_u32x2 bw = {mine ? ws0 : 0u, mine ? ws1 : 0u};
+            acc[t >> 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, __builtin_bit_cast(af_s16x4, bw), acc[t >> 3], 0, 0, 0);
+        }
+        // lane (column pair, q) of accumulator r: columns 16 t + 4 q .. + 3 of tile t = 8 r + pair; high + low parts
 #pragma unroll
-            for (int j = 0; j < AF_NMAX; ++j)
-                if (j < n) {                                    // wave-uniform: the reads of a round go out together
-                    const float wj = af_readlane(w, j);
-                    float f[8];
-                    af_unpack(xb[j * CH + (cc ^ af_swz(j))], f);
+        for (int r = 0; r < NACC; ++r) {
+            af_f32x4 v = acc[r];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += wj * f[e];
-                }
-            if (live) {
-                if (p.agg) {
-                    float *o = p.agg + par * p.agg_ld + 8 * c;
-                    *reinterpret_cast<af_f32x4 *>(o) = af_f32x4{acc[0], acc[1], acc[2], acc[3]};
-                    *reinterpret_cast<af_f32x4 *>(o + 4) = af_f32x4{acc[4], acc[5], acc[6], acc[7]};
-                }
-                if (p.agg_lp) {
-                    vec16 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
-                    *reinterpret_cast<vec16 *>(p.agg_lp + par * p.lp_ld + 8 * c) = o;
-                }
+            for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 1, 64);
+            const int t = 8 * r + (r16 >> 1);
+            if (t < NT && !(r16 & 1)) {
+                if (p.agg) *reinterpret_cast<af_f32x4 *>(p.agg + par * p.agg_ld + 16 * t + 4 * q) = v;
+                if (p.agg_lp)
+                    *reinterpret_cast<af_u32x2 *>(p.agg_lp + par * p.lp_ld + 16 * t + 4 * q) =
+                        af_u32x2{af_pack2(v[0], v[1]), af_pack2(v[2], v[3])};
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -288,6 +336,7 @@ k_attn_fused_fwd(const AttnFusedFwd p)
     }
 }
 
+// Backward.  Per-wave LDS: the row tile, d agg of the parent split into bf16 high / low parts (2 CH slots), scratch.
 template <int KS>
 __global__ void __launch_bounds__(AF_MAX_WAVES * 64)
 k_attn_fused_bwd(const AttnFusedBwd p)
@@ -298,8 +347,11 @@ k_attn_fused_bwd(const AttnFusedBwd p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const int n = p.n;
-    vec16 *xb = reinterpret_cast<vec16 *>(af_smem) + wave * (n * CH);
+    vec16 *xb = reinterpret_cast<vec16 *>(af_smem) + wave * (n * CH + 2 * CH + AF_SCRATCH);
+    vec16 *ghi = xb + n * CH, *glo = ghi + CH;
+    float *scr = reinterpret_cast<float *>(glo + CH);
     const int r16 = lane & 15, q = lane >> 4;
+    const int sw = af_swz(r16);
     const bool valid = r16 < n;
     const int h32 = lane & 31, half = lane >> 5;
 
@@ -321,9 +373,8 @@ k_attn_fused_bwd(const AttnFusedBwd p)
             const int cc = c < CH ? c : CH - 1;
             gv[r][0] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc);
             gv[r][1] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc + 4);
-            if (c >= CH) { gv[r][0] = af_f32x4{0.f, 0.f, 0.f, 0.f}; gv[r][1] = gv[r][0]; }
         }
-        const float wgt = valid ? p.ws[child] : 0.f;
+        const float wgt_raw = p.ws[child];
         const af_f32x4 xq0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q);
         const af_f32x4 xq1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q + 4);
         const af_u32x2 hlo = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 4 * q);
@@ -339,59 +390,70 @@ k_attn_fused_bwd(const AttnFusedBwd p)
         id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if (p.stop == 1) { par = nxt; continue; }
 
-        // dws[j] = <row_j, d agg>: per-lane partial sums over its column chunks, then across the wave
-        float pj[AF_NMAX];
-#pragma unroll
-        for (int j = 0; j < AF_NMAX; ++j) pj[j] = 0.f;
+        // d agg -> bf16 high and low parts in LDS (g = hi + lo to 2^-17 relative: the dot products below keep
+        // fp32-grade factors), as the B operand of every reduction step
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int c = 64 * r + lane;
-            const int cc = c < CH ? c : CH - 1;
+            if (c < CH) {
+                vec16 hi, lo;
 #pragma unroll
-            for (int j = 0; j < AF_NMAX; ++j)
-                if (j < n) {                                    // wave-uniform
-                    float f[8];
-                    af_unpack(xb[j * CH + (cc ^ af_swz(j))], f);
-                    float d = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d += f[e] * gv[r][0][e];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d += f[4 + e] * gv[r][1][e];
-                    pj[j] += d;
+                for (int e = 0; e < 4; ++e) {
+                    const float f0 = gv[r][e >> 1][2 * (e & 1)], f1 = gv[r][e >> 1][2 * (e & 1) + 1];
+                    hi[e] = af_pack2(f0, f1);
+                    lo[e] = af_pack2(f0 - af_lo(hi[e]), f1 - af_hi(hi[e]));
                 }
-        }
-        float dws = 0.f;
-#pragma unroll
-        for (int j = 0; j < AF_NMAX; ++j)
-            if (j < n) {
-                float t = pj[j];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                if (r16 == j) dws = t;
+                ghi[c] = hi;
+                glo[c] = lo;
             }
+        }
+        // dws[row] = <row, d agg> on the matrix cores: A = the tile's rows, B = d agg (the same for every MFMA column)
+        af_f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+        vec16 fa[2], fh[2], fl[2];
+        fa[0] = xb[r16 * CH + (q ^ sw)];
+        fh[0] = ghi[q];
+        fl[0] = glo[q];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                fa[(ks + 1) & 1] = xb[r16 * CH + ((4 * (ks + 1) + q) ^ sw)];
+                fh[(ks + 1) & 1] = ghi[4 * (ks + 1) + q];
+                fl[(ks + 1) & 1] = glo[4 * (ks + 1) + q];
+            }
+            dacc = af_mfma(fa[ks & 1], fh[ks & 1], dacc);
+            dacc = af_mfma(fa[ks & 1], fl[ks & 1], dacc);
+        }
+        // lane (any column, q) holds rows 4 q + reg; through the scratch words to the lane that owns the row
+        if (r16 == 0) *reinterpret_cast<af_f32x4 *>(scr + 4 * q) = dacc;
+        const float dws = valid ? scr[r16] : 0.f;
+        if (p.stop == 2) {
+            if (valid && q == 0) p.dxa[par * p.dxa_ld + r16] = dws;
+            par = nxt;
+            continue;
+        }
         // softmax backward (rows of the 16-lane group)
+        const float wgt = valid ? wgt_raw : 0.f;
         const float dot = af_group16_sum(dws * wgt);
-        const float ds = wgt * (dws - dot);
+        const float ds = wgt * (dws - dot);                     // (0 for the rows beyond the fan-out)
 
         // d a of the parent through this hop: dxa[h] = sum_j ds_j a_child[j][h]
         float dx = 0.f;
 #pragma unroll
-        for (int i = 0; i < AF_NMAX / 2; ++i)
-            if (2 * i < n) {
-                const float d0 = af_readlane(ds, 2 * i), d1 = af_readlane(ds, 2 * i + 1 < n ? 2 * i + 1 : 0);
-                const float dj = half ? (2 * i + 1 < n ? d1 : 0.f) : d0;
-                dx += dj * nav[i];
-            }
+        for (int i = 0; i < AF_NMAX / 2; ++i) {
+            const float d0 = af_readlane(ds, 2 * i), d1 = af_readlane(ds, 2 * i + 1);
+            dx += (half ? d1 : d0) * nav[i];
+        }
         dx += __shfl_xor(dx, 32, 64);
         if (lane < 32) p.dxa[par * p.dxa_ld + h32] = dx;
 
         // d a of this lane's row, its hidden units 8 q .. 8 q + 7 (no gradient reaches a last-hop row as a parent)
         vec16 dav;
-        dav[0] = pack_bf16x2(ds * xq0[0], ds * xq0[1]);
-        dav[1] = pack_bf16x2(ds * xq0[2], ds * xq0[3]);
-        dav[2] = pack_bf16x2(ds * xq1[0], ds * xq1[1]);
-        dav[3] = pack_bf16x2(ds * xq1[2], ds * xq1[3]);
+        dav[0] = af_pack2(ds * xq0[0], ds * xq0[1]);
+        dav[1] = af_pack2(ds * xq0[2], ds * xq0[3]);
+        dav[2] = af_pack2(ds * xq1[0], ds * xq1[1]);
+        dav[3] = af_pack2(ds * xq1[2], ds * xq1[3]);
         if (valid) *reinterpret_cast<vec16 *>(p.da + child * p.da_ld + 8 * q) = dav;
         // dhg^T [k][row] = sum_h W2[h][k] da[row][h]; lane (row, q) gets k = 4 q + reg and 16 + 4 q + reg
         const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -399,19 +461,18 @@ k_attn_fused_bwd(const AttnFusedBwd p)
         const af_f32x4 g1 = af_mfma(w2ta[1], dav, zero);
         float hl[4], hh[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t wl = hlo[e >> 1], wh = hhi[e >> 1];
-            hl[e] = __uint_as_float((e & 1) ? (wl & 0xffff0000u) : (wl << 16));
-            hh[e] = __uint_as_float((e & 1) ? (wh & 0xffff0000u) : (wh << 16));
+        for (int e = 0; e < 2; ++e) {
+            hl[2 * e] = af_lo(hlo[e]); hl[2 * e + 1] = af_hi(hlo[e]);
+            hh[2 * e] = af_lo(hhi[e]); hh[2 * e + 1] = af_hi(hhi[e]);
         }
         if (valid) {
             uint16_t *dr = p.dhid + child * p.dhid_ld;
             *reinterpret_cast<af_u32x2 *>(dr + 4 * q) =
-                af_u32x2{pack_bf16x2(g0[0] * (1.f - hl[0] * hl[0]), g0[1] * (1.f - hl[1] * hl[1])),
-                         pack_bf16x2(g0[2] * (1.f - hl[2] * hl[2]), g0[3] * (1.f - hl[3] * hl[3]))};
+                af_u32x2{af_pack2(g0[0] * (1.f - hl[0] * hl[0]), g0[1] * (1.f - hl[1] * hl[1])),
+                         af_pack2(g0[2] * (1.f - hl[2] * hl[2]), g0[3] * (1.f - hl[3] * hl[3]))};
             *reinterpret_cast<af_u32x2 *>(dr + 16 + 4 * q) =
-                af_u32x2{pack_bf16x2(g1[0] * (1.f - hh[0] * hh[0]), g1[1] * (1.f - hh[1] * hh[1])),
-                         pack_bf16x2(g1[2] * (1.f - hh[2] * hh[2]), g1[3] * (1.f - hh[3] * hh[3]))};
+                af_u32x2{af_pack2(g1[0] * (1.f - hh[0] * hh[0]), g1[1] * (1.f - hh[1] * hh[1])),
+                         af_pack2(g1[2] * (1.f - hh[2] * hh[2]), g1[3] * (1.f - hh[3] * hh[3]))};
         }
         __builtin_amdgcn_sched_barrier(0);
         par = nxt;
@@ -434,7 +495,10 @@ static int af_ksteps(int64_t D)
 // waves per CU that the 160 KiB hold wins; ties go to fewer, larger workgroups (fewer copies of W0).
 static bool af_geometry(int ks, int n, bool with_w0, int64_t M, int *waves, int *grid, size_t *lds)
 {
-    const int64_t ch = 4 * ks, tile = (int64_t)n * ch * 16, fixed = (with_w0 ? 32 * ch * 16 : 0) + (16 - n) * ch * 16;
+    // per wave: the row tile + scratch (+ the two halves of d agg in the backward); per workgroup: W0 (forward) and the
+    // rows the last wave's 16-row fragments read behind its tile
+    const int64_t ch = 4 * ks, tile = ((int64_t)n * ch + AF_SCRATCH + (with_w0 ? 0 : 2 * ch)) * 16;
+    const int64_t fixed = (with_w0 ? 32 * ch * 16 : 0) + (16 - n) * ch * 16;
     int best_nw = 0, best_pc = 0;
     for (int nw = 1; nw <= AF_MAX_WAVES; ++nw)
         for (int pc = 1; pc <= 16; ++pc) {
@@ -442,6 +506,10 @@ static bool af_geometry(int ks, int n, bool with_w0, int64_t M, int *waves, int 
             if (nw * pc > best_nw * best_pc || (nw * pc == best_nw * best_pc && nw > best_nw)) { best_nw = nw; best_pc = pc; }
         }
     if (!best_nw) return false;
+    if (const char *e = getenv("GSAGE_AF_WAVES")) {              // diagnostic: waves per workgroup / workgroups per CU
+        const int nw = atoi(e), pc = getenv("GSAGE_AF_PER_CU") ? atoi(getenv("GSAGE_AF_PER_CU")) : 1;
+        if (nw >= 1 && nw <= AF_MAX_WAVES && pc >= 1 && pc * (fixed + nw * tile) <= AF_LDS_BYTES) { best_nw = nw; best_pc = pc; }
+    }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -520,6 +588,7 @@ extern "C" int gsage_attn_fused_fwd(const void *table, int dtype, int64_t ld, co
     p.W2 = (const uint16_t *)W2; p.ldw2 = ldw2; p.xa = xa; p.xa_ld = xa_ld; p.M = M; p.n = n; p.D = (int32_t)D;
     p.hid = (uint16_t *)hid; p.hid_ld = hid_ld; p.a = a; p.a_ld = a_ld; p.ws = ws; p.agg = agg; p.agg_ld = agg_ld;
     p.agg_lp = (uint16_t *)agg_lp; p.lp_ld = lp_ld;
+    p.stop = getenv("GSAGE_AF_STOP") ? atoi(getenv("GSAGE_AF_STOP")) : 0;
 #define GSAGE_AF_FWD(KSV, P)                                                                                              \
     do {                                                                                                                  \
         static bool raised = false;                                                                                       \
@@ -558,6 +627,7 @@ extern "C" int gsage_attn_fused_bwd(const void *table, int dtype, int64_t ld, co
     p.g = g; p.g_ld = g_ld; p.ws = ws; p.na = na; p.na_ld = na_ld; p.xa = xa; p.xa_ld = xa_ld; p.hid = (const uint16_t *)hid;
     p.hid_ld = hid_ld; p.M = M; p.n = n; p.D = (int32_t)D; p.da = (uint16_t *)da; p.da_ld = da_ld; p.dhid = (uint16_t *)dhid;
     p.dhid_ld = dhid_ld; p.dxa = dxa; p.dxa_ld = dxa_ld;
+    p.stop = getenv("GSAGE_AF_STOP") ? atoi(getenv("GSAGE_AF_STOP")) : 0;
 #define GSAGE_AF_BWD(KSV, P)                                                                                              \
     do {                                                                                                                  \
         static bool raised = false;                                                                                       \

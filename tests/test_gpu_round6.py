@@ -210,7 +210,7 @@ def test_attention_engine_with_the_fused_hop_tracks_the_separate_launches(monkey
         tg = torch.from_numpy(rng.randint(0, C, size=(6, B, 1))).to(DEV)
         m = _model(adj, feats.shape[1], C, (32, 16), (5, 3), agg="attention")
         eng = gs.engine.FusedAttnTrainStep(m, store, gs.ProblemLosses.classification, ids[0], tg[0], capture=capture)
-        assert eng.fuse == [flag == "1", False]
+        assert eng.fuse == [flag == "1"] * 2          # (fan-outs 5 and 3: the last hop of both levels)
         preds = torch.stack([eng(ids[k], tg[k]).clone() for k in range(4)])
         torch.cuda.synchronize()
         outs[flag] = (preds.float().cpu().numpy(), eng.flat_p.clone().cpu().numpy(), float(eng.gnorm.item()))
