@@ -170,18 +170,30 @@ __device__ __forceinline__ void af_issue_tile(const uint16_t *table, int64_t ld,
     }
 }
 
+// Lane-crossing inside a 16-lane row without LDS traffic (v_*_dpp): partners i ^ 1, i ^ 2 (quad permutations), 7 - i
+// within a half row, 15 - i within the row.  A sum / max over the row taken in that order pairs equal partial results at
+// every step, so all 16 lanes end with the same bits (fp add / max commute).
+template <int CTRL>
+__device__ __forceinline__ float af_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int AF_DPP_XOR1 = 0xB1, AF_DPP_XOR2 = 0x4E, AF_DPP_HALF_MIRROR = 0x141, AF_DPP_MIRROR = 0x140;
+
 __device__ __forceinline__ float af_group16_max(float v)
 {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, af_dpp<AF_DPP_XOR1>(v));
+    v = fmaxf(v, af_dpp<AF_DPP_XOR2>(v));
+    v = fmaxf(v, af_dpp<AF_DPP_HALF_MIRROR>(v));
+    return fmaxf(v, af_dpp<AF_DPP_MIRROR>(v));
 }
 
 __device__ __forceinline__ float af_group16_sum(float v)
 {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += af_dpp<AF_DPP_XOR1>(v);
+    v += af_dpp<AF_DPP_XOR2>(v);
+    v += af_dpp<AF_DPP_HALF_MIRROR>(v);
+    return v + af_dpp<AF_DPP_MIRROR>(v);
 }
 
 // Forward.  Nothing below the tile issue depends on the fan-out except clamped row numbers: rows n .. 15 of the
@@ -244,23 +256,32 @@ k_attn_fused_fwd(const AttnFusedFwd p)
 
         // hid^T [32 x 16 rows] = W0 [32 x D] X^T; the fragments of step ks + 1 are requested before the MFMAs of step ks
         af_f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
-        vec16 fb[2], fa0[2], fa1[2];
         {
-            const int c = q ^ sw;
-            fb[0] = xb[r16 * CH + c];
-            fa0[0] = w0s[r16 * CH + c];
-            fa1[0] = w0s[(16 + r16) * CH + c];
-        }
+            constexpr int HB = 4, NB = (KS + HB - 1) / HB;      // k-steps per batch, batches
+            vec16 fb[2][HB], fa0[2][HB], fa1[2][HB];
+            auto load_batch = [&](int b, int slot) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-                const int c = (4 * (ks + 1) + q) ^ sw;
-                fb[(ks + 1) & 1] = xb[r16 * CH + c];
-                fa0[(ks + 1) & 1] = w0s[r16 * CH + c];
-                fa1[(ks + 1) & 1] = w0s[(16 + r16) * CH + c];
+                for (int u = 0; u < HB; ++u)
+                    if (b * HB + u < KS) {
+                        const int c = (4 * (b * HB + u) + q) ^ sw;
+                        fb[slot][u] = xb[r16 * CH + c];
+                        fa0[slot][u] = w0s[r16 * CH + c];
+                        fa1[slot][u] = w0s[(16 + r16) * CH + c];
+                    }
+            };
+            load_batch(0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b + 1 < NB) load_batch(b + 1, (b + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);              // (or the scheduler sinks every read to just above its MFMA)
+#pragma unroll
+                for (int u = 0; u < HB; ++u)
+                    if (b * HB + u < KS) {
+                        h0 = af_mfma(fa0[b & 1][u], fb[b & 1][u], h0);
+                        h1 = af_mfma(fa1[b & 1][u], fb[b & 1][u], h1);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            h0 = af_mfma(fa0[ks & 1], fb[ks & 1], h0);
-            h1 = af_mfma(fa1[ks & 1], fb[ks & 1], h1);
         }
         if (p.stop == 2) {
             if (valid && q == 0) p.ws[par * n + r16] = h0[0] + h1[0];
@@ -309,20 +330,43 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         af_f32x4 acc[NACC];
 #pragma unroll
         for (int r = 0; r < NACC; ++r) acc[r] = zero;
+        {
+            af_s16x4 bsel[8];                                   // column pair u of an accumulator takes tile 8 r + u
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const char *src = ((t & 1) ? t_odd : t_even) + (t >> 1) * 64;
-            const af_s16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((af_lds_s16x4 *)src);
-            const bool mine = (r16 >> 1) == (t & 7);             // column pair (t & 7) of the accumulator takes tile t
-            const af_u32x2 bw = {mine ? ws0 : 0u, mine ? ws1 : 0u};
-            acc[t >> 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, __builtin_bit_cast(af_s16x4, bw), acc[t >> 3], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const bool mine = (r16 >> 1) == u;
+                bsel[u] = __builtin_bit_cast(af_s16x4, af_u32x2{mine ? ws0 : 0u, mine ? ws1 : 0u});
+            }
+            af_s16x4 xt[2][8];
+            auto load_group = [&](int r, int slot) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 8 * r + u;
+                    if (t < NT)
+                        xt[slot][u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (af_lds_s16x4 *)(((t & 1) ? t_odd : t_even) + (t >> 1) * 64));
+                }
+            };
+            load_group(0, 0);
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                if (r + 1 < NACC) load_group(r + 1, (r + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 8 * r + u;
+                    if (t < NT)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt[r & 1][u], bsel[u], acc[r], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // lane (column pair, q) of accumulator r: columns 16 t + 4 q .. + 3 of tile t = 8 r + pair; high + low parts
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             af_f32x4 v = acc[r];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 1, 64);
+            for (int e = 0; e < 4; ++e) v[e] += af_dpp<AF_DPP_XOR1>(v[e]);
             const int t = 8 * r + (r16 >> 1);
             if (t < NT && !(r16 & 1)) {
                 if (p.agg) *reinterpret_cast<af_f32x4 *>(p.agg + par * p.agg_ld + 16 * t + 4 * q) = v;
@@ -410,20 +454,24 @@ k_attn_fused_bwd(const AttnFusedBwd p)
             }
         }
         // dws[row] = <row, d agg> on the matrix cores: A = the tile's rows, B = d agg (the same for every MFMA column)
-        af_f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
-        vec16 fa[2], fh[2], fl[2];
-        fa[0] = xb[r16 * CH + (q ^ sw)];
-        fh[0] = ghi[q];
-        fl[0] = glo[q];
+        // (two accumulators: the high and the low parts' products are independent MFMA chains)
+        af_f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacl = {0.f, 0.f, 0.f, 0.f};
+        {
+            vec16 fa[2], fh[2], fl[2];
+            fa[0] = xb[r16 * CH + (q ^ sw)];
+            fh[0] = ghi[q];
+            fl[0] = glo[q];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-                fa[(ks + 1) & 1] = xb[r16 * CH + ((4 * (ks + 1) + q) ^ sw)];
-                fh[(ks + 1) & 1] = ghi[4 * (ks + 1) + q];
-                fl[(ks + 1) & 1] = glo[4 * (ks + 1) + q];
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                    fa[(ks + 1) & 1] = xb[r16 * CH + ((4 * (ks + 1) + q) ^ sw)];
+                    fh[(ks + 1) & 1] = ghi[4 * (ks + 1) + q];
+                    fl[(ks + 1) & 1] = glo[4 * (ks + 1) + q];
+                }
+                dacc = af_mfma(fa[ks & 1], fh[ks & 1], dacc);
+                dacl = af_mfma(fa[ks & 1], fl[ks & 1], dacl);
             }
-            dacc = af_mfma(fa[ks & 1], fh[ks & 1], dacc);
-            dacc = af_mfma(fa[ks & 1], fl[ks & 1], dacc);
+            dacc += dacl;
         }
         // lane (any column, q) holds rows 4 q + reg; through the scratch words to the lane that owns the row
         if (r16 == 0) *reinterpret_cast<af_f32x4 *>(scr + 4 * q) = dacc;
