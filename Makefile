@@ -6,7 +6,7 @@ ARCH ?= gfx950
 PKG := pytorch-graphsage_amd
 SRC := $(wildcard $(PKG)/csrc/*.hip)
 OBJ := $(SRC:.hip=.o)
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-inline-asm
 
 all: hip oracle
 

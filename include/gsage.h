@@ -521,8 +521,8 @@ int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *n
  * whether a shape is covered (1 / 0; no GPU needed).  Child `pos` = parent * n + j is row `ids[pos]` of `table` (ids
  * NULL: row `row0 + pos`); every per-child array is indexed by pos, every per-parent array by the parent.
  *   forward   hid = bf16(tanh(row W0^T)) [M n, hid_ld], a = hid W2^T (fp32) [M n, a_ld] for the children;
- *             ws = softmax_j <a_child, xa_parent> [M n]; agg = sum_j ws row_j as fp32 (agg, optional) and as the bf16
- *             operand copy (agg_lp, optional), both with zero pad columns up to the next multiple of 32
+ *             ws = softmax_j <a_child, xa_parent> [M n]; agg_lp = bf16(sum_j ws row_j) [M, lp_ld], the operand copy
+ *             the fc_neib projection and its weight gradient read, with zero pad columns up to the next multiple of 32
  *             W0 / W2: the bf16 operand copies of att.0.weight [32, ldw0 >= 32 ceil(D / 32)] and att.2.weight [32, ldw2]
  *   backward  dws = <row, g_parent>, ds = ws (dws - sum ws dws); dxa[parent] = sum_j ds_j na_j (fp32 [M, dxa_ld]);
  *             da = bf16(ds xa_parent) [M n, da_ld]; dhid = bf16((da W2)(1 - hid^2)) [M n, dhid_ld] -- the rows of a
@@ -530,8 +530,8 @@ int gsage_attn_bwd(const float *g, int64_t g_ld, const float *ws, const float *n
 int gsage_attn_fused_ok(int dtype, int64_t ld, int64_t D, int32_t n, int64_t Ha);
 int gsage_attn_fused_fwd(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t row0, const void *W0,
                          int64_t ldw0, const void *W2, int64_t ldw2, const float *xa, int64_t xa_ld, int64_t M,
-                         int32_t n, int64_t D, void *hid, int64_t hid_ld, float *a, int64_t a_ld, float *ws, float *agg,
-                         int64_t agg_ld, void *agg_lp, int64_t lp_ld, void *stream);
+                         int32_t n, int64_t D, void *hid, int64_t hid_ld, float *a, int64_t a_ld, float *ws, void *agg_lp,
+                         int64_t lp_ld, void *stream);
 int gsage_attn_fused_bwd(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t row0, const void *W2T,
                          int64_t ldw2t, const float *g, int64_t g_ld, const float *ws, const float *na, int64_t na_ld,
                          const float *xa, int64_t xa_ld, const void *hid, int64_t hid_ld, int64_t M, int32_t n, int64_t D,

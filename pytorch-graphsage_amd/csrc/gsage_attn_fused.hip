@@ -51,11 +51,8 @@ struct AttnFusedFwd {
     float *a;                   // out: a of the children [M n][a_ld]
     int64_t a_ld;
     float *ws;                  // out: softmax weights [M n]
-    float *agg;                 // out (optional): fp32 aggregate [M][agg_ld]
-    int64_t agg_ld;
-    uint16_t *agg_lp;           // out (optional): bf16 operand copy [M][lp_ld]
+    uint16_t *agg_lp;           // out: bf16 operand copy of the aggregate [M][lp_ld]
     int64_t lp_ld;
-    int32_t stop;               // diagnostic (GSAGE_AF_STOP): leave a parent after phase `stop` (0 = run everything)
 };
 
 struct AttnFusedBwd {
@@ -82,7 +79,6 @@ struct AttnFusedBwd {
     int64_t dhid_ld;
     float *dxa;                 // out: d a of the parents through this hop [M][dxa_ld]
     int64_t dxa_ld;
-    int32_t stop;
 };
 
 constexpr int AF_NMAX = 16;          // children per parent (one 16-row MFMA tile)
@@ -129,12 +125,21 @@ __device__ __forceinline__ float af_tanh(float v)
     return copysignf(t, v);
 }
 
-// the n row ids of parent p: lane j < n keeps the (low dword of the) table row of child j
-__device__ __forceinline__ uint32_t af_load_id(const int64_t *ids, int64_t row0, int64_t p, int n, int lane)
+// The n row ids of parent p: lane j < n keeps the (low dword of the) table row of child j.  In two halves so that the
+// load is unconditional and its value is first looked at where the caller wants the wait: af_id_request returns what
+// the load brings (without a row list it reads the table -- any mapped address -- and the value is dropped),
+// af_id_value turns it into the row.  (A load inside a branch on `ids` makes the compiler wait for EVERY outstanding
+// request at the join.)
+__device__ __forceinline__ uint32_t af_id_request(const int64_t *ids, const void *table, int64_t p, int n, int lane)
 {
     const int64_t pos = p * n + (lane < n ? lane : n - 1);
-    if (ids) return reinterpret_cast<const uint32_t *>(ids + pos)[0];      // (row ids are < 2^31)
-    return (uint32_t)(row0 + pos);
+    const uint32_t *src = ids ? reinterpret_cast<const uint32_t *>(ids + pos) : reinterpret_cast<const uint32_t *>(table);
+    return *src;                                                           // (row ids are < 2^31: the low dword)
+}
+
+__device__ __forceinline__ uint32_t af_id_value(uint32_t requested, const int64_t *ids, int64_t row0, int64_t p, int n, int lane)
+{
+    return ids ? requested : (uint32_t)(row0 + p * n + (lane < n ? lane : n - 1));
 }
 
 __device__ __forceinline__ float af_readlane(float v, int l)
@@ -164,9 +169,12 @@ __device__ __forceinline__ void af_issue_tile(const uint16_t *table, int64_t ld,
         } else {
             id = (uint32_t)__shfl((int)idreg, row < n ? row : n - 1, 64);
         }
+        // (inline asm, not the builtin: the compiler would order every later LDS read behind ALL outstanding LDS-DMA,
+        //  i.e. wait for the NEXT parent's tile in the middle of this one's arithmetic; the waits are the callers')
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_void_t *)(xb + 64 * i));
+        const uint16_t *src = table + (int64_t)id * ld + c * 8;
         if (row < n)
-            __builtin_amdgcn_global_load_lds((global_void_t *)(table + (int64_t)id * ld + c * 8), (lds_void_t *)(xb + 64 * i), 16,
-                                             0, 0);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
     }
 }
 
@@ -196,6 +204,51 @@ __device__ __forceinline__ float af_group16_sum(float v)
     return v + af_dpp<AF_DPP_MIRROR>(v);
 }
 
+// ds_read_b64_tr_b16 as inline asm with hand-counted waits: through the builtin the compiler orders the read behind
+// EVERY outstanding vector-memory request (the intrinsic carries no memory operand), i.e. it would wait for the next
+// parent's rows in the middle of this parent's arithmetic.  LDS requests of a wave complete in issue order.
+template <int T, int NT>
+__device__ __forceinline__ void af_tr_read(af_s16x4 &dst, uint32_t a_even, uint32_t a_odd)
+{
+    if constexpr (T < NT)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"((T & 1) ? a_odd : a_even), "n"((T >> 1) * 64) : "memory");
+}
+
+template <int R, int NT>
+__device__ __forceinline__ void af_tr_group(af_s16x4 (&xt)[8], uint32_t a_even, uint32_t a_odd)
+{
+    af_tr_read<8 * R + 0, NT>(xt[0], a_even, a_odd);
+    af_tr_read<8 * R + 1, NT>(xt[1], a_even, a_odd);
+    af_tr_read<8 * R + 2, NT>(xt[2], a_even, a_odd);
+    af_tr_read<8 * R + 3, NT>(xt[3], a_even, a_odd);
+    af_tr_read<8 * R + 4, NT>(xt[4], a_even, a_odd);
+    af_tr_read<8 * R + 5, NT>(xt[5], a_even, a_odd);
+    af_tr_read<8 * R + 6, NT>(xt[6], a_even, a_odd);
+    af_tr_read<8 * R + 7, NT>(xt[7], a_even, a_odd);
+}
+
+// accumulator R of the weighted sum: its eight column tiles' fragments were requested one group ago; the next
+// group's are requested before this group's MFMAs, which wait until only those (at most eight) are outstanding
+template <int R, int NACC, int NT>
+__device__ __forceinline__ void af_wsum_groups(af_f32x4 (&acc)[NACC], af_s16x4 (&xt)[2][8], const af_s16x4 (&bsel)[8],
+                                               uint32_t a_even, uint32_t a_odd)
+{
+    if constexpr (R < NACC) {
+        constexpr int next = R + 1 < NACC ? (NT - 8 * (R + 1) < 8 ? NT - 8 * (R + 1) : 8) : 0;
+        if constexpr (R + 1 < NACC) af_tr_group<R + 1, NT>(xt[(R + 1) & 1], a_even, a_odd);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(next) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // (a last group of fewer than eight tiles: its spare column pairs take the group's tiles again, so that every
+        //  lane ends with a real tile's sums -- the stores behind are then the same for every lane)
+        constexpr int cnt = NT - 8 * R < 8 ? NT - 8 * R : 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc[R] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt[R & 1][u % cnt], bsel[u], acc[R], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        af_wsum_groups<R + 1, NACC, NT>(acc, xt, bsel, a_even, a_odd);
+    }
+}
+
 // Forward.  Nothing below the tile issue depends on the fan-out except clamped row numbers: rows n .. 15 of the
 // 16-row tile are whatever lies behind the wave's tile in LDS (any bits), they only reach MFMA outputs of their own
 // rows / carry zero weight, and every lane that owns such a row is masked where it matters.
@@ -216,11 +269,13 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         w0s[s] = *reinterpret_cast<const vec16 *>(p.W0 + row * p.ldw0 + (cp ^ af_swz(row)) * 8);
     }
     __syncthreads();
-    vec16 *xb = w0s + 32 * CH + wave * (n * CH + AF_SCRATCH);
-    float *scr = reinterpret_cast<float *>(xb + n * CH);
+    // per wave: two row tiles (the next parent's rows land while this parent is computed) and the scratch words
+    vec16 *xb0 = w0s + 32 * CH + wave * (2 * n * CH + AF_SCRATCH);
+    float *scr = reinterpret_cast<float *>(xb0 + 2 * n * CH);
     const int r16 = lane & 15, q = lane >> 4;
-    const int sw = af_swz(r16);
     const bool valid = r16 < n;
+    const int rc = valid ? r16 : n - 1;          // rows beyond the fan-out repeat the last child (masked where it matters)
+    const int sw = af_swz(rc);
 
     // att.2 as the A operand of a^T = W2 hid^T: reduction slot (q, e) is hidden unit (e < 4 ? 4 q + e : 16 + 4 q + e - 4)
     vec16 w2a[2];
@@ -237,22 +292,42 @@ k_attn_fused_fwd(const AttnFusedFwd p)
     // fetched one: its weight is zero) and byte address of this lane's piece for even / odd column tiles:
     const int trow = 4 * q + (r16 >> 2) < n ? 4 * q + (r16 >> 2) : n - 1;
     const int tsw = af_swz(trow), tb = (r16 & 3) >> 1;
-    const char *t_even = reinterpret_cast<const char *>(xb) + (trow * CH + (tb ^ tsw)) * 16 + (r16 & 1) * 8;
-    const char *t_odd = reinterpret_cast<const char *>(xb) + (trow * CH + ((2 + tb) ^ tsw)) * 16 + (r16 & 1) * 8;
+    const int t_even = (trow * CH + (tb ^ tsw)) * 16 + (r16 & 1) * 8;
+    const int t_odd = (trow * CH + ((2 + tb) ^ tsw)) * 16 + (r16 & 1) * 8;
 
+    // Software pipeline over the wave's parents: the rows of parent i + 1 are requested (into the other tile) before
+    // parent i is computed.  Requests return in issue order, so once the values requested BEHIND a tile's rows (the
+    // next parent's xa, the ids of the parent after it) have arrived the tile has landed: they are touched at the END of
+    // a trip, where the only younger requests are the trip's own stores -- every store below is executed by every lane
+    // (lanes without a result of their own repeat another lane's store, same address, same bits) so that the code is
+    // branch-free and the compiler can count them (s_waitcnt vmcnt(#stores): the stores are not waited for).  The asm
+    // statements with a memory clobber pin the issue order.
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     int64_t par = (int64_t)blockIdx.x * n_waves + wave;
-    uint32_t id_next = par < p.M ? af_load_id(p.ids, p.row0, par, n, lane) : 0u;
+    int buf = 0;
+    uint32_t id_next = 0u;                                      // (as requested: af_id_value makes it a row)
+    af_f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+    if (par < p.M) {
+        uint32_t id0 = af_id_request(p.ids, p.table, par, n, lane);
+        asm volatile("" : "+v"(id0));
+        af_issue_tile<KS>(p.table, p.ld, af_id_value(id0, p.ids, p.row0, par, n, lane), n, xb0, lane);
+        asm volatile("" ::: "memory");
+        x0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 4 * q);
+        x1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 16 + 4 * q);
+        id_next = af_id_request(p.ids, p.table, par + stride < p.M ? par + stride : p.M - 1, n, lane);
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(id_next) : : "memory");      // arrived => the first tile has landed
+    }
     while (par < p.M) {
-        const af_f32x4 x0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 4 * q);
-        const af_f32x4 x1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 16 + 4 * q);
-        af_issue_tile<KS>(p.table, p.ld, id_next, n, xb, lane);
+        const vec16 *xb = xb0 + buf * (n * CH);
         const int64_t nxt = par + stride;
-        // (unconditional: a load inside a branch makes the compiler drain every outstanding request at the join)
-        id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile has landed (this wave's own DMAs)
-        __builtin_amdgcn_sched_barrier(0);
-        if (p.stop == 1) { par = nxt; continue; }
+        if (nxt < p.M)
+            af_issue_tile<KS>(p.table, p.ld, af_id_value(id_next, p.ids, p.row0, nxt, n, lane), n, xb0 + (buf ^ 1) * (n * CH), lane);
+        asm volatile("" ::: "memory");
+        const int64_t nx = nxt < p.M ? nxt : p.M - 1, nn = nxt + stride < p.M ? nxt + stride : p.M - 1;
+        af_f32x4 xn0 = *reinterpret_cast<const af_f32x4 *>(p.xa + nx * p.xa_ld + 4 * q);
+        af_f32x4 xn1 = *reinterpret_cast<const af_f32x4 *>(p.xa + nx * p.xa_ld + 16 + 4 * q);
+        uint32_t id_nn = af_id_request(p.ids, p.table, nn, n, lane);
+        asm volatile("" ::: "memory");
 
         // hid^T [32 x 16 rows] = W0 [32 x D] X^T; the fragments of step ks + 1 are requested before the MFMAs of step ks
         af_f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
@@ -263,8 +338,8 @@ k_attn_fused_fwd(const AttnFusedFwd p)
 #pragma unroll
                 for (int u = 0; u < HB; ++u)
                     if (b * HB + u < KS) {
-                        const int c = (4 * (b * HB + u) + q) ^ sw;
-                        fb[slot][u] = xb[r16 * CH + c];
+                        const int c = (4 * (b * HB + u) + q) ^ af_swz(r16);
+                        fb[slot][u] = xb[rc * CH + ((4 * (b * HB + u) + q) ^ sw)];
                         fa0[slot][u] = w0s[r16 * CH + c];
                         fa1[slot][u] = w0s[(16 + r16) * CH + c];
                     }
@@ -283,11 +358,6 @@ k_attn_fused_fwd(const AttnFusedFwd p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (p.stop == 2) {
-            if (valid && q == 0) p.ws[par * n + r16] = h0[0] + h1[0];
-            par = nxt;
-            continue;
-        }
         vec16 hb;
         hb[0] = af_pack2(af_tanh(h0[0]), af_tanh(h0[1]));
         hb[1] = af_pack2(af_tanh(h0[2]), af_tanh(h0[3]));
@@ -296,8 +366,9 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const af_f32x4 a0v = af_mfma(w2a[0], hb, zero);          // a[row][4 q + reg]
         const af_f32x4 a1v = af_mfma(w2a[1], hb, zero);          // a[row][16 + 4 q + reg]
-        const int64_t child = par * n + r16;
-        if (valid) {
+        // (lanes of the rows beyond the fan-out computed the last child again: the same stores)
+        const int64_t child = par * n + rc;
+        {
             uint16_t *hr = p.hid + child * p.hid_ld;
             *reinterpret_cast<af_u32x2 *>(hr + 4 * q) = af_u32x2{hb[0], hb[1]};
             *reinterpret_cast<af_u32x2 *>(hr + 16 + 4 * q) = af_u32x2{hb[2], hb[3]};
@@ -316,8 +387,7 @@ k_attn_fused_fwd(const AttnFusedFwd p)
         const float mx = af_group16_max(valid ? s : -INFINITY);
         const float ex = valid ? expf(s - mx) : 0.f;
         const float w = ex / af_group16_sum(ex);                 // (0 for the rows beyond the fan-out)
-        if (valid && q == 0) p.ws[child] = w;
-        if (p.stop == 3) { par = nxt; continue; }
+        p.ws[child] = valid ? w : af_readlane(w, n - 1);
 
         // the weights as the B operand: rows 4 q .. 4 q + 3, split into bf16 high and low parts (w = hi + lo to 2^-17:
         // the sum keeps fp32-grade weights); even MFMA columns carry the high parts, odd ones the low parts
@@ -338,49 +408,44 @@ k_attn_fused_fwd(const AttnFusedFwd p)
                 bsel[u] = __builtin_bit_cast(af_s16x4, af_u32x2{mine ? ws0 : 0u, mine ? ws1 : 0u});
             }
             af_s16x4 xt[2][8];
-            auto load_group = [&](int r, int slot) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = 8 * r + u;
-                    if (t < NT)
-                        xt[slot][u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (af_lds_s16x4 *)(((t & 1) ? t_odd : t_even) + (t >> 1) * 64));
-                }
-            };
-            load_group(0, 0);
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                if (r + 1 < NACC) load_group(r + 1, (r + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = 8 * r + u;
-                    if (t < NT)
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt[r & 1][u], bsel[u], acc[r], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const uint32_t lbase = (uint32_t)(uintptr_t)(lds_void_t *)xb;
+            const uint32_t a_even = lbase + (uint32_t)t_even, a_odd = lbase + (uint32_t)t_odd;
+            __builtin_amdgcn_sched_barrier(0);
+            af_tr_group<0, NT>(xt[0], a_even, a_odd);
+            af_wsum_groups<0, NACC, NT>(acc, xt, bsel, a_even, a_odd);
         }
-        // lane (column pair, q) of accumulator r: columns 16 t + 4 q .. + 3 of tile t = 8 r + pair; high + low parts
+        // lane (column pair, q) of accumulator r: columns 16 t + 4 q .. + 3 of tile t = 8 r + pair (a spare pair: the tile
+        // it repeated); high + low parts meet in BOTH lanes of the pair (fp add commutes: the same bits, the same store)
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             af_f32x4 v = acc[r];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += af_dpp<AF_DPP_XOR1>(v[e]);
-            const int t = 8 * r + (r16 >> 1);
-            if (t < NT && !(r16 & 1)) {
-                if (p.agg) *reinterpret_cast<af_f32x4 *>(p.agg + par * p.agg_ld + 16 * t + 4 * q) = v;
-                if (p.agg_lp)
-                    *reinterpret_cast<af_u32x2 *>(p.agg_lp + par * p.lp_ld + 16 * t + 4 * q) =
-                        af_u32x2{af_pack2(v[0], v[1]), af_pack2(v[2], v[3])};
-            }
+            constexpr int full = 8;
+            const int cnt = NT - 8 * r < full ? NT - 8 * r : full;
+            const int t = 8 * r + (r16 >> 1) % cnt;
+            *reinterpret_cast<af_u32x2 *>(p.agg_lp + par * p.lp_ld + 16 * t + 4 * q) =
+                af_u32x2{af_pack2(v[0], v[1]), af_pack2(v[2], v[3])};
         }
         __builtin_amdgcn_sched_barrier(0);
-        par = nxt;
+        // the next parent's values have arrived => its tile has landed (the stores above are younger: not waited for)
+        asm volatile("" : "+v"(xn0), "+v"(xn1), "+v"(id_nn) : : "memory");
+        par = nxt; buf ^= 1; x0 = xn0; x1 = xn1; id_next = id_nn;
     }
 }
 
-// Backward.  Per-wave LDS: the row tile, d agg of the parent split into bf16 high / low parts (2 CH slots), scratch.
+// Backward.  Per-wave LDS: two row tiles (as in the forward), d agg of the parent split into bf16 high / low parts
+// (2 CH slots), scratch.
+template <int ROUNDS>
+struct AfBwdIn {                 // what a parent needs besides its rows: requested one parent ahead
+    af_f32x4 gv[ROUNDS][2];      // d agg, this lane's column chunk(s)
+    af_f32x4 xq0, xq1;           // a of the parent, hidden units 8 q .. 8 q + 7
+    af_u32x2 hlo, hhi;           // hid of this lane's row, units 4 q .. + 3 and 16 + 4 q .. + 3
+    float wgt;                   // softmax weight of this lane's row
+    float nav[AF_NMAX / 2];      // a of children 2 i + half, hidden unit lane & 31
+    uint32_t id;                 // ids of the NEXT parent (as requested: af_id_value)
+};
+
 template <int KS>
 __global__ void __launch_bounds__(AF_MAX_WAVES * 64)
 k_attn_fused_bwd(const AttnFusedBwd p)
@@ -391,12 +456,13 @@ k_attn_fused_bwd(const AttnFusedBwd p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const int n = p.n;
-    vec16 *xb = reinterpret_cast<vec16 *>(af_smem) + wave * (n * CH + 2 * CH + AF_SCRATCH);
-    vec16 *ghi = xb + n * CH, *glo = ghi + CH;
+    vec16 *xb0 = reinterpret_cast<vec16 *>(af_smem) + wave * (2 * n * CH + 2 * CH + AF_SCRATCH);
+    vec16 *ghi = xb0 + 2 * n * CH, *glo = ghi + CH;
     float *scr = reinterpret_cast<float *>(glo + CH);
     const int r16 = lane & 15, q = lane >> 4;
-    const int sw = af_swz(r16);
     const bool valid = r16 < n;
+    const int rc = valid ? r16 : n - 1;          // rows beyond the fan-out repeat the last child (masked where it matters)
+    const int sw = af_swz(rc);
     const int h32 = lane & 31, half = lane >> 5;
 
     // att.2 as the A operand of dhg^T = W2^T da^T: A[m = k][h] = W2[h][k] = W2T[k][h]
@@ -406,35 +472,63 @@ k_attn_fused_bwd(const AttnFusedBwd p)
 
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     int64_t par = (int64_t)blockIdx.x * n_waves + wave;
-    uint32_t id_next = par < p.M ? af_load_id(p.ids, p.row0, par, n, lane) : 0u;
-    while (par < p.M) {
-        const int64_t child = par * n + (valid ? r16 : n - 1);
-        // everything else this parent needs, requested ahead of the rows
-        af_f32x4 gv[ROUNDS][2];
+    auto request = [&](int64_t pr, int64_t pr_ids) {
+        AfBwdIn<ROUNDS> in;
+        const int64_t child = pr * n + rc;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int c = 64 * r + lane;
             const int cc = c < CH ? c : CH - 1;
-            gv[r][0] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc);
-            gv[r][1] = *reinterpret_cast<const af_f32x4 *>(p.g + par * p.g_ld + 8 * cc + 4);
+            in.gv[r][0] = *reinterpret_cast<const af_f32x4 *>(p.g + pr * p.g_ld + 8 * cc);
+            in.gv[r][1] = *reinterpret_cast<const af_f32x4 *>(p.g + pr * p.g_ld + 8 * cc + 4);
         }
-        const float wgt_raw = p.ws[child];
-        const af_f32x4 xq0 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q);
-        const af_f32x4 xq1 = *reinterpret_cast<const af_f32x4 *>(p.xa + par * p.xa_ld + 8 * q + 4);
-        const af_u32x2 hlo = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 4 * q);
-        const af_u32x2 hhi = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 16 + 4 * q);
-        float nav[AF_NMAX / 2];
+        in.wgt = p.ws[child];
+        in.xq0 = *reinterpret_cast<const af_f32x4 *>(p.xa + pr * p.xa_ld + 8 * q);
+        in.xq1 = *reinterpret_cast<const af_f32x4 *>(p.xa + pr * p.xa_ld + 8 * q + 4);
+        in.hlo = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 4 * q);
+        in.hhi = *reinterpret_cast<const af_u32x2 *>(p.hid + child * p.hid_ld + 16 + 4 * q);
 #pragma unroll
         for (int i = 0; i < AF_NMAX / 2; ++i) {
             const int j = 2 * i + half;
-            nav[i] = p.na[(par * n + (j < n ? j : n - 1)) * p.na_ld + h32];
+            in.nav[i] = p.na[(pr * n + (j < n ? j : n - 1)) * p.na_ld + h32];
         }
-        af_issue_tile<KS>(p.table, p.ld, id_next, n, xb, lane);
+        in.id = af_id_request(p.ids, p.table, pr_ids, n, lane);
+        return in;
+    };
+    // the pipeline of the forward kernel: rows of parent i + 1 requested before parent i is computed; everything
+    // requested behind a tile's rows is touched at the end of the trip before (requests return in issue order; every
+    // store of a trip is executed by every lane, so the compiler can count the younger requests)
+    auto touch = [&](AfBwdIn<ROUNDS> &in) {
+        asm volatile("" : "+v"(in.gv[0][0]), "+v"(in.gv[0][1]), "+v"(in.xq0), "+v"(in.xq1), "+v"(in.hlo), "+v"(in.hhi),
+                          "+v"(in.wgt), "+v"(in.id) : : "memory");
+        if constexpr (ROUNDS > 1) asm volatile("" : "+v"(in.gv[ROUNDS - 1][0]), "+v"(in.gv[ROUNDS - 1][1]));
+        asm volatile("" : "+v"(in.nav[0]), "+v"(in.nav[1]), "+v"(in.nav[2]), "+v"(in.nav[3]), "+v"(in.nav[4]),
+                          "+v"(in.nav[5]), "+v"(in.nav[6]), "+v"(in.nav[7]));
+    };
+    int buf = 0;
+    AfBwdIn<ROUNDS> cur;
+    if (par < p.M) {
+        uint32_t id0 = af_id_request(p.ids, p.table, par, n, lane);
+        asm volatile("" : "+v"(id0));
+        af_issue_tile<KS>(p.table, p.ld, af_id_value(id0, p.ids, p.row0, par, n, lane), n, xb0, lane);
+        asm volatile("" ::: "memory");
+        cur = request(par, par + stride < p.M ? par + stride : p.M - 1);
+        touch(cur);
+    }
+    while (par < p.M) {
+        const vec16 *xb = xb0 + buf * (n * CH);
+        const int64_t child = par * n + rc;
         const int64_t nxt = par + stride;
-        id_next = af_load_id(p.ids, p.row0, nxt < p.M ? nxt : p.M - 1, n, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (p.stop == 1) { par = nxt; continue; }
+        if (nxt < p.M)
+            af_issue_tile<KS>(p.table, p.ld, af_id_value(cur.id, p.ids, p.row0, nxt, n, lane), n, xb0 + (buf ^ 1) * (n * CH), lane);
+        asm volatile("" ::: "memory");
+        AfBwdIn<ROUNDS> nxin = request(nxt < p.M ? nxt : p.M - 1, nxt + stride < p.M ? nxt + stride : p.M - 1);
+        asm volatile("" ::: "memory");
+        const af_f32x4 (&gv)[ROUNDS][2] = cur.gv;
+        const af_f32x4 xq0 = cur.xq0, xq1 = cur.xq1;
+        const af_u32x2 hlo = cur.hlo, hhi = cur.hhi;
+        const float wgt_raw = cur.wgt;
+        const float (&nav)[AF_NMAX / 2] = cur.nav;
 
         // d agg -> bf16 high and low parts in LDS (g = hi + lo to 2^-17 relative: the dot products below keep
         // fp32-grade factors), as the B operand of every reduction step
@@ -458,13 +552,13 @@ k_attn_fused_bwd(const AttnFusedBwd p)
         af_f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacl = {0.f, 0.f, 0.f, 0.f};
         {
             vec16 fa[2], fh[2], fl[2];
-            fa[0] = xb[r16 * CH + (q ^ sw)];
+            fa[0] = xb[rc * CH + (q ^ sw)];
             fh[0] = ghi[q];
             fl[0] = glo[q];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
-                    fa[(ks + 1) & 1] = xb[r16 * CH + ((4 * (ks + 1) + q) ^ sw)];
+                    fa[(ks + 1) & 1] = xb[rc * CH + ((4 * (ks + 1) + q) ^ sw)];
                     fh[(ks + 1) & 1] = ghi[4 * (ks + 1) + q];
                     fl[(ks + 1) & 1] = glo[4 * (ks + 1) + q];
                 }
@@ -475,26 +569,22 @@ k_attn_fused_bwd(const AttnFusedBwd p)
         }
         // lane (any column, q) holds rows 4 q + reg; through the scratch words to the lane that owns the row
         if (r16 == 0) *reinterpret_cast<af_f32x4 *>(scr + 4 * q) = dacc;
-        const float dws = valid ? scr[r16] : 0.f;
-        if (p.stop == 2) {
-            if (valid && q == 0) p.dxa[par * p.dxa_ld + r16] = dws;
-            par = nxt;
-            continue;
-        }
-        // softmax backward (rows of the 16-lane group)
-        const float wgt = valid ? wgt_raw : 0.f;
-        const float dot = af_group16_sum(dws * wgt);
-        const float ds = wgt * (dws - dot);                     // (0 for the rows beyond the fan-out)
+        // softmax backward (rows of the 16-lane group).  The lanes of the rows beyond the fan-out repeat the last child:
+        // they stay out of the sums and of d a(parent), and issue the last child's stores again (same address, same bits)
+        const float dws = scr[rc];
+        const float dot = af_group16_sum(valid ? dws * wgt_raw : 0.f);
+        const float ds = wgt_raw * (dws - dot);
+        const float dsm = valid ? ds : 0.f;
 
         // d a of the parent through this hop: dxa[h] = sum_j ds_j a_child[j][h]
         float dx = 0.f;
 #pragma unroll
         for (int i = 0; i < AF_NMAX / 2; ++i) {
-            const float d0 = af_readlane(ds, 2 * i), d1 = af_readlane(ds, 2 * i + 1);
+            const float d0 = af_readlane(dsm, 2 * i), d1 = af_readlane(dsm, 2 * i + 1);
             dx += (half ? d1 : d0) * nav[i];
         }
-        dx += __shfl_xor(dx, 32, 64);
-        if (lane < 32) p.dxa[par * p.dxa_ld + h32] = dx;
+        dx += __shfl_xor(dx, 32, 64);                           // (both halves of the wave: the same sum, the same store)
+        p.dxa[par * p.dxa_ld + h32] = dx;
 
         // d a of this lane's row, its hidden units 8 q .. 8 q + 7 (no gradient reaches a last-hop row as a parent)
         vec16 dav;
@@ -502,7 +592,7 @@ k_attn_fused_bwd(const AttnFusedBwd p)
         dav[1] = af_pack2(ds * xq0[2], ds * xq0[3]);
         dav[2] = af_pack2(ds * xq1[0], ds * xq1[1]);
         dav[3] = af_pack2(ds * xq1[2], ds * xq1[3]);
-        if (valid) *reinterpret_cast<vec16 *>(p.da + child * p.da_ld + 8 * q) = dav;
+        *reinterpret_cast<vec16 *>(p.da + child * p.da_ld + 8 * q) = dav;
         // dhg^T [k][row] = sum_h W2[h][k] da[row][h]; lane (row, q) gets k = 4 q + reg and 16 + 4 q + reg
         const af_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const af_f32x4 g0 = af_mfma(w2ta[0], dav, zero);
@@ -513,7 +603,7 @@ k_attn_fused_bwd(const AttnFusedBwd p)
             hl[2 * e] = af_lo(hlo[e]); hl[2 * e + 1] = af_hi(hlo[e]);
             hh[2 * e] = af_lo(hhi[e]); hh[2 * e + 1] = af_hi(hhi[e]);
         }
-        if (valid) {
+        {
             uint16_t *dr = p.dhid + child * p.dhid_ld;
             *reinterpret_cast<af_u32x2 *>(dr + 4 * q) =
                 af_u32x2{af_pack2(g0[0] * (1.f - hl[0] * hl[0]), g0[1] * (1.f - hl[1] * hl[1])),
@@ -523,7 +613,8 @@ k_attn_fused_bwd(const AttnFusedBwd p)
                          af_pack2(g1[2] * (1.f - hh[2] * hh[2]), g1[3] * (1.f - hh[3] * hh[3]))};
         }
         __builtin_amdgcn_sched_barrier(0);
-        par = nxt;
+        touch(nxin);                     // arrived => the next tile has landed (the stores above are not waited for)
+        par = nxt; buf ^= 1; cur = nxin;
     }
 }
 
@@ -543,15 +634,19 @@ static int af_ksteps(int64_t D)
 // waves per CU that the 160 KiB hold wins; ties go to fewer, larger workgroups (fewer copies of W0).
 static bool af_geometry(int ks, int n, bool with_w0, int64_t M, int *waves, int *grid, size_t *lds)
 {
-    // per wave: the row tile + scratch (+ the two halves of d agg in the backward); per workgroup: W0 (forward) and the
-    // rows the last wave's 16-row fragments read behind its tile
-    const int64_t ch = 4 * ks, tile = ((int64_t)n * ch + AF_SCRATCH + (with_w0 ? 0 : 2 * ch)) * 16;
-    const int64_t fixed = (with_w0 ? 32 * ch * 16 : 0) + (16 - n) * ch * 16;
+    // per wave two row tiles (double-buffered) + scratch (+ the two halves of d agg in the backward); per workgroup W0
+    // in the forward
+    const int64_t ch = 4 * ks;
+    const int64_t tile = (2 * (int64_t)n * ch + AF_SCRATCH + (with_w0 ? 0 : 2 * ch)) * 16;
+    const int64_t fixed = with_w0 ? 32 * ch * 16 : 0;
     int best_nw = 0, best_pc = 0;
     for (int nw = 1; nw <= AF_MAX_WAVES; ++nw)
         for (int pc = 1; pc <= 16; ++pc) {
             if (pc * (fixed + nw * tile) > AF_LDS_BYTES || nw * pc > 16) break;
-            if (nw * pc > best_nw * best_pc || (nw * pc == best_nw * best_pc && nw > best_nw)) { best_nw = nw; best_pc = pc; }
+            // ties: fewer, larger workgroups in the forward (fewer copies of W0); more, smaller ones in the backward
+            // (measured at Reddit's last hop: 2 x 3 waves 40.9 us, 1 x 6 waves 43.9 us)
+            const bool tie = nw * pc == best_nw * best_pc && (with_w0 ? nw > best_nw : (nw < best_nw && nw >= 3));
+            if (nw * pc > best_nw * best_pc || tie) { best_nw = nw; best_pc = pc; }
         }
     if (!best_nw) return false;
     if (const char *e = getenv("GSAGE_AF_WAVES")) {              // diagnostic: waves per workgroup / workgroups per CU
@@ -612,7 +707,7 @@ extern "C" int gsage_attn_fused_ok(int dtype, int64_t ld, int64_t D, int32_t n, 
 extern "C" int gsage_attn_fused_fwd(const void *table, int dtype, int64_t ld, const int64_t *ids, int64_t row0,
                                     const void *W0, int64_t ldw0, const void *W2, int64_t ldw2, const float *xa,
                                     int64_t xa_ld, int64_t M, int32_t n, int64_t D, void *hid, int64_t hid_ld, float *a,
-                                    int64_t a_ld, float *ws, float *agg, int64_t agg_ld, void *agg_lp, int64_t lp_ld,
+                                    int64_t a_ld, float *ws, void *agg_lp, int64_t lp_ld,
                                     void *stream)
 {
     GSAGE_REQUIRE(gsage_attn_fused_ok(dtype, ld, D, n, 32), "attn_fused_fwd: shape not covered (bf16 rows of whole 16-byte "
@@ -621,22 +716,19 @@ extern "C" int gsage_attn_fused_fwd(const void *table, int dtype, int64_t ld, co
     const int64_t cols = 32 * (int64_t)ks;
     GSAGE_REQUIRE(M >= 0 && ldw0 >= cols && ldw0 % 8 == 0 && ldw2 >= 32 && ldw2 % 4 == 0 && xa_ld >= 32 && xa_ld % 4 == 0 &&
                   hid_ld >= 32 && hid_ld % 4 == 0 && a_ld >= 32 && a_ld % 4 == 0, "attn_fused_fwd: bad leading dimension");
-    GSAGE_REQUIRE(agg || agg_lp, "attn_fused_fwd: no output");
-    GSAGE_REQUIRE((!agg || (agg_ld >= cols && agg_ld % 4 == 0)) && (!agg_lp || (lp_ld >= cols && lp_ld % 8 == 0)),
-                  "attn_fused_fwd: output rows must hold whole 16-byte chunks up to the 32-column step");
+    GSAGE_REQUIRE(lp_ld >= cols && lp_ld % 4 == 0, "attn_fused_fwd: output rows must hold the columns up to the 32-column step");
     if (M == 0) return GSAGE_OK;
-    GSAGE_REQUIRE(table && W0 && W2 && xa && hid && a && ws, "attn_fused_fwd: null pointer");
-    GSAGE_REQUIRE((((uintptr_t)table | (uintptr_t)W0 | (uintptr_t)xa | (uintptr_t)a | (uintptr_t)agg | (uintptr_t)agg_lp) & 15) == 0 &&
-                  (((uintptr_t)W2 | (uintptr_t)hid) & 7) == 0, "attn_fused_fwd: misaligned pointer");
+    GSAGE_REQUIRE(table && W0 && W2 && xa && hid && a && ws && agg_lp, "attn_fused_fwd: null pointer");
+    GSAGE_REQUIRE((((uintptr_t)table | (uintptr_t)W0 | (uintptr_t)xa | (uintptr_t)a) & 15) == 0 &&
+                  (((uintptr_t)W2 | (uintptr_t)hid | (uintptr_t)agg_lp) & 7) == 0, "attn_fused_fwd: misaligned pointer");
     int waves, grid;
     size_t lds;
     GSAGE_REQUIRE(af_geometry(ks, n, true, M, &waves, &grid, &lds), "attn_fused_fwd: a row tile does not fit the LDS");
     AttnFusedFwd p;
     p.table = (const uint16_t *)table; p.ld = ld; p.ids = ids; p.row0 = row0; p.W0 = (const uint16_t *)W0; p.ldw0 = ldw0;
     p.W2 = (const uint16_t *)W2; p.ldw2 = ldw2; p.xa = xa; p.xa_ld = xa_ld; p.M = M; p.n = n; p.D = (int32_t)D;
-    p.hid = (uint16_t *)hid; p.hid_ld = hid_ld; p.a = a; p.a_ld = a_ld; p.ws = ws; p.agg = agg; p.agg_ld = agg_ld;
+    p.hid = (uint16_t *)hid; p.hid_ld = hid_ld; p.a = a; p.a_ld = a_ld; p.ws = ws;
     p.agg_lp = (uint16_t *)agg_lp; p.lp_ld = lp_ld;
-    p.stop = getenv("GSAGE_AF_STOP") ? atoi(getenv("GSAGE_AF_STOP")) : 0;
 #define GSAGE_AF_FWD(KSV, P)                                                                                              \
     do {                                                                                                                  \
         static bool raised = false;                                                                                       \
@@ -675,7 +767,6 @@ extern "C" int gsage_attn_fused_bwd(const void *table, int dtype, int64_t ld, co
     p.g = g; p.g_ld = g_ld; p.ws = ws; p.na = na; p.na_ld = na_ld; p.xa = xa; p.xa_ld = xa_ld; p.hid = (const uint16_t *)hid;
     p.hid_ld = hid_ld; p.M = M; p.n = n; p.D = (int32_t)D; p.da = (uint16_t *)da; p.da_ld = da_ld; p.dhid = (uint16_t *)dhid;
     p.dhid_ld = dhid_ld; p.dxa = dxa; p.dxa_ld = dxa_ld;
-    p.stop = getenv("GSAGE_AF_STOP") ? atoi(getenv("GSAGE_AF_STOP")) : 0;
 #define GSAGE_AF_BWD(KSV, P)                                                                                              \
     do {                                                                                                                  \
         static bool raised = false;                                                                                       \

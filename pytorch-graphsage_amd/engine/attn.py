@@ -99,13 +99,13 @@ class FusedAttnTrainStep(FusedTrainStep):
                        for _ in range(self.nset)]
         Ha, HL = self.Ha, self.HA_LD
         z = lambda *shape, dt=f32: torch.zeros(*shape, dtype=dt, device=dev)
-        self.hid, self.a, self.agg, self.aggc, self.ws, self.hout, self.dc = ([] for _ in range(7))
+        self.hid, self.a, self.aggc, self.ws, self.hout, self.dc = ([] for _ in range(6))
         self.dagg, self.dan, self.dax, self.da, self.dhid, self.datt, self.dx = ([] for _ in range(7))
         for l in range(L):
             R, RA, ld, h = self.rows[l], self.rall[l], self.ldin[l], self.h[l]
             last = l == L - 1
             self.hid.append(z(RA, HL, dt=T)); self.a.append(z(RA, Ha))
-            self.agg.append(z(R, ld)); self.aggc.append(z(R, ld, dt=T)); self.ws.append(z(RA - self.off[1]))
+            self.aggc.append(z(R, ld, dt=T)); self.ws.append(z(RA - self.off[1]))   # (the aggregate: operand copy only)
             self.hout.append(z(R, 2 * h, dt=f32 if last else T)); self.dc.append(z(R, 2 * h, dt=T))
             self.dagg.append(z(R, ld)); self.dan.append(z(RA, Ha)); self.dax.append(z(RA, Ha))
             self.da.append(z(RA, HL, dt=T)); self.dhid.append(z(RA, HL, dt=T))
@@ -218,12 +218,11 @@ class FusedAttnTrainStep(FusedTrainStep):
                         tab, self.code, ld, idp, 0, self.w0[l].data_ptr(), self.w0[l].shape[1], self.w2[l].data_ptr(),
                         self.w2[l].shape[1], self.a[l][r0:].data_ptr(), Ha, self.size[k], self.fan[k + 1], D,
                         self.hid[l][c0:].data_ptr(), HL, self.a[l][c0:].data_ptr(), Ha,
-                        self.ws[l][c0 - self.off[1]:].data_ptr(), self.agg[l][r0:].data_ptr(), ld,
-                        self.aggc[l][r0:].data_ptr(), ld, stream), "attn_fused_fwd")
+                        self.ws[l][c0 - self.off[1]:].data_ptr(), self.aggc[l][r0:].data_ptr(), ld, stream), "attn_fused_fwd")
                     continue
                 nat.check(lib.gsage_attn_aggregate_lp(
                     self.a[l][c0:].data_ptr(), Ha, self.a[l][r0:].data_ptr(), Ha, tab, self.code, ld,
-                    idp, self.size[k], self.fan[k + 1], Ha, D, self.agg[l][r0:].data_ptr(), ld,
+                    idp, self.size[k], self.fan[k + 1], Ha, D, None, ld,
                     self.ws[l][c0 - self.off[1]:].data_ptr(), self.aggc[l][r0:].data_ptr(), ld, stream), "attn_aggregate")
             last = l == L - 1
             out, code = self.hout[l], (nat.F32 if last else self.code)

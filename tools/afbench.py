@@ -1,6 +1,6 @@
 """Micro-benchmark of K4 / K4' with the attention MLP inside (csrc/gsage_attn_fused.hip) at Reddit's last hop
 (12 800 parents x 10 children x 602 bf16 columns from a 232 966-row table) or Pokec's (153 600 x 64): phase stops
-(GSAGE_AF_STOP) and geometry overrides (GSAGE_AF_WAVES / GSAGE_AF_PER_CU) swept in one process.
+and geometry overrides (GSAGE_AF_WAVES / GSAGE_AF_PER_CU) swept in one process.
     python tools/afbench.py [reddit|pokec] [sweep]"""
 import importlib, os, sys
 sys.path.insert(0, '.')
@@ -34,7 +34,7 @@ st = ops._stream()
 def fwd(k):
     nat.check(L.gsage_attn_fused_fwd(table.data_ptr(), nat.BF16, ld, ids[k % NF].data_ptr(), 0, w0.data_ptr(), ld, w2.data_ptr(), 64,
                                      xa.data_ptr(), 32, M, n, D, hid.data_ptr(), 64, a.data_ptr(), 32, ws.data_ptr(),
-                                     agg.data_ptr(), ld, aggc.data_ptr(), ld, st), "fwd")
+                                     aggc.data_ptr(), ld, st), "fwd")
 
 
 def bwd(k):
@@ -61,18 +61,12 @@ def timeit(fn, reps=24):
 alg = rows * D * 2
 print("%s: %d parents x %d children x %d columns = %.1f MB" % (shape, M, n, D, alg / 1e6))
 print("separate K4 (weighted sum only): %.1f us" % timeit(old_fwd))
-for stop in (0, 1, 2, 3):
-    os.environ["GSAGE_AF_STOP"] = str(stop)
-    tf = timeit(fwd)
-    tb = timeit(bwd) if stop < 3 else float('nan')
-    print("stop=%d  fwd %.1f us (%.2f TB/s)   bwd %.1f us (%.2f TB/s)" % (stop, tf, alg / tf / 1e6, tb, alg / tb / 1e6))
-os.environ["GSAGE_AF_STOP"] = "0"
+tf, tb = timeit(fwd), timeit(bwd)
+print("fused  fwd %.1f us (%.2f TB/s)   bwd %.1f us (%.2f TB/s)" % (tf, alg / tf / 1e6, tb, alg / tb / 1e6))
 if 'sweep' in sys.argv:
-    for stop in (0, 1):
-        os.environ["GSAGE_AF_STOP"] = str(stop)
-        for nw, pc in ((8, 1), (6, 1), (4, 1), (4, 2), (3, 2), (2, 2), (2, 4), (6, 2), (4, 3), (3, 4), (2, 6), (1, 8)):
-            os.environ["GSAGE_AF_WAVES"], os.environ["GSAGE_AF_PER_CU"] = str(nw), str(pc)
-            try:
-                print("stop=%d waves=%d per_cu=%d: fwd %.1f  bwd %.1f us" % (stop, nw, pc, timeit(fwd), timeit(bwd)))
-            except Exception as e:
-                print("waves=%d per_cu=%d: %r" % (nw, pc, e))
+    for nw, pc in ((8, 1), (6, 1), (5, 1), (4, 1), (3, 1), (4, 2), (3, 2), (2, 2), (2, 4), (1, 8)):
+        os.environ["GSAGE_AF_WAVES"], os.environ["GSAGE_AF_PER_CU"] = str(nw), str(pc)
+        try:
+            print("waves=%d per_cu=%d: fwd %.1f  bwd %.1f us" % (nw, pc, timeit(fwd), timeit(bwd)))
+        except Exception as e:
+            print("waves=%d per_cu=%d: %r" % (nw, pc, e))
