@@ -537,6 +537,30 @@ int gsage_attn_fused_bwd(const void *table, int dtype, int64_t ld, const int64_t
                          const float *xa, int64_t xa_ld, const void *hid, int64_t hid_ld, int64_t M, int32_t n, int64_t D,
                          void *da, int64_t da_ld, void *dhid, int64_t dhid_ld, float *dxa, int64_t dxa_ld, void *stream);
 
+/* The trainable node-embedding prep as two row pipelines (round 6; csrc/gsage_prep_rows.hip; reference nn_modules.py:126-155
+ * and its autograd).  bf16 operands, 64-wide embeddings: gsage_prep_rows_ok says whether a shape is covered (1 / 0).
+ * Frontier position pos reads table row (pos < n_seed ? spare : ids[pos]) -- the seeds all read the spare row n_nodes.
+ *   forward   eraw[pos] = bf16(table row); out[pos] = bf16(eraw[pos] W^T + bias): the embedding gather and the prep.fc
+ *             projection in one launch (W: prep.fc's bf16 operand copy [64, ldw]; `out` points at the prep's columns of
+ *             the level-0 rows)
+ *   backward  v = (dhid ? dhid W0 : DATT ? DATT : 0) + (pos < r_x ? DX[pos] : 0) + w(pos) DAGG[parent(pos)]  -- the sources
+ *             and the hop layout of gsage_attn_merge_bwd2, no ReLU mask (the prep is affine); dhid [R, lddh] bf16 with
+ *             W0T = att.0's transposed operand copy [64, ldw0t] saves the GEMM that would have produced DATT;
+ *             din0[pos] = bf16(v); bias_part[b] = column sums of v over workgroup b's rows (n_part workgroups: the
+ *             prep.fc.bias gradient's partials); d = bf16(v) WpT^T (WpT[e][c] = prep.fc.weight[c][e]); then either
+ *             g_table[row(pos)] += d with fp32 atomics -- the seeds' rows summed per 16-row tile first -- or
+ *             (deraw != NULL) deraw[pos] = d and no atomics (the sorted, deterministic table gradient of data-parallel runs) */
+int gsage_prep_rows_ok(int dtype, int64_t E);
+int gsage_prep_rows_fwd(const float *table, int64_t ldt, const int64_t *ids, int64_t n_seed, int64_t spare, const void *W,
+                        int64_t ldw, const float *bias, int64_t M, int64_t E, void *eraw, int64_t lde, void *out,
+                        int64_t ldo, void *stream);
+int gsage_prep_rows_bwd(const void *dhid, int64_t lddh, const void *W0T, int64_t ldw0t, const float *DATT, int64_t ldatt,
+                        const float *DX, int64_t ldx, int64_t r_x, const float *DAGG, int64_t ldagg, const float *ws,
+                        int32_t n_hops, const int64_t *off, const int32_t *fan, int64_t R, int64_t E, void *din0,
+                        int64_t ldd, float *bias_part, int32_t n_part, const void *WpT, int64_t ldwpt, const int64_t *ids,
+                        int64_t n_seed, int64_t spare, float *g_table, int64_t ldg, float *deraw, int64_t ldde,
+                        void *stream);
+
 /* Glue of the native attention train step (engine.FusedAttnTrainStep): what autograd ran as separate cast /
  * add / tanh-backward / expand kernels between K4, K5 and K5b.
  *   gsage_add_cast        dst[m, c] = T(a[m, c] + (b ? b[m, c] : 0))             (fp32 in, bf16 / fp32 out)

@@ -144,6 +144,10 @@ SIGNATURES = {
                                     _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "gsage_attn_fused_bwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
                                     _i64, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "gsage_prep_rows_ok": (_int, [_int, _i64]),
+    "gsage_prep_rows_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "gsage_prep_rows_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i64,
+                                   _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "gsage_attn_mlp2_fwd": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "gsage_attn_mlp2_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32,
                                    _vp]),

@@ -269,11 +269,18 @@ class FusedAttnTrainStep(FusedTrainStep):
                                               self.hid[l].data_ptr(), self.code, HL, self.w2T[l].data_ptr(),
                                               self.w2T[l].shape[1], self.da[l].data_ptr(), HL, self.dhid[l].data_ptr(), HL,
                                               R if self.fuse[l] else RA, Ha, stream), "attn_mlp2_bwd")
-            if l > 0 or self.emb:
+            rows0 = l == 0 and self.emb and self.rows_ok      # level 0 over the prep: one row pipeline (common.py)
+            if (l > 0 or self.emb) and not rows0:
                 self._gemm(self.dhid[l].data_ptr(), HL, self.w0T[l], self.datt[l].data_ptr(), nat.F32, ld, RA, D, Ha,
                            nat.ACT_NONE)
+            if l > 0 or self.emb:
                 self._gemm(dc.data_ptr(), 2 * h, self.wxT[l], self.dx[l].data_ptr(), nat.F32, ld, R, D, h, nat.ACT_NONE)
-            if l == 0 and self.emb:
+            if rows0:
+                o = 4 * self.D0               # (features in front of the prep's output take no gradient)
+                self._prep_backward_rows(s, self.dhid[0].data_ptr(), self.w0T[0][self.D0:], None, 0,
+                                         self.dx[0].data_ptr() + o, ld, self.rows[0], self.dagg[0].data_ptr() + o, ld,
+                                         self.ws[0].data_ptr())
+            elif l == 0 and self.emb:
                 self._input_grad0()
                 self._prep_backward(s)
             if l > 0:

@@ -985,6 +985,11 @@ class FusedTrainStep(object):
         self.seed_grad = torch.zeros(min(16, self.B), E, dtype=f32, device=dev)   # partial sums of the gradient of
         #                                                                             the spare row the seeds read
         self._cur_ids = self.ids_set[0]
+        # the prep as row pipelines (csrc/gsage_prep_rows.hip: gather + prep.fc in one launch; the level-0 input
+        # gradient, the bias sums, the product through prep.fc^T and the table's atomics in another);
+        # GSAGE_PREP_ROWS=0: the separate launches
+        self.rows_ok = bool(os.environ.get("GSAGE_PREP_ROWS", "1") != "0" and self.D0 % 4 == 0 and
+                            nat.lib().gsage_prep_rows_ok(self.code, E))
 
     def _emb_wgrad_problem(self):
         """(dC, A, lda, M, Ntot, K, parameter, row list) of the prep's affine: d out^T x embedding rows"""
@@ -1059,16 +1064,44 @@ class FusedTrainStep(object):
         if self.lazy_rows:       # the rows this step reads, brought up to the last update
             nat.check(lib.gsage_rows_catch_up(ctypes.byref(self.row_desc), self.seed_rows.data_ptr(), 1,
                                               ids[B:RA0].data_ptr(), RA0 - B, 0, stream), "rows_catch_up")
+        g0 = self.g0_set[s]
+        if self.rows_ok:         # table row -> bf16 -> prep.fc + bias, one launch
+            if self.D0:
+                st = self.store
+                ops.gather_mean_multi([(st.data, ids[:RA0], g0, RA0, 1)], st.ld, st.dim, self.ldin[0])
+            nat.check(lib.gsage_prep_rows_fwd(tab.data_ptr(), tab.stride(0), ids.data_ptr(), B, int(prep.n_nodes),
+                                              self.wprep.data_ptr(), self.wprep.shape[1], prep.fc.bias.data_ptr(), RA0, E,
+                                              self.eraw.data_ptr(), self.eraw.stride(0), g0.data_ptr() + self.D0 * self.esz,
+                                              self.ldin[0], stream), "prep_rows_fwd")
+            return
         # fp32 table rows -> the operand type in the gather itself (seeds read the spare row n_nodes)
         segs = [(tab, self.seed_rows, self.eraw[:B], B, 1), (tab, ids[B:RA0], self.eraw[B:], RA0 - B, 1)]
         ops.gather_mean_multi(segs, E, E, self.eraw.stride(0))
-        g0 = self.g0_set[s]
         if self.D0:              # [features | ...]: the frontier's feature rows (whole 16-byte chunks: before the affine)
             st = self.store
             ops.gather_mean_multi([(st.data, ids[:RA0], g0, RA0, 1)], st.ld, st.dim, self.ldin[0])
         ops._linear_launch(self.eraw.data_ptr(), self.eraw.stride(0), None, 0, self.wprep.data_ptr(), self.wprep.shape[1],
                            prep.fc.bias.data_ptr(), g0.data_ptr() + self.D0 * self.esz, self.ldin[0], RA0, E, E,
                            nat.ACT_NONE, 1, 0, 0, 0, self.code, self.code)
+
+    def _prep_backward_rows(self, s, dhid, w0t, datt, ldatt, dx, ldx, r_x, dagg, ldagg, ws):
+        """_input_grad0 + _prep_backward of an engine as ONE launch (self.rows_ok): the sources of the level-0 input
+        gradient as gsage_attn_merge_bwd2 takes them (pointers already at the prep's columns), or d hid + the transposed
+        operand copy of att.0 instead of the gradient through att(.) -> din0, the bias partials, the table's gradient."""
+        lib, stream = nat.lib(), ops._stream()
+        ids, B, RA0, E, L = self._cur_ids, self.B, self.off[self.L + 1], self.E, self.L
+        g = self._grad_slice(self.table)
+        sorted_rows = self.lazy_rows and self.sorted_rows       # (the rows then meet in _stage_opt_emb, from deraw)
+        nat.check(lib.gsage_prep_rows_bwd(
+            dhid, self.HA_LD if dhid else 0, w0t.data_ptr() if w0t is not None else None, w0t.shape[1] if w0t is not None else 0,
+            datt, ldatt, dx, ldx, r_x, dagg, ldagg, ws, L + 1, self.off_host, self.fan_host, RA0, E, self.din0.data_ptr(),
+            self.din0.stride(0), self.prep_bpart.data_ptr(), self.prep_bpart.shape[0], self.wprepT.data_ptr(),
+            self.wprepT.shape[1], ids.data_ptr(), B, int(self.model.prep.n_nodes), g.data_ptr(), E,
+            self.deraw.data_ptr() if sorted_rows else None, E, stream), "prep_rows_bwd")
+        if sorted_rows:
+            ns = self.seed_grad.shape[0]
+            nat.check(lib.gsage_colsum_partials(self.deraw.data_ptr(), E, B, E, self.seed_grad.data_ptr(), ns, stream),
+                      "colsum_partials")
 
     def _prep_backward(self, s):
         """level 0's input gradient (din0f fp32, din0 = its operand copy; formed by the subclass) -> prep.fc (weight:

@@ -224,3 +224,78 @@ def test_attention_engine_with_the_fused_hop_tracks_the_separate_launches(monkey
     assert abs(a[2] - b[2]) < 5e-3 * a[2]
     close_fro(b[1], a[1], "clipped gradient of the first step", 2e-2)
     assert np.abs(a[3] - b[3]).max() < 0.5 * max(1.0, np.abs(a[3]).max())
+
+
+# ---- the node-embedding prep as row pipelines (csrc/gsage_prep_rows.hip) ---------------------------------------------
+@pytest.mark.parametrize("M,n_seed", [(1000, 48), (37, 16), (515, 0), (64, 64)])
+def test_prep_rows_forward_equals_gather_then_projection(M, n_seed):
+    """gsage_prep_rows_fwd against the launches it replaces and the definition (nn_modules.py:145-151): eraw bit for
+    bit (the same rounding of the same fp32 rows), the projection to an ulp of bf16 (sums in another order)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(1)
+    N, E = 3000, 64
+    table = torch.randn(N + 2, E, generator=g).to(DEV)
+    ids = torch.randint(1, N, (M,), generator=g).to(DEV)
+    W = (torch.randn(E, E, generator=g) / 8).to(DEV)
+    Wc = W.to(BF).contiguous(); bias = torch.randn(E, generator=g).to(DEV)
+    eraw = torch.zeros(M, E, dtype=BF, device=DEV); out = torch.full((M, 128), 3.0, dtype=BF, device=DEV)
+    L = nat.lib()
+    assert L.gsage_prep_rows_ok(nat.BF16, 64) == 1 and L.gsage_prep_rows_ok(nat.F32, 64) == 0 and L.gsage_prep_rows_ok(nat.BF16, 32) == 0
+    nat.check(L.gsage_prep_rows_fwd(table.data_ptr(), E, ids.data_ptr(), n_seed, N + 1, Wc.data_ptr(), E, bias.data_ptr(), M, E,
+                                    eraw.data_ptr(), E, out.data_ptr() + 2 * 32, 128, ops._stream()), "prep_rows_fwd")
+    torch.cuda.synchronize()
+    rows = ids.clone(); rows[:n_seed] = N + 1
+    want_e = table[rows].to(BF)
+    assert torch.equal(eraw, want_e)
+    want = want_e.double() @ Wc.double().t() + bias.double()
+    torch.testing.assert_close(out[:, 32:96].double(), want, rtol=1.0 / 128, atol=1e-2)
+    assert torch.all(out[:, :32].float() == 3.0) and torch.all(out[:, 96:].float() == 3.0)
+
+
+@pytest.mark.parametrize("with_dhid,with_ws,deraw_mode", [(True, True, False), (False, False, False), (True, True, True)])
+def test_prep_rows_backward_equals_merge_sums_projection_and_scatter(with_dhid, with_ws, deraw_mode):
+    """gsage_prep_rows_bwd against the definition in fp64 (nn_modules.py:307-317 w.r.t. the level-0 rows, then 145-151):
+    the input gradient of the level-0 rows, its bf16 operand copy, the bias partials, and the table's gradient (atomics,
+    duplicates and the seeds' shared spare row included) or the d embedding rows."""
+    import ctypes
+    g = torch.Generator(device="cpu"); g.manual_seed(2)
+    B, f1, f2, E, N = 24, 5, 3, 64, 400
+    off = [0, B, B + B * f1, B + B * f1 + B * f1 * f2]
+    R, r_x = off[3], off[2]
+    ids = torch.randint(1, N, (R,), generator=g).to(DEV)
+    dhid = (torch.randn(R, 64, generator=g) * 0.1).to(BF).to(DEV); dhid[:, 32:] = 0
+    W0 = (torch.randn(32, E, generator=g) / 6).to(BF).to(DEV)
+    W0T = torch.zeros(E, 64, dtype=BF, device=DEV); W0T[:, :32] = W0.t()
+    datt = (dhid[:, :32].double() @ W0.double()).float()
+    dx = torch.randn(r_x, E, generator=g).to(DEV); dagg = torch.randn(r_x, E, generator=g).to(DEV)
+    ws = torch.rand(R - B, generator=g).to(DEV)
+    Wp = (torch.randn(E, E, generator=g) / 8).to(BF).to(DEV); WpT = Wp.t().contiguous()
+    din0 = torch.zeros(R, E, dtype=BF, device=DEV); bpart = torch.full((256, E), 9.0, device=DEV)
+    gtab = torch.zeros(N + 2, E, device=DEV); deraw = torch.zeros(R, E, device=DEV)
+    offh = (ctypes.c_int64 * 6)(*(off + [0, 0])); fanh = (ctypes.c_int32 * 6)(1, f1, f2, 1, 1, 1)
+    L = nat.lib()
+    nat.check(L.gsage_prep_rows_bwd(dhid.data_ptr() if with_dhid else None, 64, W0T.data_ptr() if with_dhid else None, 64,
+                                    None if with_dhid else datt.data_ptr(), E, dx.data_ptr(), E, r_x, dagg.data_ptr(), E,
+                                    ws.data_ptr() if with_ws else None, 3, offh, fanh, R, E, din0.data_ptr(), E, bpart.data_ptr(),
+                                    256, WpT.data_ptr(), E, ids.data_ptr(), B, N + 1, gtab.data_ptr(), E,
+                                    deraw.data_ptr() if deraw_mode else None, E, ops._stream()), "prep_rows_bwd")
+    torch.cuda.synchronize()
+    pos = torch.arange(R, device=DEV)
+    parent = torch.zeros(R, dtype=torch.long, device=DEV)
+    parent[off[1]:off[2]] = (pos[off[1]:off[2]] - off[1]) // f1
+    parent[off[2]:] = off[1] + (pos[off[2]:] - off[2]) // f2
+    w = torch.zeros(R, dtype=torch.float64, device=DEV)
+    w[B:] = ws.double() if with_ws else torch.cat([torch.full((B * f1,), 1.0 / f1), torch.full((B * f1 * f2,), 1.0 / f2)]).double().to(DEV)
+    v = datt.double().clone()
+    v[:r_x] += dx.double()
+    v += w.unsqueeze(1) * dagg.double()[parent]
+    torch.testing.assert_close(din0.double(), v, rtol=1.0 / 128, atol=2e-2)
+    torch.testing.assert_close(bpart.double().sum(0), v.sum(0), rtol=1e-4, atol=1e-3)
+    d = din0.double() @ Wp.double()                     # (the kernel multiplies the rounded operand copy, as the GEMM did)
+    if deraw_mode:
+        torch.testing.assert_close(deraw.double(), d, rtol=1e-4, atol=1e-4)
+        assert float(gtab.abs().max()) == 0.0
+    else:
+        rows = ids.clone(); rows[:B] = N + 1
+        want = torch.zeros(N + 2, E, dtype=torch.float64, device=DEV).index_add_(0, rows, d)
+        torch.testing.assert_close(gtab.double(), want, rtol=1e-4, atol=1e-3)
+        assert float(deraw.abs().max()) == 0.0
