@@ -183,7 +183,10 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
     omp = {"value": n_omp * batch / dt_omp, "cores": omp_threads,
            "sample": "%d train_steps of %d seeds, fp32, OpenMP C restatement (oracle/gsage_train_omp.c: "
                      "register-blocked AVX2 / FMA products, no BLAS) on %d threads of %d host threads (fastest of %s), "
-                     "%.1f s" % (n_omp, batch, omp_threads, ncpu, "/".join(str(t) for t in cands), dt_omp)}
+                     "%.1f s; the restatement neither pins its threads nor places the 560 MB feature table by first "
+                     "touch, so it stops scaling at about one NUMA domain of the host: context for the GPU figure, a "
+                     "few times below what a tuned multi-socket port would reach"
+                     % (n_omp, batch, omp_threads, ncpu, "/".join(str(t) for t in cands), dt_omp)}
     tp = {"value": n_t * batch / dt_t, "cores": threads,
           "sample": "%d train_steps of %d seeds, fp32, oracle/torch_ref.py (the reference's op sequence on stock "
                     "torch CPU kernels: MKL GEMMs) + C sampler, torch %d threads (fixed), %.1f s"
@@ -196,8 +199,8 @@ def cpu_baseline(data, budget_s=12.0, batch=BATCH):
 
 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md; no sparsity)
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_launches.json", "r04_pmc_launches.json",
-                                                          "r03_pmc_launches.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_launches.json", "r05_pmc_launches.json",
+                                                          "r04_pmc_launches.json", "r03_pmc_launches.json")]
 TIMING_METHOD = ("HIP start/stop events attached to the launch's dispatch inside the step's command list "
                  "(hipExtLaunchKernel), one read per step")
 
@@ -220,6 +223,32 @@ def timed_launches(eng, run_step, n_steps=48):
     eng.instrument(False)
     torch.cuda.synchronize()
     return {name: float(np.mean(v)) * 1e3 for name, v in acc.items()}
+
+
+def exchange_in_list_us(eng, run_step, n_steps=16):
+    """Data-parallel runs: the step's exchange (the collective node(s) of the step's command list) bracketed by events
+    recorded in the list itself -- mean microseconds over n_steps real steps, on every rank (the steps are collective);
+    None when the step is not one recorded list.  (Events between nodes over-state by an event packet's processing,
+    ~5 us: an upper bound on what the collective adds to the step.)"""
+    if getattr(eng, "capture_mode", None) != "cmdlist" or getattr(eng, "ddp", None) is None:
+        return None
+    try:
+        eng.instrument(True)
+        torch.cuda.synchronize()
+        for k in range(2):
+            run_step(k)
+        torch.cuda.synchronize()
+        acc = []
+        for k in range(n_steps):
+            run_step(2 + k)
+            ms = eng.last_launch_ms().get("exchange")
+            if ms is not None:
+                acc.append(ms)
+        eng.instrument(False)
+        torch.cuda.synchronize()
+        return float(np.mean(acc)) * 1e3 if acc else None
+    except Exception as e:                      # never lose the line to the instrumentation
+        return "error: %r" % (e,)
 
 
 def pmc_traffic(key):
@@ -280,8 +309,9 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
         if rows_t > rows_g and "seed_level" in us:
             # the launch that reads most of the step's frontier rows is the seed-level launch's gather role (round 5:
             # the whole last hop): it is the dominant kernel; the gather launch (hop-1 means | Adam | K1) is listed beside it
-            out = hbm_roofline(seed_name, rows_t * st.dim * elem, us["seed_level"], "reddit_seed_level", n_steps,
-                               rows_per_launch=rows_t)
+            # (the counters of THIS configuration's seed-level launch: reddit_seed_level / papers_seed_level)
+            out = hbm_roofline(seed_name, rows_t * st.dim * elem, us["seed_level"], pmc_key.replace("_gather", "_seed_level"),
+                               n_steps, rows_per_launch=rows_t)
             # (the rows the gather launch reads for the hop-1 means are the hop-1 nodes' own rows, which K5 / K5b also
             # read in place as x rows: the step's algorithmic bytes count them once, `rows_read` is what this launch moves)
             rows_h1 = sum(eng.size[1:L]) if rows_g == 0 else rows_g        # (children of every hop but the last)
@@ -331,11 +361,15 @@ def engine_roofline(eng, run_step, pmc_key, n_steps=48):
         return out
     D = eng.din[0]
     elem = 2 if eng.tdt == torch.bfloat16 else 4
-    out = hbm_roofline("k_attn_aggregate_grp (K4 in-step, last hop: %d child rows x %d %s)"
+    fused = bool(getattr(eng, "fuse", [False])[0])
+    out = hbm_roofline(("k_attn_fused_fwd (K4 with the attention MLP inside, in-step, last hop: %d child rows x %d %s, "
+                        "each row read ONCE for att(.), the softmax weights and the weighted sum)" if fused else
+                        "k_attn_aggregate_grp (K4 in-step, last hop: %d child rows x %d %s)")
                        % (rows, D, "bf16" if elem == 2 else "fp32"), rows * D * elem, us["k4"], pmc_key, n_steps,
                        rows_per_launch=rows)
     if "k4_bwd" in us:
-        out["k4_bwd_launch"] = {"kernel": "k_attn_bwd_grp (K4' in-step, last hop: the same rows read once)",
+        out["k4_bwd_launch"] = {"kernel": ("k_attn_fused_bwd (K4' with the attention MLP's backward inside" if fused else
+                                           "k_attn_bwd_grp (K4'") + " in-step, last hop: the same rows read once)",
                                 "alg_bytes_per_launch": rows * D * elem, "avg_launch_us": us["k4_bwd"],
                                 "achieved": rows * D * elem / (us["k4_bwd"] * 1e-6) / 1e9}
     return out
@@ -386,20 +420,30 @@ def _lognormal_graph(gs, n_nodes, mu, sigma, max_deg, seed=0):
     return adj, rng
 
 
-def _timed_steps(step, n_warm, n_steps, finish=None):
-    """finish: work the steps deferred (an engine's sync_rows) -- inside the timed region."""
+def _timed_steps(step, n_warm, n_steps, finish=None, ddp=None):
+    """finish: work the steps deferred (an engine's sync_rows) -- inside the timed region.  With a process group: a
+    barrier + synchronize on both sides of the timed region, the MAX over the ranks."""
+    def sync():
+        if ddp is not None:
+            ddp.barrier()
+        torch.cuda.synchronize()
     for k in range(n_warm):
         step(k)
     if finish is not None:
         finish()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for k in range(n_warm, n_warm + n_steps):
         step(k)
     if finish is not None:
         finish()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_steps
+    sync()
+    dt = time.perf_counter() - t0
+    if ddp is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / n_steps
 
 
 def _placeholder_adj():
@@ -407,7 +451,7 @@ def _placeholder_adj():
     return sparse.csr_matrix((np.array([1, 1]), np.array([0, 0]), np.array([0, 0, 1, 2])), shape=(3, 1))
 
 
-def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=111_059_956, B=BATCH):
+def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=111_059_956, B=BATCH, ddp=None):
     """BASELINE configs[4] on one GPU at its REAL size: 111 059 956 nodes, ~3.2e9 edges (int64 row offsets, 13 GB of
     int32 neighbour ids), 128-d bf16 features (28 GB), mean aggregator, three layers, fan-out 15/10/5 -- graph and
     table generated on the device (store.DeviceCSR.synthetic / FeatureStore.synthetic; ~43 GB of the 288 GB).
@@ -426,26 +470,33 @@ def extra_papers(gs, dev, steps=60, warmup=5, n_nodes=111_059_956, B=BATCH):
                             n_classes=N_CLASSES, layer_specs=specs, lr_init=0.01).to(dev)
     model.train_sampler.seed = 123
     model.train_sampler.use_device_csr(csr)
+    world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
+    if ddp is not None:
+        gs.dist.attach(model, ddp, seed=123)
     total = steps + warmup
-    rng = np.random.default_rng(0)
-    ids = torch.from_numpy(rng.integers(1, n_rows, size=(total, B))).to(dev)
-    tg = torch.from_numpy(rng.integers(0, N_CLASSES, size=(total, B, 1))).to(dev)
-    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids[0], tg[0])
+    rng = np.random.default_rng(0)              # (every rank draws the global batches and keeps its columns)
+    ids = torch.from_numpy(rng.integers(1, n_rows, size=(total, world * B))[:, rank * B:(rank + 1) * B].copy()).to(dev)
+    tg = torch.from_numpy(rng.integers(0, N_CLASSES, size=(total, world * B, 1))[:, rank * B:(rank + 1) * B].copy()).to(dev)
+    eng = gs.engine.FusedMeanTrainStep(model, store, gs.ProblemLosses.classification, ids[0], tg[0], ddp=ddp)
     eng.load_epoch(ids, tg)
-    dt = _timed_steps(lambda k: eng.step_queue(), warmup, steps)
+    dt = _timed_steps(lambda k: eng.step_queue(), warmup, steps, ddp=ddp)
     csr.check()
     rows = 1 + 15 + 150 + 750
     rec = {"config": "BASELINE configs[4] at its real size (N=%d, nnz=%d): mean, 3 layers, fan-out 15/10/5, 128-d bf16 "
                      "features (a %.1f GB table: the uncached reference point for the gather), one GPU"
                      % (n_nodes, csr.nnz, store.data.numel() * 2 / 1e9),
-           "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec", "engine": "FusedMeanTrainStep",
+           "ms_per_step": dt * 1e3, "value": world * B / dt, "unit": "seed-nodes/sec", "engine": "FusedMeanTrainStep",
            "alg_bytes_per_seed": rows * 128 * 2,
-           "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2)),
-           "roofline": engine_roofline(eng, lambda k: eng.step_queue(), "papers_gather", n_steps=32)}
+           "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 128 * 2))}
+    if ddp is None:
+        rec["roofline"] = engine_roofline(eng, lambda k: eng.step_queue(), "papers_gather", n_steps=32)
+    else:
+        rec["exchange_us"] = exchange_in_list_us(eng, lambda k: eng.step_queue())
+    rec["_engine"] = eng
     return rec
 
 
-def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fused"):
+def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fused", ddp=None):
     """BASELINE configs[3] at its SHAPE on one GPU: Pokec-sized graph (1.63 M nodes, ~6e7 edges), no features,
     trainable 64-d node embeddings (node_embedding prep), attention aggregator (hidden 32), fan-out 20/15,
     regression_mae.  The step keeps the reference's DENSE embedding-gradient semantics (every row of the 418 MB
@@ -466,13 +517,16 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
                             n_nodes=adj.shape[0], n_classes=1, layer_specs=specs, lr_init=0.01).to(dev)
     model.train_sampler.seed = 123
     model.train_sampler.csr(dev)
+    world, rank = (ddp.world, ddp.rank) if ddp is not None else (1, 0)
+    if ddp is not None:
+        gs.dist.attach(model, ddp, seed=123)
     total = steps + warmup
-    ids = torch.from_numpy(rng.integers(1, N + 1, size=(total, B))).to(dev)
-    tg = torch.from_numpy(rng.integers(15, 60, size=(total, B, 1)).astype(np.float32)).to(dev)
+    ids = torch.from_numpy(rng.integers(1, N + 1, size=(total, world * B))[:, rank * B:(rank + 1) * B].copy()).to(dev)
+    tg = torch.from_numpy(rng.integers(15, 60, size=(total, world * B, 1))[:, rank * B:(rank + 1) * B].astype(np.float32)).to(dev)
     loss_fn = gs.ProblemLosses.regression_mae
-    cls = gs.engine.fused_engine_for(model, None) if engine == "fused" else None
+    cls = gs.engine.fused_engine_for(model, None, ddp=ddp) if engine == "fused" else None
     if cls is not None:
-        step_fn = cls(model, None, loss_fn, ids[0], tg[0], capture=os.environ.get("GSAGE_POKEC_LAUNCH", "cmdlist"))
+        step_fn = cls(model, None, loss_fn, ids[0], tg[0], ddp=ddp, capture=os.environ.get("GSAGE_POKEC_LAUNCH", "cmdlist"))
         how = "%s (native attention step: K4 / K5 / K5b / K6, no autograd below the head), %s" % (
             cls.__name__, step_fn.capture_mode)
     else:
@@ -481,7 +535,7 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
     # deferred table rows (engine.sync_rows): the timed region ends with every row of the table settled, i.e. it
     # pays for one dense catch-up pass per `steps` steps (a training run pays one per epoch, before evaluation)
     deferred = bool(getattr(step_fn, "lazy_rows", False))
-    dt = _timed_steps(lambda k: step_fn(ids[k], tg[k]), warmup, steps, finish=step_fn.sync_rows if deferred else None)
+    dt = _timed_steps(lambda k: step_fn(ids[k], tg[k]), warmup, steps, finish=step_fn.sync_rows if deferred else None, ddp=ddp)
     if deferred:
         how += "; table rows updated when touched or read (gsage_rows_*: bit-identical to the dense update), " \
                "all rows settled inside the timed region"
@@ -489,13 +543,17 @@ def extra_pokec(gs, dev, steps=40, warmup=5, B=BATCH, precision=None, engine="fu
     rows = 1 + 20 + 300
     rec = {"config": "BASELINE configs[3] shape on one GPU: Pokec-sized graph (N=%d, nnz=%d), node_embedding(64) + "
                      "attention(32), fan-out 20/15, regression_mae" % (N, adj.nnz),
-           "ms_per_step": dt * 1e3, "value": B / dt, "unit": "seed-nodes/sec",
+           "ms_per_step": dt * 1e3, "value": world * B / dt, "unit": "seed-nodes/sec",
            "engine": how, "alg_bytes_per_seed": rows * 64 * 4, "dense_table_bytes_per_step": 7 * 4 * 64 * (N + 2),
            "frac_of_hbm_gather_roofline": (B / dt) / (HBM_PEAK_GBS * 1e9 / (rows * 64 * 4))}
     if cls is not None and step_fn.capture_mode == "cmdlist":
-        rec["roofline"] = engine_roofline(step_fn, lambda k: step_fn(ids[k % total], tg[k % total]), "pokec_k4",
-                                          n_steps=32)
+        if ddp is None:
+            rec["roofline"] = engine_roofline(step_fn, lambda k: step_fn(ids[k % total], tg[k % total]), "pokec_k4",
+                                              n_steps=32)
+        else:
+            rec["exchange_us"] = exchange_in_list_us(step_fn, lambda k: step_fn(ids[k % total], tg[k % total]))
         step_fn.sync_rows()
+    rec["_engine"] = step_fn
     return rec
 
 
@@ -654,6 +712,27 @@ def extra_b4096(args):
         return {"error": repr(e)}
 
 
+def extra_fp32(args):
+    """BASELINE configs[1] with fp32 storage and exact-fp32 arithmetic (`--precision fp32`: the reference's own number
+    format, reference problem.py:119; BASELINE.md section 4's tight-parity row, roofline 8 TB/s / (276 x 602 x 4 B) =
+    12.0 M seed-nodes/s): the same engine code instantiated on float.  A child process (its own feature table)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--extra", "", "--min-time", "0.3", "--batch-size", str(args.batch_size), "--precision", "fp32"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"config": "BASELINE configs[1] with fp32 features, fp32 activations and exact-fp32 MFMA "
+                          "(v_mfma_f32_32x32x2_f32): the tight-parity instantiation of the same engine",
+                "ms_per_step": line["ms_per_step"], "value": line["value"], "unit": "seed-nodes/sec", "dtype": "fp32",
+                "frac_of_hbm_gather_roofline": line["frac_of_hbm_gather_roofline"],
+                "roofline_seeds_per_s": HBM_PEAK_GBS * 1e9 / (rows_per_seed(FANOUT) * FEAT_DIM * 4),
+                "kernel_launches_per_step": line["config"].get("kernel_launches_per_step"),
+                "dominant_launch": {k: line["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us",
+                                                                         "alg_bytes_per_launch")}}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def _free_port():
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
@@ -685,6 +764,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-size", type=int, default=BATCH, help="seed nodes per GPU per step")
     ap.add_argument("--aggregator", type=str, default="mean")
+    ap.add_argument("--config", type=str, default="reddit", choices=["reddit", "pokec", "papers"],
+                    help="reddit: BASELINE configs[1] / [2] (with --aggregator) on the Reddit-shaped graph (default); pokec / "
+                         "papers: BASELINE configs[3] / configs[4] at their shapes on their own synthetic graphs -- all of "
+                         "them compose with --gpus N (seed shards, one exchange per step)")
     ap.add_argument("--fanout", type=str, default="25,10", help="per-layer fan-outs (BASELINE: 25,10)")
     ap.add_argument("--hidden", type=str, default="128,128", help="per-layer output dims")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
@@ -705,7 +788,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until it has run this many seconds in total")
-    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank,cli,b4096",
+    ap.add_argument("--extra", type=str, default="max_pool,attention,papers,pokec,ddp_1rank,cli,b4096,fp32",
                     help="comma-separated additional configurations measured after the main line (N=1 only) and "
                          "reported under `extra`: an aggregator name (same graph), `papers` / `pokec` (BASELINE "
                          "configs[4] / configs[3] shapes on their own synthetic graphs); '' for none")
@@ -729,6 +812,30 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     ops.set_compute_dtype(args.precision)
     ops.warmup(dev)
+
+    if args.config != "reddit":
+        # BASELINE configs[3] / configs[4] as the main line (one command per configuration and GPU count)
+        fn = extra_pokec if args.config == "pokec" else extra_papers
+        rec = fn(gs, dev, steps=args.steps, warmup=args.warmup, B=args.batch_size, ddp=ddp)
+        rec.pop("_engine", None)
+        if rank == 0:
+            line = {"metric": "seed-nodes/sec", "value": rec["value"], "unit": "seed-nodes/sec", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": rec["config"], "batch_per_gpu": args.batch_size,
+                               "global_batch": args.batch_size * world, "rng": "philox", "engine": rec["engine"],
+                               "parallelism": "dp%d" % world, "ranks": world,
+                               "collective": (torch.distributed.get_backend() if ddp is not None else None),
+                               "process_group_ranks": (torch.distributed.get_world_size() if ddp is not None else None),
+                               "exchange_in_list_us": rec.get("exchange_us")},
+                    "frac_of_hbm_gather_roofline": rec.get("frac_of_hbm_gather_roofline"),
+                    "roofline": rec.get("roofline"), "cpu_baseline": None, "extra": {}}
+            print(json.dumps(line))
+            sys.stdout.flush()
+        if ddp is not None:
+            ddp.barrier()
+            ddp.close()
+        return
 
     data = synthetic_reddit(seed=0)
     store = data["feats"](dev, args.precision)
@@ -815,9 +922,10 @@ def main():
             if stop:
                 break
         model.train_sampler.csr(dev).check()
+        xus = exchange_in_list_us(step_fn, run_step) if ddp is not None else None      # (collective steps: every rank)
         med = float(np.median(times))
         return {"model": model, "step_fn": step_fn, "engine": engine, "queued": queued, "use_graph": use_graph,
-                "elapsed": med, "times": times, "launches_per_step": float(np.median(launches))}
+                "elapsed": med, "times": times, "launches_per_step": float(np.median(launches)), "exchange_us": xus}
 
     res = measure(args.aggregator, args.min_time)
     elapsed, step_fn, model = res["elapsed"], res["step_fn"], res["model"]
@@ -853,6 +961,8 @@ def main():
                        "pipelined": bool(res["engine"] == "fused" and args.pipeline),
                        "batch_queue": bool(res["queued"]), "parallelism": "dp%d" % world,
                        "ranks": world, "collective": (torch.distributed.get_backend() if ddp is not None else None),
+                       "process_group_ranks": (torch.distributed.get_world_size() if ddp is not None else None),
+                       "exchange_in_list_us": res.get("exchange_us"),
                        "native_comm": bool(getattr(step_fn, "comm", None) is not None) if ddp is not None else None,
                        "one_list": bool(step_fn._one_list_ddp()) if (ddp is not None and hasattr(step_fn, "_one_list_ddp")) else None,
                        "kernel_launches_per_step": res["launches_per_step"] if args.launch != "graph" else None,
@@ -869,7 +979,7 @@ def main():
             del res, step_fn, model
             torch.cuda.empty_cache()
             names = [a for a in args.extra.split(",") if a and a != args.aggregator]
-            for agg in [a for a in names if a not in ("papers", "pokec", "ddp_1rank", "cli", "b4096")]:
+            for agg in [a for a in names if a not in ("papers", "pokec", "ddp_1rank", "cli", "b4096", "fp32")]:
                 r2 = measure(agg, min(args.min_time, 0.3))
                 e2 = r2["elapsed"]
                 rec = {"config": {"max_pool": "BASELINE configs[2] shape on one GPU",
@@ -898,6 +1008,7 @@ def main():
                 if name in names:
                     try:
                         extra[name] = fn(gs, dev)
+                        extra[name].pop("_engine", None)
                     except Exception as e:                      # never lose the main line to an extra
                         extra[name] = {"error": repr(e)}
                     torch.cuda.empty_cache()
@@ -905,6 +1016,8 @@ def main():
                 extra["ddp_1rank"] = extra_ddp_1rank(args)
             if "b4096" in names and args.batch_size != 4096:
                 extra["b4096"] = extra_b4096(args)
+            if "fp32" in names and args.precision != "fp32":
+                extra["fp32"] = extra_fp32(args)
         line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, budget_s=args.cpu_budget)

@@ -910,6 +910,16 @@ class FusedTrainStep(object):
         them apply the identical touched-row set to the deferred-row Adam."""
         if self.ddp is None:
             return
+        if getattr(self, "_marks", False) and self._in_list:           # (instrument(): events around the exchange)
+            nat.check(nat.lib().gsage_cmdlist_mark(8), "cmdlist_mark")
+            try:
+                self._exchange_nodes()
+            finally:
+                nat.check(nat.lib().gsage_cmdlist_mark(9), "cmdlist_mark")
+            return
+        self._exchange_nodes()
+
+    def _exchange_nodes(self):
         if self.emb and self.lazy_rows:
             B, RA0 = self.B, self.off[self.L + 1]
             ids = self._cur_ids
@@ -1373,13 +1383,21 @@ class FusedTrainStep(object):
         self.ids_q = [self.ids_set[0], torch.zeros_like(self.ids_set[0])]
         # K1 inside the level-0 projection's launch (mean engine, _k1_in_k5): batch i+2 is sampled at the START of
         # step i, while K5(i) and K5b(i) still read batch i's frontier as their row list -- a ring of THREE
-        self.P = 3 if (self._k1_in_k5() or self._k1_in_tail()) else 2
-        if self.P == 3:
-            self.ids_q.append(torch.zeros_like(self.ids_set[0]))
+        # WHERE batch i+2 is sampled is decided HERE, once per epoch queue (the predicates read the environment: asked
+        # again per step they could disagree with the ring built below and leave a batch unsampled): "k5" / "tail" = a
+        # sampler role of that launch (ring of three), "front" = the launch that carries the update (ring of two).
         # The seed-level launch (B / 4 workgroups: half the chip at B = 512) also gathers the first
         # rows of the NEXT batch's last-hop means on the CUs it leaves idle; K5b of the current batch
         # still reads the current operands afterwards, so the level-0 operand buffers alternate too.
+        self._k1_where = None
+        in_k5, in_tail = self._k1_in_k5(), self._k1_in_tail()
         self._tail_rows = self._tail_gather_rows()
+        if in_tail and not self._tail_rows:        # (the sampler role rides behind the gather role: none, no role)
+            in_tail = False
+        self._k1_where = "k5" if in_k5 else "tail" if in_tail else "front"
+        self.P = 3 if self._k1_where != "front" else 2
+        if self.P == 3:
+            self.ids_q.append(torch.zeros_like(self.ids_set[0]))
         while self._tail_rows and len(self.xa0_set) < self.P:
             self.xa0_set.append(torch.zeros_like(self.xa0_set[0]))
         self._front_ready, self._qstep = False, 0
@@ -1428,7 +1446,7 @@ class FusedTrainStep(object):
         that carries the first part of those gathers, and per engine its dominant kernel (pool: K3 on the last
         hop; attention: K4 on the last hop).  `last_launch_ms()` then returns their durations for the step just
         replayed: timed in place, on the stream the step runs on."""
-        assert self.capture_mode == "cmdlist" and self.ddp is None
+        assert self.capture_mode == "cmdlist"          # (with a process group: `exchange` = the collective nodes)
         self._marks = bool(on)
         torch.cuda.synchronize()
         if self.queue is not None:
@@ -1444,7 +1462,8 @@ class FusedTrainStep(object):
         else:
             cl = front = self.g_main[0].cl
         out = {}
-        for name, (a, b) in self.TIMED.items():
+        timed = dict(self.TIMED) if self.ddp is None else {"exchange": (8, 9)}
+        for name, (a, b) in timed.items():
             try:
                 out[name] = (front if name == "gather" else cl).elapsed_ms(a, b)
             except Exception:                     # this step has no such launch (e.g. nothing is gathered ahead)

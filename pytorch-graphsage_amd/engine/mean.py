@@ -342,12 +342,15 @@ class FusedMeanTrainStep(FusedTrainStep):
             w2t, dg = self.w2t[0], self.dg[0]
             self._linear(self.dc[0].data_ptr(), 2 * h, None, 0, w2t.data_ptr() + self.D0 * w2t.shape[2] * esz,
                          w2t.shape[2], dg.data_ptr(), nat.F32, 2 * E, R, E, h, nat.ACT_NONE, h, d0 * w2t.shape[2], E)
-            lp = self.din0 is not self.din0f
-            nat.check(lib.gsage_attn_merge_bwd2(
-                None, self.code, 0, None, 0, dg.data_ptr(), 2 * E, R, dg.data_ptr() + 4 * E, 2 * E, None,
-                self.din0f.data_ptr(), nat.F32, E, self.off[L + 1], E, L + 1, self.off_host, self.fan_host,
-                self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0, stream), "merge_bwd (level 0)")
-            self._prep_backward(s)
+            if self.rows_ok:        # merge, bias sums, product through prep.fc^T and the table's atomics: one row pipeline
+                self._prep_backward_rows(s, None, None, None, 0, dg.data_ptr(), 2 * E, R, dg.data_ptr() + 4 * E, 2 * E, None)
+            else:
+                lp = self.din0 is not self.din0f
+                nat.check(lib.gsage_attn_merge_bwd2(
+                    None, self.code, 0, None, 0, dg.data_ptr(), 2 * E, R, dg.data_ptr() + 4 * E, 2 * E, None,
+                    self.din0f.data_ptr(), nat.F32, E, self.off[L + 1], E, L + 1, self.off_host, self.fan_host,
+                    self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0, stream), "merge_bwd (level 0)")
+                self._prep_backward(s)
         # (2) every level's weight gradient in ONE launch: each alone fills a fraction of the chip
         probs = []
         if self.emb:
@@ -455,6 +458,8 @@ class FusedMeanTrainStep(FusedTrainStep):
         own chain) and the projection 2.8 us longer (14.0 -> 16.8: the sampler's 171 workgroups hold slots its 416
         want) -- 0.0846 against 0.0835 ms/step.  Needs the packed ReLU projection at level 0, a CSR sampler, one GPU;
         a ring of three frontier buffers (K5 / K5b of step i still read batch i's as their row list)."""
+        if getattr(self, "_k1_where", None) is not None:      # (decided in load_epoch)
+            return self._k1_where == "k5"
         return bool(self.wp and self.wp[0] is not None and self.L >= 2 and not self.dense and not self.emb and
                     self.ddp is None and os.environ.get("GSAGE_K1_IN_K5", "0") == "1")
 
@@ -464,6 +469,8 @@ class FusedMeanTrainStep(FusedTrainStep):
         gather role (~31 us at config 2) whatever else rides in it; K1's chain of dependent loads was the longer of the
         last launch's two.  Needs the matrix-core seed level with a gather role, a CSR sampler, one GPU; a ring of three
         frontier buffers as for _k1_in_k5.  GSAGE_K1_IN_TAIL=0: K1 stays in the launch that carries the update."""
+        if getattr(self, "_k1_where", None) is not None:      # (decided in load_epoch)
+            return self._k1_where == "tail"
         return bool(self.fused_tail and self._tail_on_mfma() and self.L >= 2 and not self.dense and not self.emb and
                     self.ddp is None and self.fan[self.L] in (5, 10, 15) and not self._k1_in_k5() and
                     self._tail_idle_cus(True) >= 32 and

@@ -314,12 +314,16 @@ class FusedPoolTrainStep(FusedTrainStep):
                            nat.ACT_NONE)
                 self._gemm(self.ghc[0].data_ptr(), Hm, self.wmT[0][D0:D0 + E], self.dnb[0].data_ptr(), nat.F32, E, NR, E,
                            Hm, nat.ACT_NONE)
-                lp = self.din0 is not self.din0f
-                nat.check(lib.gsage_attn_merge_bwd2(
-                    None, self.code, 0, self.dn_all.data_ptr(), E, self.dxb[0].data_ptr(), E, R, self.dzero.data_ptr(), E,
-                    None, self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host, self.fan_host,
-                    self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0, stream), "merge_bwd (level 0)")
-                self._prep_backward(s)
+                if self.rows_ok:    # (one row pipeline: common._prep_backward_rows)
+                    self._prep_backward_rows(s, None, None, self.dn_all.data_ptr(), E, self.dxb[0].data_ptr(), E, R,
+                                             self.dzero.data_ptr(), E, None)
+                else:
+                    lp = self.din0 is not self.din0f
+                    nat.check(lib.gsage_attn_merge_bwd2(
+                        None, self.code, 0, self.dn_all.data_ptr(), E, self.dxb[0].data_ptr(), E, R, self.dzero.data_ptr(), E,
+                        None, self.din0f.data_ptr(), nat.F32, E, RA0, E, L + 1, self.off_host, self.fan_host,
+                        self.din0.data_ptr() if lp else None, self.din0.stride(0) if lp else 0, stream), "merge_bwd (level 0)")
+                    self._prep_backward(s)
         probs = []
         if self.emb:
             dC, A, lda, M_, ntot, K, _prm, _rows = self._emb_wgrad_problem()

@@ -152,6 +152,15 @@ MT_PAR_MIN = 400000          # requests below this many values stay on the one-w
 MT_PAR_MAX = 80000000        # values per parallel call: 4096 jump units of 64 refills reach 1.6e8 raw words
 
 
+JUMP_TABLE_SHA256 = "2d7b0a6ba6b6c1566432f44eda5f747868391536bc0ceb09fd7efa9bc4420669"    # 39 936 words
+
+
+def jump_table_ok(tab):
+    """The jump polynomials are a constant of MT19937 (no seed enters them): a file is trusted by content, not by size."""
+    import hashlib
+    return hashlib.sha256(tab.tobytes()).hexdigest() == JUMP_TABLE_SHA256
+
+
 def mt_jump_table(device):
     """The seed-independent jump polynomials of numpy's MT19937 (gsage_mt_jump_table: 128 x 312 words) on `device`.
     Computed by the library (~1 s: Berlekamp-Massey + square-and-multiply) the first time ever, then read from
@@ -165,14 +174,21 @@ def mt_jump_table(device):
         tab = None
         if os.path.exists(path) and os.path.getsize(path) == 8 * words:
             tab = np.fromfile(path, dtype=np.uint64)
+            if not jump_table_ok(tab):           # a torn or stale file: recompute (the table is seed-independent)
+                tab = None
         if tab is None:
             tab = np.zeros(words, dtype=np.uint64)
             nat.check(L.gsage_mt_jump_table(tab.ctypes.data, words), "mt_jump_table")
+            assert jump_table_ok(tab), "gsage_mt_jump_table produced a table that is not MT19937's"
+            tmp = "%s.%d.tmp" % (path, os.getpid())        # (every rank of a data-parallel run may get here at once)
             try:
-                tab.tofile(path + ".tmp")
-                os.replace(path + ".tmp", path)
+                tab.tofile(tmp)
+                os.replace(tmp, path)
             except OSError:
-                pass
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
         _JUMP_TABLE[key] = torch.from_numpy(tab.view(np.int64)).to(device)
     return _JUMP_TABLE[key]
 

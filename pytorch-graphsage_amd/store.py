@@ -75,7 +75,8 @@ class DeviceCSR(object):
             raise ValueError("adjacency is not in the reference's sparse convention "
                              "(row i must hold its neighbours in columns 0..deg_i-1)")
         data = np.asarray(adj.data)
-        if data.size and data.dtype.itemsize > 4 and data.max() >= 2 ** 31:
+        # (ids wider than 32 bits: both bounds BEFORE narrowing -- -(2**32) + 5 would wrap to 5 and pass a check made after)
+        if data.size and data.dtype.itemsize > 4 and (data.max() >= 2 ** 31 or data.min() < 1):
             raise ValueError("neighbour ids must be 1-based positive int32 values")
         rowptr = torch.from_numpy(indptr).to(device)
         col = torch.from_numpy(data.astype(np.int32, copy=False)).to(device)

@@ -142,7 +142,13 @@ class FusedEvaluator(object):
         eng = self._engine(mode, ids)
         if eng is None:
             return evaluate(model, problem, mode=mode)
-        preds = eng.evaluate_fold(ids, live)
+        try:
+            preds = eng.evaluate_fold(ids, live)
+        except Exception as e:            # (e.g. a validation fan-out the forward-only engine's kernels refuse)
+            self.off = True
+            self.engines.pop(mode, None)
+            print('gsage: evaluation falls back to the module path (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+            return evaluate(model, problem, mode=mode)
         nodes = problem.nodes[mode]
         _, acts = problem._batch(nodes, problem.targets[nodes])
         check_samplers(model)
@@ -413,8 +419,13 @@ def train_fused(args, problem, model, ddp, start_time, cls):
                         print(dumps({"epoch": epoch, "epoch_progress": b / n_batches, "train_metric": train_metric,
                                      "val_metric": val_metric, "time": time() - start_time}))
                         sys.stdout.flush()
-        finally:
-            flush()                       # (a run that dies mid-epoch still prints the batches it scored)
+        except BaseException:
+            try:
+                flush()                   # (a run that dies mid-epoch still prints the batches it scored ...
+            except Exception:             #  ... but a failing read-back must not replace the error that ended it)
+                pass
+            raise
+        flush()
         if timing:
             torch.cuda.synchronize()
             step.timing.append({"epoch": epoch, "batches": n_batches, "seeds": int(sum(live)) if live is not None

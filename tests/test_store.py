@@ -52,7 +52,7 @@ def test_other_layouts_are_refused(rows, what):
         gs.DeviceCSR.from_scipy(_csr([(np.asarray(c), np.asarray(d)) for c, d in rows], n_cols=6), CPU)
 
 
-@pytest.mark.parametrize("bad", [0, -3, 2 ** 31, 2 ** 40])
+@pytest.mark.parametrize("bad", [0, -3, 2 ** 31, 2 ** 40, -(2 ** 32) + 5, -(2 ** 33) + 1])      # (the last two wrap into range when narrowed to int32)
 def test_ids_outside_one_based_int32_are_refused(bad):
     with pytest.raises(ValueError, match="1-based positive int32"):
         gs.DeviceCSR.from_scipy(_csr([(np.arange(3), np.array([5, bad, 7])), (np.arange(1), np.array([2]))]), CPU)

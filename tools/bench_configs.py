@@ -24,6 +24,8 @@ dev = torch.device("cuda")
 gs.ops.set_compute_dtype("bf16")
 gs.ops.warmup(dev)
 if args.config == "pokec":
-    print(json.dumps(bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup, precision=args.precision, engine=args.engine)))
+    rec = bench.extra_pokec(gs, dev, steps=args.steps, warmup=args.warmup, precision=args.precision, engine=args.engine)
 else:
-    print(json.dumps(bench.extra_papers(gs, dev, steps=args.steps, warmup=args.warmup, n_nodes=args.papers_nodes)))
+    rec = bench.extra_papers(gs, dev, steps=args.steps, warmup=args.warmup, n_nodes=args.papers_nodes)
+rec.pop("_engine", None)
+print(json.dumps(rec))

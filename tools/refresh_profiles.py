@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def json_line(path):
@@ -58,9 +58,11 @@ if len(per) == 2:
     }, open(os.path.join(PROF, tag + "_pmc_gather_launch.json"), "w"), indent=1)
 
 # per-configuration PMC passes (tools/gpu_round.sh pmcx): the launch each `extra` roofline names
-PICK = [("reddit", "reddit_gather", "k_gather_multi_adam"), ("reddit", "reddit_seed_level", "k_mean_tail_mfma"),
-        ("max_pool", "maxpool_k3", "k_pool_mlp_packed"), ("attention", "attention_k4", "k_attn_aggregate_grp"),
-        ("papers", "papers_gather", "k_gather_multi_adam"), ("pokec", "pokec_k4", "k_attn_aggregate_grp")]
+PICK = [("reddit", "reddit_gather", "k_gather_multi_adam"), ("reddit", "reddit_seed_level", "k_mean_tail_"),
+        ("max_pool", "maxpool_k3", "k_pool_mlp_packed"), ("attention", "attention_k4", "k_attn_fused_fwd"),
+        ("attention", "attention_k4_bwd", "k_attn_fused_bwd"),
+        ("papers", "papers_gather", "k_gather_multi_adam"), ("papers", "papers_seed_level", "k_mean_tail_"),
+        ("pokec", "pokec_k4", "k_attn_fused_fwd"), ("pokec", "pokec_k4_bwd", "k_attn_fused_bwd")]
 launches = {}
 for cfg, key, kname in PICK:
     rec = {}
@@ -87,6 +89,11 @@ for cfg, key, kname in PICK:
         launches[key] = rec
 if launches:
     json.dump(launches, open(os.path.join(PROF, tag + "_pmc_launches.json"), "w"), indent=1)
+
+for cfg in ("max_pool", "attention", "papers", "pokec"):
+    pth = os.path.join(OUT, "profx_%s_kernel_stats.csv" % cfg)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(PROF, "%s_%s_kernel_stats.csv" % (tag, cfg)))
 
 p = os.path.join(OUT, "parity_errors.jsonl")
 if os.path.exists(p):
