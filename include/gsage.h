@@ -859,9 +859,10 @@ int gsage_rows_adam(const gsage_row_adam *d, const int64_t *ids0, int64_t n0, co
  *   gsage_sort_rows      keys[i] = i < n0 ? ids0[i] : tail_id  (i < n0 + n_tail: a frontier's ids followed by n_tail
  *                        entries of one spare row, e.g. the row every seed reads, nn_modules.py:147-149) sorted
  *                        ascending, STABLE: ids_sorted[0:n], pos_sorted[0:n] = original positions, ascending within
- *                        equal ids.  Only the low key_bits bits are compared (ids < 2^key_bits).  rocPRIM radix sort;
- *                        temp: gsage_sort_rows_temp_bytes(n, key_bits) bytes of device scratch.  Recordable (a host-call
- *                        node: the vendor's launches are issued at replay).
+ *                        equal ids.  Only the low key_bits bits are compared (ids < 2^key_bits).  The library's own
+ *                        radix sort (round 6: 8 bits per pass, three launches per pass; rocPRIM's until then);
+ *                        temp: gsage_sort_rows_temp_bytes(n, key_bits) bytes of 16-byte-aligned device scratch.
+ *                        Recordable like any kernel of the library.
  *   gsage_segment_sum_rows   for the first entry i of every run of equal ids:
  *                        table[ids_sorted[i], 0:E] = scale * sum_{j in run, in order} rows(pos_sorted[j]),
  *                        rows(p) = p < n0 ? rows0[p * ld0 : ] : rows1[(p - n0) * ld1 : ]     (fp32, E % 4 == 0, E <= 256)

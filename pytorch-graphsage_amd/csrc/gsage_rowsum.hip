@@ -5,35 +5,125 @@
 // of every occurrence of a node in the frontier (index_add into a [n_nodes + 1, 64] tensor).  K6
 // (gsage_scatter_add_rows) forms that sum with fp32 atomics, i.e. in an order that differs from run to run and, in a
 // data-parallel run, from rank to rank: replicas that apply "the same" update would drift apart bit by bit.  Here
-// the frontier's ids are sorted once (vendor radix sort over the bits a node id needs: a plain library primitive, as
-// hipBLASLt would be for a plain GEMM) and every run of equal ids is summed IN LIST ORDER by one group of lanes and
+// the frontier's ids are sorted once and every run of equal ids is summed IN LIST ORDER by one group of lanes and
 // stored -- no atomics, no zero-fill, the same bits on every rank.  HBM-bound integer / byte work: 8 + 4 bytes per
 // entry through the sort passes, each gradient row read once, each distinct row written once.
+//
+// The sort (round 6: the library's own, rocPRIM's radix sort until then) is a stable least-significant-digit radix
+// sort over the bits a node id needs, 8 bits per pass (Pokec: 21 bits, three passes), three launches per pass:
+//   k_rs_hist     a workgroup counts the digits of its block of 2 048 entries        -> hist[digit][block]
+//   k_rs_scan     one workgroup: exclusive prefix sums over hist in (digit, block) order = where a block's entries of
+//                 a digit start in the output
+//   k_rs_scatter  a workgroup places its entries: position = start[digit][block] + the number of entries of the same
+//                 digit BEFORE it in the block.  The block is walked in eight rounds of 256 (entry = round * 256 +
+//                 thread: coalesced), the rank inside a round comes from eight wave ballots (the lanes that share all
+//                 eight digit bits) and per-wave counts in LDS -- original order is kept among equal digits, so the
+//                 sort is stable and its result depends on the keys alone.
+// Every launch goes through launch(): the sort is recorded into command lists like any other kernel.
 #include "gsage_common.h"
-
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace gsage {
 
-// keys of the sort: a frontier's ids followed by n_tail entries of one spare row
-struct KeyAt {
+constexpr int RS_BLOCK = 2048;        // entries per workgroup
+constexpr int RS_ROUNDS = RS_BLOCK / 256;
+
+// keys of the first pass: a frontier's ids followed by n_tail entries of one spare row; values: positions
+struct RsIn {
     const int64_t *ids0;
     int64_t n0, tail_id;
-    __host__ __device__ int64_t operator()(int64_t i) const { return i < n0 ? ids0[i] : tail_id; }
+    const int64_t *keys;              // later passes: the previous pass's output (ids0 == NULL)
+    const int32_t *vals;
+    __device__ __forceinline__ int64_t key(int64_t i) const { return keys ? keys[i] : (i < n0 ? ids0[i] : tail_id); }
+    __device__ __forceinline__ int32_t val(int64_t i) const { return vals ? vals[i] : (int32_t)i; }
 };
-typedef rocprim::transform_iterator<rocprim::counting_iterator<int64_t>, KeyAt, int64_t> KeyIter;
 
-static hipError_t sort_pairs(void *temp, size_t &bytes, const KeyAt &k, int64_t n, int key_bits, int64_t *keys_out,
-                             int32_t *vals_out, hipStream_t s)
+__global__ void __launch_bounds__(256)
+k_rs_hist(const RsIn in, int64_t n, int shift, int32_t *__restrict__ hist, int64_t n_blocks)
 {
-    KeyIter keys_in(rocprim::counting_iterator<int64_t>(0), k);
-    rocprim::counting_iterator<int32_t> vals_in(0);
-    return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                     (unsigned)key_bits, s, false);
+    __shared__ int32_t cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_BLOCK;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(int)((in.key(i) >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * n_blocks + blockIdx.x] = cnt[threadIdx.x];
 }
+
+// exclusive prefix sums over `total` counts, in place; one workgroup of 1 024 threads, a contiguous piece each
+__global__ void __launch_bounds__(1024)
+k_rs_scan(int32_t *__restrict__ hist, int64_t total)
+{
+    __shared__ int32_t part[1024];
+    const int64_t per = (total + 1023) / 1024, lo = per * threadIdx.x;
+    const int64_t hi = lo + per < total ? lo + per : total;
+    int32_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {              // Hillis-Steele over the 1 024 piece sums
+        const int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = part[threadIdx.x] - s;                    // exclusive prefix of this piece
+    for (int64_t i = lo; i < hi; ++i) {
+        const int32_t c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_rs_scatter(const RsIn in, int64_t n, int shift, const int32_t *__restrict__ start, int64_t n_blocks,
+             int64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out)
+{
+    __shared__ int32_t base[256];             // entries of a digit placed so far (earlier rounds) + the block's start
+    __shared__ int32_t wave_cnt[4][256];      // this round: entries of a digit in each wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    base[threadIdx.x] = start[(int64_t)threadIdx.x * n_blocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * RS_BLOCK;
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = first + r * 256 + threadIdx.x;
+        const bool live = i < n;
+        const int64_t key = live ? in.key(i) : 0;
+        const int32_t val = live ? in.val(i) : 0;
+        const int d = (int)((key >> shift) & 255);
+        // the lanes of this wave with the same digit (dead lanes match nobody)
+        uint64_t peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int before = __popcll(peers & ((1ull << lane) - 1));
+        if (live && before == 0) wave_cnt[wave][d] = __popcll(peers);        // (the first of its peers)
+        __syncthreads();
+        if (live) {
+            int32_t pos = base[d] + before;
+            for (int w = 0; w < wave; ++w) pos += wave_cnt[w][d];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        {
+            const int t = threadIdx.x;
+            base[t] += (wave_cnt[0][t] + wave_cnt[1][t]) + (wave_cnt[2][t] + wave_cnt[3][t]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) wave_cnt[w][t] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+static inline int64_t rs_align(int64_t b) { return (b + 255) / 256 * 256; }
 
 // One group of E / 4 lanes (16 for 64-wide rows) per list entry; groups whose entry is not the first of its run
 // leave at once.  A run of length 1 (the common case) is one 16-byte load and one 16-byte store per lane; longer
@@ -80,13 +170,9 @@ extern "C" {
 int64_t gsage_sort_rows_temp_bytes(int64_t n, int32_t key_bits)
 {
     if (n <= 0 || key_bits <= 0 || key_bits > 63) return -1;
-    size_t bytes = 0;
-    KeyAt k{nullptr, 0, 0};
-    if (sort_pairs(nullptr, bytes, k, n, key_bits, nullptr, nullptr, nullptr) != hipSuccess) {
-        (void)hipGetLastError();
-        return -1;
-    }
-    return (int64_t)((bytes + 255) / 256 * 256);
+    const int64_t n_blocks = ceil_div(n, RS_BLOCK);
+    // a second (key, position) buffer for the passes to alternate with + the digit counts of every block
+    return rs_align(n * 8) + rs_align(n * 4) + rs_align(256 * n_blocks * 4);
 }
 
 int gsage_sort_rows(const int64_t *ids0, int64_t n0, int64_t tail_id, int64_t n_tail, int32_t key_bits,
@@ -96,30 +182,27 @@ int gsage_sort_rows(const int64_t *ids0, int64_t n0, int64_t tail_id, int64_t n_
     GSAGE_REQUIRE(n0 >= 0 && n_tail >= 0 && n > 0 && n < ((int64_t)1 << 31), "sort_rows: bad sizes");
     GSAGE_REQUIRE((ids0 || n0 == 0) && ids_sorted && pos_sorted && temp, "sort_rows: null pointer");
     GSAGE_REQUIRE(key_bits > 0 && key_bits <= 63 && (tail_id >> key_bits) == 0, "sort_rows: ids must fit key_bits");
-    GSAGE_REQUIRE(temp_bytes >= gsage_sort_rows_temp_bytes(n, key_bits), "sort_rows: temp storage too small");
-    const KeyAt k{ids0, n0, tail_id};
-    auto run = [=](hipStream_t s) -> int {
-        size_t bytes = (size_t)temp_bytes;
-        return sort_pairs(temp, bytes, k, n, key_bits, ids_sorted, pos_sorted, s) == hipSuccess ? 0 : 1;
-    };
-    if (t_recording) {
-        // the vendor's launches are issued when the list is replayed (a host-call node)
-        t_recording->target().emplace_back([run](hipStream_t s) {
-            if (run(s) != 0) {
-                (void)hipGetLastError();
-                set_error("sort_rows: rocprim::radix_sort_pairs failed during a replay");
-                t_node_error = 1;
-            }
-        });
-        t_recording->n_marks += 1;
-        return GSAGE_OK;
+    GSAGE_REQUIRE(temp_bytes >= gsage_sort_rows_temp_bytes(n, key_bits) && ((uintptr_t)temp & 15) == 0,
+                  "sort_rows: temp storage too small or misaligned");
+    const int64_t n_blocks = ceil_div(n, RS_BLOCK);
+    int64_t *keys_t = (int64_t *)temp;
+    int32_t *vals_t = (int32_t *)((char *)temp + rs_align(n * 8));
+    int32_t *hist = (int32_t *)((char *)temp + rs_align(n * 8) + rs_align(n * 4));
+    const int passes = (key_bits + 7) / 8;
+    hipStream_t s = (hipStream_t)stream;
+    // the passes alternate between the temp pair and the output pair so that the LAST one writes the output
+    bool to_out = (passes & 1) != 0;
+    RsIn in{ids0, n0, tail_id, nullptr, nullptr};
+    for (int p = 0; p < passes; ++p) {
+        int64_t *ko = to_out ? ids_sorted : keys_t;
+        int32_t *vo = to_out ? pos_sorted : vals_t;
+        launch(k_rs_hist, dim3((unsigned)n_blocks), dim3(256), 0, s, in, n, 8 * p, hist, n_blocks);
+        launch(k_rs_scan, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * n_blocks);
+        launch(k_rs_scatter, dim3((unsigned)n_blocks), dim3(256), 0, s, in, n, 8 * p, (const int32_t *)hist, n_blocks, ko, vo);
+        in = RsIn{nullptr, 0, 0, ko, vo};
+        to_out = !to_out;
     }
-    if (run((hipStream_t)stream) != 0) {
-        set_error("sort_rows: rocprim::radix_sort_pairs: %s", hipGetErrorString(hipGetLastError()));
-        return GSAGE_ELAUNCH;
-    }
-    g_launches.fetch_add(1, std::memory_order_relaxed);
-    return GSAGE_OK;
+    return check_launch("sort_rows");
 }
 
 int gsage_segment_sum_rows(const int64_t *ids_sorted, const int32_t *pos_sorted, int64_t n, const float *rows0,

@@ -5,12 +5,24 @@ N = 232 965, D = 602 (rows padded to 640), B = 512, fan-out 25/10, hidden 128 --
 gather roles, Adam riding in the gather launch), bf16 storage against the rounding-aware oracle and fp32 storage
 against the plain fp32 oracle.  The oracle runs on the frontier's rows relabelled to a compact table (the technique
 of test_gpu_large.py): two consecutive train steps, predictions / gradient norm / weights after each."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from conftest import pkg
 from util import close, close_fro, close_update
+
+_LOG = os.environ.get("GSAGE_PARITY_LOG")
+
+
+def _note(key, **vals):
+    """measured errors -> profiles/rNN_parity_errors.jsonl (tools/gpu_round.sh sets GSAGE_PARITY_LOG)"""
+    if _LOG:
+        with open(_LOG, "a") as f:
+            f.write(json.dumps(dict(key=key, **{k: float(v) for k, v in vals.items()})) + "\n")
 
 pytestmark = pytest.mark.gpu
 gs = pkg()
@@ -35,6 +47,12 @@ def _setup():
     gs.nn_modules.SparseUniformNeighborSampler.rng_default = "compat"
 
 
+# relative Frobenius bound on the two-step Adam update, bf16 engines against the rounding-aware oracle.  Max pool: an
+# argmax that flips under another summation order moves a whole route; attention: tiny attention-MLP gradients whose
+# sign flips move an Adam update by a full lr.  (2 x the worst value measured: profiles/r06_parity_errors.jsonl)
+UPDATE_BOUND = {"mean": 5e-3, "max_pool": 5e-2, "attention": 5e-2}
+
+
 def _frontier(csr, seeds, batch, L=2):
     """the queue pipeline's frontier of batch `batch`: hop k is Philox call batch * L + k of the sampler's seed"""
     cur, hops = seeds, []
@@ -44,7 +62,7 @@ def _frontier(csr, seeds, batch, L=2):
     return hops
 
 
-@pytest.mark.parametrize("agg,prec", [("mean", "bf16"), ("mean", "fp32"), ("max_pool", "bf16")])
+@pytest.mark.parametrize("agg,prec", [("mean", "bf16"), ("mean", "fp32"), ("max_pool", "bf16"), ("attention", "bf16")])
 def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
     import bench
     from oracle import torch_ref as tref
@@ -64,6 +82,8 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
     eng = gs.engine.fused_engine_for(model, store)(model, store, gs.ProblemLosses.classification, ids[0], tg[0],
                                                    capture="cmdlist")
     assert eng.capture_mode == "cmdlist" and eng.fused_head
+    if agg == "attention":
+        assert eng.fuse[0] and not eng.fuse[1]            # the last hop (fan-out 10) through K4 / K4' with the MLP inside
     if agg == "mean":
         assert eng.fused_tail and eng.B == B and eng.fan[1:] == [25, 10]        # the seed-level kernel (k_mean_tail_mfma<25, 10> at B = 512, bf16)
     eng.load_epoch(ids, tg)
@@ -95,12 +115,18 @@ def test_bench_workload_steps_equal_the_oracle(reddit, agg, prec):
         parts = np.split(inv, np.cumsum([B, hops[0].shape[0]]))
         r = tref.train_step(w, opt, 0.01, "classification", parts[0], small, tg[s].cpu(), None, None, FAN, None, agg,
                             "identity", 232966, rounding="bf16" if bf else None, frontier=parts[1:])
+        _note("headline/%s/%s/step%d" % (agg, prec, s), preds=np.abs(preds[s] - r["preds"].numpy()).max(),
+              gnorm_rel=abs(norms[s] - r["gradnorm"]) / max(1.0, r["gradnorm"]))
         close(preds[s], r["preds"].numpy(), "preds vs oracle, step %d (%s %s)" % (s, agg, prec), *(((1e-3, 1e-3) if agg == "mean" else (3e-3, 3e-3)) if bf else (2e-4, 2e-4)))
         assert abs(norms[s] - r["gradnorm"]) <= ((1e-3 if agg == "mean" else 5e-3) if bf else 2e-4) * max(1.0, r["gradnorm"]), \
             (s, norms[s], r["gradnorm"])
+    worst = 0.0
     for k, v in model.named_parameters():
         if bf:
-            close_fro(v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy(), ("Adam updates", k),
-                      5e-3 if agg == "mean" else 5e-2)       # (max pool: an argmax that flips under bf16 moves a whole route)
+            got, want = v.detach().cpu().numpy() - w0[k].numpy(), w[k].numpy() - w0[k].numpy()
+            worst = max(worst, float(np.linalg.norm(got - want)) / max(float(np.linalg.norm(want)), 1e-12))
+            close_fro(got, want, ("Adam updates", k), UPDATE_BOUND[agg])
         else:
             close_update(v.detach().cpu().numpy(), w[k].numpy(), w0[k].numpy(), ("weights after 2 steps", k))
+    if bf:
+        _note("headline/%s/%s/update" % (agg, prec), upd_fro=worst)

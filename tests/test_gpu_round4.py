@@ -44,9 +44,11 @@ def _sort(ids, tail_id, n_tail, key_bits):
 
 
 @pytest.mark.parametrize("n0,n_tail,n_rows,E", [(5000, 16, 700, 64), (164_000, 32, 1_632_805, 64), (1, 0, 9, 8),
-                                                (3000, 7, 40, 200), (0, 5, 100, 64)])
+                                                (3000, 7, 40, 200), (0, 5, 100, 64), (2048, 0, 257, 8), (2049, 3, 70_000, 8),
+                                                (1_310_720, 128, 1_632_805, 8), (40_000, 0, 2 ** 31 - 2, 8)])
 def test_sort_rows_is_stable_and_segment_sums_are_the_in_order_sums(n0, n_tail, n_rows, E):
-    """gsage_sort_rows: the vendor radix sort over (id, position) -- ids ascending, positions ascending within equal
+    """gsage_sort_rows: the library's stable radix sort over (id, position) (round 6; rocPRIM's until then: the same
+    contract, the same test) -- ids ascending, positions ascending within equal
     ids (stable), tail entries (one spare row) behind the frontier's.  gsage_segment_sum_rows: table[id] = scale *
     (rows of the run added IN LIST ORDER): compared bit for bit with a sequential fp32 sum on the host for the
     longest runs, with a float64 index_add for all rows; rows in no run are not touched; two launches agree bit
