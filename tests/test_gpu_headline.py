@@ -49,8 +49,10 @@ def _setup():
 
 # relative Frobenius bound on the two-step Adam update, bf16 engines against the rounding-aware oracle.  Max pool: an
 # argmax that flips under another summation order moves a whole route; attention: tiny attention-MLP gradients whose
-# sign flips move an Adam update by a full lr.  (2 x the worst value measured: profiles/r06_parity_errors.jsonl)
-UPDATE_BOUND = {"mean": 5e-3, "max_pool": 5e-2, "attention": 5e-2}
+# sign flips move an Adam update by a full lr (att.0.weight; predictions and gradient norm agree to 2e-6 in the same
+# run).  Measured (profiles/r06_parity_errors.jsonl, headline/*/update): mean 3.2e-3, max pool 3.9e-2, attention 6.3e-2
+# -- the bounds are 1.3 - 2 x those (round-5 review: "2 x the measured error"; max pool's 5e-2 already sits below that).
+UPDATE_BOUND = {"mean": 5e-3, "max_pool": 5e-2, "attention": 0.13}
 
 
 def _frontier(csr, seeds, batch, L=2):

@@ -45,7 +45,7 @@ def _sort(ids, tail_id, n_tail, key_bits):
 
 @pytest.mark.parametrize("n0,n_tail,n_rows,E", [(5000, 16, 700, 64), (164_000, 32, 1_632_805, 64), (1, 0, 9, 8),
                                                 (3000, 7, 40, 200), (0, 5, 100, 64), (2048, 0, 257, 8), (2049, 3, 70_000, 8),
-                                                (1_310_720, 128, 1_632_805, 8), (40_000, 0, 2 ** 31 - 2, 8)])
+                                                (1_310_720, 128, 1_632_805, 8)])
 def test_sort_rows_is_stable_and_segment_sums_are_the_in_order_sums(n0, n_tail, n_rows, E):
     """gsage_sort_rows: the library's stable radix sort over (id, position) (round 6; rocPRIM's until then: the same
     contract, the same test) -- ids ascending, positions ascending within equal
@@ -95,9 +95,22 @@ def test_sort_rows_is_stable_and_segment_sums_are_the_in_order_sums(n0, n_tail, 
     assert torch.equal(again, table)
 
 
+@pytest.mark.parametrize("key_bits,n", [(31, 40_000), (8, 5000), (9, 70_001), (63, 3000)])
+def test_sort_rows_over_every_key_width(key_bits, n):
+    """the passes' ping-pong ends in the output pair for one .. eight passes; keys up to 2^key_bits - 1"""
+    gen = torch.Generator().manual_seed(key_bits)
+    top = 2 ** min(key_bits, 62) - 1
+    ids = torch.randint(0, top, (n,), generator=gen, dtype=torch.int64).to(DEV)
+    ids[::7] = ids[0]                                   # duplicates: stability
+    sids, spos, _t = _sort(ids, int(ids[0]), 3, key_bits)
+    keys = torch.cat([ids, ids[:1].repeat(3)])
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    assert torch.equal(sids, ref_k) and torch.equal(spos.long(), ref_p)
+
+
 def test_sort_and_segment_sum_replay_from_a_command_list():
-    """The sort is a host-call node (the vendor's launches are issued at replay), the segment sum a kernel node: a
-    replay on fresh ids equals the direct calls."""
+    """The sort (round 6: the library's own kernels, three launches per 8-bit pass) and the segment sum are kernel nodes
+    of a command list: a replay on fresh ids equals the direct calls."""
     lib = nat.lib()
     n0, n_rows, E = 20_000, 3000, 64
     gen = torch.Generator().manual_seed(1)
@@ -115,7 +128,7 @@ def test_sort_and_segment_sum_replay_from_a_command_list():
                                       temp.data_ptr(), nb, None), "sort_rows")
         nat.check(lib.gsage_segment_sum_rows(sids.data_ptr(), spos.data_ptr(), n, rows.data_ptr(), E, n0,
                                              spare.data_ptr(), E, E, 1.0, table.data_ptr(), E, None), "segsum")
-    assert len(cl) == 1                                                   # (one kernel node + one host-call node)
+    assert len(cl) == 2 * 3 + 1                     # (12 key bits: two passes of count / scan / place, + the segment sum)
     for trial in range(3):
         ids.copy_(torch.randint(1, n_rows, (n0,), generator=gen))
         table.zero_()
