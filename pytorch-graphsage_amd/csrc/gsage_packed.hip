@@ -300,7 +300,12 @@ struct PoolPackedParams {
     uint32_t *relu_mask;
 };
 
-template <int NW>
+// PN > 0 (round 6): segments of exactly PN rows, max pooling, pooled IN REGISTERS -- a wave holds all 64 rows of its
+// columns (row i of the tile sits in accumulator register (i & 3) + 4 ((i & 31) >> 3) of row block i >> 5, in the
+// lane half (i >> 2) & 1), so a segment's maximum is a chain of compares over compile-time register sets in the two
+// halves and ONE exchange between them; no fp32 tile in LDS (67 KiB per workgroup: the LDS then holds the A ring only),
+// no barrier after the main loop.  PN == 0: any fan-out, mean pooling, sign bits -- through the LDS tile as before.
+template <int NW, int PN>
 __global__ void __launch_bounds__(NW * 64)
 k_pool_mlp_packed(const PoolPackedParams p)
 {
@@ -310,7 +315,7 @@ k_pool_mlp_packed(const PoolPackedParams p)
     constexpr int NDMA = 8 / NW;                         // A DMA instructions per wave and tile
     constexpr int WAIT_STEADY = NW == 8 ? 0x4F72 : 0x4F74;   // vmcnt((PK_R - 1) * (NDMA + 8)): 18 / 20
     constexpr int ATILE = BM * CH;                       // vec16 slots per A buffer (8 KiB)
-    __shared__ vec16 smem[(BM * PK_LDT * 4) / 16];       // fp32 output tile (130 KiB) >= A ring (32 KiB)
+    __shared__ vec16 smem[PN > 0 ? PK_NBUF * ATILE : (BM * PK_LDT * 4) / 16];   // A ring (32 KiB) / + fp32 output tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -428,6 +433,50 @@ drain:
         }
     }
 
+    if constexpr (PN > 0) {
+        // ---- epilogue in registers: bias + ReLU, segment max + argmax (the first maximum of a segment wins, as in
+        //      the sequential scan of the LDS epilogue and of torch.max) ------------------------------------------
+        constexpr int G = BM / PN;                       // segments per tile
+        const int h = lane >> 5;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int64_t j = n0 + wave * 64 + cb * 32 + (lane & 31);
+            const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
+            float best[G];
+            int arg[G];
+#pragma unroll
+            for (int sg = 0; sg < G; ++sg) { best[sg] = -1.f; arg[sg] = 0; }      // (ReLU'd values are >= 0)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i0 = 32 * rb + (r & 3) + 8 * (r >> 2);         // this register's row in half 0; half 1: + 4
+                    float v = acc[rb][cb][r] + bj;
+                    v = v > 0.f ? v : 0.f;
+#pragma unroll
+                    for (int sg = 0; sg < G; ++sg) {
+                        const bool in0 = i0 / PN == sg, in1 = (i0 + 4) / PN == sg;       // (compile-time)
+                        if (!in0 && !in1) continue;
+                        const bool mine = (in0 && in1) || (in0 ? h == 0 : h == 1);
+                        const int rel = i0 - sg * PN + 4 * h;
+                        if (mine && v > best[sg]) { best[sg] = v; arg[sg] = rel; }
+                    }
+                }
+#pragma unroll
+            for (int sg = 0; sg < G; ++sg) {
+                const float ob = __shfl_xor(best[sg], 32, 64);
+                const int oa = __shfl_xor(arg[sg], 32, 64);
+                if (ob > best[sg] || (ob == best[sg] && oa < arg[sg])) { best[sg] = ob; arg[sg] = oa; }
+                const int64_t seg = (int64_t)blockIdx.x * G + sg;
+                if ((sg & 1) == h && seg * PN < p.M && j < p.N) {                  // (the halves share the stores)
+                    p.pooled[seg * p.pooled_ld + j] = best[sg];
+                    if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(best[sg]);
+                    if (p.argmax) p.argmax[seg * p.N + j] = arg[sg];
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias + ReLU'd tile -> LDS, sign bits, segment max / mean down the rows ----------
     float *tile = reinterpret_cast<float *>(smem);
     __syncthreads();                                     // the A ring is free
@@ -644,7 +693,16 @@ int gsage_pool_mlp_packed(const void *A, int64_t lda, const int64_t *a_rows, con
     p.relu_mask = relu_mask;
     const int64_t subs = ceil_div(M, p.pool_groups);
     dim3 grid((unsigned)subs, (unsigned)ceil_div(H, 256), 1);
-    launch(k_pool_mlp_packed<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // max pooling over the usual fan-outs: pooled in registers (GSAGE_POOL_REGS=0: the LDS epilogue)
+    static const bool regs = [] { const char *e = getenv("GSAGE_POOL_REGS"); return !e || atoi(e) != 0; }();
+    const bool rp = regs && pool == GSAGE_POOL_MAX && !relu_mask;
+    hipStream_t s = (hipStream_t)stream;
+    if (rp && n == 10) launch(k_pool_mlp_packed<4, 10>, grid, dim3(256), 0, s, p);
+    else if (rp && n == 25) launch(k_pool_mlp_packed<4, 25>, grid, dim3(256), 0, s, p);
+    else if (rp && n == 5) launch(k_pool_mlp_packed<4, 5>, grid, dim3(256), 0, s, p);
+    else if (rp && n == 15) launch(k_pool_mlp_packed<4, 15>, grid, dim3(256), 0, s, p);
+    else if (rp && n == 20) launch(k_pool_mlp_packed<4, 20>, grid, dim3(256), 0, s, p);
+    else launch(k_pool_mlp_packed<4, 0>, grid, dim3(256), 0, s, p);
     return check_launch("pool_mlp_packed");
 }
 

@@ -215,7 +215,9 @@ def test_linear_nt_packed_weight_operand(M, N, K, groups):
 
 @pytest.mark.parametrize("mode", ["max", "mean"])
 @pytest.mark.parametrize("M,n,D,H", [(1280, 10, 602, 512), (53, 25, 602, 512), (7, 1, 70, 130), (64, 3, 256, 64),
-                                     (3, 64, 40, 128), (33, 7, 1433, 1024), (10, 10, 128, 512)])
+                                     (3, 64, 40, 128), (33, 7, 1433, 1024), (10, 10, 128, 512),
+                                     # (round 6: fan-outs 5 / 10 / 15 / 20 / 25 pool in registers under max pooling)
+                                     (41, 5, 602, 512), (21, 15, 100, 256), (9, 20, 602, 512), (2000, 10, 602, 300)])
 def test_pool_mlp_packed_equals_pool_mlp(mode, M, n, D, H):
     """gsage_pool_mlp_packed (64 rows x 512 hidden columns per workgroup, W from the fragment-ordered
     operand) against gsage_pool_mlp: same k order inside every accumulator, so pooled values, argmax
