@@ -368,9 +368,39 @@ k_pool_mlp_packed(const PoolPackedParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int arow0 = lane & 31, arow1 = arow0 + 32;
 
+    // Fragment reads run TWO 16-deep steps ahead of the MFMAs inside a k-tile (round 6): the four MFMAs of step kk
+    // (128 clocks of the matrix pipe) cover the LDS round trip of step kk + 2's fragments; read up front and waited
+    // for together (lgkmcnt(0) before the first MFMA) the eight reads' latency was exposed once per k-tile and wave.
+    // GSAGE_PK_READ_AHEAD=0 at build time: the old order.
+#ifndef GSAGE_PK_READ_AHEAD
+#define GSAGE_PK_READ_AHEAD 1
+#endif
     auto compute_tile = [&](int kt, const vec16 (&w)[2][4]) {
         const vec16 *sA = smem + (kt % PK_NBUF) * ATILE;
         vec16 fa0[4], fa1[4];
+#if GSAGE_PK_READ_AHEAD
+        auto rd = [&](int kk) {
+            const int ch = kk * 2 + (lane >> 5);
+            fa0[kk] = sA[lds_slot(arow0, ch)];
+            fa1[kk] = sA[lds_slot(arow1, ch)];
+        };
+        rd(0);
+        rd(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            // simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14: vmcnt / expcnt left alone
+            if (kk < 3) __builtin_amdgcn_s_waitcnt(0xC27F);          // lgkmcnt(2): step kk's two reads have landed
+            else __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk<uint16_t>::run(fa0[kk], w[0][kk], acc[0][0]);
+            mma_chunk<uint16_t>::run(fa0[kk], w[1][kk], acc[0][1]);
+            mma_chunk<uint16_t>::run(fa1[kk], w[0][kk], acc[1][0]);
+            mma_chunk<uint16_t>::run(fa1[kk], w[1][kk], acc[1][1]);
+            if (kk + 2 < 4) rd(kk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ch = kk * 2 + (lane >> 5);
@@ -387,6 +417,7 @@ k_pool_mlp_packed(const PoolPackedParams p)
             mma_chunk<uint16_t>::run(fa1[kk], w[1][kk], acc[1][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
+#endif
     };
 
     // NDMA + 8 vector-memory instructions per tile and wave; see k_linear_nt_packed
@@ -438,14 +469,14 @@ drain:
         //      the sequential scan of the LDS epilogue and of torch.max) ------------------------------------------
         constexpr int G = BM / PN;                       // segments per tile
         const int h = lane >> 5;
+        float best[2][G];
+        int arg[2][G];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const int64_t j = n0 + wave * 64 + cb * 32 + (lane & 31);
-            const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
-            float best[G];
-            int arg[G];
+            const int64_t jc = n0 + wave * 64 + cb * 32 + (lane & 31);
+            const float bj = (p.bias && jc < p.N) ? p.bias[jc] : 0.f;
 #pragma unroll
-            for (int sg = 0; sg < G; ++sg) { best[sg] = -1.f; arg[sg] = 0; }      // (ReLU'd values are >= 0)
+            for (int sg = 0; sg < G; ++sg) { best[cb][sg] = -1.f; arg[cb][sg] = 0; }      // (ReLU'd values are >= 0)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -457,22 +488,34 @@ drain:
                     for (int sg = 0; sg < G; ++sg) {
                         const bool in0 = i0 / PN == sg, in1 = (i0 + 4) / PN == sg;       // (compile-time)
                         if (!in0 && !in1) continue;
+                        // (selects, not branches: a divergent `if` here costs an exec save / restore per register)
                         const bool mine = (in0 && in1) || (in0 ? h == 0 : h == 1);
-                        const int rel = i0 - sg * PN + 4 * h;
-                        if (mine && v > best[sg]) { best[sg] = v; arg[sg] = rel; }
+                        const bool take = mine && v > best[cb][sg];
+                        best[cb][sg] = take ? v : best[cb][sg];
+                        arg[cb][sg] = take ? i0 - sg * PN + 4 * h : arg[cb][sg];
                     }
                 }
 #pragma unroll
-            for (int sg = 0; sg < G; ++sg) {
-                const float ob = __shfl_xor(best[sg], 32, 64);
-                const int oa = __shfl_xor(arg[sg], 32, 64);
-                if (ob > best[sg] || (ob == best[sg] && oa < arg[sg])) { best[sg] = ob; arg[sg] = oa; }
-                const int64_t seg = (int64_t)blockIdx.x * G + sg;
-                if ((sg & 1) == h && seg * PN < p.M && j < p.N) {                  // (the halves share the stores)
-                    p.pooled[seg * p.pooled_ld + j] = best[sg];
-                    if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(best[sg]);
-                    if (p.argmax) p.argmax[seg * p.N + j] = arg[sg];
-                }
+            for (int sg = 0; sg < G; ++sg) {             // the other half's rows of the segment
+                const float ob = __shfl_xor(best[cb][sg], 32, 64);
+                const int oa = __shfl_xor(arg[cb][sg], 32, 64);
+                const bool take = ob > best[cb][sg] || (ob == best[cb][sg] && oa < arg[cb][sg]);
+                best[cb][sg] = take ? ob : best[cb][sg];
+                arg[cb][sg] = take ? oa : arg[cb][sg];
+            }
+        }
+        // both halves hold every result: half 0 stores column block 0, half 1 column block 1 -- the wave's 64 columns
+        // leave as ONE store per segment and array
+        const int64_t j = n0 + wave * 64 + lane;
+#pragma unroll
+        for (int sg = 0; sg < G; ++sg) {
+            const float bv = h ? best[1][sg] : best[0][sg];
+            const int av = h ? arg[1][sg] : arg[0][sg];
+            const int64_t seg = (int64_t)blockIdx.x * G + sg;
+            if (seg * PN < p.M && j < p.N) {
+                p.pooled[seg * p.pooled_ld + j] = bv;
+                if (p.pooled_b) p.pooled_b[seg * p.pooled_b_ld + j] = f32_to_bf16(bv);
+                if (p.argmax) p.argmax[seg * p.N + j] = av;
             }
         }
         return;
