@@ -203,7 +203,7 @@ class FusedMeanTrainStep(FusedTrainStep):
 
     def _wg_target(self):
         """K5b workgroups to plan for: the chip (one workgroup fits per CU)"""
-        return 240
+        return int(os.environ.get("GSAGE_WGRAD_TARGET", "240"))
 
     def _stage_gather(self, s, with_adam=False, ids=None, hops=None, skip_rows=0, part=None, adam=None, stop_rows=None):
         """Level-0 gathers of batch set s (x rows of every hop + each hop's neighbour means), one
