@@ -408,6 +408,10 @@ typedef struct gsage_wgrad_desc {
                                  * read A + g * a_gstride row by row, like gsage_linear_nt's a_rows_group0_only) */
 } gsage_wgrad_desc;
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream);
+/* [host] 1 when gsage_wgrad_multi gives a problem's workgroups TWO 128-row output tiles each (its waves pair up on the
+ * same rows of A: half the readers per A line; long bf16 reductions with whole tile pairs per group) -- the caller then
+ * wants slices half as long for the same number of workgroups (ops.wgrad_plan). */
+int gsage_wgrad_pair_ok(int dtype, int64_t M, int64_t Ntot, int64_t n_per_group, int64_t rows_per_split);
 /* Device counters for the NEXT gsage_wgrad_multi launch of the calling thread to advance when it starts (consumed by
  * it, also while a command list is being recorded): *tick += 1, *tick1 += inc1, *tick2 += inc2 (any may be NULL).
  * For steps without a finalisation launch (gsage_adam_desc.reduce_descs): the Adam step count, the Philox call

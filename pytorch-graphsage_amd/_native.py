@@ -100,6 +100,7 @@ SIGNATURES = {
     "gsage_wgrad_slabs": (_int, [_i64, _i64]),
     "gsage_pool_route_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _int, _i64, _vp]),
     "gsage_wgrad_multi": (_int, [_i32, _vp, _int, _vp]),
+    "gsage_wgrad_pair_ok": (_int, [_int, _i64, _i64, _i64, _i64]),
     "gsage_wgrad_ticks_next": (_int, [_vp, _vp, _i64, _vp, _i64]),
     "gsage_clip_adam_meet": (_int, [_vp, _vp]),
     "gsage_gather_adam_capacity": (_int, [_int, _i64]),

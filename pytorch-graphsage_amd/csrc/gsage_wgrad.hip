@@ -272,11 +272,11 @@ __device__ __forceinline__ void park_block(const f32x4 (&acc)[8][8], float *lds,
         }
 }
 
-__device__ __forceinline__ void reduce_store(const float *lds, int round, int wave, const WgradParams &p,
-                                             float *slab, int64_t n_base, int64_t k0, int rg, int lane)
+// residue block E of one output tile: COPIES parked copies, `step` slots apart from `slot` on, summed in that order
+template <int COPIES>
+__device__ __forceinline__ void reduce_store_block(const float *slot, int step, int E, const WgradParams &p,
+                                                   float *slab, int64_t n_base, int64_t k0, int rg, int lane)
 {
-    const int E = 4 * round + wave;
-    const float *slot = lds + (wave * 4) * WGRAD_SLOT;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t n = n_base + 8 * (4 * rg + reg) + E;
@@ -285,10 +285,30 @@ __device__ __forceinline__ void reduce_store(const float *lds, int round, int wa
             const int off = ((reg * 2 + hh) * 64 + lane) << 2;
             f32x4 v = *reinterpret_cast<const f32x4 *>(slot + off);
 #pragma unroll
-            for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4 *>(slot + q * WGRAD_SLOT + off);
+            for (int q = 1; q < COPIES; ++q) v += *reinterpret_cast<const f32x4 *>(slot + q * step * WGRAD_SLOT + off);
             const int64_t k = k0 + 4 * hh;
             if (k + 3 < p.ldk && n < p.Ntot) *reinterpret_cast<f32x4 *>(slab + n * p.ldk + k) = v;
         }
+    }
+}
+
+__device__ __forceinline__ void reduce_store(const float *lds, int round, int wave, const WgradParams &p,
+                                             float *slab, int64_t n_base, int64_t k0, int rg, int lane)
+{
+    reduce_store_block<4>(lds + (wave * 4) * WGRAD_SLOT, 1, 4 * round + wave, p, slab, n_base, k0, rg, lane);
+}
+
+// PAIR mode (below): the workgroup owns TWO output tiles, waves t and t + 2 hold the two halves of tile t's slice.  Of
+// a round's four parked blocks per tile wave w sums blocks 2 (w >> 1) and 2 (w >> 1) + 1 of its own tile w & 1
+// (slots j * 4 + t and j * 4 + t + 2, in that order) and stores them.
+__device__ __forceinline__ void reduce_store_pair(const float *lds, int round, int wave, const WgradParams &p,
+                                                  float *slab, int64_t n_base, int64_t k0, int rg, int lane)
+{
+    const int t = wave & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = 2 * (wave >> 1) + u;
+        reduce_store_block<2>(lds + (j * 4 + t) * WGRAD_SLOT, 2, 4 * round + j, p, slab, n_base, k0, rg, lane);
     }
 }
 
@@ -296,14 +316,20 @@ __device__ __forceinline__ void reduce_store(const float *lds, int round, int wa
 // take a quarter of the slice each (whole 32-row steps), then meet in LDS.  Compared with one wave
 // per tile and slice this quarters the number of partial tiles that travel through HBM to
 // gsage_finalize_grads for the same number of busy SIMDs.
+// PAIR (round 6; problems with an even number of 128-row output tiles per group and a long reduction): the workgroup owns
+// the two tiles (2 by, bz) and (2 by + 1, bz); waves 0 / 1 walk the first half of the slice for tile 0 / 1, waves 2 / 3 the
+// second half.  The two waves of a half read the SAME rows of A at the same time (the second request finds the line in
+// the CU's L1 or in flight), so a K tile's rows are wanted by half as many workgroups: at the max-pool shape every A
+// line by two instead of four -- the re-reads that miss the L2 (a slice's readers drift apart by more than the 4 MB
+// hold) were most of the launch's HBM traffic.  Same number of steps per wave, twice the slices (partial tiles).
 __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx, int64_t by, int64_t bz,
-                                                float *lds)
+                                                float *lds, bool pair = false)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15;                                           // this lane's 8 columns
     const int rg = lane >> 4;                                            // this lane's 8-row group
-    const int64_t n_base = by * 128;
+    const int64_t n_base = (pair ? 2 * by + (wave & 1) : by) * 128;
     const int64_t k_base = bz * 128;
     const int g = (int)(n_base / p.n_per_group);
     const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
@@ -311,8 +337,9 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
 
     const int64_t m_begin = bx * p.rows_per_split;
     const int64_t m_end = (m_begin + p.rows_per_split < p.M) ? m_begin + p.rows_per_split : p.M;
-    const int64_t quarter = ((m_end - m_begin + 127) / 128) * 32;   // rows per wave, whole steps
-    int64_t w_begin = m_begin + wave * quarter, w_end = w_begin + quarter;
+    const int parts = pair ? 2 : 4;
+    const int64_t quarter = ((m_end - m_begin + 32 * parts - 1) / (32 * parts)) * 32;   // rows per wave, whole steps
+    int64_t w_begin = m_begin + (pair ? wave >> 1 : wave) * quarter, w_end = w_begin + quarter;
     if (w_begin > m_end) w_begin = m_end;
     if (w_end > m_end) w_end = m_end;
 
@@ -342,14 +369,16 @@ __device__ __forceinline__ void wgrad_workgroup(const WgradParams &p, int64_t bx
     park_block<2>(acc, lds, wave, lane);
     park_block<3>(acc, lds, wave, lane);
     lds_barrier();
-    reduce_store(lds, 0, wave, p, slab, n_base, k0, rg, lane);
+    if (pair) reduce_store_pair(lds, 0, wave, p, slab, n_base, k0, rg, lane);
+    else reduce_store(lds, 0, wave, p, slab, n_base, k0, rg, lane);
     lds_barrier();
     park_block<4>(acc, lds, wave, lane);
     park_block<5>(acc, lds, wave, lane);
     park_block<6>(acc, lds, wave, lane);
     park_block<7>(acc, lds, wave, lane);
     lds_barrier();
-    reduce_store(lds, 1, wave, p, slab, n_base, k0, rg, lane);
+    if (pair) reduce_store_pair(lds, 1, wave, p, slab, n_base, k0, rg, lane);
+    else reduce_store(lds, 1, wave, p, slab, n_base, k0, rg, lane);
 }
 
 __global__ void __launch_bounds__(256, 1)
@@ -366,7 +395,8 @@ constexpr int WGRAD_MAX_PROBLEMS = 8;
 struct WgradMulti {
     WgradParams p[WGRAD_MAX_PROBLEMS];
     int32_t first[WGRAD_MAX_PROBLEMS + 1];     // workgroups [first[s], first[s+1]) belong to problem s
-    int32_t S[WGRAD_MAX_PROBLEMS], ny[WGRAD_MAX_PROBLEMS];
+    int32_t S[WGRAD_MAX_PROBLEMS], ny[WGRAD_MAX_PROBLEMS];    // (ny: tile rows -- or PAIRS of tile rows -- of the grid)
+    int32_t pair[WGRAD_MAX_PROBLEMS];
     int32_t n_prob;
     // gsage_wgrad_ticks_next: counters workgroup 0 advances when it starts (nothing in this launch reads them)
     int64_t *tick, *tick1, *tick2;
@@ -394,7 +424,7 @@ k_wgrad_multi(const WgradMulti q)
     const int bx = local % q.S[s];
     const int rest = local / q.S[s];
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds);
+    wgrad_workgroup(q.p[s], bx, rest % q.ny[s], rest / q.ny[s], lds, q.pair[s] != 0);
 }
 
 // ---- fp32 operands (exact-arithmetic parity mode) ---------------------------------------------------
@@ -563,6 +593,16 @@ int gsage_wgrad_ticks_next(int64_t *tick, int64_t *tick1, int64_t inc1, int64_t 
     return GSAGE_OK;
 }
 
+int gsage_wgrad_pair_ok(int dtype, int64_t M, int64_t Ntot, int64_t n_per_group, int64_t rows_per_split)
+{
+    // two output tiles per workgroup (k_wgrad_multi, PAIR): bf16, whole pairs of 128-row tiles that share their A
+    // operand (the same group), a reduction long enough that the operands' re-reads are what the launch waits for
+    const char *e = getenv("GSAGE_WGRAD_PAIR");
+    const int mode = e ? atoi(e) : 0;
+    return mode != 0 && dtype == GSAGE_BF16 && Ntot % 256 == 0 && (n_per_group % 256 == 0 || n_per_group >= Ntot) &&
+           M >= 65536 && rows_per_split >= 256 ? 1 : 0;
+}
+
 int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, void *stream)
 {
     const WgradTicks ticks = t_wgrad_ticks;           // (consumed before any return path: never left for a later launch)
@@ -580,11 +620,13 @@ int gsage_wgrad_multi(int32_t n_prob, const gsage_wgrad_desc *probs, int dtype, 
                                 d.n_per_group, d.rows_per_split, d.slabs, d.ldk, d.a_rows);
             if (rc != GSAGE_OK) return rc;
             q.S[s] = (int32_t)ceil_div(d.M, d.rows_per_split);
-            q.ny[s] = (int32_t)ceil_div(d.Ntot, 128);
+            q.pair[s] = gsage_wgrad_pair_ok(dtype, d.M, d.Ntot, d.n_per_group, d.rows_per_split);
+            q.ny[s] = (int32_t)ceil_div(d.Ntot, 128) / (q.pair[s] ? 2 : 1);
             q.first[s + 1] = q.first[s] + q.S[s] * q.ny[s] * (int32_t)ceil_div(d.ldk, 128);
         } else {
             q.p[s] = q.p[0];
             q.S[s] = q.ny[s] = 1;
+            q.pair[s] = 0;
             q.first[s + 1] = q.first[s];
         }
     }

@@ -183,6 +183,12 @@ class FusedPoolTrainStep(FusedTrainStep):
         # workgroups, the big problem on 200) measured SLOWER here -- 180 against 150 us: the launch is bound by what
         # its 240 big workgroups pull from HBM (785 MB per launch), and fewer, longer slices only stretch that.
         self.wg_target = {(l, key): {"m": 240, "x": 40, "n": 40}[key] for l in range(L) for key in "mxn"}
+        for l in range(L):
+            # two output tiles per workgroup (gsage_wgrad_pair_ok): slices half as long keep the workgroup count
+            for key, _prm, M, ntot, K in self._wg_shapes(l):
+                t = self.wg_target[(l, key)]
+                if nat.lib().gsage_wgrad_pair_ok(self.code, M, ntot, ntot, ops.wgrad_plan(M, ntot, K, 2 * t)[0]):
+                    self.wg_target[(l, key)] = 2 * t
         rdesc, self.slabs = [], []
         for l, layer in enumerate(self.layers):
             Hm = self.Hm[l]

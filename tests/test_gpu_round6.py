@@ -299,3 +299,38 @@ def test_prep_rows_backward_equals_merge_sums_projection_and_scatter(with_dhid, 
         want = torch.zeros(N + 2, E, dtype=torch.float64, device=DEV).index_add_(0, rows, d)
         torch.testing.assert_close(gtab.double(), want, rtol=1e-4, atol=1e-3)
         assert float(deraw.abs().max()) == 0.0
+
+
+# ---- K5b with two output tiles per workgroup (csrc/gsage_wgrad.hip, PAIR) ---------------------------------------------
+@pytest.mark.parametrize("M,ntot,K,with_rows", [(70000, 512, 602, True), (65536, 256, 128, False), (66001, 512, 90, False)])
+def test_wgrad_pairs_of_tiles_per_workgroup(monkeypatch, M, ntot, K, with_rows):
+    """gsage_wgrad_multi in PAIR mode (GSAGE_WGRAD_PAIR=1: waves 0 / 1 and 2 / 3 share their rows of A) against fp64 and
+    against the one-tile-per-workgroup launch: the same products, summed per slice in another grouping."""
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    lda = _r64(K)
+    N = 9000
+    A = torch.zeros(N if with_rows else M, lda, dtype=BF, device=DEV)
+    A[:, :K] = torch.randn(A.shape[0], K, generator=g).to(DEV).to(BF)
+    rows = torch.randint(0, N, (M,), generator=g).to(DEV) if with_rows else None
+    dC = (torch.randn(M, ntot, generator=g) * 0.1).to(DEV).to(BF)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GSAGE_WGRAD_PAIR", mode)
+        target = 240
+        rps, S, ldk = ops.wgrad_plan(M, ntot, K, target)
+        pair = nat.lib().gsage_wgrad_pair_ok(nat.BF16, M, ntot, ntot, ops.wgrad_plan(M, ntot, K, 2 * target)[0])
+        assert pair == int(mode)
+        if pair:
+            target *= 2
+            rps, S, ldk = ops.wgrad_plan(M, ntot, K, target)
+        slabs = torch.full((S, ntot, ldk), float("nan"), device=DEV)
+        ops.wgrad_multi([(dC, A, lda, 0, M, ntot, K, ntot, slabs, target, rows)])
+        torch.cuda.synchronize()
+        outs[mode] = slabs[:, :, :K].double().sum(0)
+        assert torch.isfinite(outs[mode]).all()
+    x = (A[rows] if with_rows else A)[:, :K].double()
+    want = dC.double().t() @ x
+    scale = float(want.abs().max())
+    for mode in ("0", "1"):
+        assert float((outs[mode] - want).abs().max()) < 2e-5 * scale * (M / 1000.0) ** 0.5, mode
+    assert float((outs["0"] - outs["1"]).abs().max()) < 2e-5 * scale * (M / 1000.0) ** 0.5
