@@ -127,7 +127,7 @@ int gsage_cmdlist_side_end(void);
 int gsage_cmdlist_join(void);
 void gsage_cmdlist_destroy(void *list);
 /* Host calls inside a list (ABI 4).  A data-parallel step has ONE exchange and a deterministic
- * row reduction that is a vendor sort: neither is a kernel of this library, both belong INTO the step's list so that a
+ * row reduction (a vendor sort until round 6): what is not a kernel of this library still belongs INTO the step's list so that a
  * step stays one C call (no Python between the pieces, no second list around the collective).
  *   gsage_host_call(fn, ctx, s)      [host] recording: a node that calls fn(ctx, stream) at this point of every replay
  *                                    (inside a side section: with the side stream); not recording: calls fn(ctx, s)

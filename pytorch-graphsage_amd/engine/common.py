@@ -1041,8 +1041,8 @@ class FusedTrainStep(object):
         # The table's gradient, deterministically (csrc/gsage_rowsum.hip): the frontier's ids -- every rank's, in a
         # data-parallel run -- are sorted, each run of equal ids is summed in list order and stored (no atomics, no
         # zero-fill), and the norm / Adam passes walk the sorted list (gsage_row_adam.sorted_ids).
-        # Single GPU: opt-in (GSAGE_SORTED_ROWS=1) -- the vendor sort of 164 k keys is five short launches (~0.13 ms of
-        # the Pokec-shaped step) where the atomics cost ~0.05; data-parallel: always (replicas
+        # Single GPU: opt-in (GSAGE_SORTED_ROWS=1) -- the sort's nine launches and the segment sum are ~0.1 ms of the
+        # Pokec-shaped step where the atomics cost ~0.02; data-parallel: always (replicas
         # that add the same rows in different orders would drift apart).
         self.sorted_rows = self.ddp is not None or os.environ.get("GSAGE_SORTED_ROWS", "0") == "1"
         if self.sorted_rows:
