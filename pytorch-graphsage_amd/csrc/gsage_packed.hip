@@ -258,6 +258,200 @@ drain:
 }
 
 // -------------------------------------------------------------------------------------------------
+// K5 for SHORT reductions (K <= 256: papers100M's 128-d features, round 6): weight-stationary, persistent.
+//
+// With two k-tiles per 64-row tile the kernel above never reaches its steady state: a workgroup requests its A tile
+// (16 KB) AND its whole weight block (32 KB of fragments at K = 128: two thirds of what the CU ingests), waits, runs
+// 16 MFMAs per wave and leaves -- 2 656 workgroups at configs[4]'s level 0, 127 MB through the CUs' vector-memory paths
+// for 87 MB of HBM traffic.  Here a workgroup loads its 128-column block of W ONCE (a wave's fragments of all NK
+// k-tiles: 16 NK registers) and walks `tpw` consecutive row tiles: only A moves (16 KB in, 16 KB out per tile), the
+// LDS-DMA ring runs across tile boundaries (R k-tiles = a whole number of row tiles in flight), and a tile's epilogue
+// (bias + activation -> bf16 tile in LDS -> 16-byte row chunks) is the only other traffic.
+//   * LDS-DMA and its waits are inline asm (the compiler would drain every outstanding DMA at the loop's back edge);
+//     vector-memory operations complete in issue order, so "tile j landed" is a count: the R - 1 tiles requested
+//     behind it (2 instructions per wave each) + the 4 stores of each of the TR epilogues issued since.  Every
+//     instruction of that count is issued unconditionally: row tiles past the end repeat the last tile, rows past M the
+//     last row -- the same values stored to the same addresses again.
+//   * the rows' table ids (a_rows) of all the workgroup's tiles are read once into LDS.
+// -------------------------------------------------------------------------------------------------
+constexpr int WS_TPW = 8;                      // row tiles per workgroup (at most)
+constexpr int WS_LDT = BN + 8;                 // bf16 elements per row of the output staging tile
+
+template <int NK> constexpr int ws_ring() { return NK == 3 ? 3 : 4; }           // k-tiles in flight (a multiple of NK)
+template <int NK> constexpr size_t ws_lds_bytes()
+{
+    return (size_t)(ws_ring<NK>() + 1) * BM * CH * 16 + (size_t)BM * WS_LDT * 2 + (size_t)WS_TPW * 2 * 256 * 4;
+}
+
+template <int N>
+__device__ __forceinline__ void ws_wait_vm()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BASE + STEP t for the (unrolled, hence constant) t = 0 .. 3
+template <int BASE, int STEP>
+__device__ __forceinline__ void ws_wait_vm_sel(int t)
+{
+    if (t == 0) ws_wait_vm<BASE>();
+    else if (t == 1) ws_wait_vm<BASE + STEP>();
+    else if (t == 2) ws_wait_vm<BASE + 2 * STEP>();
+    else ws_wait_vm<BASE + 3 * STEP>();
+}
+
+template <int ACT, int NK>
+__global__ void __launch_bounds__(256)
+k_linear_nt_packed_ws(const PackedParams p, const int tpw)
+{
+    constexpr int R = ws_ring<NK>(), TR = R / NK, NBUF = R + 1, ATILE = BM * CH, NST = 4;
+    constexpr int STEADY = 2 * (R - 1) + NST * TR;        // vector-memory instructions younger than a tile about to be read
+    extern __shared__ __attribute__((aligned(16))) char ws_smem[];
+    vec16 *ring = reinterpret_cast<vec16 *>(ws_smem);
+    uint16_t *stage = reinterpret_cast<uint16_t *>(ws_smem + (size_t)NBUF * ATILE * 16);
+    uint32_t *rid_s = reinterpret_cast<uint32_t *>(ws_smem + (size_t)NBUF * ATILE * 16 + (size_t)BM * WS_LDT * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    const int64_t n0 = (int64_t)blockIdx.y * BN;
+    const int64_t n_tiles = (p.M + BM - 1) / BM;
+    const int64_t tile0 = (int64_t)blockIdx.x * tpw;
+    const uint16_t *A = p.A + (int64_t)g * p.a_gstride;
+    const int64_t *a_rows = (p.a_rows && (g == 0 || !p.a_rows_group0_only)) ? p.a_rows : nullptr;
+
+    // the two rows this lane requests per k-tile (as in k_linear_nt_packed) and their chunk, swizzled on the source side
+    const int cdst = lane & 7;
+    int rowof[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int Rr = 32 * s2 + 8 * wave + (lane >> 3);
+        rowof[s2] = (Rr & ~9) | ((Rr & 1) << 3) | ((Rr >> 3) & 1);
+    }
+    for (int t = 0; t < tpw; ++t) {
+        int64_t tile = tile0 + t;
+        if (tile >= n_tiles) tile = n_tiles - 1;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            int64_t m = tile * BM + rowof[s2];
+            if (m >= p.M) m = p.M - 1;
+            rid_s[(t * 2 + s2) * 256 + tid] = (uint32_t)(a_rows ? a_rows[m] : m);
+        }
+    }
+    // this wave's 32 columns of W, every k-tile: registers for the whole launch
+    const vec16 *wp = reinterpret_cast<const vec16 *>(p.Wp + (int64_t)g * p.wp_gstride) +
+                      (((n0 >> 5) + wave) * p.kc_total) * 64 + lane;
+    vec16 wr[NK][4];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wr[kt][kk] = wp[(int64_t)(kt * 4 + kk) * 64];
+    const int jl = wave * 32 + (lane & 31);
+    float bj = p.bias ? p.bias[(int64_t)g * p.N + n0 + jl] : 0.f;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_void_t *)ring;
+    const uint32_t dst0 = (uint32_t)((8 * wave) * CH * 16), dst1 = (uint32_t)((32 + 8 * wave) * CH * 16);
+
+    // k-tile kt of local row tile t (past the workgroup's last tile: that tile again) -> ring buffer `buf`
+    auto issue = [&](int t, int kt, int buf) {
+        const int tc = t < tpw ? t : tpw - 1;
+        const uint32_t r0 = rid_s[(tc * 2 + 0) * 256 + tid], r1 = rid_s[(tc * 2 + 1) * 256 + tid];
+        const uint16_t *s0 = A + (int64_t)r0 * p.lda + (cdst ^ (rowof[0] & 7)) * 8 + kt * 64;
+        const uint16_t *s1 = A + (int64_t)r1 * p.lda + (cdst ^ (rowof[1] & 7)) * 8 + kt * 64;
+        const uint32_t base = ring_lds + (uint32_t)(buf * ATILE * 16);
+        const uint32_t m0a = __builtin_amdgcn_readfirstlane(base + dst0), m0b = __builtin_amdgcn_readfirstlane(base + dst1);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(s0), "s"(m0a) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(s1), "s"(m0b) : "memory", "m0");
+    };
+    f32x16_t acc0, acc1;
+    const int arow0 = lane & 31, arow1 = arow0 + 32;
+    auto compute = [&](int buf, const vec16 (&w)[4]) {
+        const vec16 *sA = ring + buf * ATILE;
+        vec16 fa0[4], fa1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = kk * 2 + (lane >> 5);
+            fa0[kk] = sA[lds_slot(arow0, ch)];
+            fa1[kk] = sA[lds_slot(arow1, ch)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            mma_chunk<uint16_t>::run(fa0[kk], w[kk], acc0);
+            mma_chunk<uint16_t>::run(fa1[kk], w[kk], acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // bias + activation -> bf16 tile in LDS -> 16-byte row chunks; FOUR stores per thread, every one of them issued
+    auto epilogue = [&](int t) {
+        int64_t tile = tile0 + t;
+        if (tile >= n_tiles) tile = n_tiles - 1;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x16_t &acc = rb ? acc1 : acc0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                stage[i * WS_LDT + jl] = f32_to_bf16(apply_act(acc[r] + bj, ACT));
+            }
+        }
+        __syncthreads();
+        const int64_t cbase = (int64_t)g * p.c_gstride + n0;
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int qd = tid + 256 * u, row = qd >> 4, ch = qd & 15;
+            int64_t m = tile * BM + row;
+            if (m >= p.M) m = p.M - 1;                    // (that row's values: rows past M were read from row M - 1)
+            const vec16 v = *reinterpret_cast<const vec16 *>(stage + row * WS_LDT + ch * 8);
+            *reinterpret_cast<vec16 *>((uint16_t *)p.C + m * p.ldc + cbase + ch * 8) = v;
+        }
+    };
+    auto zero = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    };
+
+    // the first R k-tiles (TR row tiles) go out before anything is waited for
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (the ids are in LDS, W and the bias in registers)
+    // (W and the bias count as read HERE: the compiler's own waits for them land before the first LDS-DMA request, where
+    //  they cost nothing -- it does not see those requests and would otherwise wait for all of them at W's first use)
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+        asm volatile("" : "+v"(wr[kt][0]), "+v"(wr[kt][1]), "+v"(wr[kt][2]), "+v"(wr[kt][3]));
+    asm volatile("" : "+v"(bj));
+#pragma unroll
+    for (int j = 0; j < R; ++j) issue(j / NK, j % NK, j);
+    int buf = 0;
+    // row tiles 0 .. TR - 1: the epilogues issued so far are counted one by one
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+        zero();
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            ws_wait_vm_sel<2 * (R - 1), NST>(t);
+            __builtin_amdgcn_s_barrier();
+            compute(buf, wr[kt]);
+            issue(t + TR, kt, (buf + R) % NBUF);
+            buf = (buf + 1) % NBUF;
+        }
+        epilogue(t);
+    }
+    for (int t = TR; t < tpw; ++t) {
+        zero();
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            ws_wait_vm<STEADY>();
+            __builtin_amdgcn_s_barrier();
+            compute(buf, wr[kt]);
+            issue(t + TR, kt, buf == 0 ? NBUF - 1 : buf - 1);          // (buf + R) % NBUF with NBUF = R + 1
+            buf = buf + 1 == NBUF ? 0 : buf + 1;
+        }
+        epilogue(t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (requests past the end must not land in the next workgroup's LDS)
+}
+
+// -------------------------------------------------------------------------------------------------
 // K3 with the packed weight operand: pooling MLP, 64 rows x (NW x 64) hidden columns per workgroup.
 //
 // The 64 x 128-tile K3 above reads every A tile once per 128 hidden columns (4 x 164 MB on the hop-2
@@ -704,6 +898,57 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
         if (gd->n == 10) launch(k_linear_nt_packed<ACT_RELU, 10, false>, grid, dim3(256), 0, s, p, tg, hp);
         else launch(k_linear_nt_packed<ACT_RELU, 5, false>, grid, dim3(256), 0, s, p, tg, hp);
         return check_launch("linear_nt_packed");
+    }
+    {
+        // short reductions into bf16 rows: the weight-stationary persistent kernel (GSAGE_K5_WS=0: never)
+        const char *ws_env = getenv("GSAGE_K5_WS");
+        const bool ws_on = !ws_env || atoi(ws_env) != 0;
+        const int nk = (int)ceil_div(K, 64);
+        const int tr = nk == 1 ? 4 : nk == 2 ? 2 : 1;
+        const int64_t n_tiles = ceil_div(M, BM);
+        if (ws_on && c_dtype == GSAGE_BF16 && nk <= 4 && N % BN == 0 && ldc % 8 == 0 && c_gstride % 8 == 0 &&
+            ((uintptr_t)C % 16) == 0 && n_tiles >= 4 * tr && (act == ACT_RELU || act == ACT_NONE)) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+                else (void)hipGetLastError();
+            } else (void)hipGetLastError();
+            // two workgroups fit a CU: aim at one round of 2 x CUs workgroups over all column blocks and groups
+            const int64_t slices = (int64_t)grid.y * groups;
+            int64_t per = ceil_div(2 * (int64_t)cus, slices);
+            if (per < 1) per = 1;
+            int64_t tpw = ceil_div(n_tiles, per);
+            if (tpw < tr) tpw = tr;
+            if (tpw > WS_TPW) tpw = WS_TPW;
+            grid.x = (unsigned)ceil_div(n_tiles, tpw);
+#define GSAGE_WS_LAUNCH(ACTV, NKV)                                                                                        \
+            do {                                                                                                      \
+                static bool raised = false;                                                                           \
+                if (!raised) {                                                                                        \
+                    if (hipFuncSetAttribute((const void *)k_linear_nt_packed_ws<ACTV, NKV>,                           \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_lds_bytes<NKV>()) != hipSuccess) { \
+                        (void)hipGetLastError();                                                                      \
+                        set_error("linear_nt_packed: cannot raise the dynamic LDS limit");                          \
+                        return GSAGE_ELAUNCH;                                                                         \
+                    }                                                                                                 \
+                    raised = true;                                                                                    \
+                }                                                                                                     \
+                launch(k_linear_nt_packed_ws<ACTV, NKV>, grid, dim3(256), ws_lds_bytes<NKV>(), s, p, (int)tpw);       \
+            } while (0)
+#define GSAGE_WS_NK(ACTV)                                                                                                 \
+            do {                                                                                                      \
+                if (nk == 1) GSAGE_WS_LAUNCH(ACTV, 1);                                                                \
+                else if (nk == 2) GSAGE_WS_LAUNCH(ACTV, 2);                                                           \
+                else if (nk == 3) GSAGE_WS_LAUNCH(ACTV, 3);                                                           \
+                else GSAGE_WS_LAUNCH(ACTV, 4);                                                                        \
+            } while (0)
+            if (act == ACT_RELU) GSAGE_WS_NK(ACT_RELU);
+            else GSAGE_WS_NK(ACT_NONE);
+#undef GSAGE_WS_NK
+#undef GSAGE_WS_LAUNCH
+            return check_launch("linear_nt_packed");
+        }
     }
     if (act == ACT_RELU)
         launch(k_linear_nt_packed<ACT_RELU, 0, false>, grid, dim3(256), 0, s, p, tg, hp);

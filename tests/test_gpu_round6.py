@@ -334,3 +334,40 @@ def test_wgrad_pairs_of_tiles_per_workgroup(monkeypatch, M, ntot, K, with_rows):
     for mode in ("0", "1"):
         assert float((outs[mode] - want).abs().max()) < 2e-5 * scale * (M / 1000.0) ** 0.5, mode
     assert float((outs["0"] - outs["1"]).abs().max()) < 2e-5 * scale * (M / 1000.0) ** 0.5
+
+
+# ---- K5 for short reductions: weight-stationary persistent workgroups (csrc/gsage_packed.hip, k_linear_nt_packed_ws) -------
+@pytest.mark.parametrize("M,N,K,groups,act", [(84992, 128, 128, 2, 1), (5000, 256, 128, 2, 1), (1031, 128, 64, 1, 0),
+                                              (3000, 128, 192, 2, 1), (4097, 384, 256, 1, 1), (700, 128, 100, 2, 0),
+                                              (256, 128, 128, 1, 1), (20000, 128, 40, 2, 1)])
+def test_linear_nt_packed_weight_stationary_equals_the_tile_per_workgroup_kernel(monkeypatch, M, N, K, groups, act):
+    """gsage_linear_nt_packed with bf16 output and K <= 256 runs the weight-stationary kernel (W in registers for the
+    launch, a workgroup walks several row tiles, LDS-DMA ring across tile boundaries): the same MFMAs in the same order
+    as the one-tile-per-workgroup kernel (GSAGE_K5_WS=0) -- torch.equal --, both within bf16 of fp64; ragged M, one to
+    four k-tiles, several column blocks, two groups with the row list on group 0, rows beyond the output untouched."""
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K)
+    ld = _r64(K)
+    n_src = M + 37
+    A = torch.zeros(groups, n_src, ld, dtype=BF, device=DEV)
+    A[:, :, :K] = torch.randn(groups, n_src, K, generator=g).to(DEV).to(BF)
+    W = (torch.randn(groups, N, K, generator=g) / np.sqrt(K)).to(DEV)
+    bias = torch.randn(groups, N, generator=g).to(DEV)
+    rows = torch.randperm(n_src, generator=g)[:M].to(DEV).contiguous()
+    Wp = ops.pack_weight(W)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GSAGE_K5_WS", mode)
+        C = torch.full((M + 3, groups * N + 8), -7.0, dtype=BF, device=DEV)
+        ops._linear_packed_launch(A.data_ptr(), ld, rows.data_ptr(), 1, Wp.data_ptr(), bias.data_ptr(), C.data_ptr(),
+                                  C.stride(0), M, N, K, act, groups, n_src * ld, N, nat.BF16)
+        torch.cuda.synchronize()
+        outs[mode] = C
+    assert torch.equal(outs["0"], outs["1"])
+    C = outs["1"]
+    assert torch.all(C[M:].float() == -7.0) and torch.all(C[:, groups * N:].float() == -7.0)
+    for gi in range(groups):
+        a = (A[0][rows] if gi == 0 else A[gi][:M])[:, :K].double()
+        want = a @ W[gi].to(BF).double().t() + bias[gi].double()
+        if act == 1:
+            want = torch.relu(want)
+        torch.testing.assert_close(C[:M, gi * N:(gi + 1) * N].double(), want, rtol=2 ** -7, atol=2 ** -7)
