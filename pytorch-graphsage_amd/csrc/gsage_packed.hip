@@ -919,6 +919,7 @@ int gsage_linear_nt_packed(const void *A, int64_t lda, const int64_t *a_rows, in
             int64_t per = ceil_div(2 * (int64_t)cus, slices);
             if (per < 1) per = 1;
             int64_t tpw = ceil_div(n_tiles, per);
+            if (const char *e = getenv("GSAGE_K5_WS_TPW")) tpw = atoi(e);          // (a sweep knob)
             if (tpw < tr) tpw = tr;
             if (tpw > WS_TPW) tpw = WS_TPW;
             grid.x = (unsigned)ceil_div(n_tiles, tpw);
