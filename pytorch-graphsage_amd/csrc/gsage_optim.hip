@@ -567,6 +567,65 @@ k_bwd_merge(const MergeParams q)
     }
 }
 
+// bf16 rows of whole 16-byte chunks: EIGHT columns per thread (16-byte accesses on the bf16 side: a wave-wide request
+// costs the address path the same whatever its width) and two items per trip, their six loads requested together.
+// Same arithmetic per element as k_bwd_merge: the same bits.  (Round 6: the 3-layer configs[4] step spent 30 us here on
+// 104 MB -- a dependent round trip per item and thread.)
+__global__ void __launch_bounds__(256)
+k_bwd_merge_v8(const MergeParams q)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int chunks = q.D / 8;
+    const int64_t total = q.R * chunks;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const uint16_t *H = (const uint16_t *)q.H;
+    uint16_t *dH = (uint16_t *)q.dH;
+    for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += 2 * stride) {
+        f32x4 gx[2][2], ga[2][2];
+        u32x4 h[2];
+        int64_t m[2];
+        int c[2];
+        bool live[2], child[2];
+        float inv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t t = t0 + u * stride;
+            live[u] = t < total;
+            const int64_t tc = live[u] ? t : t0;
+            m[u] = tc / chunks;
+            c[u] = (int)(tc - m[u] * chunks) * 8;
+            int k = 0;
+#pragma unroll
+            for (int j = 1; j < 6; ++j)
+                if (j < q.n_hops && m[u] >= q.off[j]) k = j;
+            child[u] = k >= 1;
+            const int kc = child[u] ? k : 1;
+            const int64_t parent = child[u] ? q.off[kc - 1] + (m[u] - q.off[kc]) / q.fan[kc] : 0;
+            inv[u] = 1.f / (float)q.fan[kc];
+            const int64_t mx = m[u] < q.r_x ? m[u] : 0;
+            const float *px = q.DG + mx * q.ldg + c[u], *pa = q.DG + parent * q.ldg + q.dagg_off + c[u];
+            gx[u][0] = *reinterpret_cast<const f32x4 *>(px);
+            gx[u][1] = *reinterpret_cast<const f32x4 *>(px + 4);
+            ga[u][0] = *reinterpret_cast<const f32x4 *>(pa);
+            ga[u][1] = *reinterpret_cast<const f32x4 *>(pa + 4);
+            h[u] = *reinterpret_cast<const u32x4 *>(H + m[u] * q.ldh + c[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float g0 = 0.f, g1 = 0.f;
+                if (m[u] < q.r_x) { g0 = gx[u][w >> 1][2 * (w & 1)]; g1 = gx[u][w >> 1][2 * (w & 1) + 1]; }
+                if (child[u]) { g0 += ga[u][w >> 1][2 * (w & 1)] * inv[u]; g1 += ga[u][w >> 1][2 * (w & 1) + 1] * inv[u]; }
+                const float h0 = bf16_to_f32((uint16_t)(h[u][w] & 0xffff)), h1 = bf16_to_f32((uint16_t)(h[u][w] >> 16));
+                o[w] = pack_bf16x2(h0 > 0.f ? g0 : 0.f, h1 > 0.f ? g1 : 0.f);
+            }
+            if (live[u]) *reinterpret_cast<u32x4 *>(dH + m[u] * q.ldo + c[u]) = o;
+        }
+    }
+}
+
 // ---- backward routing of the max pool (K3) ------------------------------------------------------
 // hidden[i*n + j, c] receives g[i, c] iff row j won the max of (segment i, channel c) and the max
 // is positive (ReLU), else 0 -- autograd of nn_modules.py:224-226,240.  One thread = 8 channels of
@@ -1092,6 +1151,10 @@ int gsage_bwd_merge(const void *H, int dtype, int64_t ldh, const float *DG, int6
     for (int i = 0; i < 6; ++i) { q.off[i] = i < n_hops ? off[i] : 0; q.fan[i] = i < n_hops ? fan[i] : 1; }
     if (dtype == GSAGE_F32)
         launch(k_bwd_merge<float>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, q);
+    else if (!(getenv("GSAGE_MERGE_V8") && atoi(getenv("GSAGE_MERGE_V8")) == 0) &&      // (=0: the 4-column kernel, for A/B)
+             D % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0 && dagg_off % 4 == 0 &&
+             (((uintptr_t)H | (uintptr_t)dH | (uintptr_t)DG) & 15) == 0)
+        launch(k_bwd_merge_v8, dim3(grid_for(ceil_div(R * (D / 8), 2), 4096)), dim3(256), 0, (hipStream_t)stream, q);
     else
         launch(k_bwd_merge<uint16_t>, dim3(grid_for(R * (D / 4), 4096)), dim3(256), 0, (hipStream_t)stream, q);
     return check_launch("bwd_merge");

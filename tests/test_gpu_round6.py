@@ -371,3 +371,41 @@ def test_linear_nt_packed_weight_stationary_equals_the_tile_per_workgroup_kernel
         if act == 1:
             want = torch.relu(want)
         torch.testing.assert_close(C[:M, gi * N:(gi + 1) * N].double(), want, rtol=2 ** -7, atol=2 ** -7)
+
+
+# ---- inter-level backward routing, eight columns per thread (csrc/gsage_optim.hip, k_bwd_merge_v8) --------------------
+@pytest.mark.parametrize("B,fans,D", [(512, (15, 10), 256), (37, (5, 3), 128), (64, (10,), 64), (9, (4, 3, 2), 40)])
+def test_bwd_merge_eight_columns_per_thread_equals_the_four_column_kernel(monkeypatch, B, fans, D):
+    """gsage_bwd_merge on bf16 rows of whole 16-byte chunks (k_bwd_merge_v8) against the 4-column kernel (GSAGE_MERGE_V8=0):
+    torch.equal; and against the definition (reference: autograd of nn_modules.py:197-202 w.r.t. the level's input, the ReLU
+    of models.py's layer below)."""
+    import ctypes
+    g = torch.Generator(device="cpu"); g.manual_seed(B + D)
+    sizes = [B]
+    for f in fans:
+        sizes.append(sizes[-1] * f)
+    off = [0]
+    for sz in sizes:
+        off.append(off[-1] + sz)
+    n_hops = len(sizes)
+    R, r_x = off[n_hops], off[n_hops - 1]
+    H = torch.relu(torch.randn(R, D, generator=g)).to(BF).to(DEV)
+    DG = torch.randn(r_x, 2 * D, generator=g).to(DEV)
+    offh = (ctypes.c_int64 * 6)(*(off[:n_hops] + [0] * (6 - n_hops)))
+    fanh = (ctypes.c_int32 * 6)(*([1] + list(fans) + [1] * (5 - len(fans))))
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GSAGE_MERGE_V8", mode)
+        dH = torch.full((R + 1, D), -3.0, dtype=BF, device=DEV)
+        nat.check(nat.lib().gsage_bwd_merge(H.data_ptr(), nat.BF16, D, DG.data_ptr(), 2 * D, D, dH.data_ptr(), D, R, r_x, D,
+                                            n_hops, offh, fanh, ops._stream()), "bwd_merge")
+        torch.cuda.synchronize()
+        outs[mode] = dH
+    assert torch.equal(outs["0"], outs["1"]) and torch.all(outs["1"][R].float() == -3.0)
+    want = torch.zeros(R, D, dtype=torch.float64, device=DEV)
+    want[:r_x] += DG[:, :D].double()
+    for k in range(1, n_hops):
+        parent = off[k - 1] + torch.arange(sizes[k], device=DEV) // fans[k - 1]
+        want[off[k]:off[k + 1]] += DG[parent, D:].double() / fans[k - 1]
+    want = torch.where(H.double() > 0, want, torch.zeros_like(want))
+    torch.testing.assert_close(outs["1"][:R].double(), want, rtol=2 ** -7, atol=1e-6)
