@@ -131,6 +131,41 @@ __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict_
                     sq += s[e] * s[e];
                 }
         }
+    } else if (d.S >= 128 && (int64_t)d.rows * d.cols * 16 <= gstride) {
+        // very many partials of very few elements (the max pool's MLP bias: 512 channels x 512 partial rows): four waves
+        // to an element would still walk 128 partials each -- 16 dependent rounds, the longest chain of the max-pool
+        // step's finalisation (17 us).  Sixteen threads to an element, a sixteenth of the partials each (four rounds at
+        // S = 512), met in LDS in slice order.
+        const int64_t total = (int64_t)d.rows * d.cols;
+        const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int s0 = (d.S * sl) / 16, s1 = (d.S * (sl + 1)) / 16;
+        for (int64_t t0 = (int64_t)bx * 16; t0 < total; t0 += (int64_t)gx * 16) {
+            const int64_t t = t0 + el;
+            float s = 0.f;
+            if (t < total) {
+                const int64_t r = t / d.cols;
+                const float *src = d.src + r * d.ld + (t - r * d.cols);
+                int i = s0;
+                for (; i + 8 <= s1; i += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(i + u) * d.stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; i < s1; ++i) s += src[(int64_t)i * d.stride];
+            }
+            lds_barrier();
+            red4[threadIdx.x] = s;
+            lds_barrier();
+            if (sl == 0 && t < total) {
+                float tot = red4[el];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) tot += red4[16 * k + el];
+                flat_g[d.out_off + t] = tot;
+                sq += tot * tot;
+            }
+        }
     } else if (d.S >= 32 && (int64_t)d.rows * d.cols * 4 <= gstride) {
         // few elements, many partials (the seed-level kernel's per-workgroup head gradients: 10.5 k
         // elements x 128 partials): one thread per element would walk all S partials alone -- 16
