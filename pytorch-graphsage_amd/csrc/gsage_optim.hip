@@ -95,7 +95,7 @@ k_adam_meet(const AdamParams a)
 __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict__ descs,
                                                    float *__restrict__ flat_g,
                                                    float *__restrict__ partial_sq, int bx, int by, int gx,
-                                                   float *red, float *red4)
+                                                   float *red, float *red4, float *red16f)
 {
     const ReduceDesc d = descs[by];
     const int64_t gstride = (int64_t)gx * 256;
@@ -130,6 +130,54 @@ __device__ __forceinline__ void finalize_workgroup(const ReduceDesc *__restrict_
                     dst[e] = s[e];
                     sq += s[e] * s[e];
                 }
+        }
+    } else if (d.S >= 64 && d.ld % 4 == 0 && d.stride % 4 == 0 && ((uintptr_t)d.src & 15) == 0 &&
+               (int64_t)d.rows * ((d.cols + 3) / 4) * 2 <= gstride) {
+        // MANY partial tiles of a matrix too small to fill its grid row with 4-column chunks (configs[4]'s level 0: K5b's
+        // 120 slices of a 256 x 128 gradient -- one thread per element walked 15 dependent rounds of 4-byte loads, the
+        // launch's longest chain: 9.6 us).  16-byte loads as above, and SL threads to a chunk, a share of the partials each
+        // (two rounds at S = 120, SL = 8), met in LDS in slice order.
+        const int cpr = (d.cols + 3) / 4;
+        const int64_t total = (int64_t)d.rows * cpr;
+        int SL = 2;
+        while (SL < 16 && total * (SL * 2) <= gstride) SL *= 2;
+        const int epw = 256 / SL;                                   // chunks per workgroup and trip
+        const int el = threadIdx.x % epw, sl = threadIdx.x / epw;
+        const int s0 = (d.S * sl) / SL, s1 = (d.S * (sl + 1)) / SL;
+        f32x4 *red16 = reinterpret_cast<f32x4 *>(red16f);
+        for (int64_t t0 = (int64_t)bx * epw; t0 < total; t0 += (int64_t)gx * epw) {
+            const int64_t t = t0 + el;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int64_t r = 0;
+            int c = 0;
+            if (t < total) {
+                r = t / cpr;
+                c = (int)(t - r * cpr) * 4;
+                const float *src = d.src + r * d.ld + c;
+                int i = s0;
+                for (; i + 8 <= s1; i += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(i + u) * d.stride);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; i < s1; ++i) s += *reinterpret_cast<const f32x4 *>(src + (int64_t)i * d.stride);
+            }
+            lds_barrier();
+            red16[threadIdx.x] = s;
+            lds_barrier();
+            if (sl == 0 && t < total) {
+                f32x4 tot = red16[el];
+                for (int k = 1; k < SL; ++k) tot += red16[k * epw + el];
+                float *dst = flat_g + d.out_off + r * d.cols + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < d.cols) {
+                        dst[e] = tot[e];
+                        sq += tot[e] * tot[e];
+                    }
+            }
         }
     } else if (d.S >= 128 && (int64_t)d.rows * d.cols * 16 <= gstride) {
         // very many partials of very few elements (the max pool's MLP bias: 512 channels x 512 partial rows): four waves
@@ -229,12 +277,13 @@ k_finalize_grads(const ReduceDesc *__restrict__ descs, float *__restrict__ flat_
 {
     __shared__ float red[4];
     __shared__ float red4[256];
+    __shared__ __attribute__((aligned(16))) float red16f[1024];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (tick) *tick += 1;
         if (tick1) *tick1 += inc1;
         if (tick2) *tick2 += inc2;
     }
-    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red, red4);
+    finalize_workgroup(descs, flat_g, partial_sq, blockIdx.x, blockIdx.y, gridDim.x, red, red4, red16f);
 }
 
 __global__ void k_step_inc(int64_t *step) { *step += 1; }
